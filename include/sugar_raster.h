@@ -1,0 +1,118 @@
+/*
+ * sugar_raster.h -- C ABI of the MI355X-native (gfx950) differentiable Gaussian rasterizer.
+ *
+ * This is the drop-in boundary for the one hot path of Anttwo/SuGaR: the tile rasterizer that the
+ * reference reaches through
+ *     DGR = gaussian_splatting/submodules/diff-gaussian-rasterization
+ *     CudaRasterizer::Rasterizer::{forward,backward,markVisible}   DGR/cuda_rasterizer/rasterizer.h:24-84
+ * bound to Python by DGR/rasterize_points.cu:35-217 and DGR/ext.cpp:15-19, plus
+ *     SimpleKNN::knn / distCUDA2    simple-knn/simple_knn.h:15-19, simple-knn/spatial.cu:15-26.
+ *
+ * Plain pointers and sizes only (no torch types).  Every pointer is a DEVICE pointer unless said
+ * otherwise; a null pointer means "input absent", exactly like the reference (DGR/cuda_rasterizer/
+ * forward.cu:205,241).  `stream` is a hipStream_t passed as void*; all work is enqueued on it.
+ * The library never frees caller memory; scratch comes from the three allocation callbacks (the
+ * std::function<char*(size_t)> allocators of rasterizer.h:24-27 made C-callable).
+ *
+ * Return convention: functions return >= 0 on success and a negative SGR_E_* code on failure;
+ * sgr_last_error() gives the message for the calling thread.
+ */
+#ifndef SUGAR_RASTER_H_INCLUDED
+#define SUGAR_RASTER_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGR_ABI_VERSION 1
+
+#define SGR_E_INVALID (-1) /* bad argument (e.g. NUM_CHANNELS != 3 path, rasterizer_impl.cu:242-245) */
+#define SGR_E_HIP (-2)     /* a HIP runtime call or kernel failed (CHECK_CUDA, auxiliary.h:166-173) */
+#define SGR_E_ALLOC (-3)   /* an allocation callback returned NULL */
+
+/* Scratch allocator: must return a device buffer of at least `bytes` bytes, 256-byte aligned, that
+ * stays valid until the matching backward has run.  Replaces resizeFunctional, rasterize_points.cu:27-33. */
+typedef char* (*sgr_alloc_fn)(void* user, size_t bytes);
+
+int sgr_abi_version(void);
+const char* sgr_last_error(void);
+
+/* Rasterizer::forward, DGR/cuda_rasterizer/rasterizer.h:31-55 / rasterizer_impl.cu:198-336.
+ *   P Gaussians, D active SH degree, M SH coefficients per Gaussian (0 if shs == NULL).
+ *   means3D[P*3], shs[P*M*3], colors_precomp[P*3], opacities[P], scales[P*3], rotations[P*4],
+ *   cov3D_precomp[P*6], viewmatrix[16], projmatrix[16], cam_pos[3], background[3]  (all float32).
+ *   out_color[3*H*W] and radii[P] are written (radii may be NULL).
+ * Returns num_rendered (Gaussian x tile instances), or a negative error code.
+ * The layout of the three scratch buffers is private to this library (a15 in SURVEY.md section 8a). */
+int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user,
+                    sgr_alloc_fn binning_alloc, void* binning_user,
+                    sgr_alloc_fn img_alloc, void* img_user,
+                    int P, int D, int M,
+                    const float* background, int width, int height,
+                    const float* means3D, const float* shs, const float* colors_precomp,
+                    const float* opacities, const float* scales, float scale_modifier,
+                    const float* rotations, const float* cov3D_precomp,
+                    const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                    float tan_fovx, float tan_fovy, int prefiltered,
+                    float* out_color, int* radii, int debug, void* stream);
+
+/* Rasterizer::backward, DGR/cuda_rasterizer/rasterizer.h:57-84 / rasterizer_impl.cu:340-434.
+ *   R = the value sgr_forward returned; geom/binning/img = the buffers its callbacks handed out.
+ *   dL_dpix[3*H*W] in; gradient outputs (float32):
+ *     dL_dmean2D[P*3] (x,y used; NDC-scaled, backward.cu:460-461), dL_dconic[P*4] (slots 0,1,3 used),
+ *     dL_dopacity[P], dL_dcolor[P*3], dL_dmean3D[P*3], dL_dcov3D[P*6], dL_dsh[P*M*3],
+ *     dL_dscale[P*3], dL_drot[P*4].
+ *   Every output row is fully written by this call (rows of culled Gaussians are set to zero), so the
+ *   caller does NOT need to pre-zero them; pre-zeroed buffers (rasterize_points.cu:151-159) work too. */
+int sgr_backward(int P, int D, int M, int64_t R,
+                 const float* background, int width, int height,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* scales, float scale_modifier, const float* rotations,
+                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii,
+                 char* geom_buffer, char* binning_buffer, char* img_buffer,
+                 const float* dL_dpix,
+                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                 float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                 int debug, void* stream);
+
+/* Rasterizer::markVisible, DGR/cuda_rasterizer/rasterizer.h:24-29 / rasterizer_impl.cu:141-153.
+ * present[P] is one byte per Gaussian (bool). */
+int sgr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+/* Scratch sizes (bytes) for a given problem; the callbacks are asked for exactly these. */
+size_t sgr_geom_bytes(int P);
+size_t sgr_img_bytes(int width, int height);
+size_t sgr_binning_bytes(int64_t R);
+
+/* ---- introspection for parity tests (read-only views into the private scratch layout) ---------
+ * Each returns a byte offset into the corresponding buffer.  The geometry record of Gaussian i is
+ * 12 floats at geom + sgr_geom_rec_offset() + 48*i:
+ *   {x, y, conic.x, conic.y, conic.z, opacity, r, g, b, depth, bitcast(radius), bitcast(clamped bits)} */
+size_t sgr_geom_rec_offset(int P);
+size_t sgr_img_final_T_offset(int width, int height);   /* float[W*H] */
+size_t sgr_img_n_contrib_offset(int width, int height); /* uint32[W*H] */
+size_t sgr_img_tile_start_offset(int width, int height);/* uint32[T+1]: tile t owns [start[t], start[t+1]) */
+size_t sgr_img_tile_maxc_offset(int width, int height); /* uint32[T]: max n_contrib over the tile's pixels */
+size_t sgr_binning_point_list_offset(int64_t R);        /* uint32[R]: Gaussian ids, tile-major, depth order */
+
+/* ---- k-NN helpers sharing the Gaussian position buffer ------------------------------------------
+ * sgr_dist2: simple_knn._C.distCUDA2 (simple-knn/spatial.cu:15-26 -> SimpleKNN::knn, simple-knn/
+ *   simple_knn.cu:185-221): meanDists[i] = mean of the 3 smallest SQUARED distances from point i to the
+ *   other points (simple_knn.cu:182).  points[P*3] -> meanDists[P].
+ * sgr_knn: the exact K-nearest-neighbour query SuGaR obtains from pytorch3d.ops.knn_points
+ *   (sugar_scene/sugar_model.py:49,235,1028,1342): for each of N query points the K (<= 32) nearest of
+ *   M reference points; dists[N*K] squared distances ascending, idx[N*K] int64 reference indices
+ *   (equal distances: lower index first).  When query and reference are the same buffer the point itself
+ *   comes first with distance 0. */
+int sgr_dist2(int P, const float* points, float* meanDists, void* stream);
+int sgr_knn(int N, const float* query, int M, const float* ref, int K, float* dists, int64_t* idx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUGAR_RASTER_H_INCLUDED */

@@ -1,0 +1,65 @@
+"""ctypes loader for sugar_amd/libsugar_raster.so (the C ABI of include/sugar_raster.h).
+
+There is NO fallback: if the HIP library is missing or a symbol of the ABI is absent, importing the
+rasterizer fails loudly.  The CPU oracle under oracle/ is test infrastructure and is never used here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsugar_raster.so")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+# symbol -> (restype, argtypes); must list every function declared in include/sugar_raster.h
+_vp, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
+SIGNATURES = {
+    "sgr_abi_version": (_i, []),
+    "sgr_last_error": (C.c_char_p, []),
+    "sgr_forward": (_i64, [ALLOC_FN, _vp, ALLOC_FN, _vp, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp,
+                           _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp]),
+    "sgr_backward": (_i, [_i, _i, _i, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp,
+                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "sgr_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    "sgr_geom_bytes": (_sz, [_i]),
+    "sgr_img_bytes": (_sz, [_i, _i]),
+    "sgr_binning_bytes": (_sz, [_i64]),
+    "sgr_geom_rec_offset": (_sz, [_i]),
+    "sgr_img_final_T_offset": (_sz, [_i, _i]),
+    "sgr_img_n_contrib_offset": (_sz, [_i, _i]),
+    "sgr_img_tile_start_offset": (_sz, [_i, _i]),
+    "sgr_img_tile_maxc_offset": (_sz, [_i, _i]),
+    "sgr_binning_point_list_offset": (_sz, [_i64]),
+    "sgr_dist2": (_i, [_i, _vp, _vp, _vp]),
+    "sgr_knn": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the gfx950 HIP rasterizer is not built. Run `python -m sugar_amd.build` "
+            "(or __graft_entry__.build()). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"{LIB_PATH} does not export `{name}` (ABI mismatch; rebuild)") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sgr_abi_version() != 1:
+        raise ImportError("sugar_raster ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().sgr_last_error().decode(errors="replace")

@@ -1,0 +1,85 @@
+"""Build recipe for the gfx950 rasterizer library (sugar_amd/libsugar_raster.so).
+
+hipcc cross-compiles without a GPU, so this runs in the build container and on the GPU box alike.
+The library is built IN-TREE (git-ignored, but shipped to the GPU box by gpurun).
+
+    python -m sugar_amd.build [--force]
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libsugar_raster.so")
+ARCH = "gfx950"
+
+# translation unit -> extra flags.  The per-Gaussian and binning kernels carry the pixel-exact contract
+# (individually rounded IEEE ops, see csrc/preprocess.hip); the blend kernels may contract to FMA.
+SOURCES = {
+    "preprocess.hip": ["-ffp-contract=off"],
+    "binning.hip": ["-ffp-contract=off"],
+    "blend.hip": [],
+    "knn.hip": ["-ffp-contract=off"],
+    "capi.hip": [],
+}
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the gfx950 rasterizer cannot be built")
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)) + ["../../include/sugar_raster.h"]:
+        p = os.path.join(CSRC, name)
+        if os.path.isfile(p):
+            h.update(name.encode())
+            h.update(open(p, "rb").read())
+    h.update(repr((SOURCES, COMMON)).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    stamp = OUT + ".stamp"
+    dig = _digest()
+    if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return OUT
+    hipcc = _hipcc()
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    procs = []
+    for src, extra in SOURCES.items():
+        path = os.path.join(CSRC, src)
+        if not os.path.exists(path):
+            continue
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc, *COMMON, *extra, "-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
+        if verbose and out:
+            print(out.decode())
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT, *objs]
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

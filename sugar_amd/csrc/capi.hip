@@ -1,0 +1,204 @@
+// capi.hip -- host orchestration and the C ABI of include/sugar_raster.h.
+//
+// Mirrors the call structure of CudaRasterizer::Rasterizer::{forward,backward,markVisible}
+// (DGR/cuda_rasterizer/rasterizer_impl.cu:141-153, 198-336, 340-434) on a caller-supplied HIP stream.
+#include "../../include/sugar_raster.h"
+#include "sgr_common.h"
+
+#include <mutex>
+#include <string>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(SGR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+// debug mode = the reference's CHECK_CUDA (auxiliary.h:166-173): synchronise and check after every stage
+#define STAGE_CHECK(what)                                                                               \
+    do {                                                                                                \
+        hipError_t e_ = hipGetLastError();                                                              \
+        if (e_ == hipSuccess && debug) e_ = hipStreamSynchronize(s);                                    \
+        if (e_ != hipSuccess) return fail(SGR_E_HIP, std::string(what) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// one small pinned readback slot per calling thread (the forward reads R and the max tile count once)
+struct Pinned {
+    uint32_t* p = nullptr;
+    ~Pinned() { /* leaked on purpose: the HIP runtime may already be gone at thread exit */ }
+};
+thread_local Pinned g_pinned;
+
+}  // namespace
+
+extern "C" {
+
+int sgr_abi_version(void) { return SGR_ABI_VERSION; }
+const char* sgr_last_error(void) { return g_err.c_str(); }
+
+size_t sgr_geom_bytes(int P) { return sgr_align((size_t)(P > 0 ? P : 1) * sizeof(GeomRec)); }
+size_t sgr_img_bytes(int width, int height) { return sgr_img_layout(width, height).total; }
+size_t sgr_binning_bytes(int64_t R) { return sgr_bin_layout(R).total; }
+size_t sgr_geom_rec_offset(int) { return 0; }
+size_t sgr_img_final_T_offset(int w, int h) { return sgr_img_layout(w, h).final_T; }
+size_t sgr_img_n_contrib_offset(int w, int h) { return sgr_img_layout(w, h).n_contrib; }
+size_t sgr_img_tile_start_offset(int w, int h) { return sgr_img_layout(w, h).tile_start; }
+size_t sgr_img_tile_maxc_offset(int w, int h) { return sgr_img_layout(w, h).tile_maxc; }
+size_t sgr_binning_point_list_offset(int64_t R) { return sgr_bin_layout(R).point_list; }
+
+int sgr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* stream)
+{
+    (void)projmatrix;
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0) return fail(SGR_E_INVALID, "P < 0");
+    sgr_launch_mark_visible(P, means3D, viewmatrix, present, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SGR_E_HIP, std::string("mark_visible: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binning_alloc, void* binning_user,
+                    sgr_alloc_fn img_alloc, void* img_user, int P, int D, int M, const float* background, int width,
+                    int height, const float* means3D, const float* shs, const float* colors_precomp,
+                    const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                    const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                    float tan_fovx, float tan_fovy, int prefiltered, float* out_color, int* radii, int debug,
+                    void* stream)
+{
+    (void)prefiltered;  // the reference only uses it to trap on an inconsistent pre-filter (auxiliary.h:156-160)
+    hipStream_t s = (hipStream_t)stream;
+    if (P <= 0 || width <= 0 || height <= 0) return fail(SGR_E_INVALID, "P, width and height must be positive");
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !background || !out_color)
+        return fail(SGR_E_INVALID, "null required pointer");
+    if (!shs && !colors_precomp) return fail(SGR_E_INVALID, "need SHs or precomputed colours");
+    if (shs && !colors_precomp && (M <= 0 || M > 16 || (D + 1) * (D + 1) > M || D < 0 || D > 3))
+        return fail(SGR_E_INVALID, "SH degree / coefficient count out of range (D <= 3, (D+1)^2 <= M <= 16)");
+    if (shs && !colors_precomp && !cam_pos) return fail(SGR_E_INVALID, "cam_pos required with SHs");
+    if (!cov3D_precomp && (!scales || !rotations)) return fail(SGR_E_INVALID, "need scales+rotations or cov3D_precomp");
+
+    const ImgLayout IL = sgr_img_layout(width, height);
+    char* geom = geom_alloc(geom_user, sgr_geom_bytes(P));
+    char* img = img_alloc(img_user, IL.total);
+    if (!geom || !img) return fail(SGR_E_ALLOC, "geometry/image scratch allocation failed");
+
+    GeomRec* rec = reinterpret_cast<GeomRec*>(geom);
+    float* final_T = reinterpret_cast<float*>(img + IL.final_T);
+    uint32_t* n_contrib = reinterpret_cast<uint32_t*>(img + IL.n_contrib);
+    uint32_t* tile_start = reinterpret_cast<uint32_t*>(img + IL.tile_start);
+    uint32_t* tile_cursor = reinterpret_cast<uint32_t*>(img + IL.tile_cursor);
+    uint32_t* tile_maxc = reinterpret_cast<uint32_t*>(img + IL.tile_maxc);
+    uint32_t* header = reinterpret_cast<uint32_t*>(img + IL.header);
+
+    // tile_start doubles as the per-tile counter array until the scan overwrites it with offsets:
+    // the counts live in tile_cursor during preprocess, the scan reads them, then the cursor is re-zeroed.
+    HIP_TRY(hipMemsetAsync(tile_cursor, 0, (size_t)IL.T * 4, s));
+
+    PreprocessArgs pa;
+    pa.P = P; pa.D = D; pa.M = shs ? M : 0;
+    pa.means3D = means3D; pa.scales = scales; pa.scale_modifier = scale_modifier; pa.rotations = rotations;
+    pa.opacities = opacities; pa.shs = shs; pa.cov3D_precomp = cov3D_precomp; pa.colors_precomp = colors_precomp;
+    pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.cam_pos = cam_pos;
+    pa.W = width; pa.H = height; pa.tan_fovx = tan_fovx; pa.tan_fovy = tan_fovy;
+    pa.focal_y = height / (2.0f * tan_fovy);  // rasterizer_impl.cu:222-223
+    pa.focal_x = width / (2.0f * tan_fovx);
+    pa.gx = IL.gx; pa.gy = IL.gy;
+    pa.radii = radii; pa.rec = rec; pa.tile_count = tile_cursor;
+    sgr_launch_preprocess_fwd(pa, s);
+    STAGE_CHECK("preprocess");
+
+    sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, s);
+    STAGE_CHECK("tile_scan");
+
+    if (!g_pinned.p) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_pinned.p), 64, hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(tile_cursor, 0, (size_t)IL.T * 4, s));
+    HIP_TRY(hipStreamSynchronize(s));  // the one host round trip of the forward (rasterizer_impl.cu:280-281)
+    const int64_t R = (int64_t)g_pinned.p[SGR_HDR_R];
+    const uint32_t max_count = g_pinned.p[SGR_HDR_MAXCOUNT];
+
+    const BinLayout BL = sgr_bin_layout(R);
+    char* binning = binning_alloc(binning_user, BL.total);
+    if (!binning) return fail(SGR_E_ALLOC, "binning scratch allocation failed");
+    uint64_t* keys = reinterpret_cast<uint64_t*>(binning + BL.keys);
+    uint32_t* point_list = reinterpret_cast<uint32_t*>(binning + BL.point_list);
+
+    if (R > 0) {
+        sgr_launch_scatter(P, IL.gx, IL.gy, rec, tile_start, tile_cursor, keys, s);
+        STAGE_CHECK("scatter");
+        sgr_launch_tile_sort(IL.T, max_count, tile_start, keys, point_list, s);
+        STAGE_CHECK("tile_sort");
+    }
+    sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
+                         tile_maxc, out_color, s);
+    STAGE_CHECK("blend_fwd");
+    return R;
+}
+
+int sgr_backward(int P, int D, int M, int64_t R, const float* background, int width, int height, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer,
+                 char* binning_buffer, char* img_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                 float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                 float* dL_dscale, float* dL_drot, int debug, void* stream)
+{
+    (void)radii;  // the private geometry record carries the radius
+    hipStream_t s = (hipStream_t)stream;
+    if (P <= 0 || width <= 0 || height <= 0) return fail(SGR_E_INVALID, "P, width and height must be positive");
+    if (!geom_buffer || !binning_buffer || !img_buffer || !dL_dpix) return fail(SGR_E_INVALID, "null scratch / dL_dpix");
+    if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
+        return fail(SGR_E_INVALID, "null gradient output");
+    const bool use_sh = shs && !colors_precomp;
+    if (use_sh && !dL_dsh) return fail(SGR_E_INVALID, "dL_dsh required with SHs");
+    if (!cov3D_precomp && (!dL_dscale || !dL_drot)) return fail(SGR_E_INVALID, "dL_dscale/dL_drot required");
+
+    const ImgLayout IL = sgr_img_layout(width, height);
+    const BinLayout BL = sgr_bin_layout(R);
+    const GeomRec* rec = reinterpret_cast<const GeomRec*>(geom_buffer);
+    const float* final_T = reinterpret_cast<const float*>(img_buffer + IL.final_T);
+    const uint32_t* n_contrib = reinterpret_cast<const uint32_t*>(img_buffer + IL.n_contrib);
+    const uint32_t* tile_start = reinterpret_cast<const uint32_t*>(img_buffer + IL.tile_start);
+    const uint32_t* tile_maxc = reinterpret_cast<const uint32_t*>(img_buffer + IL.tile_maxc);
+    const uint32_t* point_list = reinterpret_cast<const uint32_t*>(binning_buffer + BL.point_list);
+
+    // the blend backward accumulates with atomics: its four targets start from zero
+    HIP_TRY(hipMemsetAsync(dL_dmean2D, 0, (size_t)P * 3 * 4, s));
+    HIP_TRY(hipMemsetAsync(dL_dconic, 0, (size_t)P * 4 * 4, s));
+    HIP_TRY(hipMemsetAsync(dL_dopacity, 0, (size_t)P * 4, s));
+    HIP_TRY(hipMemsetAsync(dL_dcolor, 0, (size_t)P * 3 * 4, s));
+    if (R > 0) {
+        sgr_launch_blend_bwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
+                             tile_maxc, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, s);
+        STAGE_CHECK("blend_bwd");
+    }
+    PreprocessBwdArgs pb;
+    pb.P = P; pb.D = D; pb.M = use_sh ? M : 0;
+    pb.means3D = means3D; pb.shs = use_sh ? shs : nullptr;
+    pb.scales = cov3D_precomp ? nullptr : scales; pb.rotations = cov3D_precomp ? nullptr : rotations;
+    pb.scale_modifier = scale_modifier; pb.cov3D_precomp = cov3D_precomp;
+    pb.viewmatrix = viewmatrix; pb.projmatrix = projmatrix; pb.cam_pos = cam_pos;
+    pb.W = width; pb.H = height; pb.tan_fovx = tan_fovx; pb.tan_fovy = tan_fovy;
+    pb.focal_y = height / (2.0f * tan_fovy);
+    pb.focal_x = width / (2.0f * tan_fovx);
+    pb.rec = rec;
+    pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dcolor = dL_dcolor;
+    pb.dL_dmean3D = dL_dmean3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_dsh = use_sh ? dL_dsh : nullptr;
+    pb.dL_dscale = cov3D_precomp ? nullptr : dL_dscale; pb.dL_drot = cov3D_precomp ? nullptr : dL_drot;
+    sgr_launch_preprocess_bwd(pb, s);
+    STAGE_CHECK("preprocess_bwd");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,485 @@
+// preprocess.hip -- per-Gaussian kernels for gfx950: frustum test, forward preprocess (projection, EWA
+// covariance, tile rectangle, SH colour, per-tile instance counting) and the fused backward preprocess.
+//
+// Replaces (does not translate) the reference kernels
+//   checkFrustum        DGR/cuda_rasterizer/rasterizer_impl.cu:54-66
+//   preprocessCUDA fwd  DGR/cuda_rasterizer/forward.cu:155-256  (+ computeCov3D :118-152, computeCov2D :74-113,
+//                       computeColorFromSH :20-71, getRect auxiliary.h:46-56, ndc2Pix :41-44)
+//   computeCov2DCUDA    DGR/cuda_rasterizer/backward.cu:144-274   } fused into ONE kernel here: the reference
+//   preprocessCUDA bwd  DGR/cuda_rasterizer/backward.cu:346-396   } round-trips dL_dmeans / dL_dcov3D through HBM
+//
+// Arithmetic contract: this translation unit is compiled with -ffp-contract=off; every float op is an
+// individually rounded IEEE operation in the order written, which is the order of oracle/cpu_rasterizer.c.
+// Radii, tile rectangles and depth keys therefore match the oracle bit for bit.
+//
+// MI355X notes: one lane per Gaussian, 256-thread blocks (4 waves).  All per-Gaussian state that the
+// blend kernels gather later is emitted as ONE 48-byte record (GeomRec), so a gather touches one or two
+// 128-B lines instead of the reference's three separate arrays; cov3D is recomputed in the backward
+// instead of being stored (24 B/Gaussian of HBM traffic each way for ~40 flops).
+#include "sgr_common.h"
+
+namespace {
+
+__device__ __constant__ const float SH_C0 = 0.28209479177387814f;
+__device__ __constant__ const float SH_C1 = 0.4886025119029199f;
+__device__ __constant__ const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                                 -1.0925484305920792f, 0.5462742152960396f};
+__device__ __constant__ const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                                 0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                                 -0.5900435899266435f};
+
+__device__ __forceinline__ float fmin_(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float fmax_(float a, float b) { return a > b ? a : b; }
+
+// float -> int with saturation and NaN -> 0 (what v_cvt_i32_f32 does; spelled out so it cannot be UB)
+__device__ __forceinline__ int f2i_sat(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)v;
+}
+
+__device__ __forceinline__ float ndc2pix(float v, int S)
+{
+    return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5);
+}
+
+}  // namespace
+
+// shared with binning.hip through sgr_device.h
+#include "sgr_device.h"
+
+namespace {
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 xform4x3(V3 p, const float* m)
+{
+    V3 t;
+    t.x = m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12];
+    t.y = m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13];
+    t.z = m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14];
+    return t;
+}
+
+__device__ __forceinline__ void quat_to_glmR(const float* q, float R[3][3])
+{
+    float r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+    R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+    R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* scale, float mod, const float* rot, float c6[6])
+{
+    float s[3] = {mod * scale[0], mod * scale[1], mod * scale[2]};
+    float R[3][3], M[3][3];
+    quat_to_glmR(rot, R);
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) M[c][k] = s[k] * R[c][k];
+#define SIG(c, r) (M[r][0] * M[c][0] + M[r][1] * M[c][1] + M[r][2] * M[c][2])
+    c6[0] = SIG(0, 0); c6[1] = SIG(0, 1); c6[2] = SIG(0, 2);
+    c6[3] = SIG(1, 1); c6[4] = SIG(1, 2); c6[5] = SIG(2, 2);
+#undef SIG
+}
+
+// T = J * Rw2c (2x3), with the 1.3*tanfov clamp of forward.cu:80-87
+__device__ __forceinline__ void compute_T(V3 mean, float fx, float fy, float tanx, float tany, const float* v,
+                                          float T[2][3], V3& t, float& txtz, float& tytz)
+{
+    t = xform4x3(mean, v);
+    const float limx = 1.3f * tanx;
+    const float limy = 1.3f * tany;
+    txtz = t.x / t.z;
+    tytz = t.y / t.z;
+    t.x = fmin_(limx, fmax_(-limx, txtz)) * t.z;
+    t.y = fmin_(limy, fmax_(-limy, tytz)) * t.z;
+    float J00 = fx / t.z, J02 = -(fx * t.x) / (t.z * t.z);
+    float J11 = fy / t.z, J12 = -(fy * t.y) / (t.z * t.z);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        T[0][r] = v[4 * r + 0] * J00 + v[4 * r + 2] * J02;
+        T[1][r] = v[4 * r + 1] * J11 + v[4 * r + 2] * J12;
+    }
+}
+
+__device__ __forceinline__ void cov2d_from_T(const float T[2][3], const float* c3, float& a, float& b, float& c)
+{
+    float V[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
+    float A[3][2];
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+        for (int r = 0; r < 2; r++) A[cc][r] = T[r][0] * V[cc][0] + T[r][1] * V[cc][1] + T[r][2] * V[cc][2];
+    a = A[0][0] * T[0][0] + A[1][0] * T[0][1] + A[2][0] * T[0][2];
+    b = A[0][1] * T[0][0] + A[1][1] * T[0][1] + A[2][1] * T[0][2];
+    c = A[0][1] * T[1][0] + A[1][1] * T[1][1] + A[2][1] * T[1][2];
+}
+
+// SH -> RGB for channel c; sh points at this Gaussian's [M][3] coefficient block
+__device__ __forceinline__ float sh_channel(int deg, const float* sh, int c, float x, float y, float z)
+{
+#define SH(k) sh[3 * (k) + c]
+    float r = SH_C0 * SH(0);
+    if (deg > 0) {
+        r = r - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z;
+            float xy = x * y, yz = y * z, xz = x * z;
+            r = r + SH_C2[0] * xy * SH(4) + SH_C2[1] * yz * SH(5) + SH_C2[2] * (2.0f * zz - xx - yy) * SH(6) +
+                SH_C2[3] * xz * SH(7) + SH_C2[4] * (xx - yy) * SH(8);
+            if (deg > 2) {
+                r = r + SH_C3[0] * y * (3.0f * xx - yy) * SH(9) + SH_C3[1] * xy * z * SH(10) +
+                    SH_C3[2] * y * (4.0f * zz - xx - yy) * SH(11) +
+                    SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
+                    SH_C3[4] * x * (4.0f * zz - xx - yy) * SH(13) + SH_C3[5] * z * (xx - yy) * SH(14) +
+                    SH_C3[6] * x * (xx - 3.0f * yy) * SH(15);
+            }
+        }
+    }
+#undef SH
+    return r + 0.5f;
+}
+
+// Load this Gaussian's SH block into registers.  The [P,M,3] layout gives each lane 12*M contiguous
+// bytes; with M == 16 and a 16-B aligned base that is twelve dwordx4 loads per lane.
+template <int MAXC>
+__device__ __forceinline__ void load_sh(const float* shs, size_t idx, int M, float* sh)
+{
+    const float* src = shs + idx * (size_t)M * 3;
+    const int n = M * 3;
+    if (MAXC == 48 && n == 48 && ((uintptr_t)src & 15) == 0) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            float4 v = s4[i];
+            sh[4 * i] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MAXC; i++) sh[i] = (i < n) ? src[i] : 0.0f;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_mark_visible(int P, const float* __restrict__ means3D,
+                                                      const float* __restrict__ viewmatrix, uint8_t* __restrict__ present)
+{
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    V3 p = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
+    V3 pv = xform4x3(p, viewmatrix);
+    present[idx] = (pv.z <= 0.2f) ? 0 : 1;
+}
+
+__global__ void __launch_bounds__(256) k_preprocess_fwd(PreprocessArgs a)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.P) return;
+    GeomRec rec;
+    rec.radius = 0;
+    rec.clamped = 0;
+    rec.x = rec.y = rec.cx = rec.cy = rec.cz = rec.opacity = rec.r = rec.g = rec.b = rec.depth = 0.0f;
+    int out_radius = 0;
+
+    const size_t i3 = 3 * (size_t)idx;
+    V3 p_orig = {a.means3D[i3], a.means3D[i3 + 1], a.means3D[i3 + 2]};
+    const float* vm = a.viewmatrix;
+    const float* pm = a.projmatrix;
+    V3 p_view = xform4x3(p_orig, vm);
+    bool alive = !(p_view.z <= 0.2f);  // in_frustum, auxiliary.h:152-163
+
+    if (alive) {
+        float hx = pm[0] * p_orig.x + pm[4] * p_orig.y + pm[8] * p_orig.z + pm[12];
+        float hy = pm[1] * p_orig.x + pm[5] * p_orig.y + pm[9] * p_orig.z + pm[13];
+        float hw = pm[3] * p_orig.x + pm[7] * p_orig.y + pm[11] * p_orig.z + pm[15];
+        float p_w = 1.0f / (hw + 0.0000001f);
+        float proj_x = hx * p_w, proj_y = hy * p_w;
+
+        float c6[6];
+        if (a.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+        } else {
+            float sc[3] = {a.scales[i3], a.scales[i3 + 1], a.scales[i3 + 2]};
+            const float4 q4 = *reinterpret_cast<const float4*>(a.rotations + 4 * (size_t)idx);
+            float q[4] = {q4.x, q4.y, q4.z, q4.w};
+            cov3d_from_scale_rot(sc, a.scale_modifier, q, c6);
+        }
+        float T[2][3], txtz, tytz; V3 t;
+        compute_T(p_orig, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, vm, T, t, txtz, tytz);
+        float cx, cy, cz;
+        cov2d_from_T(T, c6, cx, cy, cz);
+        cx += 0.3f; cz += 0.3f;
+        float det = (cx * cz - cy * cy);
+        if (det != 0.0f) {
+            float det_inv = 1.f / det;
+            float conx = cz * det_inv, cony = -cy * det_inv, conz = cx * det_inv;
+            float mid = 0.5f * (cx + cz);
+            float lambda1 = mid + sqrtf(fmax_(0.1f, mid * mid - det));
+            float lambda2 = mid - sqrtf(fmax_(0.1f, mid * mid - det));
+            float my_radius = ceilf(3.f * sqrtf(fmax_(lambda1, lambda2)));
+            float pix_x = ndc2pix(proj_x, a.W), pix_y = ndc2pix(proj_y, a.H);
+            int r_int = f2i_sat(my_radius);
+            int minx, miny, maxx, maxy;
+            sgr_get_rect(pix_x, pix_y, r_int, a.gx, a.gy, minx, miny, maxx, maxy);
+            if ((maxx - minx) * (maxy - miny) != 0) {
+                if (a.colors_precomp) {
+                    rec.r = a.colors_precomp[i3]; rec.g = a.colors_precomp[i3 + 1]; rec.b = a.colors_precomp[i3 + 2];
+                } else {
+                    float dx = p_orig.x - a.cam_pos[0], dy = p_orig.y - a.cam_pos[1], dz = p_orig.z - a.cam_pos[2];
+                    float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                    dx = dx / len; dy = dy / len; dz = dz / len;
+                    float sh[48];
+                    load_sh<48>(a.shs, idx, a.M, sh);
+                    float c0 = sh_channel(a.D, sh, 0, dx, dy, dz);
+                    float c1 = sh_channel(a.D, sh, 1, dx, dy, dz);
+                    float c2 = sh_channel(a.D, sh, 2, dx, dy, dz);
+                    rec.clamped = (c0 < 0 ? 1u : 0u) | (c1 < 0 ? 2u : 0u) | (c2 < 0 ? 4u : 0u);
+                    rec.r = fmax_(c0, 0.0f); rec.g = fmax_(c1, 0.0f); rec.b = fmax_(c2, 0.0f);
+                }
+                rec.x = pix_x; rec.y = pix_y; rec.cx = conx; rec.cy = cony; rec.cz = conz;
+                rec.opacity = a.opacities[idx];
+                rec.depth = p_view.z;
+                rec.radius = r_int;
+                out_radius = r_int;
+                // per-tile instance counting (first half of the counting sort that replaces
+                // duplicateWithKeys + the 64-bit global radix sort, rasterizer_impl.cu:70-111,303-308)
+                for (int y = miny; y < maxy; y++)
+                    for (int x = minx; x < maxx; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
+            }
+        }
+    }
+    float4* dst = reinterpret_cast<float4*>(a.rec + idx);
+    const float4* srcv = reinterpret_cast<const float4*>(&rec);
+    dst[0] = srcv[0]; dst[1] = srcv[1]; dst[2] = srcv[2];
+    if (a.radii) a.radii[idx] = out_radius;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused backward preprocess: K9 (conic grad -> cov2D -> cov3D + mean) and K10 (mean2D -> mean3D, SH backward,
+// cov3D -> scale/rotation).  Writes every output row (zeros for culled Gaussians).
+__global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.P) return;
+    const size_t i3 = 3 * (size_t)idx;
+    const GeomRec* rp = a.rec + idx;
+    const int radius = rp->radius;
+    float dmean[3] = {0, 0, 0}, dcov[6] = {0, 0, 0, 0, 0, 0};
+    const int n_sh = a.M * 3;
+    if (!(radius > 0)) {
+        a.dL_dmean3D[i3] = 0; a.dL_dmean3D[i3 + 1] = 0; a.dL_dmean3D[i3 + 2] = 0;
+        for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = 0;
+        if (a.dL_dsh) for (int k = 0; k < n_sh; k++) a.dL_dsh[(size_t)idx * n_sh + k] = 0;
+        if (a.dL_dscale) { a.dL_dscale[i3] = 0; a.dL_dscale[i3 + 1] = 0; a.dL_dscale[i3 + 2] = 0; }
+        if (a.dL_drot) { float4 z = {0, 0, 0, 0}; *reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = z; }
+        return;
+    }
+    V3 mean = {a.means3D[i3], a.means3D[i3 + 1], a.means3D[i3 + 2]};
+    const float* v = a.viewmatrix;
+    float sc[3] = {0, 0, 0}, q[4] = {0, 0, 0, 0};
+    float c6[6];
+    if (a.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+    } else {
+        sc[0] = a.scales[i3]; sc[1] = a.scales[i3 + 1]; sc[2] = a.scales[i3 + 2];
+        const float4 q4 = *reinterpret_cast<const float4*>(a.rotations + 4 * (size_t)idx);
+        q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+        cov3d_from_scale_rot(sc, a.scale_modifier, q, c6);
+    }
+    // ---- K9, backward.cu:144-274
+    {
+        const float4 gc = *reinterpret_cast<const float4*>(a.dL_dconic + 4 * (size_t)idx);
+        float g0 = gc.x, g1 = gc.y, g3 = gc.w;
+        float T[2][3], txtz, tytz; V3 t;
+        compute_T(mean, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, v, T, t, txtz, tytz);
+        const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+        const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.0f : 1.0f;
+        const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.0f : 1.0f;
+        float ca, cb, cc;
+        cov2d_from_T(T, c6, ca, cb, cc);
+        ca += 0.3f; cc += 0.3f;
+        float denom = ca * cc - cb * cb;
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        float V[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-cc * cc * g0 + 2 * cb * cc * g1 + (denom - ca * cc) * g3);
+            dL_dc = denom2inv * (-ca * ca * g3 + 2 * ca * cb * g1 + (denom - ca * cc) * g0);
+            dL_db = denom2inv * 2 * (cb * cc * g0 - (denom + 2 * cb * cb) * g1 + ca * cb * g3);
+            dcov[0] = (T[0][0] * T[0][0] * dL_da + T[0][0] * T[1][0] * dL_db + T[1][0] * T[1][0] * dL_dc);
+            dcov[3] = (T[0][1] * T[0][1] * dL_da + T[0][1] * T[1][1] * dL_db + T[1][1] * T[1][1] * dL_dc);
+            dcov[5] = (T[0][2] * T[0][2] * dL_da + T[0][2] * T[1][2] * dL_db + T[1][2] * T[1][2] * dL_dc);
+            dcov[1] = 2 * T[0][0] * T[0][1] * dL_da + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_db + 2 * T[1][0] * T[1][1] * dL_dc;
+            dcov[2] = 2 * T[0][0] * T[0][2] * dL_da + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_db + 2 * T[1][0] * T[1][2] * dL_dc;
+            dcov[4] = 2 * T[0][2] * T[0][1] * dL_da + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_db + 2 * T[1][1] * T[1][2] * dL_dc;
+        }
+        float dL_dT00 = 2 * (T[0][0] * V[0][0] + T[0][1] * V[0][1] + T[0][2] * V[0][2]) * dL_da + (T[1][0] * V[0][0] + T[1][1] * V[0][1] + T[1][2] * V[0][2]) * dL_db;
+        float dL_dT01 = 2 * (T[0][0] * V[1][0] + T[0][1] * V[1][1] + T[0][2] * V[1][2]) * dL_da + (T[1][0] * V[1][0] + T[1][1] * V[1][1] + T[1][2] * V[1][2]) * dL_db;
+        float dL_dT02 = 2 * (T[0][0] * V[2][0] + T[0][1] * V[2][1] + T[0][2] * V[2][2]) * dL_da + (T[1][0] * V[2][0] + T[1][1] * V[2][1] + T[1][2] * V[2][2]) * dL_db;
+        float dL_dT10 = 2 * (T[1][0] * V[0][0] + T[1][1] * V[0][1] + T[1][2] * V[0][2]) * dL_dc + (T[0][0] * V[0][0] + T[0][1] * V[0][1] + T[0][2] * V[0][2]) * dL_db;
+        float dL_dT11 = 2 * (T[1][0] * V[1][0] + T[1][1] * V[1][1] + T[1][2] * V[1][2]) * dL_dc + (T[0][0] * V[1][0] + T[0][1] * V[1][1] + T[0][2] * V[1][2]) * dL_db;
+        float dL_dT12 = 2 * (T[1][0] * V[2][0] + T[1][1] * V[2][1] + T[1][2] * V[2][2]) * dL_dc + (T[0][0] * V[2][0] + T[0][1] * V[2][1] + T[0][2] * V[2][2]) * dL_db;
+        float dL_dJ00 = v[0] * dL_dT00 + v[4] * dL_dT01 + v[8] * dL_dT02;
+        float dL_dJ02 = v[2] * dL_dT00 + v[6] * dL_dT01 + v[10] * dL_dT02;
+        float dL_dJ11 = v[1] * dL_dT10 + v[5] * dL_dT11 + v[9] * dL_dT12;
+        float dL_dJ12 = v[2] * dL_dT10 + v[6] * dL_dT11 + v[10] * dL_dT12;
+        float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+        float h_x = a.focal_x, h_y = a.focal_y;
+        float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+        float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+        float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
+        dmean[0] = v[0] * dL_dtx + v[1] * dL_dty + v[2] * dL_dtz;
+        dmean[1] = v[4] * dL_dtx + v[5] * dL_dty + v[6] * dL_dtz;
+        dmean[2] = v[8] * dL_dtx + v[9] * dL_dty + v[10] * dL_dtz;
+    }
+    // ---- K10, backward.cu:346-396
+    {
+        const float* proj = a.projmatrix;
+        float hw = proj[3] * mean.x + proj[7] * mean.y + proj[11] * mean.z + proj[15];
+        float m_w = 1.0f / (hw + 0.0000001f);
+        float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+        float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+        float gx = a.dL_dmean2D[i3], gy = a.dL_dmean2D[i3 + 1];
+        float ddx = (proj[0] * m_w - proj[3] * mul1) * gx + (proj[1] * m_w - proj[3] * mul2) * gy;
+        float ddy = (proj[4] * m_w - proj[7] * mul1) * gx + (proj[5] * m_w - proj[7] * mul2) * gy;
+        float ddz = (proj[8] * m_w - proj[11] * mul1) * gx + (proj[9] * m_w - proj[11] * mul2) * gy;
+        dmean[0] += ddx; dmean[1] += ddy; dmean[2] += ddz;
+    }
+    if (a.shs) {  // computeColorFromSH backward, backward.cu:20-139
+        V3 dir_orig = {mean.x - a.cam_pos[0], mean.y - a.cam_pos[1], mean.z - a.cam_pos[2]};
+        float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+        float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+        float sh[48], dsh[48];
+        load_sh<48>(a.shs, idx, a.M, sh);
+#pragma unroll
+        for (int k = 0; k < 48; k++) dsh[k] = 0.0f;
+        const uint32_t clamped = rp->clamped;
+        const int deg = a.D;
+        float dL_ddir[3] = {0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+#define SH(k) sh[3 * (k) + c]
+#define DSH(k) dsh[3 * (k) + c]
+            float dL_dRGB = a.dL_dcolor[i3 + c] * (((clamped >> c) & 1u) ? 0.0f : 1.0f);
+            float dRGBdx = 0, dRGBdy = 0, dRGBdz = 0;
+            DSH(0) = SH_C0 * dL_dRGB;
+            if (deg > 0) {
+                DSH(1) = (-SH_C1 * y) * dL_dRGB; DSH(2) = (SH_C1 * z) * dL_dRGB; DSH(3) = (-SH_C1 * x) * dL_dRGB;
+                dRGBdx = -SH_C1 * SH(3); dRGBdy = -SH_C1 * SH(1); dRGBdz = SH_C1 * SH(2);
+                if (deg > 1) {
+                    float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    DSH(4) = (SH_C2[0] * xy) * dL_dRGB; DSH(5) = (SH_C2[1] * yz) * dL_dRGB;
+                    DSH(6) = (SH_C2[2] * (2.f * zz - xx - yy)) * dL_dRGB; DSH(7) = (SH_C2[3] * xz) * dL_dRGB;
+                    DSH(8) = (SH_C2[4] * (xx - yy)) * dL_dRGB;
+                    dRGBdx += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8);
+                    dRGBdy += SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) + SH_C2[4] * 2.f * -y * SH(8);
+                    dRGBdz += SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7);
+                    if (deg > 2) {
+                        DSH(9) = (SH_C3[0] * y * (3.f * xx - yy)) * dL_dRGB; DSH(10) = (SH_C3[1] * xy * z) * dL_dRGB;
+                        DSH(11) = (SH_C3[2] * y * (4.f * zz - xx - yy)) * dL_dRGB;
+                        DSH(12) = (SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * dL_dRGB;
+                        DSH(13) = (SH_C3[4] * x * (4.f * zz - xx - yy)) * dL_dRGB;
+                        DSH(14) = (SH_C3[5] * z * (xx - yy)) * dL_dRGB; DSH(15) = (SH_C3[6] * x * (xx - 3.f * yy)) * dL_dRGB;
+                        dRGBdx += (SH_C3[0] * SH(9) * 3.f * 2.f * xy + SH_C3[1] * SH(10) * yz + SH_C3[2] * SH(11) * -2.f * xy +
+                                   SH_C3[3] * SH(12) * -3.f * 2.f * xz + SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                                   SH_C3[5] * SH(14) * 2.f * xz + SH_C3[6] * SH(15) * 3.f * (xx - yy));
+                        dRGBdy += (SH_C3[0] * SH(9) * 3.f * (xx - yy) + SH_C3[1] * SH(10) * xz +
+                                   SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * SH(12) * -3.f * 2.f * yz +
+                                   SH_C3[4] * SH(13) * -2.f * xy + SH_C3[5] * SH(14) * -2.f * yz + SH_C3[6] * SH(15) * -3.f * 2.f * xy);
+                        dRGBdz += (SH_C3[1] * SH(10) * xy + SH_C3[2] * SH(11) * 4.f * 2.f * yz +
+                                   SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * SH(13) * 4.f * 2.f * xz +
+                                   SH_C3[5] * SH(14) * (xx - yy));
+                    }
+                }
+            }
+#undef SH
+#undef DSH
+            dL_ddir[0] += dRGBdx * dL_dRGB; dL_ddir[1] += dRGBdy * dL_dRGB; dL_ddir[2] += dRGBdz * dL_dRGB;
+        }
+        // dnormvdv, auxiliary.h:107-117
+        {
+            V3 vv = dir_orig;
+            float sum2 = vv.x * vv.x + vv.y * vv.y + vv.z * vv.z;
+            float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            float ox = ((+sum2 - vv.x * vv.x) * dL_ddir[0] - vv.y * vv.x * dL_ddir[1] - vv.z * vv.x * dL_ddir[2]) * invsum32;
+            float oy = (-vv.x * vv.y * dL_ddir[0] + (sum2 - vv.y * vv.y) * dL_ddir[1] - vv.z * vv.y * dL_ddir[2]) * invsum32;
+            float oz = (-vv.x * vv.z * dL_ddir[0] - vv.y * vv.z * dL_ddir[1] + (sum2 - vv.z * vv.z) * dL_ddir[2]) * invsum32;
+            dmean[0] += ox; dmean[1] += oy; dmean[2] += oz;
+        }
+        float* dst = a.dL_dsh + (size_t)idx * n_sh;
+        if (n_sh == 48 && ((uintptr_t)dst & 15) == 0) {
+            float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+            for (int i = 0; i < 12; i++) { float4 o = {dsh[4 * i], dsh[4 * i + 1], dsh[4 * i + 2], dsh[4 * i + 3]}; d4[i] = o; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 48; i++) if (i < n_sh) dst[i] = dsh[i];
+        }
+    }
+    if (a.scales) {  // computeCov3D backward, backward.cu:278-341
+        float r = q[0], x = q[1], y = q[2], z = q[3];
+        float R[3][3], M[3][3];
+        quat_to_glmR(q, R);
+        float s[3] = {a.scale_modifier * sc[0], a.scale_modifier * sc[1], a.scale_modifier * sc[2]};
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) M[c][k] = s[k] * R[c][k];
+        const float* d = dcov;
+        float Dm[3][3] = {{d[0], 0.5f * d[1], 0.5f * d[2]}, {0.5f * d[1], d[3], 0.5f * d[4]}, {0.5f * d[2], 0.5f * d[4], d[5]}};
+        float X[3][3], dM[3][3], dMt[3][3];
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) X[c][k] = 2.0f * M[c][k];
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int rr = 0; rr < 3; rr++) dM[c][rr] = X[0][rr] * Dm[c][0] + X[1][rr] * Dm[c][1] + X[2][rr] * Dm[c][2];
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int rr = 0; rr < 3; rr++) dMt[c][rr] = dM[rr][c];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            a.dL_dscale[i3 + k] = R[0][k] * dMt[k][0] + R[1][k] * dMt[k][1] + R[2][k] * dMt[k][2];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int rr = 0; rr < 3; rr++) dMt[k][rr] *= s[k];
+        float4 dq;
+        dq.x = 2 * z * (dMt[0][1] - dMt[1][0]) + 2 * y * (dMt[2][0] - dMt[0][2]) + 2 * x * (dMt[1][2] - dMt[2][1]);
+        dq.y = 2 * y * (dMt[1][0] + dMt[0][1]) + 2 * z * (dMt[2][0] + dMt[0][2]) + 2 * r * (dMt[1][2] - dMt[2][1]) - 4 * x * (dMt[2][2] + dMt[1][1]);
+        dq.z = 2 * x * (dMt[1][0] + dMt[0][1]) + 2 * r * (dMt[2][0] - dMt[0][2]) + 2 * z * (dMt[1][2] + dMt[2][1]) - 4 * y * (dMt[2][2] + dMt[0][0]);
+        dq.w = 2 * r * (dMt[0][1] - dMt[1][0]) + 2 * x * (dMt[2][0] + dMt[0][2]) + 2 * y * (dMt[1][2] + dMt[2][1]) - 4 * z * (dMt[1][1] + dMt[0][0]);
+        *reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = dq;
+    }
+    a.dL_dmean3D[i3] = dmean[0]; a.dL_dmean3D[i3 + 1] = dmean[1]; a.dL_dmean3D[i3 + 2] = dmean[2];
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+}
+
+}  // namespace
+
+void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s)
+{
+    if (P <= 0) return;
+    hipLaunchKernelGGL(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, viewmatrix, present);
+}
+
+void sgr_launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s)
+{
+    if (a.P <= 0) return;
+    hipLaunchKernelGGL(k_preprocess_fwd, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+}
+
+void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
+{
+    if (a.P <= 0) return;
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+}

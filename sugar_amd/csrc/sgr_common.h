@@ -1,0 +1,99 @@
+// sgr_common.h -- shared declarations of the gfx950 rasterizer (private to sugar_amd/csrc).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define SGR_TILE_X 16  // BLOCK_X, DGR/cuda_rasterizer/config.h:16 (part of the pixel-exact contract)
+#define SGR_TILE_Y 16  // BLOCK_Y, DGR/cuda_rasterizer/config.h:17
+#define SGR_TILE_PIX 256
+
+// ---- private scratch layouts -----------------------------------------------------------------
+// geom  : [ GeomRec rec[P] ]                                   48 B / Gaussian (AoS: one gather = 1-2 lines)
+// img   : [ final_T f32[WH] | n_contrib u32[WH] | tile_start u32[T+1] | tile_cursor u32[T] |
+//           tile_maxc u32[T] | header u32[8] ]
+// binning: [ keys u64[R] | point_list u32[R] ]
+struct GeomRec {
+    float x, y, cx, cy;          // pixel-space mean, conic.x, conic.y
+    float cz, opacity, r, g;     // conic.z, opacity, colour
+    float b, depth;              // colour, view-space depth
+    int radius;                  // 0 = culled
+    uint32_t clamped;            // bit c set <=> SH colour channel c was clamped at 0
+};
+static_assert(sizeof(GeomRec) == 48, "GeomRec must be 48 bytes");
+
+static inline size_t sgr_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct ImgLayout {
+    size_t final_T, n_contrib, tile_start, tile_cursor, tile_maxc, header, total;
+    int gx, gy, T;
+};
+static inline ImgLayout sgr_img_layout(int W, int H)
+{
+    ImgLayout L;
+    L.gx = (W + SGR_TILE_X - 1) / SGR_TILE_X;
+    L.gy = (H + SGR_TILE_Y - 1) / SGR_TILE_Y;
+    L.T = L.gx * L.gy;
+    size_t off = 0;
+    L.final_T = off;     off = sgr_align(off + (size_t)W * H * 4);
+    L.n_contrib = off;   off = sgr_align(off + (size_t)W * H * 4);
+    L.tile_start = off;  off = sgr_align(off + (size_t)(L.T + 1) * 4);
+    L.tile_cursor = off; off = sgr_align(off + (size_t)L.T * 4);
+    L.tile_maxc = off;   off = sgr_align(off + (size_t)L.T * 4);
+    L.header = off;      off = sgr_align(off + 64);
+    L.total = off;
+    return L;
+}
+struct BinLayout { size_t keys, point_list, total; };
+static inline BinLayout sgr_bin_layout(int64_t R)
+{
+    BinLayout L;
+    size_t off = 0;
+    L.keys = off;       off = sgr_align(off + (size_t)R * 8);
+    L.point_list = off; off = sgr_align(off + (size_t)R * 4);
+    L.total = off < 256 ? 256 : off;
+    return L;
+}
+
+// header words written by the tile scan
+#define SGR_HDR_R 0        // total instances (low 32 bits)
+#define SGR_HDR_MAXCOUNT 1 // largest per-tile instance count
+#define SGR_HDR_R_HI 2     // high 32 bits of R
+
+// ---- kernel launchers (defined in the .hip translation units) --------------------------------
+struct PreprocessArgs {
+    int P, D, M;
+    const float* means3D; const float* scales; float scale_modifier; const float* rotations;
+    const float* opacities; const float* shs; const float* cov3D_precomp; const float* colors_precomp;
+    const float* viewmatrix; const float* projmatrix; const float* cam_pos;
+    int W, H; float tan_fovx, tan_fovy, focal_x, focal_y;
+    int gx, gy;
+    int* radii; GeomRec* rec; uint32_t* tile_count;
+};
+void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
+void sgr_launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
+
+struct PreprocessBwdArgs {
+    int P, D, M;
+    const float* means3D; const float* shs; const float* scales; const float* rotations; float scale_modifier;
+    const float* cov3D_precomp; const float* viewmatrix; const float* projmatrix; const float* cam_pos;
+    int W, H; float tan_fovx, tan_fovy, focal_x, focal_y;
+    const GeomRec* rec;
+    const float* dL_dmean2D; const float* dL_dconic; const float* dL_dcolor;
+    float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
+};
+void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
+
+void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* header, hipStream_t s);
+void sgr_launch_scatter(int P, int gx, int gy, const GeomRec* rec, const uint32_t* tile_start, uint32_t* tile_cursor,
+                        uint64_t* keys, hipStream_t s);
+void sgr_launch_tile_sort(int T, uint32_t max_count, const uint32_t* tile_start, uint64_t* keys, uint32_t* point_list,
+                          hipStream_t s);
+
+void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
+                          const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
+                          float* out_color, hipStream_t s);
+void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
+                          const GeomRec* rec, const float* bg, const float* final_T, const uint32_t* n_contrib,
+                          const uint32_t* tile_maxc, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                          float* dL_dopacity, float* dL_dcolor, hipStream_t s);

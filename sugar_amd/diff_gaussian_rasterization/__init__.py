@@ -1,0 +1,284 @@
+"""MI355X-native implementation of the reference's `diff_gaussian_rasterization` Python API.
+
+Mirrors DGR/diff_gaussian_rasterization/__init__.py (DGR = gaussian_splatting/submodules/
+diff-gaussian-rasterization): same names, same 12-field settings tuple (:157-169), same `forward` keyword
+arguments and exceptions (:187-195), same returns `(color[3,H,W] float32, radii[P] int32)`, same backward
+gradient order (:143-155), same debug-dump behaviour (:83-90,:132-139).  Underneath, `_C` is a thin ctypes
+binding of the C ABI in include/sugar_raster.h (hand-written HIP kernels for gfx950) playing the role of the
+reference's pybind module (DGR/ext.cpp:15-19, DGR/rasterize_points.cu:35-217).
+
+There is no CPU path: tensors must live on a ROCm device and the HIP library must be built.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    copied_tensors = [item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple]
+    return tuple(copied_tensors)
+
+
+def _ptr(t: torch.Tensor | None):
+    """Device pointer of a tensor, or NULL for the reference's "absent input" convention: unused optional
+    inputs arrive as empty (CPU) tensors (DGR/diff_gaussian_rasterization/__init__.py:197-207)."""
+    if t is None or t.numel() == 0:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _dev_f32(t: torch.Tensor, device, name: str) -> torch.Tensor:
+    if t.numel() == 0:
+        return t
+    if t.device != device:
+        raise RuntimeError(f"{name} is on {t.device} but means3D is on {device}: the HIP rasterizer needs all "
+                           "inputs on the same ROCm device (there is no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+class _Scratch:
+    """The three opaque scratch tensors (geomBuffer, binningBuffer, imgBuffer of rasterize_points.cu:73-78),
+    handed to the C ABI through allocation callbacks."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensors = {}
+        self._cbs = {}
+
+    def cb(self, name: str):
+        def alloc(_user, nbytes):
+            t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            self.tensors[name] = t
+            return t.data_ptr()
+
+        fn = _lib.ALLOC_FN(alloc)
+        self._cbs[name] = fn
+        return fn
+
+
+class _CModule:
+    """ctypes stand-in for the reference's pybind module `_C` (DGR/ext.cpp:15-19)."""
+
+    @staticmethod
+    def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                            viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                            prefiltered, debug):
+        if means3D.ndimension() != 2 or means3D.size(1) != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:57-59
+        if not means3D.is_cuda:
+            raise RuntimeError("the HIP rasterizer needs tensors on a ROCm device (got CPU tensors); "
+                               "there is no CPU fallback")
+        lib = _lib.load()
+        dev = means3D.device
+        P, H, W = means3D.size(0), int(image_height), int(image_width)
+        if P == 0:  # rasterize_points.cu:68-69,81
+            empty = torch.empty(0, dtype=torch.uint8, device=dev)
+            return (0, torch.zeros(3, H, W, dtype=torch.float32, device=dev),
+                    torch.zeros(0, dtype=torch.int32, device=dev), empty, empty.clone(), empty.clone())
+        means3D = _dev_f32(means3D, dev, "means3D")
+        background = _dev_f32(background, dev, "bg")
+        colors = _dev_f32(colors, dev, "colors_precomp")
+        opacity = _dev_f32(opacity, dev, "opacities")
+        scales = _dev_f32(scales, dev, "scales")
+        rotations = _dev_f32(rotations, dev, "rotations")
+        cov3D_precomp = _dev_f32(cov3D_precomp, dev, "cov3D_precomp")
+        viewmatrix = _dev_f32(viewmatrix, dev, "viewmatrix")
+        projmatrix = _dev_f32(projmatrix, dev, "projmatrix")
+        sh = _dev_f32(sh, dev, "shs")
+        campos = _dev_f32(campos, dev, "campos")
+        M = sh.size(1) if sh.numel() != 0 else 0  # rasterize_points.cu:83-87
+        out_color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        radii = torch.empty(P, dtype=torch.int32, device=dev)
+        scratch = _Scratch(dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rendered = lib.sgr_forward(
+                scratch.cb("geom"), None, scratch.cb("binning"), None, scratch.cb("img"), None,
+                P, int(degree), int(M), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
+                _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
+                _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                _ptr(out_color), _ptr(radii), int(bool(debug)), C.c_void_p(stream))
+        if rendered < 0:
+            raise RuntimeError(f"sgr_forward failed ({rendered}): {_lib.last_error()}")
+        t = scratch.tensors
+        return int(rendered), out_color, radii, t["geom"], t["binning"], t["img"]
+
+    @staticmethod
+    def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
+                                     cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
+                                     degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+        lib = _lib.load()
+        dev = means3D.device
+        P = means3D.size(0)
+        H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+        M = sh.size(1) if sh.numel() != 0 else 0
+        f = dict(dtype=torch.float32, device=dev)
+        use_cov = cov3D_precomp.numel() != 0
+        # Every row of these is written by sgr_backward, so no 300 MB of zero-fill per call
+        # (the reference allocates nine torch::zeros, rasterize_points.cu:151-159).
+        dL_dmeans3D = torch.empty(P, 3, **f)
+        dL_dmeans2D = torch.empty(P, 3, **f)
+        dL_dcolors = torch.empty(P, 3, **f)
+        dL_dconic = torch.empty(P, 2, 2, **f)
+        dL_dopacity = torch.empty(P, 1, **f)
+        dL_dcov3D = torch.empty(P, 6, **f)
+        dL_dsh = torch.empty(P, M, 3, **f)
+        dL_dscales = torch.zeros(P, 3, **f) if use_cov else torch.empty(P, 3, **f)
+        dL_drotations = torch.zeros(P, 4, **f) if use_cov else torch.empty(P, 4, **f)
+        if P != 0:
+            means3D = _dev_f32(means3D, dev, "means3D")
+            dL = _dev_f32(dL_dout_color, dev, "dL_dout_color")
+            colors = _dev_f32(colors, dev, "colors_precomp"); scales = _dev_f32(scales, dev, "scales")
+            rotations = _dev_f32(rotations, dev, "rotations"); sh = _dev_f32(sh, dev, "shs")
+            cov3D_precomp = _dev_f32(cov3D_precomp, dev, "cov3D_precomp")
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                rc = lib.sgr_backward(
+                    P, int(degree), int(M), int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
+                    _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix.contiguous()),
+                    _ptr(projmatrix.contiguous()), _ptr(campos.contiguous()), float(tan_fovx), float(tan_fovy), _ptr(radii),
+                    _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL),
+                    _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D),
+                    _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations), int(bool(debug)),
+                    C.c_void_p(stream))
+            if rc < 0:
+                raise RuntimeError(f"sgr_backward failed ({rc}): {_lib.last_error()}")
+        return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+    @staticmethod
+    def mark_visible(means3D, viewmatrix, projmatrix):
+        lib = _lib.load()
+        if not means3D.is_cuda:
+            raise RuntimeError("the HIP rasterizer needs tensors on a ROCm device; there is no CPU fallback")
+        dev = means3D.device
+        P = means3D.size(0)
+        present = torch.zeros(P, dtype=torch.bool, device=dev)
+        if P != 0:
+            means3D = _dev_f32(means3D, dev, "means3D")
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                rc = lib.sgr_mark_visible(P, _ptr(means3D), _ptr(_dev_f32(viewmatrix, dev, "viewmatrix")),
+                                          _ptr(_dev_f32(projmatrix, dev, "projmatrix")), _ptr(present), C.c_void_p(stream))
+            if rc < 0:
+                raise RuntimeError(f"sgr_mark_visible failed ({rc}): {_lib.last_error()}")
+        return present
+
+
+_C = _CModule
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        # argument order of the C++ entry point, DGR/rasterize_points.h:18-38
+        args = (raster_settings.bg, means3D, colors_precomp, opacities, scales, rotations,
+                raster_settings.scale_modifier, cov3Ds_precomp, raster_settings.viewmatrix,
+                raster_settings.projmatrix, raster_settings.tanfovx, raster_settings.tanfovy,
+                raster_settings.image_height, raster_settings.image_width, sh, raster_settings.sh_degree,
+                raster_settings.campos, raster_settings.prefiltered, raster_settings.debug)
+        if raster_settings.debug:
+            cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
+            try:
+                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise ex
+        else:
+            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                              binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _):
+        num_rendered = ctx.num_rendered
+        raster_settings = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
+         imgBuffer) = ctx.saved_tensors
+        args = (raster_settings.bg, means3D, radii, colors_precomp, scales, rotations, raster_settings.scale_modifier,
+                cov3Ds_precomp, raster_settings.viewmatrix, raster_settings.projmatrix, raster_settings.tanfovx,
+                raster_settings.tanfovy, grad_out_color, sh, raster_settings.sh_degree, raster_settings.campos,
+                geomBuffer, num_rendered, binningBuffer, imgBuffer, raster_settings.debug)
+        if raster_settings.debug:
+            cpu_args = cpu_deep_copy_tuple(args)
+            try:
+                (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
+                 grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise ex
+        else:
+            (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
+             grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(*args)
+        # gradient order of DGR/diff_gaussian_rasterization/__init__.py:143-155
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
+                grad_cov3Ds_precomp, None)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        # Mark visible points (based on frustum culling for camera) with a boolean
+        with torch.no_grad():
+            raster_settings = self.raster_settings
+            visible = _C.mark_visible(positions, raster_settings.viewmatrix, raster_settings.projmatrix)
+        return visible
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        raster_settings = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        if shs is None:
+            shs = torch.Tensor([])
+        if colors_precomp is None:
+            colors_precomp = torch.Tensor([])
+        if scales is None:
+            scales = torch.Tensor([])
+        if rotations is None:
+            rotations = torch.Tensor([])
+        if cov3D_precomp is None:
+            cov3D_precomp = torch.Tensor([])
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   raster_settings)
