@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark: 3DGS/SuGaR train step on 1M Gaussians @ 1920x1080 (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = rasterizer forward (SH degree 3, scale/rotation in-rasterizer) -> 0.8*L1 + 0.2*(1-SSIM) -> backward ->
+Adam over 59 floats/Gaussian, on synthetic data resident in HBM.  With N ranks every rank
+renders its own view of the same replica and the parameter gradients are summed by one RCCL all-reduce
+("weak" scaling: one view per GPU per step; value = views/s over all ranks).
+
+Prints ONE JSON line (rank 0).  Besides the contract fields it carries
+  roofline     -- forward blend kernel (the kernel BASELINE.json grades): algorithmic bytes / HIP-event time
+  cpu_baseline -- the CPU oracle (oracle/, a port of the reference rasterizer) on the host cores, rasterizer
+                  forward+backward of ONE view of the same workload
+  stages_ms    -- per-stage HIP-event averages of the rasterizer, ms_fwd_bwd = their sum.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+STAGES = ["preprocess", "tile_scan", "scatter", "tile_sort", "blend_fwd", "blend_bwd", "preprocess_bwd"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="metric", help="synthetic config name (sugar_amd/synthetic.py)")
+    ap.add_argument("--gaussians", type=int, default=None, help="override the Gaussian count (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the HIP rasterizer has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    from sugar_amd import build, _lib, synthetic as syn
+    if rank == 0:
+        build.build()
+    if world > 1:
+        dist.barrier()
+    lib = _lib.load()
+    from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
+    from sugar_amd.train_step import GaussianParams, ViewShardedTrainer
+
+    scene, cams, bg = syn.make_config(args.workload, P=args.gaussians)
+    P = scene.means3D.shape[0]
+    W, H = cams[0].image_width, cams[0].image_height
+    cams_d = [c._replace(viewmatrix=c.viewmatrix.to(dev), projmatrix=c.projmatrix.to(dev), campos=c.campos.to(dev)) for c in cams]
+    bg_d = bg.to(dev)
+    gtor = torch.Generator().manual_seed(1234)
+    gts = [torch.rand(3, H, W, generator=gtor).to(dev) for _ in range(len(cams))]
+    params = GaussianParams(scene, dev)
+    trainer = ViewShardedTrainer(params, GaussianRasterizer, GaussianRasterizationSettings, bg_d)
+
+    def cam_index(step):
+        return (step * world + rank) % len(cams)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for s in range(args.warmup):
+        trainer.step(cams_d[cam_index(s)], gts[cam_index(s)])
+    walked = torch.zeros((), dtype=torch.int64, device=dev)
+    walked_b = torch.zeros((), dtype=torch.int64, device=dev)
+    rendered = 0
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    off_walk = lib.sgr_img_tile_walked_offset(W, H)
+    off_maxc = lib.sgr_img_tile_maxc_offset(W, H)
+    lib.sgr_profile_enable(1)
+    sync_all()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, args.warmup + args.steps):
+        trainer.step(cams_d[cam_index(s)], gts[cam_index(s)])
+        lf = _C.last_forward
+        img = lf["img"]
+        walked += img[off_walk: off_walk + 4 * T].view(torch.int32).sum()
+        walked_b += img[off_maxc: off_maxc + 4 * T].view(torch.int32).sum()
+        rendered += lf["num_rendered"]
+    sync_all()
+    t1 = time.perf_counter()
+    lib.sgr_profile_enable(0)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+
+    ms = (C.c_double * len(STAGES))()
+    cnt = (C.c_int64 * len(STAGES))()
+    lib.sgr_profile_read(ms, cnt, len(STAGES))
+    stages = {n: (ms[i] / cnt[i] if cnt[i] else 0.0) for i, n in enumerate(STAGES)}
+
+    if rank == 0:
+        K = args.steps
+        R_f = float(walked.item()) / K
+        R_b = float(walked_b.item()) / K
+        R = rendered / K
+        blend_ms = stages["blend_fwd"]
+        alg_bytes = 40.0 * R_f + 20.0 * W * H + 8.0 * T + 12.0  # SURVEY.md section 8d, forward blend
+        achieved = alg_bytes / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_blend_fwd.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "train_step_images_per_sec",
+            "value": world * K / elapsed,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {P} Gaussians @ {W}x{H}, SH degree 3, 3DGS train step "
+                            "(raster fwd -> 0.8 L1 + 0.2 DSSIM -> bwd -> Adam, 59 floats/Gaussian), 8 orbit cameras cycled",
+                "views_per_step": world,
+                "parallelism": f"view-sharded dp{world}, one flat RCCL all-reduce of parameter grads",
+                "instances_per_view": R, "instances_walked_fwd": R_f, "instances_walked_bwd": R_b,
+            },
+            "ms_fwd_bwd": sum(stages.values()),
+            "stages_ms": stages,
+            "roofline": {
+                "kernel": "k_blend_fwd", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": blend_ms,
+                "pair_evals_per_s": (256.0 * R_f) / (blend_ms * 1e-3) if blend_ms > 0 else 0.0,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, cams[0], bg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scene, cam, bg):
+    """The CPU oracle (a port of the reference rasterizer, oracle/cpu_rasterizer.c) on the host cores: rasterizer
+    forward + backward of ONE view of the same workload."""
+    from oracle import cpu_oracle as orc
+    cores = os.cpu_count() or 1
+    orc.set_threads(cores)
+    H, W = cam.image_height, cam.image_width
+    g = np.random.default_rng(0).standard_normal((3, H, W)).astype(np.float32)
+    kw = dict(shs=scene.shs.numpy(), scales=scene.scales.numpy(), rotations=scene.rotations.numpy(),
+              viewmatrix=cam.viewmatrix.numpy(), projmatrix=cam.projmatrix.numpy(), campos=cam.campos.numpy(),
+              bg=bg.numpy(), W=W, H=H, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy)
+    t0 = time.perf_counter()
+    st = orc.forward(scene.means3D.numpy(), scene.opacities.numpy(), **kw)
+    t1 = time.perf_counter()
+    orc.backward(st, g)
+    t2 = time.perf_counter()
+    return {"value": 1.0 / (t2 - t0), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 view, rasterizer forward ({t1 - t0:.2f} s) + backward ({t2 - t1:.2f} s) only (no loss/Adam), "
+                      f"{scene.means3D.shape[0]} Gaussians @ {W}x{H}, OpenMP over {cores} threads "
+                      "(binning sort is single-threaded)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -98,7 +98,16 @@ size_t sgr_img_final_T_offset(int width, int height);   /* float[W*H] */
 size_t sgr_img_n_contrib_offset(int width, int height); /* uint32[W*H] */
 size_t sgr_img_tile_start_offset(int width, int height);/* uint32[T+1]: tile t owns [start[t], start[t+1]) */
 size_t sgr_img_tile_maxc_offset(int width, int height); /* uint32[T]: max n_contrib over the tile's pixels */
+size_t sgr_img_tile_walked_offset(int width, int height);/* uint32[T]: furthest list position any pixel examined */
 size_t sgr_binning_point_list_offset(int64_t R);        /* uint32[R]: Gaussian ids, tile-major, depth order */
+
+/* ---- optional per-stage timing (HIP events recorded on the caller's stream, per calling thread) --
+ * Stages: 0 preprocess, 1 tile scan, 2 scatter, 3 per-tile sort, 4 blend forward, 5 blend backward,
+ * 6 preprocess backward.  sgr_profile_read synchronises the recorded events, returns the summed
+ * milliseconds and launch counts per stage since the last read, and clears the record. */
+#define SGR_N_STAGES 7
+void sgr_profile_enable(int on);
+int sgr_profile_read(double* ms_sum, int64_t* count, int n_stages);
 
 /* ---- k-NN helpers sharing the Gaussian position buffer ------------------------------------------
  * sgr_dist2: simple_knn._C.distCUDA2 (simple-knn/spatial.cu:15-26 -> SimpleKNN::knn, simple-knn/

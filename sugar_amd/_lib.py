@@ -31,7 +31,10 @@ SIGNATURES = {
     "sgr_img_n_contrib_offset": (_sz, [_i, _i]),
     "sgr_img_tile_start_offset": (_sz, [_i, _i]),
     "sgr_img_tile_maxc_offset": (_sz, [_i, _i]),
+    "sgr_img_tile_walked_offset": (_sz, [_i, _i]),
     "sgr_binning_point_list_offset": (_sz, [_i64]),
+    "sgr_profile_enable": (None, [_i]),
+    "sgr_profile_read": (_i, [_vp, _vp, _i]),
     "sgr_dist2": (_i, [_i, _vp, _vp, _vp]),
     "sgr_knn": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
 }

@@ -28,11 +28,13 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
                                                    const uint32_t* __restrict__ point_list,
                                                    const GeomRec* __restrict__ rec, const float* __restrict__ bg,
                                                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                   uint32_t* __restrict__ tile_maxc, float* __restrict__ out_color)
+                                                   uint32_t* __restrict__ tile_maxc, uint32_t* __restrict__ tile_walked,
+                                                   float* __restrict__ out_color)
 {
     __shared__ StageFwd st;
     __shared__ int s_done[4];
     __shared__ uint32_t s_maxc[4];
+    __shared__ uint32_t s_walk[4];
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x;
@@ -91,9 +93,15 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
     // deepest contributor of the tile, consumed by the backward
     uint32_t mc = inside ? last_contributor : 0u;
     for (int o = 32; o > 0; o >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, o));
-    if ((tid & 63) == 0) s_maxc[wave] = mc;
+    // furthest list position any pixel looked at (R_f of the roofline accounting)
+    uint32_t wk = inside ? contributor : 0u;
+    for (int o = 32; o > 0; o >>= 1) wk = max(wk, (uint32_t)__shfl_xor((int)wk, o));
+    if ((tid & 63) == 0) { s_maxc[wave] = mc; s_walk[wave] = wk; }
     __syncthreads();
-    if (tid == 0) tile_maxc[tile] = max(max(s_maxc[0], s_maxc[1]), max(s_maxc[2], s_maxc[3]));
+    if (tid == 0) {
+        tile_maxc[tile] = max(max(s_maxc[0], s_maxc[1]), max(s_maxc[2], s_maxc[3]));
+        tile_walked[tile] = max(max(s_walk[0], s_walk[1]), max(s_walk[2], s_walk[3]));
+    }
 }
 
 struct StageBwd {
@@ -212,10 +220,10 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
 
 void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
-                          float* out_color, hipStream_t s)
+                          uint32_t* tile_walked, float* out_color, hipStream_t s)
 {
     hipLaunchKernelGGL(k_blend_fwd, dim3(gx * gy), dim3(256), 0, s, W, H, gx, tile_start, point_list, rec, bg, final_T,
-                       n_contrib, tile_maxc, out_color);
+                       n_contrib, tile_maxc, tile_walked, out_color);
 }
 
 void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,

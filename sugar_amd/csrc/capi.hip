@@ -7,6 +7,7 @@
 
 #include <mutex>
 #include <string>
+#include <vector>
 
 namespace {
 
@@ -40,6 +41,39 @@ struct Pinned {
 };
 thread_local Pinned g_pinned;
 
+// ---- optional per-stage timing with HIP events on the caller's stream (bench.py's roofline leg) ----------
+struct Prof {
+    bool on = false;
+    struct Rec { int stage; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+thread_local Prof g_prof;
+
+struct StageTimer {
+    hipStream_t s; int stage; hipEvent_t a = nullptr, b = nullptr; bool live = false;
+    StageTimer(hipStream_t s_, int stage_) : s(s_), stage(stage_)
+    {
+        if (g_prof.on && g_prof.recs.size() < 65536) {
+            a = g_prof.get(); b = g_prof.get();
+            live = a && b;
+            if (live) (void)hipEventRecord(a, s);
+        }
+    }
+    void stop()
+    {
+        if (live) { (void)hipEventRecord(b, s); g_prof.recs.push_back({stage, a, b}); live = false; }
+    }
+    ~StageTimer() { stop(); }
+};
+
 }  // namespace
 
 extern "C" {
@@ -55,7 +89,24 @@ size_t sgr_img_final_T_offset(int w, int h) { return sgr_img_layout(w, h).final_
 size_t sgr_img_n_contrib_offset(int w, int h) { return sgr_img_layout(w, h).n_contrib; }
 size_t sgr_img_tile_start_offset(int w, int h) { return sgr_img_layout(w, h).tile_start; }
 size_t sgr_img_tile_maxc_offset(int w, int h) { return sgr_img_layout(w, h).tile_maxc; }
+size_t sgr_img_tile_walked_offset(int w, int h) { return sgr_img_layout(w, h).tile_walked; }
 size_t sgr_binning_point_list_offset(int64_t R) { return sgr_bin_layout(R).point_list; }
+
+void sgr_profile_enable(int on) { g_prof.on = on != 0; }
+
+int sgr_profile_read(double* ms_sum, int64_t* count, int n_stages)
+{
+    for (int i = 0; i < n_stages; i++) { ms_sum[i] = 0.0; count[i] = 0; }
+    for (auto& r : g_prof.recs) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.a, r.b);
+        if (e == hipSuccess && r.stage < n_stages) { ms_sum[r.stage] += ms; count[r.stage]++; }
+        g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b);
+    }
+    g_prof.recs.clear();
+    return 0;
+}
 
 int sgr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
                      void* stream)
@@ -99,6 +150,7 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     uint32_t* tile_start = reinterpret_cast<uint32_t*>(img + IL.tile_start);
     uint32_t* tile_cursor = reinterpret_cast<uint32_t*>(img + IL.tile_cursor);
     uint32_t* tile_maxc = reinterpret_cast<uint32_t*>(img + IL.tile_maxc);
+    uint32_t* tile_walked = reinterpret_cast<uint32_t*>(img + IL.tile_walked);
     uint32_t* header = reinterpret_cast<uint32_t*>(img + IL.header);
 
     // tile_start doubles as the per-tile counter array until the scan overwrites it with offsets:
@@ -115,10 +167,10 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     pa.focal_x = width / (2.0f * tan_fovx);
     pa.gx = IL.gx; pa.gy = IL.gy;
     pa.radii = radii; pa.rec = rec; pa.tile_count = tile_cursor;
-    sgr_launch_preprocess_fwd(pa, s);
+    { StageTimer t(s, SGR_STAGE_PREPROCESS); sgr_launch_preprocess_fwd(pa, s); }
     STAGE_CHECK("preprocess");
 
-    sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, s);
+    { StageTimer t(s, SGR_STAGE_SCAN); sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, s); }
     STAGE_CHECK("tile_scan");
 
     if (!g_pinned.p) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_pinned.p), 64, hipHostMallocDefault));
@@ -135,13 +187,16 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     uint32_t* point_list = reinterpret_cast<uint32_t*>(binning + BL.point_list);
 
     if (R > 0) {
-        sgr_launch_scatter(P, IL.gx, IL.gy, rec, tile_start, tile_cursor, keys, s);
+        { StageTimer t(s, SGR_STAGE_SCATTER); sgr_launch_scatter(P, IL.gx, IL.gy, rec, tile_start, tile_cursor, keys, s); }
         STAGE_CHECK("scatter");
-        sgr_launch_tile_sort(IL.T, max_count, tile_start, keys, point_list, s);
+        { StageTimer t(s, SGR_STAGE_SORT); sgr_launch_tile_sort(IL.T, max_count, tile_start, keys, point_list, s); }
         STAGE_CHECK("tile_sort");
     }
-    sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
-                         tile_maxc, out_color, s);
+    {
+        StageTimer t(s, SGR_STAGE_BLEND_FWD);
+        sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
+                             tile_maxc, tile_walked, out_color, s);
+    }
     STAGE_CHECK("blend_fwd");
     return R;
 }
@@ -179,8 +234,11 @@ int sgr_backward(int P, int D, int M, int64_t R, const float* background, int wi
     HIP_TRY(hipMemsetAsync(dL_dopacity, 0, (size_t)P * 4, s));
     HIP_TRY(hipMemsetAsync(dL_dcolor, 0, (size_t)P * 3 * 4, s));
     if (R > 0) {
-        sgr_launch_blend_bwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
-                             tile_maxc, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, s);
+        {
+            StageTimer t(s, SGR_STAGE_BLEND_BWD);
+            sgr_launch_blend_bwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
+                                 tile_maxc, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, s);
+        }
         STAGE_CHECK("blend_bwd");
     }
     PreprocessBwdArgs pb;
@@ -196,7 +254,7 @@ int sgr_backward(int P, int D, int M, int64_t R, const float* background, int wi
     pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dcolor = dL_dcolor;
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_dsh = use_sh ? dL_dsh : nullptr;
     pb.dL_dscale = cov3D_precomp ? nullptr : dL_dscale; pb.dL_drot = cov3D_precomp ? nullptr : dL_drot;
-    sgr_launch_preprocess_bwd(pb, s);
+    { StageTimer t(s, SGR_STAGE_PREPROCESS_BWD); sgr_launch_preprocess_bwd(pb, s); }
     STAGE_CHECK("preprocess_bwd");
     return 0;
 }

@@ -11,7 +11,7 @@
 // ---- private scratch layouts -----------------------------------------------------------------
 // geom  : [ GeomRec rec[P] ]                                   48 B / Gaussian (AoS: one gather = 1-2 lines)
 // img   : [ final_T f32[WH] | n_contrib u32[WH] | tile_start u32[T+1] | tile_cursor u32[T] |
-//           tile_maxc u32[T] | header u32[8] ]
+//           tile_maxc u32[T] | tile_walked u32[T] | header u32[8] ]
 // binning: [ keys u64[R] | point_list u32[R] ]
 struct GeomRec {
     float x, y, cx, cy;          // pixel-space mean, conic.x, conic.y
@@ -25,7 +25,7 @@ static_assert(sizeof(GeomRec) == 48, "GeomRec must be 48 bytes");
 static inline size_t sgr_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct ImgLayout {
-    size_t final_T, n_contrib, tile_start, tile_cursor, tile_maxc, header, total;
+    size_t final_T, n_contrib, tile_start, tile_cursor, tile_maxc, tile_walked, header, total;
     int gx, gy, T;
 };
 static inline ImgLayout sgr_img_layout(int W, int H)
@@ -40,6 +40,7 @@ static inline ImgLayout sgr_img_layout(int W, int H)
     L.tile_start = off;  off = sgr_align(off + (size_t)(L.T + 1) * 4);
     L.tile_cursor = off; off = sgr_align(off + (size_t)L.T * 4);
     L.tile_maxc = off;   off = sgr_align(off + (size_t)L.T * 4);
+    L.tile_walked = off; off = sgr_align(off + (size_t)L.T * 4);
     L.header = off;      off = sgr_align(off + 64);
     L.total = off;
     return L;
@@ -59,6 +60,10 @@ static inline BinLayout sgr_bin_layout(int64_t R)
 #define SGR_HDR_R 0        // total instances (low 32 bits)
 #define SGR_HDR_MAXCOUNT 1 // largest per-tile instance count
 #define SGR_HDR_R_HI 2     // high 32 bits of R
+
+// stage ids of the optional event profile (sgr_profile_read)
+enum { SGR_STAGE_PREPROCESS = 0, SGR_STAGE_SCAN, SGR_STAGE_SCATTER, SGR_STAGE_SORT, SGR_STAGE_BLEND_FWD,
+       SGR_STAGE_BLEND_BWD, SGR_STAGE_PREPROCESS_BWD, SGR_STAGE_COUNT };
 
 // ---- kernel launchers (defined in the .hip translation units) --------------------------------
 struct PreprocessArgs {
@@ -92,7 +97,7 @@ void sgr_launch_tile_sort(int T, uint32_t max_count, const uint32_t* tile_start,
 
 void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
-                          float* out_color, hipStream_t s);
+                          uint32_t* tile_walked, float* out_color, hipStream_t s);
 void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, const float* final_T, const uint32_t* n_contrib,
                           const uint32_t* tile_maxc, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,

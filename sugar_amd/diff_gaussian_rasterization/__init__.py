@@ -67,6 +67,8 @@ class _Scratch:
 class _CModule:
     """ctypes stand-in for the reference's pybind module `_C` (DGR/ext.cpp:15-19)."""
 
+    last_forward: dict = {}
+
     @staticmethod
     def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                             viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
@@ -109,6 +111,9 @@ class _CModule:
         if rendered < 0:
             raise RuntimeError(f"sgr_forward failed ({rendered}): {_lib.last_error()}")
         t = scratch.tensors
+        # introspection only (bench.py's roofline accounting, parity tests): the most recent forward's scratch
+        _CModule.last_forward = dict(num_rendered=int(rendered), W=W, H=H, P=P, geom=t["geom"], binning=t["binning"],
+                                     img=t["img"])
         return int(rendered), out_color, radii, t["geom"], t["binning"], t["img"]
 
     @staticmethod

@@ -1,0 +1,176 @@
+"""CPU tests that pin the oracle (oracle/cpu_rasterizer.c):
+  * against golden vectors produced by the reference's own Python helpers (tests/golden/make_golden.py),
+  * against an independent PyTorch-autograd restatement (analytic backward == autograd, float64),
+  * on the edge cases the domain has (culled Gaussians, empty tiles, partial tiles, R == 0, ties)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_oracle as orc, torch_cpu_rasterizer as tr
+from sugar_amd import synthetic as syn
+from tests import parity_utils as pu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_helpers.npz"))
+
+
+def _fwd(scene, cam, bg, **opts):
+    return pu.run_oracle(scene, cam, bg, **opts)
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_colour_matches_reference_eval_sh(deg):
+    """forward.cu:20-71 restated in C == sugar_utils/spherical_harmonics.py:eval_sh (+0.5, clamp)"""
+    means, campos, shs = GOLD["means"], GOLD["campos"], GOLD["shs"]
+    cam = syn.look_at_camera(tuple(campos.tolist()), (0.0, 0.0, 0.0), 640, 640, fovx_deg=80.0)
+    P = means.shape[0]
+    st = orc.forward(means, np.full((P, 1), 0.5, np.float32), shs=shs, scales=np.full((P, 3), 0.01, np.float32),
+                     rotations=np.tile(np.array([[1, 0, 0, 0]], np.float32), (P, 1)), viewmatrix=cam.viewmatrix.numpy(),
+                     projmatrix=cam.projmatrix.numpy(), campos=campos, bg=np.zeros(3, np.float32), W=640, H=640,
+                     tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, sh_degree=deg)
+    vis = st["radii"] > 0
+    assert vis.sum() > 0.8 * P
+    np.testing.assert_allclose(st["rgb"][vis], GOLD[f"rgb_deg{deg}"][vis], rtol=2e-5, atol=2e-6)
+    # clamp flags follow the sign of the unclamped value
+    assert np.array_equal(st["clamped"][vis].astype(bool), (GOLD[f"rgb_deg{deg}"][vis] <= 0) & (st["rgb"][vis] == 0))
+
+
+@pytest.mark.parametrize("mod,key", [(1.0, "cov3D_mod1"), (1.7, "cov3D_mod1p7")])
+def test_cov3d_matches_reference_build_covariance(mod, key):
+    """forward.cu:118-152 restated in C == build_scaling_rotation/strip_symmetric (general_utils.py:64-110)"""
+    P = GOLD["scales"].shape[0]
+    cam = syn.look_at_camera((0.0, -4.0, 0.5), (0.0, 0.0, 0.0), 320, 320)
+    st = orc.forward(GOLD["means"], np.full((P, 1), 0.5, np.float32), colors_precomp=np.full((P, 3), 0.5, np.float32),
+                     scales=GOLD["scales"], rotations=GOLD["rots"], viewmatrix=cam.viewmatrix.numpy(),
+                     projmatrix=cam.projmatrix.numpy(), campos=cam.campos.numpy(), bg=np.zeros(3, np.float32), W=320, H=320,
+                     tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, scale_modifier=mod)
+    alive = st["depths"] != 0  # cov3D is written for every Gaussian that passes the near cull
+    assert alive.sum() == P
+    np.testing.assert_allclose(st["cov3D"], GOLD[key], rtol=3e-5, atol=1e-9)
+
+
+def test_projection_helpers_match_reference():
+    import math
+    P = syn.get_projection_matrix(0.01, 100.0, math.radians(60.0), math.radians(41.0)).numpy()
+    np.testing.assert_array_equal(P, GOLD["proj_znear0p01_zfar100_fovx60_fovy41"])
+
+
+def test_analytic_backward_matches_autograd_float64():
+    """backward.cu restated in C vs autograd through an independent float64 PyTorch restatement."""
+    P, W, H = 600, 64, 48
+    scene = syn.make_scene(P, 3, 0.02, 0.15)
+    cam = syn.orbit_cameras(W, H)[1]
+    bg = torch.tensor([0.3, 0.6, 0.1])
+    st = _fwd(scene, cam, bg)
+    g = np.random.default_rng(0).standard_normal((3, H, W)).astype(np.float32)
+    gr = orc.backward(st, g)
+    dt = torch.float64
+    inp = {k: getattr(scene, k).to(dt).requires_grad_(True) for k in ["means3D", "scales", "rotations", "opacities", "shs"]}
+    m2d = torch.zeros(P, 3, dtype=dt, requires_grad=True)
+    img, nc = tr.render(inp["means3D"], m2d, inp["opacities"], shs=inp["shs"], scales=inp["scales"], rotations=inp["rotations"],
+                        viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix, campos=cam.campos, bg=bg, W=W, H=H,
+                        tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, point_list=st["point_list"], ranges=st["ranges"],
+                        radii=st["radii"])
+    assert np.abs(img.detach().numpy() - st["color"]).max() < 5e-6
+    assert (nc.numpy().reshape(-1) != st["n_contrib"]).mean() < 1e-3
+    (img * torch.tensor(g, dtype=dt)).sum().backward()
+    pairs = [(inp["means3D"].grad, gr["dL_dmeans3D"]), (m2d.grad[:, :2], gr["dL_dmeans2D"][:, :2]),
+             (inp["opacities"].grad, gr["dL_dopacity"]), (inp["scales"].grad, gr["dL_dscales"]),
+             (inp["rotations"].grad, gr["dL_drotations"]), (inp["shs"].grad, gr["dL_dsh"])]
+    for a, b in pairs:
+        a = a.numpy().astype(np.float64); b = b.astype(np.float64)
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-5
+
+
+def test_analytic_backward_precomputed_paths():
+    P, W, H = 400, 48, 48
+    scene = syn.make_scene(P, 5, 0.03, 0.2)
+    cam = syn.orbit_cameras(W, H)[3]
+    bg = torch.tensor([1.0, 1.0, 1.0])
+    st = _fwd(scene, cam, bg, use_sh=False, use_cov=True, scale_modifier=1.2)
+    g = np.random.default_rng(1).standard_normal((3, H, W)).astype(np.float32)
+    gr = orc.backward(st, g)
+    dt = torch.float64
+    col = pu.precomputed_colors(scene).to(dt).requires_grad_(True)
+    cov = pu.precomputed_cov(scene, 1.2).to(dt).requires_grad_(True)
+    m = scene.means3D.to(dt).requires_grad_(True)
+    op = scene.opacities.to(dt).requires_grad_(True)
+    img, _ = tr.render(m, torch.zeros(P, 3, dtype=dt), op, colors_precomp=col, cov3D_precomp=cov, viewmatrix=cam.viewmatrix,
+                       projmatrix=cam.projmatrix, campos=cam.campos, bg=bg, W=W, H=H, tanfovx=cam.tanfovx,
+                       tanfovy=cam.tanfovy, point_list=st["point_list"], ranges=st["ranges"], radii=st["radii"])
+    (img * torch.tensor(g, dtype=dt)).sum().backward()
+    for a, b in [(col.grad, gr["dL_dcolors"]), (cov.grad, gr["dL_dcov3D"]), (m.grad, gr["dL_dmeans3D"])]:
+        a = a.numpy().astype(np.float64); b = b.astype(np.float64)
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 5e-5
+
+
+def test_binning_invariants():
+    """Properties of K3-K6 (rasterizer_impl.cu:70-138,277-317): offsets, key order, stable ties, ranges."""
+    scene = syn.make_scene(5000, 8, 0.01, 0.2)
+    cam = syn.orbit_cameras(250, 190)[2]  # partial tiles in both directions
+    st = _fwd(scene, cam, torch.zeros(3))
+    R = st["num_rendered"]
+    assert R == int(st["tiles_touched"].astype(np.int64).sum())
+    keys = st["point_list_keys"]
+    assert np.all(keys[1:] >= keys[:-1])
+    # ties (same tile, same depth bits) keep ascending Gaussian index = stability of the radix sort
+    same = keys[1:] == keys[:-1]
+    assert np.all(st["point_list"][1:][same] > st["point_list"][:-1][same])
+    gx, gy = st["grid"]
+    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    counts = np.bincount(tiles, minlength=gx * gy)
+    lens = (st["ranges"][:, 1] - st["ranges"][:, 0]).astype(np.int64)
+    assert np.array_equal(counts, lens)
+    assert np.all(st["ranges"][counts == 0] == 0)  # untouched tiles keep the memset value
+    # each instance's depth bits equal its Gaussian's depth
+    dbits = (keys & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    assert np.array_equal(dbits, st["depths"].view(np.uint32)[st["point_list"]])
+
+
+def test_duplicate_depth_ties_are_index_ordered():
+    """Two coincident Gaussians have identical depth bits: order in every tile list must be by index."""
+    scene = syn.make_scene(50, 2, 0.05, 0.2)
+    m = scene.means3D.clone(); m[10] = m[30]
+    scene = scene._replace(means3D=m)
+    st = _fwd(scene, syn.orbit_cameras(96, 96)[0], torch.zeros(3))
+    pl = st["point_list"]
+    for t in range(st["ranges"].shape[0]):
+        seg = pl[st["ranges"][t, 0]: st["ranges"][t, 1]].tolist()
+        if 10 in seg and 30 in seg:
+            assert seg.index(10) + 1 == seg.index(30)
+
+
+def test_everything_culled_and_empty_cases():
+    scene = syn.make_scene(100, 4, 0.01, 0.05)
+    behind = syn.look_at_camera((0.0, -3.0, 0.0), (0.0, -6.0, 0.0), 64, 64)  # looks away from the cloud
+    st = _fwd(scene, behind, torch.tensor([0.2, 0.4, 0.6]))
+    assert st["num_rendered"] == 0 and np.all(st["radii"] == 0)
+    np.testing.assert_allclose(st["color"][0], 0.2); np.testing.assert_allclose(st["color"][2], 0.6)
+    assert np.all(st["final_T"] == 1.0) and np.all(st["n_contrib"] == 0)
+    g = orc.backward(st, np.ones((3, 64, 64), np.float32))
+    assert all(np.all(v == 0) for v in g.values())
+    assert not orc.mark_visible(scene.means3D.numpy(), behind.viewmatrix.numpy(), behind.projmatrix.numpy()).any()
+
+
+def test_near_plane_threshold():
+    """in_frustum: p_view.z <= 0.2 is culled (auxiliary.h:152-163)"""
+    cam = syn.look_at_camera((0.0, -1.0, 0.0), (0.0, 0.0, 0.0), 64, 64)
+    pts = np.array([[0.0, -0.8, 0.0], [0.0, -0.79, 0.0], [0.0, 0.5, 0.0]], np.float32)  # depths 0.2, 0.21, 1.5
+    vis = orc.mark_visible(pts, cam.viewmatrix.numpy(), cam.projmatrix.numpy())
+    assert vis.tolist() == [False, True, True]
+
+
+def test_get_higher_msb():
+    from oracle.cpu_oracle import lib
+    f = lib().orc_getHigherMsb
+    assert [f(n) for n in (1, 2, 255, 256, 2500, 8160, 32400)] == [1, 2, 8, 9, 12, 13, 15]
+
+
+def test_dist2_matches_kdtree():
+    """simple_knn.cu:147-183: mean of the 3 smallest squared distances to other points"""
+    from scipy.spatial import cKDTree
+    pts = np.random.default_rng(3).standard_normal((2000, 3)).astype(np.float32)
+    d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
+    ref = (d[:, 1:] ** 2).mean(axis=1)
+    np.testing.assert_allclose(orc.dist2(pts), ref, rtol=1e-4)
