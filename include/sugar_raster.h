@@ -101,7 +101,7 @@ size_t sgr_img_tile_maxc_offset(int width, int height); /* uint32[T]: max n_cont
 size_t sgr_img_tile_walked_offset(int width, int height);/* uint32[T]: furthest list position any pixel examined */
 size_t sgr_binning_point_list_offset(int64_t R);        /* uint32[R]: Gaussian ids, tile-major, depth order */
 
-/* ---- optional per-stage timing (HIP events recorded on the caller's stream, per calling thread) --
+/* ---- optional per-stage timing (HIP events recorded on the caller's stream, process-wide) --
  * Stages: 0 preprocess, 1 tile scan, 2 scatter, 3 per-tile sort, 4 blend forward, 5 blend backward,
  * 6 preprocess backward.  sgr_profile_read synchronises the recorded events, returns the summed
  * milliseconds and launch counts per stage since the last read, and clears the record. */

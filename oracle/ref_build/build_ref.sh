@@ -1,0 +1,29 @@
+#!/usr/bin/env bash
+# Builds oracle/_ref/libref_rasterizer.so: the REFERENCE rasterizer (INRIA diff-gaussian-rasterization as vendored by
+# SuGaR) compiled by hipcc for gfx950 from its sources where they lie under /root/reference.  TEST INFRASTRUCTURE ONLY
+# (parity checker and A/B timing baseline on the GPU box); never linked into or loaded by the product.
+#
+# The sources are used unmodified except that nvcc's whitespace-tolerant launch token "<< <...>> >" is respelled
+# "<<<...>>>" on the fly (clang requires the contiguous token); the respelled stream lives in a temp dir that is deleted,
+# nothing from the reference is copied into the repository.  CUDA-only headers resolve to the shims in ./shim.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+DGR=/root/reference/gaussian_splatting/submodules/diff-gaussian-rasterization
+OUT="$HERE/../_ref"
+[ -d "$DGR" ] || { echo "[build_ref] $DGR not present (GPU box): using the prebuilt $OUT if any"; exit 0; }
+STAMP="$OUT/.stamp"
+SIG="$(cat "$DGR"/cuda_rasterizer/*.cu "$DGR"/cuda_rasterizer/*.h "$HERE"/ref_capi.cpp "$HERE"/shim/*.h "$HERE"/build_ref.sh | sha256sum | cut -d' ' -f1)"
+if [ -f "$OUT/libref_rasterizer.so" ] && [ -f "$STAMP" ] && [ "$(cat "$STAMP")" = "$SIG" ]; then exit 0; fi
+mkdir -p "$OUT"
+TMP="$(mktemp -d)"; trap 'rm -rf "$TMP"' EXIT
+FLAGS="-x hip -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -I$HERE/shim -I$DGR/third_party/glm -I$DGR/cuda_rasterizer"
+pids=()
+for f in forward backward rasterizer_impl; do
+  sed -E 's/<<[[:space:]]+</<<</g; s/>>[[:space:]]+>/>>>/g' "$DGR/cuda_rasterizer/$f.cu" > "$TMP/$f.cu"
+  hipcc $FLAGS -c "$TMP/$f.cu" -o "$TMP/$f.o" & pids+=($!)
+done
+hipcc $FLAGS -c "$HERE/ref_capi.cpp" -o "$TMP/ref_capi.o" & pids+=($!)
+for p in "${pids[@]}"; do wait "$p"; done
+hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT/libref_rasterizer.so" "$TMP"/forward.o "$TMP"/backward.o "$TMP"/rasterizer_impl.o "$TMP"/ref_capi.o
+echo "$SIG" > "$STAMP"
+echo "[build_ref] built $OUT/libref_rasterizer.so"

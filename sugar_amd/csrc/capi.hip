@@ -55,21 +55,30 @@ struct Prof {
         return e;
     }
 };
-thread_local Prof g_prof;
+Prof g_prof;            // process-wide: autograd runs the backward on its own thread
+std::mutex g_prof_mu;
 
 struct StageTimer {
     hipStream_t s; int stage; hipEvent_t a = nullptr, b = nullptr; bool live = false;
     StageTimer(hipStream_t s_, int stage_) : s(s_), stage(stage_)
     {
-        if (g_prof.on && g_prof.recs.size() < 65536) {
-            a = g_prof.get(); b = g_prof.get();
-            live = a && b;
+        if (g_prof.on) {
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            if (g_prof.recs.size() < 65536) {
+                a = g_prof.get(); b = g_prof.get();
+                live = a && b;
+            }
             if (live) (void)hipEventRecord(a, s);
         }
     }
     void stop()
     {
-        if (live) { (void)hipEventRecord(b, s); g_prof.recs.push_back({stage, a, b}); live = false; }
+        if (live) {
+            (void)hipEventRecord(b, s);
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            g_prof.recs.push_back({stage, a, b});
+            live = false;
+        }
     }
     ~StageTimer() { stop(); }
 };
@@ -96,6 +105,7 @@ void sgr_profile_enable(int on) { g_prof.on = on != 0; }
 
 int sgr_profile_read(double* ms_sum, int64_t* count, int n_stages)
 {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (int i = 0; i < n_stages; i++) { ms_sum[i] = 0.0; count[i] = 0; }
     for (auto& r : g_prof.recs) {
         float ms = 0.f;

@@ -106,8 +106,8 @@ def test_long_tile_lists_use_large_sort_paths():
     g = torch.Generator().manual_seed(3)
     P = 40000
     base = syn.make_scene(P, 13, 0.004, 0.01)
-    m = torch.randn(P, 3, generator=g) * 0.01  # everything lands in a handful of tiles
-    m[: P // 2] += torch.tensor([0.25, 0.0, 0.1])
+    m = torch.randn(P, 3, generator=g) * 0.002  # two tight clusters: one tile with 30000, one with 10000 instances
+    m[: P // 4] += torch.tensor([0.0, 0.6, 0.3])
     scene = base._replace(means3D=m.contiguous(), opacities=torch.full((P, 1), 0.02))
     st, hp = _check(scene, syn.orbit_cameras(160, 128)[0], torch.zeros(3), grads=False)
     lens = st["ranges"][:, 1] - st["ranges"][:, 0]
