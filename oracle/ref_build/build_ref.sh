@@ -17,13 +17,19 @@ if [ -f "$OUT/libref_rasterizer.so" ] && [ -f "$STAMP" ] && [ "$(cat "$STAMP")" 
 mkdir -p "$OUT"
 TMP="$(mktemp -d)"; trap 'rm -rf "$TMP"' EXIT
 FLAGS="-x hip -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w -I$HERE/shim -I$DGR/third_party/glm -I$DGR/cuda_rasterizer"
+# Two builds of the same sources:
+#   libref_rasterizer.so            compiler defaults (FMA contraction on, like nvcc's default -fmad=true): the A/B baseline
+#   libref_rasterizer_nocontract.so -ffp-contract=off: every float op individually rounded, i.e. the arithmetic contract of
+#                                   oracle/cpu_rasterizer.c and of the product's preprocess kernels -> compared BIT-EXACTLY
 pids=()
 for f in forward backward rasterizer_impl; do
   sed -E 's/<<[[:space:]]+</<<</g; s/>>[[:space:]]+>/>>>/g' "$DGR/cuda_rasterizer/$f.cu" > "$TMP/$f.cu"
   hipcc $FLAGS -c "$TMP/$f.cu" -o "$TMP/$f.o" & pids+=($!)
+  hipcc $FLAGS -ffp-contract=off -c "$TMP/$f.cu" -o "$TMP/${f}_nc.o" & pids+=($!)
 done
 hipcc $FLAGS -c "$HERE/ref_capi.cpp" -o "$TMP/ref_capi.o" & pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
 hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT/libref_rasterizer.so" "$TMP"/forward.o "$TMP"/backward.o "$TMP"/rasterizer_impl.o "$TMP"/ref_capi.o
+hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT/libref_rasterizer_nocontract.so" "$TMP"/forward_nc.o "$TMP"/backward_nc.o "$TMP"/rasterizer_impl_nc.o "$TMP"/ref_capi.o
 echo "$SIG" > "$STAMP"
-echo "[build_ref] built $OUT/libref_rasterizer.so"
+echo "[build_ref] built $OUT/libref_rasterizer.so and libref_rasterizer_nocontract.so"

@@ -17,27 +17,36 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_ref", "libref_rasterizer.so")
+LIB_PATH = os.path.join(_HERE, "_ref", "libref_rasterizer.so")  # compiler-default FMA contraction (A/B baseline)
+LIB_PATH_NOCONTRACT = os.path.join(_HERE, "_ref", "libref_rasterizer_nocontract.so")  # -ffp-contract=off (bit-exact pin)
 _ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
-_lib = None
+_libs = {}
+_variant = "default"
 
 
 def available() -> bool:
-    return os.path.exists(LIB_PATH)
+    return os.path.exists(LIB_PATH) and os.path.exists(LIB_PATH_NOCONTRACT)
+
+
+def use(variant: str):
+    """Select "default" (FMA contraction as the compiler does it) or "nocontract" (individually rounded ops)."""
+    global _variant
+    assert variant in ("default", "nocontract")
+    _variant = variant
 
 
 def lib():
-    global _lib
-    if _lib is None:
-        _lib = C.CDLL(LIB_PATH)
+    if _variant not in _libs:
+        L = C.CDLL(LIB_PATH if _variant == "default" else LIB_PATH_NOCONTRACT)
         vp, i, f = C.c_void_p, C.c_int, C.c_float
-        _lib.ref_forward.restype = i
-        _lib.ref_forward.argtypes = [_ALLOC, vp, _ALLOC, vp, _ALLOC, vp, i, i, i, vp, i, i, vp, vp, vp, vp, vp, f, vp, vp, vp,
-                                     vp, vp, f, f, i, vp, vp, i]
-        _lib.ref_backward.restype = None
-        _lib.ref_backward.argtypes = [i, i, i, i, vp, i, i, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f, vp, vp, vp, vp, vp,
-                                      vp, vp, vp, vp, vp, vp, vp, vp, vp, i]
-    return _lib
+        L.ref_forward.restype = i
+        L.ref_forward.argtypes = [_ALLOC, vp, _ALLOC, vp, _ALLOC, vp, i, i, i, vp, i, i, vp, vp, vp, vp, vp, f, vp, vp, vp,
+                                  vp, vp, f, f, i, vp, vp, i]
+        L.ref_backward.restype = None
+        L.ref_backward.argtypes = [i, i, i, i, vp, i, i, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f, vp, vp, vp, vp, vp,
+                                   vp, vp, vp, vp, vp, vp, vp, vp, vp, i]
+        _libs[_variant] = L
+    return _libs[_variant]
 
 
 def _p(t):
