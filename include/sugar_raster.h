@@ -121,6 +121,19 @@ int sgr_profile_read(double* ms_sum, int64_t* count, int n_stages);
 int sgr_dist2(int P, const float* points, float* meanDists, void* stream);
 int sgr_knn(int N, const float* query, int M, const float* ref, int K, float* dists, int64_t* idx, void* stream);
 
+/* ---- fused photometric loss of the train step ---------------------------------------------------
+ * loss = (1 - lambda) * mean|img - gt| + lambda * (1 - mean(SSIM(img, gt))), window 11, sigma 1.5, zero padding:
+ * l1_loss / ssim of sugar_utils/loss_utils.py:17-63 as combined at gaussian_splatting/train.py:88-90 and
+ * sugar_trainers/coarse_sdf.py:456-457.  img, gt: [channels, height, width] float32.
+ *   forward : loss_out[3] = {loss, l1 mean, ssim mean}; `scratch` (sgr_l1_ssim_scratch_bytes) keeps the per-pixel SSIM
+ *             partials for the backward.
+ *   backward: grad_img[c,h,w] = grad_loss[0] * dloss/dimg (grad_loss is a device scalar; gt receives no gradient). */
+size_t sgr_l1_ssim_scratch_bytes(int channels, int width, int height);
+int sgr_l1_ssim_forward(int channels, int width, int height, const float* img, const float* gt, float lambda,
+                        char* scratch, float* loss_out, void* stream);
+int sgr_l1_ssim_backward(int channels, int width, int height, const float* img, const float* gt, float lambda,
+                         const char* scratch, const float* grad_loss, float* grad_img, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,9 @@ SIGNATURES = {
     "sgr_binning_point_list_offset": (_sz, [_i64]),
     "sgr_profile_enable": (None, [_i]),
     "sgr_profile_read": (_i, [_vp, _vp, _i]),
+    "sgr_l1_ssim_scratch_bytes": (_sz, [_i, _i, _i]),
+    "sgr_l1_ssim_forward": (_i, [_i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
+    "sgr_l1_ssim_backward": (_i, [_i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "sgr_dist2": (_i, [_i, _vp, _vp, _vp]),
     "sgr_knn": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
 }

@@ -25,6 +25,7 @@ SOURCES = {
     "binning.hip": ["-ffp-contract=off"],
     "blend.hip": [],
     "knn.hip": ["-ffp-contract=off"],
+    "loss.hip": [],
     "capi.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

@@ -1,0 +1,204 @@
+// loss.hip -- fused photometric loss of the train step for gfx950:
+//     loss = (1 - lambda) * mean|x - y| + lambda * (1 - mean(SSIM(x, y)))
+// Restates l1_loss / ssim / _ssim of sugar_utils/loss_utils.py:17-63 as used by the train step
+// (gaussian_splatting/train.py:88-90; sugar_trainers/coarse_sdf.py:456-457,536).  The reference evaluates SSIM with five
+// grouped 11x11 conv2d calls plus ~25 elementwise kernels and their autograd twins; on an MI355X that costs far more than
+// the rasterizer it scores.  Here the window is applied separably through LDS and the backward is analytic:
+//
+//   forward kernel : per 16x16 tile, stage x, y (+5 px halo, zero padded like conv2d(padding=5)) in LDS, horizontal then
+//                    vertical 11-tap pass for {x, y, x^2, y^2, xy}, SSIM map value S and the three partials
+//                    dS/dmu1, dS/dE[x^2], dS/dE[xy]; tile sums of S and |x-y| go to two double accumulators.
+//   backward kernel: dL/dx = gL * [ (1-lambda)/N * sign(x-y) - lambda/N * ( G*(dS/dmu1) + 2x * G*(dS/dE[x^2]) + y * G*(dS/dE[xy]) ) ]
+//                    (G is symmetric, so the adjoint of the window is the same separable filter).
+// HBM traffic: x, y read twice, three partial maps written and read once: ~9 floats per pixel-channel in total.
+#include "../../include/sugar_raster.h"
+#include "sgr_common.h"
+
+namespace {
+
+#define LT 16          // output tile edge
+#define LH 5           // window half width (window_size 11)
+#define LR (LT + 2 * LH)  // 26: staged region edge
+
+struct Win { float w[11]; };
+
+__device__ __forceinline__ float ld_pad(const float* __restrict__ img, int W, int H, int x, int y)
+{
+    return (x >= 0 && x < W && y >= 0 && y < H) ? img[(size_t)y * W + x] : 0.0f;
+}
+
+__global__ void __launch_bounds__(256) k_l1_ssim_fwd(int W, int H, const float* __restrict__ X, const float* __restrict__ Y,
+                                                     Win win, float* __restrict__ dm1, float* __restrict__ ds1,
+                                                     float* __restrict__ ds12, double* __restrict__ acc)
+{
+    __shared__ float sx[LR][LR + 1];
+    __shared__ float sy[LR][LR + 1];
+    __shared__ float hq[5][LR][LT + 1];
+    __shared__ float red[2][4];
+    const int c = blockIdx.z;
+    const size_t plane = (size_t)c * W * H;
+    const float* x = X + plane;
+    const float* y = Y + plane;
+    const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < LR * LR; i += 256) {
+        const int r = i / LR, cc = i - r * LR;
+        sx[r][cc] = ld_pad(x, W, H, x0 + cc - LH, y0 + r - LH);
+        sy[r][cc] = ld_pad(y, W, H, x0 + cc - LH, y0 + r - LH);
+    }
+    __syncthreads();
+    // horizontal pass: LR rows x LT columns, five quantities
+    for (int i = tid; i < LR * LT; i += 256) {
+        const int r = i / LT, cc = i - r * LT;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const float w = win.w[k];
+            const float vx = sx[r][cc + k], vy = sy[r][cc + k];
+            a0 += w * vx; a1 += w * vy; a2 += w * vx * vx; a3 += w * vy * vy; a4 += w * vx * vy;
+        }
+        hq[0][r][cc] = a0; hq[1][r][cc] = a1; hq[2][r][cc] = a2; hq[3][r][cc] = a3; hq[4][r][cc] = a4;
+    }
+    __syncthreads();
+    const int lx = tid & 15, ly = tid >> 4;
+    const int px = x0 + lx, py = y0 + ly;
+    float s_val = 0.f, l1_val = 0.f;
+    if (px < W && py < H) {
+        float mu1 = 0.f, mu2 = 0.f, ex2 = 0.f, ey2 = 0.f, exy = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const float w = win.w[k];
+            mu1 += w * hq[0][ly + k][lx]; mu2 += w * hq[1][ly + k][lx]; ex2 += w * hq[2][ly + k][lx];
+            ey2 += w * hq[3][ly + k][lx]; exy += w * hq[4][ly + k][lx];
+        }
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+        const float sig1 = ex2 - mu1_sq, sig2 = ey2 - mu2_sq, sig12 = exy - mu12;
+        const float A = 2.f * mu12 + C1, B = 2.f * sig12 + C2, Cc = mu1_sq + mu2_sq + C1, D = sig1 + sig2 + C2;
+        const float inv_cd = 1.0f / (Cc * D);
+        const float S = A * B * inv_cd;
+        const size_t o = plane + (size_t)py * W + px;
+        dm1[o] = 2.f * mu2 * (B - A) * inv_cd - 2.f * mu1 * S * (D - Cc) * inv_cd;
+        ds1[o] = -S / D;
+        ds12[o] = 2.f * A * inv_cd;
+        s_val = S;
+        l1_val = fabsf(sx[ly + LH][lx + LH] - sy[ly + LH][lx + LH]);
+    }
+    for (int o = 32; o > 0; o >>= 1) { s_val += __shfl_xor(s_val, o); l1_val += __shfl_xor(l1_val, o); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s_val; red[1][tid >> 6] = l1_val; }
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(&acc[0], (double)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
+        atomicAdd(&acc[1], (double)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
+    }
+}
+
+__global__ void k_l1_ssim_finish(const double* __restrict__ acc, double n, float lambda, float* __restrict__ loss)
+{
+    const double ssim_mean = acc[0] / n, l1_mean = acc[1] / n;
+    loss[0] = (float)((1.0 - (double)lambda) * l1_mean + (double)lambda * (1.0 - ssim_mean));
+    loss[1] = (float)l1_mean;
+    loss[2] = (float)ssim_mean;
+}
+
+__global__ void __launch_bounds__(256) k_l1_ssim_bwd(int W, int H, const float* __restrict__ X, const float* __restrict__ Y,
+                                                     Win win, const float* __restrict__ dm1, const float* __restrict__ ds1,
+                                                     const float* __restrict__ ds12, const float* __restrict__ grad_loss,
+                                                     float lambda, float inv_n, float* __restrict__ dX)
+{
+    __shared__ float sm[3][LR][LR + 1];
+    __shared__ float hq[3][LR][LT + 1];
+    const int c = blockIdx.z;
+    const size_t plane = (size_t)c * W * H;
+    const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < LR * LR; i += 256) {
+        const int r = i / LR, cc = i - r * LR;
+        const int gx = x0 + cc - LH, gy = y0 + r - LH;
+        sm[0][r][cc] = ld_pad(dm1 + plane, W, H, gx, gy);
+        sm[1][r][cc] = ld_pad(ds1 + plane, W, H, gx, gy);
+        sm[2][r][cc] = ld_pad(ds12 + plane, W, H, gx, gy);
+    }
+    __syncthreads();
+    for (int i = tid; i < LR * LT; i += 256) {
+        const int r = i / LT, cc = i - r * LT;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const float w = win.w[k];
+            a0 += w * sm[0][r][cc + k]; a1 += w * sm[1][r][cc + k]; a2 += w * sm[2][r][cc + k];
+        }
+        hq[0][r][cc] = a0; hq[1][r][cc] = a1; hq[2][r][cc] = a2;
+    }
+    __syncthreads();
+    const int lx = tid & 15, ly = tid >> 4;
+    const int px = x0 + lx, py = y0 + ly;
+    if (px < W && py < H) {
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const float w = win.w[k];
+            g0 += w * hq[0][ly + k][lx]; g1 += w * hq[1][ly + k][lx]; g2 += w * hq[2][ly + k][lx];
+        }
+        const size_t o = plane + (size_t)py * W + px;
+        const float xv = X[o], yv = Y[o];
+        const float d = xv - yv;
+        const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+        const float dssim = g0 + 2.f * xv * g1 + yv * g2;
+        dX[o] = grad_loss[0] * inv_n * ((1.f - lambda) * sgn - lambda * dssim);
+    }
+}
+
+Win make_window()
+{
+    // gaussian(11, 1.5) of sugar_utils/loss_utils.py:23-25, float32 like torch.Tensor([...]) / sum
+    Win w;
+    float s = 0.f;
+    for (int i = 0; i < 11; i++) { w.w[i] = (float)exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); s += w.w[i]; }
+    for (int i = 0; i < 11; i++) w.w[i] = w.w[i] / s;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sgr_l1_ssim_scratch_bytes(int channels, int width, int height)
+{
+    return sgr_align((size_t)channels * width * height * 4) * 3 + 256;
+}
+
+int sgr_l1_ssim_forward(int channels, int width, int height, const float* img, const float* gt, float lambda,
+                        char* scratch, float* loss_out, void* stream)
+{
+    if (channels <= 0 || width <= 0 || height <= 0 || !img || !gt || !scratch || !loss_out) return SGR_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t plane = sgr_align((size_t)channels * width * height * 4);
+    float* dm1 = reinterpret_cast<float*>(scratch);
+    float* ds1 = reinterpret_cast<float*>(scratch + plane);
+    float* ds12 = reinterpret_cast<float*>(scratch + 2 * plane);
+    double* acc = reinterpret_cast<double*>(scratch + 3 * plane);
+    if (hipMemsetAsync(acc, 0, 16, s) != hipSuccess) return SGR_E_HIP;
+    dim3 grid((width + LT - 1) / LT, (height + LT - 1) / LT, channels);
+    hipLaunchKernelGGL(k_l1_ssim_fwd, grid, dim3(256), 0, s, width, height, img, gt, make_window(), dm1, ds1, ds12, acc);
+    hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(1), 0, s, acc, (double)channels * width * height, lambda, loss_out);
+    return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
+}
+
+int sgr_l1_ssim_backward(int channels, int width, int height, const float* img, const float* gt, float lambda,
+                         const char* scratch, const float* grad_loss, float* grad_img, void* stream)
+{
+    if (channels <= 0 || width <= 0 || height <= 0 || !img || !gt || !scratch || !grad_loss || !grad_img) return SGR_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t plane = sgr_align((size_t)channels * width * height * 4);
+    const float* dm1 = reinterpret_cast<const float*>(scratch);
+    const float* ds1 = reinterpret_cast<const float*>(scratch + plane);
+    const float* ds12 = reinterpret_cast<const float*>(scratch + 2 * plane);
+    dim3 grid((width + LT - 1) / LT, (height + LT - 1) / LT, channels);
+    const float inv_n = (float)(1.0 / ((double)channels * width * height));
+    hipLaunchKernelGGL(k_l1_ssim_bwd, grid, dim3(256), 0, s, width, height, img, gt, make_window(), dm1, ds1, ds12, grad_loss,
+                       lambda, inv_n, grad_img);
+    return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
+}
+
+}  // extern "C"

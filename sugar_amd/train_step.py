@@ -62,8 +62,16 @@ def ssim(img1, img2, window_size=11, size_average=True):
 
 
 def photometric_loss(image, gt, lambda_dssim=0.2):
-    """gaussian_splatting/train.py:88-90"""
+    """gaussian_splatting/train.py:88-90 with stock PyTorch ops (the parity reference of the fused HIP loss)"""
     return (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim(image, gt))
+
+
+def train_loss(image, gt, lambda_dssim=0.2, fused=True):
+    """The step's loss: the fused HIP kernels (sugar_amd/csrc/loss.hip) on a ROCm device, stock PyTorch otherwise."""
+    if fused and image.is_cuda:
+        from .fused_loss import l1_ssim_loss
+        return l1_ssim_loss(image, gt, lambda_dssim)
+    return photometric_loss(image, gt, lambda_dssim)
 
 
 # ---------------------------------------------------------------- parameters
@@ -134,7 +142,9 @@ def render(params: GaussianParams, cam, bg, rasterizer_cls, settings_cls, sh_deg
 class ViewShardedTrainer:
     """One optimisation step over a batch of `world_size` views, one view per rank."""
 
-    def __init__(self, params: GaussianParams, rasterizer_cls, settings_cls, bg, sh_degree=3, lambda_dssim=0.2):
+    def __init__(self, params: GaussianParams, rasterizer_cls, settings_cls, bg, sh_degree=3, lambda_dssim=0.2,
+                 fused_loss=True):
+        self.fused_loss = fused_loss
         self.params = params
         self.opt = params.make_optimizer()
         self.rasterizer_cls, self.settings_cls = rasterizer_cls, settings_cls
@@ -144,7 +154,7 @@ class ViewShardedTrainer:
     def step(self, cam, gt_image):
         self.params.flat_grad.zero_()
         pkg = render(self.params, cam, self.bg, self.rasterizer_cls, self.settings_cls, self.sh_degree)
-        loss = photometric_loss(pkg["render"], gt_image, self.lambda_dssim)
+        loss = train_loss(pkg["render"], gt_image, self.lambda_dssim, self.fused_loss)
         loss.backward()
         if self.world > 1:
             # the only collective on the path: sum of the per-view parameter gradients (then mean over views)

@@ -76,6 +76,17 @@ def main():
     out["w2v_R"] = R
     out["w2v_t"] = t
     out["w2v"] = gr_mod.getWorld2View2(R, t)
+    # photometric loss: sugar_utils/loss_utils.py (l1_loss, ssim) combined as gaussian_splatting/train.py:88-90
+    lu = _load("ref_lu", f"{REF}/sugar_utils/loss_utils.py")
+    img = torch.rand(3, 37, 45, generator=g, requires_grad=True)
+    gt = (img.detach() + 0.25 * torch.randn(3, 37, 45, generator=g)).clamp(0, 1)
+    gt[:, :5, :7] = img.detach()[:, :5, :7]  # an exactly-equal patch: sign(0) = 0 in the L1 gradient
+    lam = 0.2
+    loss = (1.0 - lam) * lu.l1_loss(img, gt) + lam * (1.0 - lu.ssim(img, gt))
+    loss.backward()
+    out["loss_img"] = img.detach().numpy(); out["loss_gt"] = gt.numpy()
+    out["loss_value"] = np.float32(loss.item()); out["loss_grad"] = img.grad.numpy()
+    out["loss_l1"] = np.float32(lu.l1_loss(img, gt).item()); out["loss_ssim"] = np.float32(lu.ssim(img, gt).item())
     np.savez(os.path.join(HERE, "reference_helpers.npz"), **out)
     print("wrote", os.path.join(HERE, "reference_helpers.npz"), {k: v.shape for k, v in out.items()})
 

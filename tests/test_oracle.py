@@ -174,3 +174,13 @@ def test_dist2_matches_kdtree():
     d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
     ref = (d[:, 1:] ** 2).mean(axis=1)
     np.testing.assert_allclose(orc.dist2(pts), ref, rtol=1e-4)
+
+
+def test_restated_loss_matches_reference_loss_utils():
+    """sugar_amd.train_step.photometric_loss (stock PyTorch restatement) == sugar_utils/loss_utils.py golden values"""
+    from sugar_amd.train_step import photometric_loss
+    img = torch.tensor(GOLD["loss_img"], requires_grad=True)
+    loss = photometric_loss(img, torch.tensor(GOLD["loss_gt"]), 0.2)
+    loss.backward()
+    assert abs(float(loss) - float(GOLD["loss_value"])) < 1e-6
+    np.testing.assert_allclose(img.grad.numpy(), GOLD["loss_grad"], rtol=1e-4, atol=1e-8)
