@@ -5,13 +5,16 @@
 //   duplicateWithKeys  (64-bit tile|depth keys)          :70-111
 //   cub::DeviceRadixSort::SortPairs over R instances     :303-308   (6 passes x 24 B x R at 1080p)
 //   cudaMemset + identifyTileRanges                      :310-317, :116-138
-// with a counting sort on the tile id (the counts come from the preprocess kernel's per-tile atomics)
-// followed by an independent in-LDS sort of each tile's bucket:
-//   tile_scan  : exclusive scan of tile_count[T] -> tile_start[T+1]; ranges fall out for free
-//   scatter    : every (Gaussian, tile) instance claims a slot in its tile's bucket and stores the
-//                64-bit key (depth_bits << 32 | gaussian_id)
-//   tile_sort  : one workgroup per tile sorts its bucket in LDS (bitonic, u64 keys) and writes the ids.
-// HBM traffic per instance: 8 B scatter + 8 B read + 4 B write, versus ~144 B for the radix sort.
+// with a multi-workgroup counting sort on the tile id followed by an independent in-LDS sort of each tile's bucket.
+// No global atomics: workgroup b of a persistent grid owns a contiguous slice of Gaussians and a private LDS histogram.
+//   (preprocess): blk_hist[b][t] = instances of tile t among workgroup b's Gaussians          (LDS atomics)
+//   hist_scan  : column-wise exclusive scan over b (in place) + per-tile totals
+//   tile_scan  : exclusive scan of the totals -> tile_start[T+1]; ranges fall out for free; R and the largest count
+//   scatter    : workgroup b re-walks its slice; slot = tile_start[t] + blk_hist[b][t] + (LDS atomic rank); stores the
+//                64-bit key (depth_bits << 32 | gaussian_id).  A workgroup's instances of a tile are contiguous.
+//   tile_sort  : one workgroup per tile sorts its bucket in LDS (bitonic network on u64 keys) and writes the ids.
+// HBM traffic per instance: 8 B scatter + 8 B read + 4 B write (+ 16 B per (workgroup, tile) of histogram traffic),
+// versus ~144 B per instance for the 6-pass radix sort of 12-byte pairs.
 //
 // Order contract: within a tile the reference's stable sort orders by depth bits, ties by ascending
 // Gaussian index (the emission order of duplicateWithKeys).  Sorting the composite key
@@ -56,10 +59,65 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __res
     }
 }
 
-// ---- scatter: one lane per Gaussian (v1: serial loop over the Gaussian's tile rectangle) ------
-__global__ void __launch_bounds__(256) k_scatter(int P, int gx, int gy, const GeomRec* __restrict__ rec,
-                                                 const uint32_t* __restrict__ tile_start,
-                                                 uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys)
+// ---- column scan of the per-workgroup histograms --------------------------------------------
+// One lane per tile walks the n_blocks rows (coalesced across tiles): blk_hist[b][t] becomes the exclusive prefix over b,
+// tile_count[t] the total.  Loads are issued UNROLL at a time so each lane keeps several rows in flight.
+__global__ void __launch_bounds__(256) k_hist_scan(int T, int n_blocks, uint32_t* __restrict__ blk_hist,
+                                                   uint32_t* __restrict__ tile_count)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    constexpr int UNROLL = 16;
+    uint32_t run = 0;
+    int b = 0;
+    for (; b + UNROLL <= n_blocks; b += UNROLL) {
+        uint32_t v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) v[u] = blk_hist[(size_t)(b + u) * T + t];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) { blk_hist[(size_t)(b + u) * T + t] = run; run += v[u]; }
+    }
+    for (; b < n_blocks; b++) { const uint32_t v = blk_hist[(size_t)b * T + t]; blk_hist[(size_t)b * T + t] = run; run += v; }
+    tile_count[t] = run;
+}
+
+// ---- scatter ---------------------------------------------------------------------------------
+// LDS variant: persistent grid matching the preprocess kernel's slices.  s_base[t] starts at
+// tile_start[t] + (exclusive prefix of this workgroup's predecessors) and is bumped with returning LDS atomics.
+__global__ void __launch_bounds__(256) k_scatter_lds(int P, int gx, int gy, int per_block, const GeomRec* __restrict__ rec,
+                                                     const uint32_t* __restrict__ tile_start,
+                                                     const uint32_t* __restrict__ blk_hist, uint64_t* __restrict__ keys)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_base[];
+    const int T = gx * gy;
+    const uint32_t* mine = blk_hist + (size_t)blockIdx.x * T;
+    for (int i = threadIdx.x; i < T; i += 256) s_base[i] = tile_start[i] + mine[i];
+    __syncthreads();
+    const int begin = blockIdx.x * per_block;
+    const int end = min(P, begin + per_block);
+    for (int base = begin; base < end; base += 256) {
+        const int idx = base + threadIdx.x;
+        if (idx >= end) continue;
+        const float4* rp = reinterpret_cast<const float4*>(rec + idx);
+        const float4 r2 = rp[2];
+        const int radius = __float_as_int(r2.z);
+        if (!(radius > 0)) continue;
+        const float4 r0 = rp[0];
+        int minx, miny, maxx, maxy;
+        sgr_get_rect(r0.x, r0.y, radius, gx, gy, minx, miny, maxx, maxy);
+        const uint64_t key = ((uint64_t)__float_as_uint(r2.y) << 32) | (uint32_t)idx;
+        for (int y = miny; y < maxy; y++)
+            for (int x = minx; x < maxx; x++) {
+                const uint32_t slot = atomicAdd(&s_base[y * gx + x], 1u);
+                keys[slot] = key;
+            }
+    }
+}
+
+// Fallback (tile histogram too large for LDS): one lane per Gaussian, returning global atomics on a cursor array.
+__global__ void __launch_bounds__(256) k_scatter_atomic(int P, int gx, int gy, const GeomRec* __restrict__ rec,
+                                                        const uint32_t* __restrict__ tile_start,
+                                                        uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P) return;
@@ -154,32 +212,48 @@ void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_star
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, tile_count, tile_start, header);
 }
 
-void sgr_launch_scatter(int P, int gx, int gy, const GeomRec* rec, const uint32_t* tile_start, uint32_t* tile_cursor,
-                        uint64_t* keys, hipStream_t s)
+void sgr_launch_hist_scan(int T, int n_blocks, uint32_t* blk_hist, uint32_t* tile_count, hipStream_t s)
 {
-    if (P <= 0) return;
-    hipLaunchKernelGGL(k_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, gy, rec, tile_start, tile_cursor, keys);
+    hipLaunchKernelGGL(k_hist_scan, dim3((T + 255) / 256), dim3(256), 0, s, T, n_blocks, blk_hist, tile_count);
 }
 
-#define SGR_SORT_SMALL 2048u   // <= 16 KB of LDS per workgroup: many tiles per CU
-#define SGR_SORT_LARGE 16384u  // <= 128 KB of LDS: one tile per CU
+void sgr_launch_scatter(int P, int gx, int gy, const GeomRec* rec, const uint32_t* tile_start, uint32_t* tile_cursor,
+                        const uint32_t* blk_hist, int n_blocks, int per_block, uint64_t* keys, hipStream_t s)
+{
+    if (P <= 0) return;
+    if (blk_hist) {
+        const size_t lds = (size_t)gx * gy * 4;
+        static size_t configured = 0;
+        if (lds > configured) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+            configured = lds;
+        }
+        hipLaunchKernelGGL(k_scatter_lds, dim3(n_blocks), dim3(256), lds, s, P, gx, gy, per_block, rec, tile_start, blk_hist, keys);
+    } else {
+        hipLaunchKernelGGL(k_scatter_atomic, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, gy, rec, tile_start, tile_cursor, keys);
+    }
+}
 
+// Size classes of the per-tile sort: LDS per workgroup bounds how many tiles a CU sorts concurrently.
+//   count <= 1024  :   8 KB, 128 threads      count <= 4096 : 32 KB, 256 threads
+//   count <= 16384 : 128 KB, 1024 threads     larger        : in place in global memory (degenerate scenes)
 void sgr_launch_tile_sort(int T, uint32_t max_count, const uint32_t* tile_start, uint64_t* keys, uint32_t* point_list,
                           hipStream_t s)
 {
     if (T <= 0 || max_count == 0) return;
-    hipLaunchKernelGGL(k_tile_sort_lds<256>, dim3(T), dim3(256), SGR_SORT_SMALL * 8, s, tile_start, 0u, SGR_SORT_SMALL,
-                       keys, point_list);
-    if (max_count > SGR_SORT_SMALL) {
+    hipLaunchKernelGGL(k_tile_sort_lds<128>, dim3(T), dim3(128), 1024 * 8, s, tile_start, 0u, 1024u, keys, point_list);
+    if (max_count > 1024u)
+        hipLaunchKernelGGL(k_tile_sort_lds<256>, dim3(T), dim3(256), 4096 * 8, s, tile_start, 1024u, 4096u, keys, point_list);
+    if (max_count > 4096u) {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_sort_lds<1024>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, SGR_SORT_LARGE * 8);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_tile_sort_lds<1024>, dim3(T), dim3(1024), SGR_SORT_LARGE * 8, s, tile_start, SGR_SORT_SMALL,
-                           SGR_SORT_LARGE, keys, point_list);
+        hipLaunchKernelGGL(k_tile_sort_lds<1024>, dim3(T), dim3(1024), 16384 * 8, s, tile_start, 4096u, 16384u, keys, point_list);
     }
-    if (max_count > SGR_SORT_LARGE)
-        hipLaunchKernelGGL(k_tile_sort_global, dim3(T), dim3(1024), 0, s, tile_start, SGR_SORT_LARGE, keys, point_list);
+    if (max_count > 16384u)
+        hipLaunchKernelGGL(k_tile_sort_global, dim3(T), dim3(1024), 0, s, tile_start, 16384u, keys, point_list);
 }

@@ -163,9 +163,10 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     uint32_t* tile_walked = reinterpret_cast<uint32_t*>(img + IL.tile_walked);
     uint32_t* header = reinterpret_cast<uint32_t*>(img + IL.header);
 
-    // tile_start doubles as the per-tile counter array until the scan overwrites it with offsets:
-    // the counts live in tile_cursor during preprocess, the scan reads them, then the cursor is re-zeroed.
-    HIP_TRY(hipMemsetAsync(tile_cursor, 0, (size_t)IL.T * 4, s));
+    uint32_t* blk_hist = IL.n_blocks ? reinterpret_cast<uint32_t*>(img + IL.blk_hist) : nullptr;
+    const int per_block = IL.n_blocks ? (((P + IL.n_blocks - 1) / IL.n_blocks + 255) / 256) * 256 : 0;
+    // tile_cursor holds the per-tile instance counts until the tile scan has consumed them
+    if (!blk_hist) HIP_TRY(hipMemsetAsync(tile_cursor, 0, (size_t)IL.T * 4, s));
 
     PreprocessArgs pa;
     pa.P = P; pa.D = D; pa.M = shs ? M : 0;
@@ -177,15 +178,20 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     pa.focal_x = width / (2.0f * tan_fovx);
     pa.gx = IL.gx; pa.gy = IL.gy;
     pa.radii = radii; pa.rec = rec; pa.tile_count = tile_cursor;
+    pa.blk_hist = blk_hist; pa.n_blocks = IL.n_blocks; pa.per_block = per_block;
     { StageTimer t(s, SGR_STAGE_PREPROCESS); sgr_launch_preprocess_fwd(pa, s); }
     STAGE_CHECK("preprocess");
 
-    { StageTimer t(s, SGR_STAGE_SCAN); sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, s); }
+    {
+        StageTimer t(s, SGR_STAGE_SCAN);
+        if (blk_hist) sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
+        sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, s);
+    }
     STAGE_CHECK("tile_scan");
 
     if (!g_pinned.p) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_pinned.p), 64, hipHostMallocDefault));
     HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 16, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemsetAsync(tile_cursor, 0, (size_t)IL.T * 4, s));
+    if (!blk_hist) HIP_TRY(hipMemsetAsync(tile_cursor, 0, (size_t)IL.T * 4, s));
     HIP_TRY(hipStreamSynchronize(s));  // the one host round trip of the forward (rasterizer_impl.cu:280-281)
     const int64_t R = (int64_t)g_pinned.p[SGR_HDR_R];
     const uint32_t max_count = g_pinned.p[SGR_HDR_MAXCOUNT];
@@ -197,7 +203,7 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     uint32_t* point_list = reinterpret_cast<uint32_t*>(binning + BL.point_list);
 
     if (R > 0) {
-        { StageTimer t(s, SGR_STAGE_SCATTER); sgr_launch_scatter(P, IL.gx, IL.gy, rec, tile_start, tile_cursor, keys, s); }
+        { StageTimer t(s, SGR_STAGE_SCATTER); sgr_launch_scatter(P, IL.gx, IL.gy, rec, tile_start, tile_cursor, blk_hist, IL.n_blocks, per_block, keys, s); }
         STAGE_CHECK("scatter");
         { StageTimer t(s, SGR_STAGE_SORT); sgr_launch_tile_sort(IL.T, max_count, tile_start, keys, point_list, s); }
         STAGE_CHECK("tile_sort");

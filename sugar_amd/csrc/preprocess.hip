@@ -174,10 +174,10 @@ __global__ void __launch_bounds__(256) k_mark_visible(int P, const float* __rest
     present[idx] = (pv.z <= 0.2f) ? 0 : 1;
 }
 
-__global__ void __launch_bounds__(256) k_preprocess_fwd(PreprocessArgs a)
+// One Gaussian: writes its GeomRec and radius, returns its tile rectangle (empty when culled).
+__device__ __forceinline__ void preprocess_one(const PreprocessArgs& a, const int idx, int& minx, int& miny, int& maxx, int& maxy)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
+    minx = miny = maxx = maxy = 0;
     GeomRec rec;
     rec.radius = 0;
     rec.clamped = 0;
@@ -223,9 +223,10 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreprocessArgs a)
             float my_radius = ceilf(3.f * sqrtf(fmax_(lambda1, lambda2)));
             float pix_x = ndc2pix(proj_x, a.W), pix_y = ndc2pix(proj_y, a.H);
             int r_int = f2i_sat(my_radius);
-            int minx, miny, maxx, maxy;
-            sgr_get_rect(pix_x, pix_y, r_int, a.gx, a.gy, minx, miny, maxx, maxy);
-            if ((maxx - minx) * (maxy - miny) != 0) {
+            int rx0, ry0, rx1, ry1;
+            sgr_get_rect(pix_x, pix_y, r_int, a.gx, a.gy, rx0, ry0, rx1, ry1);
+            if ((rx1 - rx0) * (ry1 - ry0) != 0) {
+                minx = rx0; miny = ry0; maxx = rx1; maxy = ry1;
                 if (a.colors_precomp) {
                     rec.r = a.colors_precomp[i3]; rec.g = a.colors_precomp[i3 + 1]; rec.b = a.colors_precomp[i3 + 2];
                 } else {
@@ -245,10 +246,6 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreprocessArgs a)
                 rec.depth = p_view.z;
                 rec.radius = r_int;
                 out_radius = r_int;
-                // per-tile instance counting (first half of the counting sort that replaces
-                // duplicateWithKeys + the 64-bit global radix sort, rasterizer_impl.cu:70-111,303-308)
-                for (int y = miny; y < maxy; y++)
-                    for (int x = minx; x < maxx; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
             }
         }
     }
@@ -256,6 +253,45 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreprocessArgs a)
     const float4* srcv = reinterpret_cast<const float4*>(&rec);
     dst[0] = srcv[0]; dst[1] = srcv[1]; dst[2] = srcv[2];
     if (a.radii) a.radii[idx] = out_radius;
+}
+
+// Per-tile instance counting is the first half of the counting sort that replaces duplicateWithKeys + the 64-bit global
+// radix sort (rasterizer_impl.cu:70-111,303-308).
+//
+// LDS variant (default): a persistent grid of a.n_blocks workgroups, each owning a contiguous slice of Gaussians and a
+// private histogram over all T tiles in LDS (32 KB at 1080p, 127 KB at 4K).  Counting costs LDS atomics only; the
+// histogram is written once, coalesced, to blk_hist[block][tile].  No global atomics anywhere in the binning.
+__global__ void __launch_bounds__(256) k_preprocess_fwd_lds(PreprocessArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
+    const int T = a.gx * a.gy;
+    for (int i = threadIdx.x; i < T; i += 256) s_hist[i] = 0u;
+    __syncthreads();
+    const int begin = blockIdx.x * a.per_block;
+    const int end = min(a.P, begin + a.per_block);
+    for (int base = begin; base < end; base += 256) {
+        const int idx = base + threadIdx.x;
+        if (idx < end) {
+            int minx, miny, maxx, maxy;
+            preprocess_one(a, idx, minx, miny, maxx, maxy);
+            for (int y = miny; y < maxy; y++)
+                for (int x = minx; x < maxx; x++) atomicAdd(&s_hist[y * a.gx + x], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* dst = a.blk_hist + (size_t)blockIdx.x * T;
+    for (int i = threadIdx.x; i < T; i += 256) dst[i] = s_hist[i];
+}
+
+// Fallback for tile grids whose histogram does not fit in LDS (> ~38k tiles): one lane per Gaussian, global atomics.
+__global__ void __launch_bounds__(256) k_preprocess_fwd_atomic(PreprocessArgs a)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.P) return;
+    int minx, miny, maxx, maxy;
+    preprocess_one(a, idx, minx, miny, maxx, maxy);
+    for (int y = miny; y < maxy; y++)
+        for (int x = minx; x < maxx; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -475,7 +511,18 @@ void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatri
 void sgr_launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s)
 {
     if (a.P <= 0) return;
-    hipLaunchKernelGGL(k_preprocess_fwd, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+    if (a.blk_hist) {
+        const size_t lds = (size_t)a.gx * a.gy * 4;
+        static size_t configured = 0;
+        if (lds > configured) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_preprocess_fwd_lds),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            configured = lds;
+        }
+        hipLaunchKernelGGL(k_preprocess_fwd_lds, dim3(a.n_blocks), dim3(256), lds, s, a);
+    } else {
+        hipLaunchKernelGGL(k_preprocess_fwd_atomic, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+    }
 }
 
 void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)

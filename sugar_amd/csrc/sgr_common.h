@@ -7,11 +7,13 @@
 #define SGR_TILE_X 16  // BLOCK_X, DGR/cuda_rasterizer/config.h:16 (part of the pixel-exact contract)
 #define SGR_TILE_Y 16  // BLOCK_Y, DGR/cuda_rasterizer/config.h:17
 #define SGR_TILE_PIX 256
+#define SGR_BIN_BLOCKS 512          // persistent binning grid: 2 workgroups per CU on the 256-CU MI355X
+#define SGR_BIN_LDS_MAX (150 * 1024) // largest per-workgroup tile histogram kept in LDS (160 KB per CU)
 
 // ---- private scratch layouts -----------------------------------------------------------------
 // geom  : [ GeomRec rec[P] ]                                   48 B / Gaussian (AoS: one gather = 1-2 lines)
 // img   : [ final_T f32[WH] | n_contrib u32[WH] | tile_start u32[T+1] | tile_cursor u32[T] |
-//           tile_maxc u32[T] | tile_walked u32[T] | header u32[8] ]
+//           tile_maxc u32[T] | tile_walked u32[T] | header u32[8] | blk_hist u32[n_blocks][T] ]
 // binning: [ keys u64[R] | point_list u32[R] ]
 struct GeomRec {
     float x, y, cx, cy;          // pixel-space mean, conic.x, conic.y
@@ -25,7 +27,8 @@ static_assert(sizeof(GeomRec) == 48, "GeomRec must be 48 bytes");
 static inline size_t sgr_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct ImgLayout {
-    size_t final_T, n_contrib, tile_start, tile_cursor, tile_maxc, tile_walked, header, total;
+    size_t final_T, n_contrib, tile_start, tile_cursor, tile_maxc, tile_walked, header, blk_hist, total;
+    int n_blocks;  // persistent binning grid (0: histogram does not fit in LDS, global-atomic fallback)
     int gx, gy, T;
 };
 static inline ImgLayout sgr_img_layout(int W, int H)
@@ -42,6 +45,8 @@ static inline ImgLayout sgr_img_layout(int W, int H)
     L.tile_maxc = off;   off = sgr_align(off + (size_t)L.T * 4);
     L.tile_walked = off; off = sgr_align(off + (size_t)L.T * 4);
     L.header = off;      off = sgr_align(off + 64);
+    L.n_blocks = ((size_t)L.T * 4 <= SGR_BIN_LDS_MAX) ? SGR_BIN_BLOCKS : 0;
+    L.blk_hist = off;    off = sgr_align(off + (size_t)L.n_blocks * L.T * 4);
     L.total = off;
     return L;
 }
@@ -73,7 +78,10 @@ struct PreprocessArgs {
     const float* viewmatrix; const float* projmatrix; const float* cam_pos;
     int W, H; float tan_fovx, tan_fovy, focal_x, focal_y;
     int gx, gy;
-    int* radii; GeomRec* rec; uint32_t* tile_count;
+    int* radii; GeomRec* rec;
+    uint32_t* tile_count;  // global-atomic fallback: per-tile counters (zeroed by the caller)
+    uint32_t* blk_hist;    // LDS path: [n_blocks][T] per-workgroup tile histograms (null selects the fallback)
+    int n_blocks, per_block;  // persistent grid of the LDS path: workgroup b owns Gaussians [b*per_block, (b+1)*per_block)
 };
 void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 void sgr_launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
@@ -89,9 +97,10 @@ struct PreprocessBwdArgs {
 };
 void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
 
+void sgr_launch_hist_scan(int T, int n_blocks, uint32_t* blk_hist, uint32_t* tile_count, hipStream_t s);
 void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* header, hipStream_t s);
 void sgr_launch_scatter(int P, int gx, int gy, const GeomRec* rec, const uint32_t* tile_start, uint32_t* tile_cursor,
-                        uint64_t* keys, hipStream_t s);
+                        const uint32_t* blk_hist, int n_blocks, int per_block, uint64_t* keys, hipStream_t s);
 void sgr_launch_tile_sort(int T, uint32_t max_count, const uint32_t* tile_start, uint64_t* keys, uint32_t* point_list,
                           hipStream_t s);
 

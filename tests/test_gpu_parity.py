@@ -206,3 +206,11 @@ def test_knn_and_dist2_match_oracle():
     dd, ii = cKDTree(pts.numpy().astype(np.float64)).query(pts.numpy().astype(np.float64), k=K)
     np.testing.assert_allclose(d.cpu().numpy(), dd ** 2, rtol=1e-4, atol=1e-7)
     assert (i.cpu().numpy() == ii).mean() > 0.999 and np.array_equal(i[:, 0].cpu().numpy(), np.arange(3000))
+
+
+def test_huge_tile_grid_uses_global_atomic_binning_fallback():
+    """> 38400 tiles: the per-workgroup tile histogram no longer fits in LDS (sgr_common.h: SGR_BIN_LDS_MAX)."""
+    scene = syn.make_scene(3000, 33, 0.02, 0.2)
+    cam = syn.orbit_cameras(3200, 3136)[1]
+    assert ((3200 + 15) // 16) * ((3136 + 15) // 16) * 4 > 150 * 1024
+    _check(scene, cam, torch.zeros(3), grads=False)
