@@ -8,10 +8,10 @@
 // GeomRec (three dwordx4 loads from one or two cache lines) and the whole workgroup then walks the batch
 // with uniform-address (broadcast, conflict-free) LDS reads.
 //
-// Backward (v1): the per-(pixel, Gaussian) gradient terms are reduced across the 64 lanes of a wave with a
-// butterfly before touching memory, so a (tile, Gaussian) pair costs 4 x 9 global atomics instead of the
-// reference's up to 256 x 9 (backward.cu:523-554).  The walk starts at the tile's deepest contributor
-// (tile_maxc, recorded by the forward) instead of at the end of the tile's list.
+// Backward: see the comment above k_blend_bwd -- per-pair terms are transposed through a wave-private LDS panel and
+// summed in registers, so a (tile, Gaussian) pair costs at most one 48-byte record of global atomics instead of the
+// reference's up to 256 x 9 (backward.cu:523-554).  The walk starts at the tile's deepest contributor (tile_maxc,
+// recorded by the forward) instead of at the end of the tile's list.
 #include "sgr_common.h"
 
 namespace {
@@ -104,39 +104,59 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
     }
 }
 
-struct StageBwd {
-    float4 a[BATCH];
-    float4 b[BATCH];
-    float c[BATCH];
-    uint32_t id[BATCH];
-};
+// ---------------------------------------------------------------------------------------------
+// Backward blend.
+//
+// The reference adds nine floats with global atomics for every contributing (pixel, Gaussian) pair
+// (backward.cu:523-554).  Here a workgroup walks its tile's list back to front in batches of 64 Gaussians, and every
+// wave alternates two lane mappings over sub-batches of 16 Gaussians:
+//
+//   phase A  lane = pixel (16x4 strip of the wave).  The per-pixel recurrence of backward.cu:486-534 (T /= 1-alpha,
+//            accum_rec, dL_dalpha) runs sequentially over the 16 Gaussians; for each pair the lane stores just
+//            Z = G * dL_dalpha and Wt = alpha * T into a wave-private LDS panel zw[g][pixel].
+//   phase B  lane = (Gaussian g, pixel row q).  Each lane streams the 16 pixels of its row out of the panel and
+//            accumulates, in registers, the colour sums  sum Wt*dL_dpix  and the moments  sum Z, sum Z*dx, sum Z*dx^2
+//            (dy is constant along a row, so the y-moments factor out).  No cross-lane traffic at all in the loop;
+//            one 4-lane shuffle reduction per sub-batch, then LDS float atomics into a per-workgroup table.
+//
+// All gradient terms of a pair are linear in {Wt*g_c, Z, Z*dx, Z*dy, Z*dx^2, Z*dx*dy, Z*dy^2} with per-Gaussian
+// coefficients (backward.cu:538-554), so only those nine sums leave the workgroup: at most one 48-byte record of global
+// float atomics per (tile, Gaussian), into acc[P][12].  The coefficients are applied once per Gaussian by the fused
+// backward-preprocess kernel.  The panel's row stride (65 float2) makes both the phase-A writes and the phase-B reads
+// bank-conflict free.
+#define BWD_BATCH 64
+#define BWD_SUB 16
+#define ZW_STRIDE 65
 
-__device__ __forceinline__ float wave_sum(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+struct __attribute__((aligned(16))) BwdShared {
+    float4 a[BWD_BATCH];                  // x, y, conic.x, conic.y
+    float4 b[BWD_BATCH];                  // conic.z, opacity, r, g
+    float c[BWD_BATCH];                   // b
+    uint32_t id[BWD_BATCH];
+    float part[BWD_BATCH][12];            // per-workgroup sums of the current batch
+    float gpix[3][256];                   // dL_dpix of the tile's pixels, [channel][wave*64 + lane]
+    float2 zw[4][BWD_SUB * ZW_STRIDE];    // wave-private (Z, Wt) panels
+};
 
 __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const uint32_t* __restrict__ tile_start,
                                                    const uint32_t* __restrict__ point_list,
                                                    const GeomRec* __restrict__ rec, const float* __restrict__ bg,
                                                    const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                                                    const uint32_t* __restrict__ tile_maxc, const float* __restrict__ dL_dpix,
-                                                   float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
-                                                   float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor)
+                                                   float* __restrict__ acc)
 {
-    __shared__ StageBwd st;
+    __shared__ BwdShared sh;
     const int tile = blockIdx.x;
+    const int total = (int)tile_maxc[tile];  // entries at list positions > tile_maxc contribute to no pixel
+    if (total == 0) return;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int px = tx * SGR_TILE_X + (tid & 15), py = ty * SGR_TILE_Y + (tid >> 4);
+    const int wave = tid >> 6, lane = tid & 63;
+    const int x0 = tx * SGR_TILE_X, y0 = ty * SGR_TILE_Y;
+    const int px = x0 + (tid & 15), py = y0 + (tid >> 4);
     const bool inside = px < W && py < H;
     const float pixfx = (float)px, pixfy = (float)py;
     const uint32_t r0 = tile_start[tile];
-    const int total = (int)tile_maxc[tile];  // entries at list positions > tile_maxc contribute to no pixel
-    if (total == 0) return;
 
     const size_t pix_id = (size_t)W * py + px;
     const size_t HW = (size_t)H * W;
@@ -149,70 +169,112 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;  // accum_rec
     float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;     // last_color
     float last_alpha = 0.f;
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
-    // walk list positions total, total-1, ..., 1 (1-based, as n_contrib counts them)
-    for (int base = 0; base < total; base += BATCH) {
-        __syncthreads();
-        const int nb = min(BATCH, total - base);
+    // phase-B lane role and the dL_dpix of its 16-pixel row, kept in registers for the whole kernel
+    const int bg_g = lane & 15, bq = lane >> 4;
+    sh.gpix[0][tid] = g0; sh.gpix[1][tid] = g1; sh.gpix[2][tid] = g2;
+    for (int i = tid; i < BWD_BATCH * 12; i += 256) (&sh.part[0][0])[i] = 0.f;
+    __syncthreads();
+    float rg0[16], rg1[16], rg2[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int p = wave * 64 + bq * 16 + i;
+        rg0[i] = sh.gpix[0][p]; rg1[i] = sh.gpix[1][p]; rg2[i] = sh.gpix[2][p];
+    }
+    const float rowy = (float)(y0 + wave * 4 + bq);
+    float2* zw = sh.zw[wave];
+
+    for (int base = 0; base < total; base += BWD_BATCH) {
+        const int nb = min(BWD_BATCH, total - base);
         if (tid < nb) {
             const uint32_t id = point_list[r0 + (uint32_t)(total - 1 - base - tid)];
             const float4* rp = reinterpret_cast<const float4*>(rec + id);
             const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
-            st.a[tid] = v0; st.b[tid] = v1; st.c[tid] = v2.x; st.id[tid] = id;
+            sh.a[tid] = v0; sh.b[tid] = v1; sh.c[tid] = v2.x; sh.id[tid] = id;
         }
         __syncthreads();
-        for (int j = 0; j < nb; j++) {
-            const int pos = total - base - j;  // 1-based list position of this entry
-            const float4 a = st.a[j];
-            const float4 b = st.b[j];
-            const float dx = a.x - pixfx, dy = a.y - pixfy;
-            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-            const float G = __expf(power);
-            const float alpha = fminf(0.99f, b.y * G);
-            const bool active = (pos <= last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (__ballot(active) == 0ull) continue;  // wave-uniform
-            float dcol0 = 0.f, dcol1 = 0.f, dcol2 = 0.f, dmx = 0.f, dmy = 0.f, dcx = 0.f, dcy = 0.f, dcz = 0.f, dop = 0.f;
-            if (active) {
-                T = T / (1.f - alpha);
-                const float dchannel_dcolor = alpha * T;
-                const float c0 = b.z, c1 = b.w, c2 = st.c[j];
-                acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = c0;
-                acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = c1;
-                acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = c2;
-                float dL_dalpha = (c0 - acc0) * g0 + (c1 - acc1) * g1 + (c2 - acc2) * g2;
-                dcol0 = dchannel_dcolor * g0; dcol1 = dchannel_dcolor * g1; dcol2 = dchannel_dcolor * g2;
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-                const float dL_dG = b.y * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                const float dG_ddely = -gdy * b.x - gdx * a.w;
-                dmx = dL_dG * dG_ddelx * ddelx_dx;
-                dmy = dL_dG * dG_ddely * ddely_dy;
-                dcx = -0.5f * gdx * dx * dL_dG;
-                dcy = -0.5f * gdx * dy * dL_dG;
-                dcz = -0.5f * gdy * dy * dL_dG;
-                dop = G * dL_dalpha;
+        for (int sb = 0; sb < nb; sb += BWD_SUB) {
+            const int ns = min(BWD_SUB, nb - sb);
+            // ---------------- phase A: lane = pixel
+            uint32_t gmask = 0;  // wave-uniform: Gaussians of this sub-batch that touch the wave's strip
+            for (int g = 0; g < ns; g++) {
+                const int j = sb + g;
+                const int pos = total - base - j;  // 1-based list position of this entry
+                const float4 a = sh.a[j];
+                const float4 b = sh.b[j];
+                const float dx = a.x - pixfx, dy = a.y - pixfy;
+                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+                const float G = __expf(power);
+                const float alpha = fminf(0.99f, b.y * G);
+                const bool active = (pos <= last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                if (__ballot(active) == 0ull) continue;  // wave-uniform
+                gmask |= 1u << g;
+                float Z = 0.f, Wt = 0.f;
+                if (active) {
+                    T = T / (1.f - alpha);
+                    Wt = alpha * T;
+                    const float c0 = b.z, c1 = b.w, c2 = sh.c[j];
+                    acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = c0;
+                    acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = c1;
+                    acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = c2;
+                    float dL_dalpha = (c0 - acc0) * g0 + (c1 - acc1) * g1 + (c2 - acc2) * g2;
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                    Z = G * dL_dalpha;
+                }
+                zw[g * ZW_STRIDE + lane] = make_float2(Z, Wt);
             }
-            dcol0 = wave_sum(dcol0); dcol1 = wave_sum(dcol1); dcol2 = wave_sum(dcol2);
-            dmx = wave_sum(dmx); dmy = wave_sum(dmy);
-            dcx = wave_sum(dcx); dcy = wave_sum(dcy); dcz = wave_sum(dcz);
-            dop = wave_sum(dop);
-            if (lane == 0) {
-                const size_t id = st.id[j];
-                atomicAdd(&dL_dcolor[3 * id + 0], dcol0);
-                atomicAdd(&dL_dcolor[3 * id + 1], dcol1);
-                atomicAdd(&dL_dcolor[3 * id + 2], dcol2);
-                atomicAdd(&dL_dmean2D[3 * id + 0], dmx);
-                atomicAdd(&dL_dmean2D[3 * id + 1], dmy);
-                atomicAdd(&dL_dconic[4 * id + 0], dcx);
-                atomicAdd(&dL_dconic[4 * id + 1], dcy);
-                atomicAdd(&dL_dconic[4 * id + 3], dcz);
-                atomicAdd(&dL_dopacity[id], dop);
+            if (gmask == 0) continue;  // wave-uniform
+            // the panel is exchanged between lanes of ONE wave: LDS operations of a wave execute in order, so a
+            // wave-scope fence (compiler ordering) is all that is needed, no workgroup barrier
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---------------- phase B: lane = (Gaussian bg_g, row bq)
+            if ((gmask >> bg_g) & 1u) {
+                const float4 a = sh.a[sb + bg_g];
+                const float dyr = a.y - rowy;
+                float s0 = 0.f, sx = 0.f, sxx = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
+                const float2* row = zw + bg_g * ZW_STRIDE + bq * 16;
+                const float xb = a.x - (float)x0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const float2 v = row[i];
+                    const float dxi = xb - (float)i;
+                    const float zx = v.x * dxi;
+                    s0 += v.x; sx += zx; sxx += zx * dxi;
+                    k0 += v.y * rg0[i]; k1 += v.y * rg1[i]; k2 += v.y * rg2[i];
+                }
+                float o[9] = {k0, k1, k2, s0, sx, dyr * s0, sxx, dyr * sx, dyr * dyr * s0};
+#pragma unroll
+                for (int v = 0; v < 9; v++) {
+                    o[v] += __shfl_xor(o[v], 16);
+                    o[v] += __shfl_xor(o[v], 32);
+                }
+                if (bq == 0) {
+                    float* dst = sh.part[sb + bg_g];
+#pragma unroll
+                    for (int v = 0; v < 9; v++) atomicAdd(&dst[v], o[v]);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        // flush this batch: 4 lanes per Gaussian, 3 values each; untouched Gaussians cost nothing
+        {
+            const int g = tid >> 2, cpart = tid & 3;
+            if (g < nb && cpart < 3) {
+                float* src = &sh.part[g][cpart * 3];
+                float* dst = acc + (size_t)sh.id[g] * 12 + cpart * 3;
+#pragma unroll
+                for (int v = 0; v < 3; v++) {
+                    const float val = src[v];
+                    if (val != 0.f) { atomicAdd(&dst[v], val); src[v] = 0.f; }
+                }
             }
         }
+        __syncthreads();
     }
 }
 
@@ -228,9 +290,8 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
 
 void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, const float* final_T, const uint32_t* n_contrib,
-                          const uint32_t* tile_maxc, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
-                          float* dL_dopacity, float* dL_dcolor, hipStream_t s)
+                          const uint32_t* tile_maxc, const float* dL_dpix, float* acc, hipStream_t s)
 {
     hipLaunchKernelGGL(k_blend_bwd, dim3(gx * gy), dim3(256), 0, s, W, H, gx, tile_start, point_list, rec, bg, final_T,
-                       n_contrib, tile_maxc, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+                       n_contrib, tile_maxc, dL_dpix, acc);
 }

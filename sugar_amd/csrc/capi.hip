@@ -90,7 +90,7 @@ extern "C" {
 int sgr_abi_version(void) { return SGR_ABI_VERSION; }
 const char* sgr_last_error(void) { return g_err.c_str(); }
 
-size_t sgr_geom_bytes(int P) { return sgr_align((size_t)(P > 0 ? P : 1) * sizeof(GeomRec)); }
+size_t sgr_geom_bytes(int P) { return sgr_geom_total(P); }
 size_t sgr_img_bytes(int width, int height) { return sgr_img_layout(width, height).total; }
 size_t sgr_binning_bytes(int64_t R) { return sgr_bin_layout(R).total; }
 size_t sgr_geom_rec_offset(int) { return 0; }
@@ -244,19 +244,15 @@ int sgr_backward(int P, int D, int M, int64_t R, const float* background, int wi
     const uint32_t* tile_maxc = reinterpret_cast<const uint32_t*>(img_buffer + IL.tile_maxc);
     const uint32_t* point_list = reinterpret_cast<const uint32_t*>(binning_buffer + BL.point_list);
 
-    // the blend backward accumulates with atomics: its four targets start from zero
-    HIP_TRY(hipMemsetAsync(dL_dmean2D, 0, (size_t)P * 3 * 4, s));
-    HIP_TRY(hipMemsetAsync(dL_dconic, 0, (size_t)P * 4 * 4, s));
-    HIP_TRY(hipMemsetAsync(dL_dopacity, 0, (size_t)P * 4, s));
-    HIP_TRY(hipMemsetAsync(dL_dcolor, 0, (size_t)P * 3 * 4, s));
+    // the blend backward accumulates nine sums per Gaussian with atomics into the private acc[P][12] table
+    float* acc = reinterpret_cast<float*>(geom_buffer + sgr_geom_acc_offset(P));
+    HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * 48, s));
     if (R > 0) {
-        {
-            StageTimer t(s, SGR_STAGE_BLEND_BWD);
-            sgr_launch_blend_bwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
-                                 tile_maxc, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, s);
-        }
-        STAGE_CHECK("blend_bwd");
+        StageTimer t(s, SGR_STAGE_BLEND_BWD);
+        sgr_launch_blend_bwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
+                             tile_maxc, dL_dpix, acc, s);
     }
+    STAGE_CHECK("blend_bwd");
     PreprocessBwdArgs pb;
     pb.P = P; pb.D = D; pb.M = use_sh ? M : 0;
     pb.means3D = means3D; pb.shs = use_sh ? shs : nullptr;
@@ -267,7 +263,8 @@ int sgr_backward(int P, int D, int M, int64_t R, const float* background, int wi
     pb.focal_y = height / (2.0f * tan_fovy);
     pb.focal_x = width / (2.0f * tan_fovx);
     pb.rec = rec;
-    pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dcolor = dL_dcolor;
+    pb.acc = acc;
+    pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_dsh = use_sh ? dL_dsh : nullptr;
     pb.dL_dscale = cov3D_precomp ? nullptr : dL_dscale; pb.dL_drot = cov3D_precomp ? nullptr : dL_drot;
     { StageTimer t(s, SGR_STAGE_PREPROCESS_BWD); sgr_launch_preprocess_bwd(pb, s); }

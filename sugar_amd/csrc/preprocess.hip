@@ -307,6 +307,10 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
     float dmean[3] = {0, 0, 0}, dcov[6] = {0, 0, 0, 0, 0, 0};
     const int n_sh = a.M * 3;
     if (!(radius > 0)) {
+        a.dL_dmean2D[i3] = 0; a.dL_dmean2D[i3 + 1] = 0; a.dL_dmean2D[i3 + 2] = 0;
+        { float4 z4 = {0, 0, 0, 0}; *reinterpret_cast<float4*>(a.dL_dconic + 4 * (size_t)idx) = z4; }
+        a.dL_dopacity[idx] = 0;
+        a.dL_dcolor[i3] = 0; a.dL_dcolor[i3 + 1] = 0; a.dL_dcolor[i3 + 2] = 0;
         a.dL_dmean3D[i3] = 0; a.dL_dmean3D[i3 + 1] = 0; a.dL_dmean3D[i3 + 2] = 0;
         for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = 0;
         if (a.dL_dsh) for (int k = 0; k < n_sh; k++) a.dL_dsh[(size_t)idx * n_sh + k] = 0;
@@ -327,10 +331,26 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
         q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
         cov3d_from_scale_rot(sc, a.scale_modifier, q, c6);
     }
+    // ---- finish the blend backward: apply the per-Gaussian coefficients of backward.cu:538-554 to the nine sums
+    float dcol[3], dm2x, dm2y;
+    float g0, g1, g3;
+    {
+        const float4* ap = reinterpret_cast<const float4*>(a.acc + 12 * (size_t)idx);
+        const float4 s0 = ap[0], s1 = ap[1], s2 = ap[2];  // {k0,k1,k2,S0} {Sx,Sy,Sxx,Sxy} {Syy,-,-,-}
+        const float op = rp->opacity, cx = rp->cx, cy = rp->cy, cz = rp->cz;
+        dcol[0] = s0.x; dcol[1] = s0.y; dcol[2] = s0.z;
+        const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+        dm2x = -(op * ddelx_dx) * (cx * s1.x + cy * s1.y);
+        dm2y = -(op * ddely_dy) * (cz * s1.y + cy * s1.x);
+        g0 = -0.5f * op * s1.z; g1 = -0.5f * op * s1.w; g3 = -0.5f * op * s2.x;
+        a.dL_dmean2D[i3] = dm2x; a.dL_dmean2D[i3 + 1] = dm2y; a.dL_dmean2D[i3 + 2] = 0;
+        float4 gc = {g0, g1, 0.f, g3};
+        *reinterpret_cast<float4*>(a.dL_dconic + 4 * (size_t)idx) = gc;
+        a.dL_dopacity[idx] = s0.w;
+        a.dL_dcolor[i3] = dcol[0]; a.dL_dcolor[i3 + 1] = dcol[1]; a.dL_dcolor[i3 + 2] = dcol[2];
+    }
     // ---- K9, backward.cu:144-274
     {
-        const float4 gc = *reinterpret_cast<const float4*>(a.dL_dconic + 4 * (size_t)idx);
-        float g0 = gc.x, g1 = gc.y, g3 = gc.w;
         float T[2][3], txtz, tytz; V3 t;
         compute_T(mean, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, v, T, t, txtz, tytz);
         const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
@@ -380,7 +400,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
         float m_w = 1.0f / (hw + 0.0000001f);
         float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
         float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-        float gx = a.dL_dmean2D[i3], gy = a.dL_dmean2D[i3 + 1];
+        float gx = dm2x, gy = dm2y;
         float ddx = (proj[0] * m_w - proj[3] * mul1) * gx + (proj[1] * m_w - proj[3] * mul2) * gy;
         float ddy = (proj[4] * m_w - proj[7] * mul1) * gx + (proj[5] * m_w - proj[7] * mul2) * gy;
         float ddz = (proj[8] * m_w - proj[11] * mul1) * gx + (proj[9] * m_w - proj[11] * mul2) * gy;
@@ -401,7 +421,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
         for (int c = 0; c < 3; c++) {
 #define SH(k) sh[3 * (k) + c]
 #define DSH(k) dsh[3 * (k) + c]
-            float dL_dRGB = a.dL_dcolor[i3 + c] * (((clamped >> c) & 1u) ? 0.0f : 1.0f);
+            float dL_dRGB = dcol[c] * (((clamped >> c) & 1u) ? 0.0f : 1.0f);
             float dRGBdx = 0, dRGBdy = 0, dRGBdz = 0;
             DSH(0) = SH_C0 * dL_dRGB;
             if (deg > 0) {

@@ -11,7 +11,8 @@
 #define SGR_BIN_LDS_MAX (150 * 1024) // largest per-workgroup tile histogram kept in LDS (160 KB per CU)
 
 // ---- private scratch layouts -----------------------------------------------------------------
-// geom  : [ GeomRec rec[P] ]                                   48 B / Gaussian (AoS: one gather = 1-2 lines)
+// geom  : [ GeomRec rec[P] | acc f32[P][12] ]   48 B / Gaussian record (AoS: one gather = 1-2 lines) + the
+//                                                backward's per-Gaussian accumulator (zeroed by each backward)
 // img   : [ final_T f32[WH] | n_contrib u32[WH] | tile_start u32[T+1] | tile_cursor u32[T] |
 //           tile_maxc u32[T] | tile_walked u32[T] | header u32[8] | blk_hist u32[n_blocks][T] ]
 // binning: [ keys u64[R] | point_list u32[R] ]
@@ -25,6 +26,8 @@ struct GeomRec {
 static_assert(sizeof(GeomRec) == 48, "GeomRec must be 48 bytes");
 
 static inline size_t sgr_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline size_t sgr_geom_acc_offset(int P) { return sgr_align((size_t)(P > 0 ? P : 1) * 48); }
+static inline size_t sgr_geom_total(int P) { return sgr_geom_acc_offset(P) + sgr_align((size_t)(P > 0 ? P : 1) * 48); }
 
 struct ImgLayout {
     size_t final_T, n_contrib, tile_start, tile_cursor, tile_maxc, tile_walked, header, blk_hist, total;
@@ -92,7 +95,8 @@ struct PreprocessBwdArgs {
     const float* cov3D_precomp; const float* viewmatrix; const float* projmatrix; const float* cam_pos;
     int W, H; float tan_fovx, tan_fovy, focal_x, focal_y;
     const GeomRec* rec;
-    const float* dL_dmean2D; const float* dL_dconic; const float* dL_dcolor;
+    const float* acc;  // [P][12] sums from the blend backward: {dcol r,g,b, S0, Sx, Sy, Sxx, Sxy, Syy, pad x3}
+    float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor;  // written here from acc
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
 };
 void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
@@ -109,5 +113,4 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
                           uint32_t* tile_walked, float* out_color, hipStream_t s);
 void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, const float* final_T, const uint32_t* n_contrib,
-                          const uint32_t* tile_maxc, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
-                          float* dL_dopacity, float* dL_dcolor, hipStream_t s);
+                          const uint32_t* tile_maxc, const float* dL_dpix, float* acc, hipStream_t s);
