@@ -134,6 +134,16 @@ int sgr_l1_ssim_forward(int channels, int width, int height, const float* img, c
 int sgr_l1_ssim_backward(int channels, int width, int height, const float* img, const float* gt, float lambda,
                          const char* scratch, const float* grad_loss, float* grad_img, void* stream);
 
+/* ---- one-launch Adam over a flat parameter buffer -----------------------------------------------
+ * torch.optim.Adam semantics (eps inside the bias-corrected denominator, no weight decay / amsgrad) as configured by
+ * gaussian_splatting/scene/gaussian_model.py:152-166.  n (multiple of 4) floats in params / grads / exp_avg / exp_avg_sq;
+ * the learning rate of element i is given by up to 8 segments k (HOST arrays): for seg_begin[k] <= i < seg_end[k] it is
+ * seg_lr_a[k] when (i - seg_begin[k]) % seg_period[k] < seg_split[k], else seg_lr_b[k]; elements in no segment keep
+ * lr 0 (their moments still update).  `step` is the 1-based step count used for bias correction. */
+int sgr_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n_seg,
+                  const long long* seg_begin, const long long* seg_end, const float* seg_lr_a, const float* seg_lr_b,
+                  const int* seg_period, const int* seg_split, float beta1, float beta2, float eps, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

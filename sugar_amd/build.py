@@ -26,6 +26,7 @@ SOURCES = {
     "blend.hip": [],
     "knn.hip": ["-ffp-contract=off"],
     "loss.hip": [],
+    "adam.hip": [],
     "capi.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

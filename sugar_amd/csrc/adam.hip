@@ -1,0 +1,82 @@
+// adam.hip -- one-launch Adam over the flat parameter buffer of the train step (gfx950).
+//
+// The reference optimises six tensors with torch.optim.Adam(lr per group, eps=1e-15)
+// (gaussian_splatting/scene/gaussian_model.py:152-166; learning rates arguments/__init__.py:74-83), i.e. the update
+//     m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
+// Here all parameters live in ONE contiguous float buffer (sugar_amd/train_step.py: GaussianParams.flat), so the step is a
+// single HBM-streaming kernel: 16 B read + 12 B written per parameter, float4-vectorised, no per-tensor launches.  The
+// learning rate is a function of the element index through a small segment table; inside a segment it may alternate
+// with a period (the SH tensor [P,M,3] has lr_a for the 3 DC coefficients and lr_b for the other 3*(M-1) of every
+// Gaussian: feature_lr and feature_lr/20).
+#include "../../include/sugar_raster.h"
+#include "sgr_common.h"
+
+namespace {
+
+#define ADAM_MAX_SEG 8
+struct AdamSegs {
+    int n;
+    long long begin[ADAM_MAX_SEG], end[ADAM_MAX_SEG];
+    float lr_a[ADAM_MAX_SEG], lr_b[ADAM_MAX_SEG];
+    int period[ADAM_MAX_SEG], split[ADAM_MAX_SEG];
+};
+
+__device__ __forceinline__ float lr_of(const AdamSegs& sg, long long i)
+{
+    float lr = 0.f;
+#pragma unroll
+    for (int k = 0; k < ADAM_MAX_SEG; k++)
+        if (k < sg.n && i >= sg.begin[k] && i < sg.end[k])
+            lr = ((int)((i - sg.begin[k]) % sg.period[k]) < sg.split[k]) ? sg.lr_a[k] : sg.lr_b[k];
+    return lr;
+}
+
+__global__ void __launch_bounds__(256) k_adam(long long n4, float4* __restrict__ p, const float4* __restrict__ g,
+                                              float4* __restrict__ m, float4* __restrict__ v, AdamSegs sg, float b1, float b2,
+                                              float eps, float bc1, float bc2_sqrt)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 gg = g[i];
+        float4 pp = p[i], mm = m[i], vv = v[i];
+        float* pf = reinterpret_cast<float*>(&pp);
+        float* mf = reinterpret_cast<float*>(&mm);
+        float* vf = reinterpret_cast<float*>(&vv);
+        const float* gf = reinterpret_cast<const float*>(&gg);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const float lr = lr_of(sg, 4 * i + c);
+            mf[c] = b1 * mf[c] + (1.f - b1) * gf[c];
+            vf[c] = b2 * vf[c] + (1.f - b2) * gf[c] * gf[c];
+            const float denom = sqrtf(vf[c]) / bc2_sqrt + eps;
+            pf[c] -= (lr / bc1) * (mf[c] / denom);
+        }
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+}  // namespace
+
+extern "C" int sgr_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n_seg,
+                             const long long* seg_begin, const long long* seg_end, const float* seg_lr_a,
+                             const float* seg_lr_b, const int* seg_period, const int* seg_split, float beta1, float beta2,
+                             float eps, int step, void* stream)
+{
+    if (n <= 0) return 0;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n_seg < 0 || n_seg > ADAM_MAX_SEG || step < 1 || (n & 3)) return SGR_E_INVALID;
+    AdamSegs sg;
+    sg.n = n_seg;
+    for (int k = 0; k < ADAM_MAX_SEG; k++) {
+        const bool on = k < n_seg;
+        sg.begin[k] = on ? seg_begin[k] : 0; sg.end[k] = on ? seg_end[k] : 0;
+        sg.lr_a[k] = on ? seg_lr_a[k] : 0.f; sg.lr_b[k] = on ? seg_lr_b[k] : 0.f;
+        sg.period[k] = on && seg_period[k] > 0 ? seg_period[k] : 1; sg.split[k] = on ? seg_split[k] : 1;
+    }
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    const long long n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n4, reinterpret_cast<float4*>(params),
+                       reinterpret_cast<const float4*>(grads), reinterpret_cast<float4*>(exp_avg),
+                       reinterpret_cast<float4*>(exp_avg_sq), sg, beta1, beta2, eps, bc1, bc2_sqrt);
+    return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
+}

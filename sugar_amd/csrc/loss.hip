@@ -29,7 +29,7 @@ __device__ __forceinline__ float ld_pad(const float* __restrict__ img, int W, in
 
 __global__ void __launch_bounds__(256) k_l1_ssim_fwd(int W, int H, const float* __restrict__ X, const float* __restrict__ Y,
                                                      Win win, float* __restrict__ dm1, float* __restrict__ ds1,
-                                                     float* __restrict__ ds12, double* __restrict__ acc)
+                                                     float* __restrict__ ds12, float2* __restrict__ partial)
 {
     __shared__ float sx[LR][LR + 1];
     __shared__ float sy[LR][LR + 1];
@@ -87,18 +87,30 @@ __global__ void __launch_bounds__(256) k_l1_ssim_fwd(int W, int H, const float* 
     for (int o = 32; o > 0; o >>= 1) { s_val += __shfl_xor(s_val, o); l1_val += __shfl_xor(l1_val, o); }
     if ((tid & 63) == 0) { red[0][tid >> 6] = s_val; red[1][tid >> 6] = l1_val; }
     __syncthreads();
+    // one partial per workgroup; k_l1_ssim_finish adds them in double (24k same-address device atomics cost 0.5 ms)
     if (tid == 0) {
-        atomicAdd(&acc[0], (double)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
-        atomicAdd(&acc[1], (double)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
+        const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partial[blk] = make_float2(red[0][0] + red[0][1] + red[0][2] + red[0][3], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
     }
 }
 
-__global__ void k_l1_ssim_finish(const double* __restrict__ acc, double n, float lambda, float* __restrict__ loss)
+__global__ void __launch_bounds__(1024) k_l1_ssim_finish(const float2* __restrict__ partial, int n_partial, double n,
+                                                         float lambda, float* __restrict__ loss)
 {
-    const double ssim_mean = acc[0] / n, l1_mean = acc[1] / n;
-    loss[0] = (float)((1.0 - (double)lambda) * l1_mean + (double)lambda * (1.0 - ssim_mean));
-    loss[1] = (float)l1_mean;
-    loss[2] = (float)ssim_mean;
+    __shared__ double s0[16], s1[16];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < n_partial; i += 1024) { const float2 v = partial[i]; a += (double)v.x; b += (double)v.y; }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if ((threadIdx.x & 63) == 0) { s0[threadIdx.x >> 6] = a; s1[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ssim_sum = 0.0, l1_sum = 0.0;
+        for (int w = 0; w < 16; w++) { ssim_sum += s0[w]; l1_sum += s1[w]; }
+        const double ssim_mean = ssim_sum / n, l1_mean = l1_sum / n;
+        loss[0] = (float)((1.0 - (double)lambda) * l1_mean + (double)lambda * (1.0 - ssim_mean));
+        loss[1] = (float)l1_mean;
+        loss[2] = (float)ssim_mean;
+    }
 }
 
 __global__ void __launch_bounds__(256) k_l1_ssim_bwd(int W, int H, const float* __restrict__ X, const float* __restrict__ Y,
@@ -165,7 +177,8 @@ extern "C" {
 
 size_t sgr_l1_ssim_scratch_bytes(int channels, int width, int height)
 {
-    return sgr_align((size_t)channels * width * height * 4) * 3 + 256;
+    const size_t blocks = (size_t)((width + LT - 1) / LT) * ((height + LT - 1) / LT) * channels;
+    return sgr_align((size_t)channels * width * height * 4) * 3 + sgr_align(blocks * sizeof(float2));
 }
 
 int sgr_l1_ssim_forward(int channels, int width, int height, const float* img, const float* gt, float lambda,
@@ -177,11 +190,11 @@ int sgr_l1_ssim_forward(int channels, int width, int height, const float* img, c
     float* dm1 = reinterpret_cast<float*>(scratch);
     float* ds1 = reinterpret_cast<float*>(scratch + plane);
     float* ds12 = reinterpret_cast<float*>(scratch + 2 * plane);
-    double* acc = reinterpret_cast<double*>(scratch + 3 * plane);
-    if (hipMemsetAsync(acc, 0, 16, s) != hipSuccess) return SGR_E_HIP;
+    float2* partial = reinterpret_cast<float2*>(scratch + 3 * plane);
     dim3 grid((width + LT - 1) / LT, (height + LT - 1) / LT, channels);
-    hipLaunchKernelGGL(k_l1_ssim_fwd, grid, dim3(256), 0, s, width, height, img, gt, make_window(), dm1, ds1, ds12, acc);
-    hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(1), 0, s, acc, (double)channels * width * height, lambda, loss_out);
+    hipLaunchKernelGGL(k_l1_ssim_fwd, grid, dim3(256), 0, s, width, height, img, gt, make_window(), dm1, ds1, ds12, partial);
+    hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(1024), 0, s, partial, (int)(grid.x * grid.y * grid.z),
+                       (double)channels * width * height, lambda, loss_out);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 

@@ -76,23 +76,28 @@ def train_loss(image, gt, lambda_dssim=0.2, fused=True):
 
 # ---------------------------------------------------------------- parameters
 class GaussianParams:
-    """Raw (pre-activation) 3DGS parameters, 59 floats per Gaussian at SH degree 3, stored as views of ONE flat
-    buffer so that the data-parallel gradient exchange is a single all-reduce of one contiguous tensor."""
+    """Raw (pre-activation) 3DGS parameters, 59 floats per Gaussian at SH degree 3, stored as views of ONE flat buffer:
+    the data-parallel gradient exchange is a single all-reduce of one contiguous tensor and the optimiser a single
+    streaming kernel.  The SH coefficients are ONE [P,M,3] tensor (the layout the rasterizer consumes); the reference keeps
+    f_dc / f_rest apart and torch.cat()s them every step (gaussian_model.py:108-111: 192 MB of copies per step at 1M)."""
 
-    NAMES = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
-    LRS = dict(xyz=0.00016, f_dc=0.0025, f_rest=0.0025 / 20.0, opacity=0.05, scaling=0.005, rotation=0.001)
+    NAMES = ("xyz", "features", "opacity", "scaling", "rotation")
+    # arguments/__init__.py:74-83 (position lr at its initial value; f_rest runs at feature_lr / 20, gaussian_model.py:158)
+    LRS = dict(xyz=0.00016, features=0.0025, opacity=0.05, scaling=0.005, rotation=0.001)
+    REST_LR = 0.0025 / 20.0
 
     def __init__(self, scene, device):
         P = scene.means3D.shape[0]
         M = scene.shs.shape[1]
         self.P, self.M = P, M
-        shapes = dict(xyz=(P, 3), f_dc=(P, 1, 3), f_rest=(P, M - 1, 3), opacity=(P, 1), scaling=(P, 3), rotation=(P, 4))
+        shapes = dict(xyz=(P, 3), features=(P, M, 3), opacity=(P, 1), scaling=(P, 3), rotation=(P, 4))
         sizes = {k: int(torch.tensor(v).prod()) for k, v in shapes.items()}
         # keep every view 256-byte aligned inside the flat buffer (vector loads in the kernels)
         offs, off = {}, 0
         for k in self.NAMES:
             offs[k] = off
             off += (sizes[k] + 63) // 64 * 64
+        self.offsets, self.sizes = offs, sizes
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
         self.flat_grad = torch.zeros(off, dtype=torch.float32, device=device)
         self.params = {}
@@ -103,25 +108,74 @@ class GaussianParams:
             self.params[k] = v
         with torch.no_grad():
             self.params["xyz"].copy_(scene.means3D)
-            self.params["f_dc"].copy_(scene.shs[:, :1])
-            self.params["f_rest"].copy_(scene.shs[:, 1:])
+            self.params["features"].copy_(scene.shs)
             o = scene.opacities.clamp(1e-6, 1 - 1e-6)
             self.params["opacity"].copy_(torch.log(o / (1 - o)))  # inverse sigmoid
             self.params["scaling"].copy_(torch.log(scene.scales))
             self.params["rotation"].copy_(scene.rotations)
 
     def activated(self):
-        """gaussian_model.py:92-117: exp / normalize / sigmoid / cat"""
+        """gaussian_model.py:92-117: exp / normalize / sigmoid"""
         p = self.params
         return dict(means3D=p["xyz"], scales=torch.exp(p["scaling"]), rotations=F.normalize(p["rotation"]),
-                    opacities=torch.sigmoid(p["opacity"]), shs=torch.cat((p["f_dc"], p["f_rest"]), dim=1))
+                    opacities=torch.sigmoid(p["opacity"]), shs=p["features"])
 
     def make_optimizer(self):
-        groups = [{"params": [self.params[k]], "lr": self.LRS[k], "name": k} for k in self.NAMES]
-        try:
-            return torch.optim.Adam(groups, lr=0.0, eps=1e-15, fused=self.flat.is_cuda)
-        except (RuntimeError, TypeError):
-            return torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        return FlatAdam(self) if self.flat.is_cuda else _torch_adam(self)
+
+
+def _torch_adam(params: GaussianParams):
+    """Stock torch.optim.Adam with the reference's six groups (gaussian_model.py:152-166); f_dc / f_rest are strided views
+    of the single SH tensor.  Used on CPU (tests) and as the parity reference of FlatAdam."""
+    p = params.params
+    feat = p["features"]
+    with torch.no_grad():
+        f_dc, f_rest = feat[:, :1], feat[:, 1:]
+    f_dc.grad, f_rest.grad = feat.grad[:, :1], feat.grad[:, 1:]
+    groups = [{"params": [p["xyz"]], "lr": params.LRS["xyz"], "name": "xyz"},
+              {"params": [f_dc], "lr": params.LRS["features"], "name": "f_dc"},
+              {"params": [f_rest], "lr": params.REST_LR, "name": "f_rest"},
+              {"params": [p["opacity"]], "lr": params.LRS["opacity"], "name": "opacity"},
+              {"params": [p["scaling"]], "lr": params.LRS["scaling"], "name": "scaling"},
+              {"params": [p["rotation"]], "lr": params.LRS["rotation"], "name": "rotation"}]
+    return torch.optim.Adam(groups, lr=0.0, eps=1e-15, foreach=False)
+
+
+class FlatAdam:
+    """One-launch Adam over GaussianParams.flat (sugar_amd/csrc/adam.hip) with the same per-group learning rates."""
+
+    def __init__(self, params: GaussianParams, betas=(0.9, 0.999), eps=1e-15):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib = C, _lib.load()
+        self.params = params
+        self.betas, self.eps, self.t = betas, eps, 0
+        self.exp_avg = torch.zeros_like(params.flat)
+        self.exp_avg_sq = torch.zeros_like(params.flat)
+        segs = []
+        for k in params.NAMES:
+            b, e = params.offsets[k], params.offsets[k] + params.sizes[k]
+            if k == "features":
+                segs.append((b, e, params.LRS[k], params.REST_LR, 3 * params.M, 3))
+            else:
+                segs.append((b, e, params.LRS[k], params.LRS[k], 1, 1))
+        n = len(segs)
+        self._seg = ((C.c_longlong * n)(*[s[0] for s in segs]), (C.c_longlong * n)(*[s[1] for s in segs]),
+                     (C.c_float * n)(*[s[2] for s in segs]), (C.c_float * n)(*[s[3] for s in segs]),
+                     (C.c_int * n)(*[s[4] for s in segs]), (C.c_int * n)(*[s[5] for s in segs]))
+        self._n = n
+
+    def step(self):
+        C, p = self._C, self.params
+        self.t += 1
+        dev = p.flat.device
+        with torch.cuda.device(dev):
+            rc = self._lib.sgr_adam_step(p.flat.numel(), C.c_void_p(p.flat.data_ptr()), C.c_void_p(p.flat_grad.data_ptr()),
+                                         C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()), self._n,
+                                         *self._seg, self.betas[0], self.betas[1], self.eps, self.t,
+                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc < 0:
+            raise RuntimeError(f"sgr_adam_step failed ({rc})")
 
 
 def render(params: GaussianParams, cam, bg, rasterizer_cls, settings_cls, sh_degree=3, debug=False):

@@ -68,6 +68,7 @@ def test_flat_parameter_views_and_grads_alias():
     scene = syn.make_scene(10, 1, 0.01, 0.1)
     p = GaussianParams(scene, torch.device("cpu"))
     assert sum(v.numel() for v in p.params.values()) == 10 * 59
+    assert p.params["features"].shape == (10, 16, 3)
     p.params["xyz"].grad.fill_(3.0)
     assert float(p.flat_grad.sum()) == 3.0 * 30
     a = p.activated()
