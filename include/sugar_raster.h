@@ -102,8 +102,8 @@ size_t sgr_img_tile_walked_offset(int width, int height);/* uint32[T]: furthest 
 size_t sgr_binning_point_list_offset(int64_t R);        /* uint32[R]: Gaussian ids, tile-major, depth order */
 
 /* ---- optional per-stage timing (HIP events recorded on the caller's stream, process-wide) --
- * Stages: 0 preprocess, 1 tile scan, 2 scatter, 3 per-tile sort, 4 blend forward, 5 blend backward,
- * 6 preprocess backward.  sgr_profile_read synchronises the recorded events, returns the summed
+ * Stages: 0 preprocess, 1 ordered tile count + scans, 2 ordered scatter into the tile lists, 3 global depth sort of
+ * the Gaussians, 4 blend forward, 5 blend backward, 6 preprocess backward.  sgr_profile_read synchronises the recorded events, returns the summed
  * milliseconds and launch counts per stage since the last read, and clears the record. */
 #define SGR_N_STAGES 7
 void sgr_profile_enable(int on);

@@ -1,30 +1,218 @@
-// binning.hip -- per-tile binning for gfx950: tile scan, bucket scatter, per-tile depth sort.
+// binning.hip -- depth-ordered tile binning for gfx950.
 //
-// Replaces the reference's global pipeline
-//   cub::DeviceScan::InclusiveSum over P Gaussians      DGR/cuda_rasterizer/rasterizer_impl.cu:277
-//   duplicateWithKeys  (64-bit tile|depth keys)          :70-111
-//   cub::DeviceRadixSort::SortPairs over R instances     :303-308   (6 passes x 24 B x R at 1080p)
-//   cudaMemset + identifyTileRanges                      :310-317, :116-138
-// with a multi-workgroup counting sort on the tile id followed by an independent in-LDS sort of each tile's bucket.
-// No global atomics: workgroup b of a persistent grid owns a contiguous slice of Gaussians and a private LDS histogram.
-//   (preprocess): blk_hist[b][t] = instances of tile t among workgroup b's Gaussians          (LDS atomics)
-//   hist_scan  : column-wise exclusive scan over b (in place) + per-tile totals
-//   tile_scan  : exclusive scan of the totals -> tile_start[T+1]; ranges fall out for free; R and the largest count
-//   scatter    : workgroup b re-walks its slice; slot = tile_start[t] + blk_hist[b][t] + (LDS atomic rank); stores the
-//                64-bit key (depth_bits << 32 | gaussian_id).  A workgroup's instances of a tile are contiguous.
-//   tile_sort  : one workgroup per tile sorts its bucket in LDS (bitonic network on u64 keys) and writes the ids.
-// HBM traffic per instance: 8 B scatter + 8 B read + 4 B write (+ 16 B per (workgroup, tile) of histogram traffic),
-// versus ~144 B per instance for the 6-pass radix sort of 12-byte pairs.
+// Replaces the reference's instance-level pipeline
+//   cub::DeviceScan::InclusiveSum over P Gaussians       DGR/cuda_rasterizer/rasterizer_impl.cu:277
+//   duplicateWithKeys  (64-bit tile|depth key per instance) :70-111
+//   cub::DeviceRadixSort::SortPairs over R instances      :303-308   (6 passes x 24 B x R; R ~ 19 P at 1080p)
+//   cudaMemset + identifyTileRanges                       :310-317, :116-138
+// by sorting the P GAUSSIANS by depth once and then binning them into tiles IN THAT ORDER with a stable counting sort,
+// so every tile's list comes out depth-sorted and no per-instance sort exists at all:
 //
-// Order contract: within a tile the reference's stable sort orders by depth bits, ties by ascending
-// Gaussian index (the emission order of duplicateWithKeys).  Sorting the composite key
-// (depth_bits << 32 | id) reproduces that order exactly and makes the result independent of the order
-// in which the scatter's atomics were served.
+//   gsort      : stable LSD radix sort (4 x 8-bit passes) of (depth_bits, gaussian_id) over the P Gaussians.  Culled
+//                Gaussians carry key 0xFFFFFFFF and sink to the end.  Ties keep ascending id.
+//   bin_count  : a persistent grid of single-wave workgroups; workgroup b owns a contiguous slice of the sorted order and
+//                a private histogram over all T tiles in LDS.  The wave takes its Gaussians ONE AT A TIME, in order, and
+//                spreads that Gaussian's tile rectangle over its 64 lanes (LDS atomics on distinct tiles).
+//   hist_scan  : column-wise exclusive scan over b of blk_hist[b][t] (in place) + per-tile totals
+//   tile_scan  : exclusive scan of the totals -> tile_start[T+1] (the ranges), R, largest tile count
+//   bin_scatter: same walk as bin_count; slot = tile_start[t] + blk_hist[b][t] + (running LDS counter) and the Gaussian id
+//                goes straight into point_list.  Slices are ordered, a wave processes its slice sequentially, and one
+//                Gaussian never hits a tile twice, so the per-tile order is exactly the sorted order.
+//
+// Order contract: the reference's stable radix sort orders a tile's list by depth bits, ties by ascending Gaussian index
+// (emission order of duplicateWithKeys).  (depth_bits, id) ascending is the same order -- verified bit-exactly against the
+// oracle and against the reference's own code (tests/test_gpu_parity.py, tests/test_gpu_reference.py).
+//
+// HBM traffic: ~100 B per Gaussian for the sort, 4 B per instance for point_list, 16 B per (workgroup, tile) of histogram
+// traffic -- versus ~144 B per INSTANCE for the reference's 6-pass radix sort of 12-byte pairs.  No global atomics.
 #include "sgr_device.h"
 
 namespace {
 
-// ---- tile scan: one 1024-thread workgroup, T <= a few 10^4 -----------------------------------
+#define WAVE_FENCE()                                          \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                      \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Global stable radix sort of (u32 key, u32 value) pairs, 8 bits per pass.
+// ---------------------------------------------------------------------------------------------------------------------
+#define RS_ITEMS 2048  // keys per workgroup chunk
+
+// per-chunk digit histogram, written digit-major: hist[digit * n_chunks + chunk]
+__global__ void __launch_bounds__(256) k_rs_hist(int n, const uint32_t* __restrict__ keys, int shift, int n_chunks,
+                                                 uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RS_ITEMS;
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS / 256; i++) {
+        const int k = base + i * 256 + threadIdx.x;
+        if (k < n) atomicAdd(&s_h[(keys[k] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * n_chunks + blockIdx.x] = s_h[threadIdx.x];
+}
+
+// exclusive scan of a flat u32 array in place (single 1024-thread workgroup; n <= a few 10^5)
+__global__ void __launch_bounds__(1024) k_scan_inplace(int n, uint32_t* __restrict__ a)
+{
+    __shared__ uint32_t s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int b = tid * per, e = min(n, b + per);
+    uint32_t sum = 0;
+    for (int i = b; i < e; i++) sum += a[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        uint32_t v = (tid >= o) ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - sum;
+    for (int i = b; i < e; i++) { const uint32_t v = a[i]; a[i] = run; run += v; }
+}
+
+// One wave per chunk walks its keys 64 at a time IN ORDER.  Within a group of 64 the rank among equal digits comes from
+// eight ballots (wave-wide match); across groups a per-digit running offset lives in LDS.  Stable by construction.
+__global__ void __launch_bounds__(64) k_rs_scatter(int n, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                   uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int shift,
+                                                   int n_chunks, const uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t s_off[256];
+    const int lane = threadIdx.x;
+    for (int d = lane; d < 256; d += 64) s_off[d] = hist[(size_t)d * n_chunks + blockIdx.x];
+    WAVE_FENCE();
+    const int base = blockIdx.x * RS_ITEMS;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int g = 0; g < RS_ITEMS; g += 64) {
+        const int k = base + g + lane;
+        const bool live = k < n;
+        const unsigned long long live_mask = __ballot(live);
+        if (live_mask == 0ull) break;
+        const uint32_t key = live ? keys_in[k] : 0xFFFFFFFFu;
+        const uint32_t val = live ? (vals_in ? vals_in[k] : (uint32_t)k) : 0u;
+        const uint32_t digit = (key >> shift) & 255u;
+        unsigned long long same = live_mask;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (digit >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            same &= bit ? bal : ~bal;
+        }
+        const uint32_t rank = (uint32_t)__popcll(same & below);
+        const uint32_t cnt = (uint32_t)__popcll(same);
+        uint32_t off = 0;
+        if (live) off = s_off[digit];
+        WAVE_FENCE();
+        if (live) {
+            const uint32_t dst = off + rank;
+            keys_out[dst] = key;
+            vals_out[dst] = val;
+            if (rank == 0) s_off[digit] = off + cnt;
+        }
+        WAVE_FENCE();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Ordered binning (count and scatter share one walk).
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool SCATTER, bool LDS_COUNTERS>
+__global__ void __launch_bounds__(64) k_bin_ordered(int P, int gx, int gy, int per_block, const uint32_t* __restrict__ order,
+                                                    const GeomRec* __restrict__ rec, const uint32_t* __restrict__ tile_start,
+                                                    uint32_t* __restrict__ blk_hist, uint32_t* __restrict__ point_list)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_lds[];
+    const int T = gx * gy;
+    const int lane = threadIdx.x;
+    uint32_t* row = blk_hist + (size_t)blockIdx.x * T;
+    // counters: LDS when the tile grid fits, otherwise this workgroup's private row of blk_hist in global memory
+    uint32_t* cnt = LDS_COUNTERS ? s_lds : row;
+    if (SCATTER) {
+        for (int t = lane; t < T; t += 64) cnt[t] = tile_start[t] + row[t];
+    } else {
+        for (int t = lane; t < T; t += 64) cnt[t] = 0u;
+    }
+    if (!LDS_COUNTERS) __threadfence_block();
+    WAVE_FENCE();
+    const int begin = blockIdx.x * per_block;
+    const int end = min(P, begin + per_block);
+    for (int base = begin; base < end; base += 64) {
+        const int s = base + lane;
+        int id = 0, minx = 0, miny = 0, w = 1, n = 0;
+        if (s < end) {
+            id = (int)order[s];
+            const float4* rp = reinterpret_cast<const float4*>(rec + id);
+            const float4 r2 = rp[2];
+            const int radius = __float_as_int(r2.z);
+            if (radius > 0) {
+                const float4 r0 = rp[0];
+                int maxx, maxy;
+                sgr_get_rect(r0.x, r0.y, radius, gx, gy, minx, miny, maxx, maxy);
+                w = maxx - minx;
+                n = w * (maxy - miny);
+            }
+        }
+        unsigned long long todo = __ballot(n > 0);
+        while (todo) {  // one Gaussian at a time, in sorted order
+            const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+            todo &= todo - 1;
+            const int jn = __builtin_amdgcn_readlane(n, j);
+            const int jw = __builtin_amdgcn_readlane(w, j);
+            const int jx = __builtin_amdgcn_readlane(minx, j);
+            const int jy = __builtin_amdgcn_readlane(miny, j);
+            const uint32_t jid = (uint32_t)__builtin_amdgcn_readlane(id, j);
+            const float inv_w = 1.0f / (float)jw;
+            for (int k = lane; k < jn; k += 64) {
+                const int ty = (int)(((float)k + 0.5f) * inv_w);
+                const int tx = k - ty * jw;
+                const int t = (jy + ty) * gx + jx + tx;
+                if (SCATTER) {
+                    const uint32_t slot = atomicAdd(&cnt[t], 1u);
+                    point_list[slot] = jid;
+                } else {
+                    atomicAdd(&cnt[t], 1u);
+                }
+            }
+            // a Gaussian's tiles are distinct, but the NEXT Gaussian may hit the same tile: keep the walk ordered
+            if (SCATTER) WAVE_FENCE();
+        }
+    }
+    if (!SCATTER && LDS_COUNTERS) {
+        WAVE_FENCE();
+        for (int t = lane; t < T; t += 64) row[t] = cnt[t];
+    }
+}
+
+// ---- column scan of the per-workgroup histograms --------------------------------------------
+// One lane per tile walks the n_blocks rows (coalesced across tiles): blk_hist[b][t] becomes the exclusive prefix over b,
+// tile_count[t] the total.  Loads are issued UNROLL at a time so each lane keeps several rows in flight.
+__global__ void __launch_bounds__(64) k_hist_scan(int T, int n_blocks, uint32_t* __restrict__ blk_hist,
+                                                  uint32_t* __restrict__ tile_count)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= T) return;
+    constexpr int UNROLL = 32;
+    uint32_t run = 0;
+    int b = 0;
+    for (; b + UNROLL <= n_blocks; b += UNROLL) {
+        uint32_t v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) v[u] = blk_hist[(size_t)(b + u) * T + t];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) { blk_hist[(size_t)(b + u) * T + t] = run; run += v[u]; }
+    }
+    for (; b < n_blocks; b++) { const uint32_t v = blk_hist[(size_t)b * T + t]; blk_hist[(size_t)b * T + t] = run; run += v; }
+    tile_count[t] = run;
+}
+
+// ---- tile scan: one 1024-thread workgroup, T <= a few 10^5 -----------------------------------
 __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __restrict__ tile_count,
                                                     uint32_t* __restrict__ tile_start, uint32_t* __restrict__ header)
 {
@@ -36,11 +224,9 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __res
     uint32_t sum = 0, mx = 0;
     for (int i = b; i < e; i++) { uint32_t c = tile_count[i]; sum += c; mx = max(mx, c); }
     s_part[tid] = sum;
-    // wave max
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
     if ((tid & 63) == 0) s_max[tid >> 6] = mx;
     __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
     for (int o = 1; o < 1024; o <<= 1) {
         uint32_t v = (tid >= o) ? s_part[tid - o] : 0;
         __syncthreads();
@@ -59,201 +245,79 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __res
     }
 }
 
-// ---- column scan of the per-workgroup histograms --------------------------------------------
-// One lane per tile walks the n_blocks rows (coalesced across tiles): blk_hist[b][t] becomes the exclusive prefix over b,
-// tile_count[t] the total.  Loads are issued UNROLL at a time so each lane keeps several rows in flight.
-__global__ void __launch_bounds__(256) k_hist_scan(int T, int n_blocks, uint32_t* __restrict__ blk_hist,
-                                                   uint32_t* __restrict__ tile_count)
+template <bool SCATTER>
+void launch_bin(int P, int gx, int gy, int n_blocks, int per_block, bool lds, const uint32_t* order, const GeomRec* rec,
+                const uint32_t* tile_start, uint32_t* blk_hist, uint32_t* point_list, hipStream_t s)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= T) return;
-    constexpr int UNROLL = 16;
-    uint32_t run = 0;
-    int b = 0;
-    for (; b + UNROLL <= n_blocks; b += UNROLL) {
-        uint32_t v[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) v[u] = blk_hist[(size_t)(b + u) * T + t];
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) { blk_hist[(size_t)(b + u) * T + t] = run; run += v[u]; }
-    }
-    for (; b < n_blocks; b++) { const uint32_t v = blk_hist[(size_t)b * T + t]; blk_hist[(size_t)b * T + t] = run; run += v; }
-    tile_count[t] = run;
-}
-
-// ---- scatter ---------------------------------------------------------------------------------
-// LDS variant: persistent grid matching the preprocess kernel's slices.  s_base[t] starts at
-// tile_start[t] + (exclusive prefix of this workgroup's predecessors) and is bumped with returning LDS atomics.
-__global__ void __launch_bounds__(256) k_scatter_lds(int P, int gx, int gy, int per_block, const GeomRec* __restrict__ rec,
-                                                     const uint32_t* __restrict__ tile_start,
-                                                     const uint32_t* __restrict__ blk_hist, uint64_t* __restrict__ keys)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_base[];
-    const int T = gx * gy;
-    const uint32_t* mine = blk_hist + (size_t)blockIdx.x * T;
-    for (int i = threadIdx.x; i < T; i += 256) s_base[i] = tile_start[i] + mine[i];
-    __syncthreads();
-    const int begin = blockIdx.x * per_block;
-    const int end = min(P, begin + per_block);
-    for (int base = begin; base < end; base += 256) {
-        const int idx = base + threadIdx.x;
-        if (idx >= end) continue;
-        const float4* rp = reinterpret_cast<const float4*>(rec + idx);
-        const float4 r2 = rp[2];
-        const int radius = __float_as_int(r2.z);
-        if (!(radius > 0)) continue;
-        const float4 r0 = rp[0];
-        int minx, miny, maxx, maxy;
-        sgr_get_rect(r0.x, r0.y, radius, gx, gy, minx, miny, maxx, maxy);
-        const uint64_t key = ((uint64_t)__float_as_uint(r2.y) << 32) | (uint32_t)idx;
-        for (int y = miny; y < maxy; y++)
-            for (int x = minx; x < maxx; x++) {
-                const uint32_t slot = atomicAdd(&s_base[y * gx + x], 1u);
-                keys[slot] = key;
-            }
-    }
-}
-
-// Fallback (tile histogram too large for LDS): one lane per Gaussian, returning global atomics on a cursor array.
-__global__ void __launch_bounds__(256) k_scatter_atomic(int P, int gx, int gy, const GeomRec* __restrict__ rec,
-                                                        const uint32_t* __restrict__ tile_start,
-                                                        uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys)
-{
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
-    const float4* rp = reinterpret_cast<const float4*>(rec + idx);
-    const float4 r0 = rp[0];
-    const float4 r2 = rp[2];
-    const int radius = __float_as_int(r2.z);
-    if (!(radius > 0)) return;
-    int minx, miny, maxx, maxy;
-    sgr_get_rect(r0.x, r0.y, radius, gx, gy, minx, miny, maxx, maxy);
-    const uint64_t key = ((uint64_t)__float_as_uint(r2.y) << 32) | (uint32_t)idx;
-    for (int y = miny; y < maxy; y++)
-        for (int x = minx; x < maxx; x++) {
-            const int t = y * gx + x;
-            const uint32_t slot = tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
-            keys[slot] = key;
+    const size_t bytes = (size_t)gx * gy * 4;
+    if (lds) {
+        static size_t configured = 0;
+        if (bytes > configured) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_ordered<SCATTER, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            configured = bytes;
         }
-}
-
-// ---- per-tile sort ---------------------------------------------------------------------------
-// Bitonic sorting network for an ARBITRARY count n (no physical padding): the "flip + disperse" form in
-// which every comparator points the same way (min to the lower index).  Positions >= n behave as +inf;
-// since a comparator (i < l) only swaps when s[i] > s[l], a virtual +inf at l never moves, so pairs
-// with l >= n are simply skipped.  Works for LDS and global pointers alike.
-template <int NT, typename Ptr>
-__device__ __forceinline__ void bitonic_sort_n(Ptr s, uint32_t n, int tid)
-{
-    uint32_t N = 1, logN = 0;
-    while (N < n) { N <<= 1; logN++; }
-    for (uint32_t lk = 1; lk <= logN; lk++) {
-        const uint32_t k = 1u << lk, half = k >> 1;
-        for (uint32_t t = tid; t < (N >> 1); t += NT) {  // flip
-            const uint32_t blk = t >> (lk - 1), off = t & (half - 1);
-            const uint32_t i = blk * k + off, l = blk * k + (k - 1 - off);
-            if (l < n) {
-                const uint64_t a = s[i], b = s[l];
-                if (a > b) { s[i] = b; s[l] = a; }
-            }
-        }
-        __syncthreads();
-        for (uint32_t j = k >> 2; j > 0; j >>= 1) {  // disperse
-            for (uint32_t t = tid; t < (N >> 1); t += NT) {
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const uint32_t l = i | j;
-                if (l < n) {
-                    const uint64_t a = s[i], b = s[l];
-                    if (a > b) { s[i] = b; s[l] = a; }
-                }
-            }
-            __syncthreads();
-        }
+        hipLaunchKernelGGL((k_bin_ordered<SCATTER, true>), dim3(n_blocks), dim3(64), bytes, s, P, gx, gy, per_block, order, rec,
+                           tile_start, blk_hist, point_list);
+    } else {
+        hipLaunchKernelGGL((k_bin_ordered<SCATTER, false>), dim3(n_blocks), dim3(64), 0, s, P, gx, gy, per_block, order, rec,
+                           tile_start, blk_hist, point_list);
     }
-}
-
-// Tiles with lo < count <= hi are sorted in LDS by this launch; other tiles exit immediately.
-template <int NT>
-__global__ void __launch_bounds__(NT) k_tile_sort_lds(const uint32_t* __restrict__ tile_start, uint32_t lo, uint32_t hi,
-                                                      const uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
-    const int tile = blockIdx.x;
-    const uint32_t b = tile_start[tile], e = tile_start[tile + 1];
-    const uint32_t n = e - b;
-    if (n <= lo || n > hi) return;
-    const int tid = threadIdx.x;
-    for (uint32_t i = tid; i < n; i += NT) s[i] = keys[b + i];
-    __syncthreads();
-    bitonic_sort_n<NT>(s, n, tid);
-    for (uint32_t i = tid; i < n; i += NT) point_list[b + i] = (uint32_t)s[i];
-}
-
-// Fallback for tiles too large for LDS: the same network directly on the bucket in global memory
-// (one 1024-thread workgroup per tile; slow, only for degenerate scenes).
-__global__ void __launch_bounds__(1024) k_tile_sort_global(const uint32_t* __restrict__ tile_start, uint32_t lo,
-                                                           uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list)
-{
-    const int tile = blockIdx.x;
-    const uint32_t b = tile_start[tile], e = tile_start[tile + 1];
-    const uint32_t n = e - b;
-    if (n <= lo) return;
-    const int tid = threadIdx.x;
-    volatile uint64_t* s = keys + b;
-    bitonic_sort_n<1024>(s, n, tid);
-    for (uint32_t i = tid; i < n; i += 1024) point_list[b + i] = (uint32_t)s[i];
 }
 
 }  // namespace
 
-void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* header, hipStream_t s)
+size_t sgr_sort_scratch_bytes(int P)
 {
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, tile_count, tile_start, header);
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    const size_t chunks = (n + RS_ITEMS - 1) / RS_ITEMS;
+    return sgr_align(n * 4) * 4 + sgr_align(chunks * 256 * 4);
+}
+
+// keys_a (the first array of sort_scratch) must hold the keys, written by the preprocess kernel; on return *order_out
+// points at the sorted Gaussian ids (inside sort_scratch).
+void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_out, hipStream_t s)
+{
+    const size_t n = (size_t)P;
+    const size_t arr = sgr_align(n * 4);
+    uint32_t* keys_a = reinterpret_cast<uint32_t*>(sort_scratch);
+    uint32_t* keys_b = reinterpret_cast<uint32_t*>(sort_scratch + arr);
+    uint32_t* vals_a = reinterpret_cast<uint32_t*>(sort_scratch + 2 * arr);
+    uint32_t* vals_b = reinterpret_cast<uint32_t*>(sort_scratch + 3 * arr);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(sort_scratch + 4 * arr);
+    const int chunks = (P + RS_ITEMS - 1) / RS_ITEMS;
+    const uint32_t* kin = keys_a; const uint32_t* vin = nullptr;
+    for (int pass = 0; pass < 4; pass++) {
+        uint32_t* kout = (pass & 1) ? keys_a : keys_b;
+        uint32_t* vout = (pass & 1) ? vals_a : vals_b;
+        const int shift = 8 * pass;
+        hipLaunchKernelGGL(k_rs_hist, dim3(chunks), dim3(256), 0, s, P, kin, shift, chunks, hist);
+        hipLaunchKernelGGL(k_scan_inplace, dim3(1), dim3(1024), 0, s, 256 * chunks, hist);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(chunks), dim3(64), 0, s, P, kin, vin, kout, vout, shift, chunks, hist);
+        kin = kout; vin = vout;
+    }
+    *order_out = vals_a;  // pass 0 -> b, 1 -> a, 2 -> b, 3 -> a
+}
+
+void sgr_launch_bin_count(int P, int gx, int gy, int n_blocks, int per_block, bool lds, const uint32_t* order,
+                          const GeomRec* rec, uint32_t* blk_hist, hipStream_t s)
+{
+    launch_bin<false>(P, gx, gy, n_blocks, per_block, lds, order, rec, nullptr, blk_hist, nullptr, s);
+}
+
+void sgr_launch_bin_scatter(int P, int gx, int gy, int n_blocks, int per_block, bool lds, const uint32_t* order,
+                            const GeomRec* rec, const uint32_t* tile_start, uint32_t* blk_hist, uint32_t* point_list,
+                            hipStream_t s)
+{
+    launch_bin<true>(P, gx, gy, n_blocks, per_block, lds, order, rec, tile_start, blk_hist, point_list, s);
 }
 
 void sgr_launch_hist_scan(int T, int n_blocks, uint32_t* blk_hist, uint32_t* tile_count, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_hist_scan, dim3((T + 255) / 256), dim3(256), 0, s, T, n_blocks, blk_hist, tile_count);
+    hipLaunchKernelGGL(k_hist_scan, dim3((T + 63) / 64), dim3(64), 0, s, T, n_blocks, blk_hist, tile_count);
 }
 
-void sgr_launch_scatter(int P, int gx, int gy, const GeomRec* rec, const uint32_t* tile_start, uint32_t* tile_cursor,
-                        const uint32_t* blk_hist, int n_blocks, int per_block, uint64_t* keys, hipStream_t s)
+void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* header, hipStream_t s)
 {
-    if (P <= 0) return;
-    if (blk_hist) {
-        const size_t lds = (size_t)gx * gy * 4;
-        static size_t configured = 0;
-        if (lds > configured) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds);
-            configured = lds;
-        }
-        hipLaunchKernelGGL(k_scatter_lds, dim3(n_blocks), dim3(256), lds, s, P, gx, gy, per_block, rec, tile_start, blk_hist, keys);
-    } else {
-        hipLaunchKernelGGL(k_scatter_atomic, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, gy, rec, tile_start, tile_cursor, keys);
-    }
-}
-
-// Size classes of the per-tile sort: LDS per workgroup bounds how many tiles a CU sorts concurrently.
-//   count <= 1024  :   8 KB, 128 threads      count <= 4096 : 32 KB, 256 threads
-//   count <= 16384 : 128 KB, 1024 threads     larger        : in place in global memory (degenerate scenes)
-void sgr_launch_tile_sort(int T, uint32_t max_count, const uint32_t* tile_start, uint64_t* keys, uint32_t* point_list,
-                          hipStream_t s)
-{
-    if (T <= 0 || max_count == 0) return;
-    hipLaunchKernelGGL(k_tile_sort_lds<128>, dim3(T), dim3(128), 1024 * 8, s, tile_start, 0u, 1024u, keys, point_list);
-    if (max_count > 1024u)
-        hipLaunchKernelGGL(k_tile_sort_lds<256>, dim3(T), dim3(256), 4096 * 8, s, tile_start, 1024u, 4096u, keys, point_list);
-    if (max_count > 4096u) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_sort_lds<1024>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(k_tile_sort_lds<1024>, dim3(T), dim3(1024), 16384 * 8, s, tile_start, 4096u, 16384u, keys, point_list);
-    }
-    if (max_count > 16384u)
-        hipLaunchKernelGGL(k_tile_sort_global, dim3(T), dim3(1024), 0, s, tile_start, 16384u, keys, point_list);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, tile_count, tile_start, header);
 }

@@ -163,10 +163,9 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     uint32_t* tile_walked = reinterpret_cast<uint32_t*>(img + IL.tile_walked);
     uint32_t* header = reinterpret_cast<uint32_t*>(img + IL.header);
 
-    uint32_t* blk_hist = IL.n_blocks ? reinterpret_cast<uint32_t*>(img + IL.blk_hist) : nullptr;
-    const int per_block = IL.n_blocks ? (((P + IL.n_blocks - 1) / IL.n_blocks + 255) / 256) * 256 : 0;
-    // tile_cursor holds the per-tile instance counts until the tile scan has consumed them
-    if (!blk_hist) HIP_TRY(hipMemsetAsync(tile_cursor, 0, (size_t)IL.T * 4, s));
+    uint32_t* blk_hist = reinterpret_cast<uint32_t*>(img + IL.blk_hist);
+    char* sort_scratch = geom + sgr_geom_sort_offset(P);
+    const int per_block = (((P + IL.n_blocks - 1) / IL.n_blocks + 63) / 64) * 64;
 
     PreprocessArgs pa;
     pa.P = P; pa.D = D; pa.M = shs ? M : 0;
@@ -177,37 +176,38 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     pa.focal_y = height / (2.0f * tan_fovy);  // rasterizer_impl.cu:222-223
     pa.focal_x = width / (2.0f * tan_fovx);
     pa.gx = IL.gx; pa.gy = IL.gy;
-    pa.radii = radii; pa.rec = rec; pa.tile_count = tile_cursor;
-    pa.blk_hist = blk_hist; pa.n_blocks = IL.n_blocks; pa.per_block = per_block;
+    pa.radii = radii; pa.rec = rec; pa.sort_keys = reinterpret_cast<uint32_t*>(sort_scratch);
     { StageTimer t(s, SGR_STAGE_PREPROCESS); sgr_launch_preprocess_fwd(pa, s); }
     STAGE_CHECK("preprocess");
 
+    const uint32_t* order = nullptr;
+    { StageTimer t(s, SGR_STAGE_SORT); sgr_launch_gaussian_sort(P, sort_scratch, &order, s); }
+    STAGE_CHECK("gaussian_sort");
+
     {
         StageTimer t(s, SGR_STAGE_SCAN);
-        if (blk_hist) sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
+        sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, IL.lds_counters, order, rec, blk_hist, s);
+        sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
         sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, s);
     }
-    STAGE_CHECK("tile_scan");
+    STAGE_CHECK("bin_count");
 
     if (!g_pinned.p) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_pinned.p), 64, hipHostMallocDefault));
     HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 16, hipMemcpyDeviceToHost, s));
-    if (!blk_hist) HIP_TRY(hipMemsetAsync(tile_cursor, 0, (size_t)IL.T * 4, s));
     HIP_TRY(hipStreamSynchronize(s));  // the one host round trip of the forward (rasterizer_impl.cu:280-281)
     const int64_t R = (int64_t)g_pinned.p[SGR_HDR_R];
-    const uint32_t max_count = g_pinned.p[SGR_HDR_MAXCOUNT];
 
     const BinLayout BL = sgr_bin_layout(R);
     char* binning = binning_alloc(binning_user, BL.total);
     if (!binning) return fail(SGR_E_ALLOC, "binning scratch allocation failed");
-    uint64_t* keys = reinterpret_cast<uint64_t*>(binning + BL.keys);
     uint32_t* point_list = reinterpret_cast<uint32_t*>(binning + BL.point_list);
 
     if (R > 0) {
-        { StageTimer t(s, SGR_STAGE_SCATTER); sgr_launch_scatter(P, IL.gx, IL.gy, rec, tile_start, tile_cursor, blk_hist, IL.n_blocks, per_block, keys, s); }
-        STAGE_CHECK("scatter");
-        { StageTimer t(s, SGR_STAGE_SORT); sgr_launch_tile_sort(IL.T, max_count, tile_start, keys, point_list, s); }
-        STAGE_CHECK("tile_sort");
+        StageTimer t(s, SGR_STAGE_SCATTER);
+        sgr_launch_bin_scatter(P, IL.gx, IL.gy, IL.n_blocks, per_block, IL.lds_counters, order, rec, tile_start, blk_hist,
+                               point_list, s);
     }
+    STAGE_CHECK("bin_scatter");
     {
         StageTimer t(s, SGR_STAGE_BLEND_FWD);
         sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,

@@ -1,5 +1,5 @@
 // preprocess.hip -- per-Gaussian kernels for gfx950: frustum test, forward preprocess (projection, EWA
-// covariance, tile rectangle, SH colour, per-tile instance counting) and the fused backward preprocess.
+// covariance, tile rectangle, SH colour, depth-sort key) and the fused backward preprocess.
 //
 // Replaces (does not translate) the reference kernels
 //   checkFrustum        DGR/cuda_rasterizer/rasterizer_impl.cu:54-66
@@ -253,45 +253,16 @@ __device__ __forceinline__ void preprocess_one(const PreprocessArgs& a, const in
     const float4* srcv = reinterpret_cast<const float4*>(&rec);
     dst[0] = srcv[0]; dst[1] = srcv[1]; dst[2] = srcv[2];
     if (a.radii) a.radii[idx] = out_radius;
+    // key of the global depth sort (binning.hip): depth > 0.2, so the float bit pattern orders like the value
+    a.sort_keys[idx] = out_radius > 0 ? __float_as_uint(rec.depth) : 0xFFFFFFFFu;
 }
 
-// Per-tile instance counting is the first half of the counting sort that replaces duplicateWithKeys + the 64-bit global
-// radix sort (rasterizer_impl.cu:70-111,303-308).
-//
-// LDS variant (default): a persistent grid of a.n_blocks workgroups, each owning a contiguous slice of Gaussians and a
-// private histogram over all T tiles in LDS (32 KB at 1080p, 127 KB at 4K).  Counting costs LDS atomics only; the
-// histogram is written once, coalesced, to blk_hist[block][tile].  No global atomics anywhere in the binning.
-__global__ void __launch_bounds__(256) k_preprocess_fwd_lds(PreprocessArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
-    const int T = a.gx * a.gy;
-    for (int i = threadIdx.x; i < T; i += 256) s_hist[i] = 0u;
-    __syncthreads();
-    const int begin = blockIdx.x * a.per_block;
-    const int end = min(a.P, begin + a.per_block);
-    for (int base = begin; base < end; base += 256) {
-        const int idx = base + threadIdx.x;
-        if (idx < end) {
-            int minx, miny, maxx, maxy;
-            preprocess_one(a, idx, minx, miny, maxx, maxy);
-            for (int y = miny; y < maxy; y++)
-                for (int x = minx; x < maxx; x++) atomicAdd(&s_hist[y * a.gx + x], 1u);
-        }
-    }
-    __syncthreads();
-    uint32_t* dst = a.blk_hist + (size_t)blockIdx.x * T;
-    for (int i = threadIdx.x; i < T; i += 256) dst[i] = s_hist[i];
-}
-
-// Fallback for tile grids whose histogram does not fit in LDS (> ~38k tiles): one lane per Gaussian, global atomics.
-__global__ void __launch_bounds__(256) k_preprocess_fwd_atomic(PreprocessArgs a)
+__global__ void __launch_bounds__(256) k_preprocess_fwd(PreprocessArgs a)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.P) return;
     int minx, miny, maxx, maxy;
     preprocess_one(a, idx, minx, miny, maxx, maxy);
-    for (int y = miny; y < maxy; y++)
-        for (int x = minx; x < maxx; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -531,18 +502,7 @@ void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatri
 void sgr_launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s)
 {
     if (a.P <= 0) return;
-    if (a.blk_hist) {
-        const size_t lds = (size_t)a.gx * a.gy * 4;
-        static size_t configured = 0;
-        if (lds > configured) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_preprocess_fwd_lds),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            configured = lds;
-        }
-        hipLaunchKernelGGL(k_preprocess_fwd_lds, dim3(a.n_blocks), dim3(256), lds, s, a);
-    } else {
-        hipLaunchKernelGGL(k_preprocess_fwd_atomic, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
-    }
+    hipLaunchKernelGGL(k_preprocess_fwd, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
 }
 
 void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)

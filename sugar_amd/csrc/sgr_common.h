@@ -7,15 +7,16 @@
 #define SGR_TILE_X 16  // BLOCK_X, DGR/cuda_rasterizer/config.h:16 (part of the pixel-exact contract)
 #define SGR_TILE_Y 16  // BLOCK_Y, DGR/cuda_rasterizer/config.h:17
 #define SGR_TILE_PIX 256
-#define SGR_BIN_BLOCKS 512          // persistent binning grid: 2 workgroups per CU on the 256-CU MI355X
-#define SGR_BIN_LDS_MAX (150 * 1024) // largest per-workgroup tile histogram kept in LDS (160 KB per CU)
+#define SGR_NUM_CUS 256              // MI355X
+#define SGR_BIN_LDS_MAX (150 * 1024) // LDS budget per CU for the binning histograms (160 KB per CU)
 
 // ---- private scratch layouts -----------------------------------------------------------------
-// geom  : [ GeomRec rec[P] | acc f32[P][12] ]   48 B / Gaussian record (AoS: one gather = 1-2 lines) + the
-//                                                backward's per-Gaussian accumulator (zeroed by each backward)
-// img   : [ final_T f32[WH] | n_contrib u32[WH] | tile_start u32[T+1] | tile_cursor u32[T] |
+// geom  : [ GeomRec rec[P] | acc f32[P][12] | sort scratch ]   48 B / Gaussian record (AoS: one gather = 1-2 lines),
+//           the backward's per-Gaussian accumulator (zeroed by each backward), and the depth sort's ping-pong
+//           key/value arrays (the sorted Gaussian order stays there for the backward-free forward only)
+// img   : [ final_T f32[WH] | n_contrib u32[WH] | tile_start u32[T+1] | tile_count u32[T] |
 //           tile_maxc u32[T] | tile_walked u32[T] | header u32[8] | blk_hist u32[n_blocks][T] ]
-// binning: [ keys u64[R] | point_list u32[R] ]
+// binning: [ point_list u32[R] ]
 struct GeomRec {
     float x, y, cx, cy;          // pixel-space mean, conic.x, conic.y
     float cz, opacity, r, g;     // conic.z, opacity, colour
@@ -27,11 +28,14 @@ static_assert(sizeof(GeomRec) == 48, "GeomRec must be 48 bytes");
 
 static inline size_t sgr_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline size_t sgr_geom_acc_offset(int P) { return sgr_align((size_t)(P > 0 ? P : 1) * 48); }
-static inline size_t sgr_geom_total(int P) { return sgr_geom_acc_offset(P) + sgr_align((size_t)(P > 0 ? P : 1) * 48); }
+size_t sgr_sort_scratch_bytes(int P);  // binning.hip
+static inline size_t sgr_geom_sort_offset(int P) { return sgr_geom_acc_offset(P) + sgr_align((size_t)(P > 0 ? P : 1) * 48); }
+static inline size_t sgr_geom_total(int P) { return sgr_geom_sort_offset(P) + sgr_sort_scratch_bytes(P); }
 
 struct ImgLayout {
     size_t final_T, n_contrib, tile_start, tile_cursor, tile_maxc, tile_walked, header, blk_hist, total;
-    int n_blocks;  // persistent binning grid (0: histogram does not fit in LDS, global-atomic fallback)
+    int n_blocks;      // persistent single-wave binning grid
+    bool lds_counters; // the per-workgroup tile histogram fits in LDS (else: the workgroup's blk_hist row in global memory)
     int gx, gy, T;
 };
 static inline ImgLayout sgr_img_layout(int W, int H)
@@ -48,17 +52,22 @@ static inline ImgLayout sgr_img_layout(int W, int H)
     L.tile_maxc = off;   off = sgr_align(off + (size_t)L.T * 4);
     L.tile_walked = off; off = sgr_align(off + (size_t)L.T * 4);
     L.header = off;      off = sgr_align(off + 64);
-    L.n_blocks = ((size_t)L.T * 4 <= SGR_BIN_LDS_MAX) ? SGR_BIN_BLOCKS : 0;
+    L.lds_counters = (size_t)L.T * 4 <= SGR_BIN_LDS_MAX;
+    {   // single-wave workgroups per CU: bounded by LDS (one T-entry histogram each), at most 8
+        size_t per_cu = L.lds_counters ? SGR_BIN_LDS_MAX / ((size_t)L.T * 4) : 2;
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        L.n_blocks = (int)(SGR_NUM_CUS * per_cu);
+    }
     L.blk_hist = off;    off = sgr_align(off + (size_t)L.n_blocks * L.T * 4);
     L.total = off;
     return L;
 }
-struct BinLayout { size_t keys, point_list, total; };
+struct BinLayout { size_t point_list, total; };
 static inline BinLayout sgr_bin_layout(int64_t R)
 {
     BinLayout L;
     size_t off = 0;
-    L.keys = off;       off = sgr_align(off + (size_t)R * 8);
     L.point_list = off; off = sgr_align(off + (size_t)R * 4);
     L.total = off < 256 ? 256 : off;
     return L;
@@ -70,7 +79,7 @@ static inline BinLayout sgr_bin_layout(int64_t R)
 #define SGR_HDR_R_HI 2     // high 32 bits of R
 
 // stage ids of the optional event profile (sgr_profile_read)
-enum { SGR_STAGE_PREPROCESS = 0, SGR_STAGE_SCAN, SGR_STAGE_SCATTER, SGR_STAGE_SORT, SGR_STAGE_BLEND_FWD,
+enum { SGR_STAGE_PREPROCESS = 0, SGR_STAGE_SCAN /* bin_count + scans */, SGR_STAGE_SCATTER, SGR_STAGE_SORT /* depth sort */, SGR_STAGE_BLEND_FWD,
        SGR_STAGE_BLEND_BWD, SGR_STAGE_PREPROCESS_BWD, SGR_STAGE_COUNT };
 
 // ---- kernel launchers (defined in the .hip translation units) --------------------------------
@@ -82,9 +91,7 @@ struct PreprocessArgs {
     int W, H; float tan_fovx, tan_fovy, focal_x, focal_y;
     int gx, gy;
     int* radii; GeomRec* rec;
-    uint32_t* tile_count;  // global-atomic fallback: per-tile counters (zeroed by the caller)
-    uint32_t* blk_hist;    // LDS path: [n_blocks][T] per-workgroup tile histograms (null selects the fallback)
-    int n_blocks, per_block;  // persistent grid of the LDS path: workgroup b owns Gaussians [b*per_block, (b+1)*per_block)
+    uint32_t* sort_keys;  // [P] depth bits of visible Gaussians, 0xFFFFFFFF for culled ones (input of the depth sort)
 };
 void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 void sgr_launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
@@ -101,12 +108,14 @@ struct PreprocessBwdArgs {
 };
 void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
 
+void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_out, hipStream_t s);
+void sgr_launch_bin_count(int P, int gx, int gy, int n_blocks, int per_block, bool lds, const uint32_t* order,
+                          const GeomRec* rec, uint32_t* blk_hist, hipStream_t s);
+void sgr_launch_bin_scatter(int P, int gx, int gy, int n_blocks, int per_block, bool lds, const uint32_t* order,
+                            const GeomRec* rec, const uint32_t* tile_start, uint32_t* blk_hist, uint32_t* point_list,
+                            hipStream_t s);
 void sgr_launch_hist_scan(int T, int n_blocks, uint32_t* blk_hist, uint32_t* tile_count, hipStream_t s);
 void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* header, hipStream_t s);
-void sgr_launch_scatter(int P, int gx, int gy, const GeomRec* rec, const uint32_t* tile_start, uint32_t* tile_cursor,
-                        const uint32_t* blk_hist, int n_blocks, int per_block, uint64_t* keys, hipStream_t s);
-void sgr_launch_tile_sort(int T, uint32_t max_count, const uint32_t* tile_start, uint64_t* keys, uint32_t* point_list,
-                          hipStream_t s);
 
 void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
