@@ -38,7 +38,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------------
 // Global stable radix sort of (u32 key, u32 value) pairs, 8 bits per pass.
 // ---------------------------------------------------------------------------------------------------------------------
-#define RS_ITEMS 2048  // keys per workgroup chunk
+#define RS_ITEMS 1024  // keys per workgroup chunk (one wave scatters a chunk: 16 keys per lane held in registers)
 
 // per-chunk digit histogram, written digit-major: hist[digit * n_chunks + chunk]
 __global__ void __launch_bounds__(256) k_rs_hist(int n, const uint32_t* __restrict__ keys, int shift, int n_chunks,
@@ -57,46 +57,74 @@ __global__ void __launch_bounds__(256) k_rs_hist(int n, const uint32_t* __restri
     hist[(size_t)threadIdx.x * n_chunks + blockIdx.x] = s_h[threadIdx.x];
 }
 
-// exclusive scan of a flat u32 array in place (single 1024-thread workgroup; n <= a few 10^5)
-__global__ void __launch_bounds__(1024) k_scan_inplace(int n, uint32_t* __restrict__ a)
+// Row scan: workgroup d turns hist[d][0..n_chunks) into its exclusive prefix over the chunks and writes the row total.
+// (The prefix ACROSS digits is taken from the 256 totals inside the scatter kernel.)
+__global__ void __launch_bounds__(256) k_rs_scan_rows(int n_chunks, uint32_t* __restrict__ hist, uint32_t* __restrict__ totals)
 {
-    __shared__ uint32_t s_part[1024];
+    __shared__ uint32_t s_part[256];
+    uint32_t* row = hist + (size_t)blockIdx.x * n_chunks;
     const int tid = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int b = tid * per, e = min(n, b + per);
+    const int per = (n_chunks + 255) / 256;
+    const int b = tid * per, e = min(n_chunks, b + per);
     uint32_t sum = 0;
-    for (int i = b; i < e; i++) sum += a[i];
+    for (int i = b; i < e; i++) sum += row[i];
     s_part[tid] = sum;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
+    for (int o = 1; o < 256; o <<= 1) {
         uint32_t v = (tid >= o) ? s_part[tid - o] : 0;
         __syncthreads();
         s_part[tid] += v;
         __syncthreads();
     }
     uint32_t run = s_part[tid] - sum;
-    for (int i = b; i < e; i++) { const uint32_t v = a[i]; a[i] = run; run += v; }
+    for (int i = b; i < e; i++) { const uint32_t v = row[i]; row[i] = run; run += v; }
+    if (tid == 255) totals[blockIdx.x] = s_part[255];
 }
 
 // One wave per chunk walks its keys 64 at a time IN ORDER.  Within a group of 64 the rank among equal digits comes from
 // eight ballots (wave-wide match); across groups a per-digit running offset lives in LDS.  Stable by construction.
 __global__ void __launch_bounds__(64) k_rs_scatter(int n, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int shift,
-                                                   int n_chunks, const uint32_t* __restrict__ hist)
+                                                   int n_chunks, const uint32_t* __restrict__ hist,
+                                                   const uint32_t* __restrict__ totals)
 {
     __shared__ uint32_t s_off[256];
     const int lane = threadIdx.x;
-    for (int d = lane; d < 256; d += 64) s_off[d] = hist[(size_t)d * n_chunks + blockIdx.x];
+    {   // digit bases: exclusive scan of the 256 row totals (4 per lane + wave scan), plus this chunk's offset in the row
+        const uint32_t t0 = totals[4 * lane], t1 = totals[4 * lane + 1], t2 = totals[4 * lane + 2], t3 = totals[4 * lane + 3];
+        const uint32_t mine = t0 + t1 + t2 + t3;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+            if (lane >= o) incl += v;
+        }
+        const uint32_t base = incl - mine;
+        const size_t c = blockIdx.x;
+        s_off[4 * lane + 0] = base + hist[(size_t)(4 * lane + 0) * n_chunks + c];
+        s_off[4 * lane + 1] = base + t0 + hist[(size_t)(4 * lane + 1) * n_chunks + c];
+        s_off[4 * lane + 2] = base + t0 + t1 + hist[(size_t)(4 * lane + 2) * n_chunks + c];
+        s_off[4 * lane + 3] = base + t0 + t1 + t2 + hist[(size_t)(4 * lane + 3) * n_chunks + c];
+    }
     WAVE_FENCE();
     const int base = blockIdx.x * RS_ITEMS;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int g = 0; g < RS_ITEMS; g += 64) {
-        const int k = base + g + lane;
+    // all loads of the chunk are issued before the ordered walk starts (the walk itself is a dependent chain)
+    uint32_t rk[RS_ITEMS / 64], rv[RS_ITEMS / 64];
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS / 64; i++) {
+        const int k = base + i * 64 + lane;
+        rk[i] = (k < n) ? keys_in[k] : 0xFFFFFFFFu;
+        rv[i] = (k < n) ? (vals_in ? vals_in[k] : (uint32_t)k) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS / 64; i++) {
+        const int k = base + i * 64 + lane;
         const bool live = k < n;
         const unsigned long long live_mask = __ballot(live);
         if (live_mask == 0ull) break;
-        const uint32_t key = live ? keys_in[k] : 0xFFFFFFFFu;
-        const uint32_t val = live ? (vals_in ? vals_in[k] : (uint32_t)k) : 0u;
+        const uint32_t key = rk[i];
+        const uint32_t val = rv[i];
         const uint32_t digit = (key >> shift) & 255u;
         unsigned long long same = live_mask;
 #pragma unroll
@@ -271,7 +299,7 @@ size_t sgr_sort_scratch_bytes(int P)
 {
     const size_t n = (size_t)(P > 0 ? P : 1);
     const size_t chunks = (n + RS_ITEMS - 1) / RS_ITEMS;
-    return sgr_align(n * 4) * 4 + sgr_align(chunks * 256 * 4);
+    return sgr_align(n * 4) * 4 + sgr_align(chunks * 256 * 4) + 1024;
 }
 
 // keys_a (the first array of sort_scratch) must hold the keys, written by the preprocess kernel; on return *order_out
@@ -286,14 +314,15 @@ void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_
     uint32_t* vals_b = reinterpret_cast<uint32_t*>(sort_scratch + 3 * arr);
     uint32_t* hist = reinterpret_cast<uint32_t*>(sort_scratch + 4 * arr);
     const int chunks = (P + RS_ITEMS - 1) / RS_ITEMS;
+    uint32_t* totals = reinterpret_cast<uint32_t*>(sort_scratch + 4 * arr + sgr_align((size_t)chunks * 256 * 4));
     const uint32_t* kin = keys_a; const uint32_t* vin = nullptr;
     for (int pass = 0; pass < 4; pass++) {
         uint32_t* kout = (pass & 1) ? keys_a : keys_b;
         uint32_t* vout = (pass & 1) ? vals_a : vals_b;
         const int shift = 8 * pass;
         hipLaunchKernelGGL(k_rs_hist, dim3(chunks), dim3(256), 0, s, P, kin, shift, chunks, hist);
-        hipLaunchKernelGGL(k_scan_inplace, dim3(1), dim3(1024), 0, s, 256 * chunks, hist);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(chunks), dim3(64), 0, s, P, kin, vin, kout, vout, shift, chunks, hist);
+        hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(256), 0, s, chunks, hist, totals);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(chunks), dim3(64), 0, s, P, kin, vin, kout, vout, shift, chunks, hist, totals);
         kin = kout; vin = vout;
     }
     *order_out = vals_a;  // pass 0 -> b, 1 -> a, 2 -> b, 3 -> a

@@ -11,6 +11,7 @@ There is no CPU path: tensors must live on a ROCm device and the HIP library mus
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import NamedTuple
 
@@ -18,6 +19,31 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
+
+
+# Optional gradient sinks (extension, not part of the reference API): inside `with grad_sink(means3D=buf, shs=buf)` the
+# backward of every rasterizer call made in the block writes dL/dmeans3D and dL/dshs straight into the given buffers and
+# returns those buffers as the gradients, instead of allocating fresh tensors.  The train step points them at its flat
+# gradient buffer, so the 192 MB SH gradient is produced in place and never copied or accumulated.
+_GRAD_SINK: dict = {}
+
+
+@contextlib.contextmanager
+def grad_sink(**buffers):
+    global _GRAD_SINK
+    old = _GRAD_SINK
+    _GRAD_SINK = {k: v for k, v in buffers.items() if v is not None}
+    try:
+        yield
+    finally:
+        _GRAD_SINK = old
+
+
+def _sink_or_empty(sink, name, shape, **f):
+    t = sink.get(name) if sink else None
+    if t is not None and tuple(t.shape) == tuple(shape) and t.dtype == f["dtype"] and t.device == f["device"] and t.is_contiguous():
+        return t
+    return torch.empty(*shape, **f)
 
 
 def cpu_deep_copy_tuple(input_tuple):
@@ -119,7 +145,7 @@ class _CModule:
     @staticmethod
     def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                      cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
-                                     degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+                                     degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, grad_out=None):
         lib = _lib.load()
         dev = means3D.device
         P = means3D.size(0)
@@ -129,13 +155,13 @@ class _CModule:
         use_cov = cov3D_precomp.numel() != 0
         # Every row of these is written by sgr_backward, so no 300 MB of zero-fill per call
         # (the reference allocates nine torch::zeros, rasterize_points.cu:151-159).
-        dL_dmeans3D = torch.empty(P, 3, **f)
+        dL_dmeans3D = _sink_or_empty(grad_out, "means3D", (P, 3), **f)
         dL_dmeans2D = torch.empty(P, 3, **f)
         dL_dcolors = torch.empty(P, 3, **f)
         dL_dconic = torch.empty(P, 2, 2, **f)
         dL_dopacity = torch.empty(P, 1, **f)
         dL_dcov3D = torch.empty(P, 6, **f)
-        dL_dsh = torch.empty(P, M, 3, **f)
+        dL_dsh = _sink_or_empty(grad_out, "shs", (P, M, 3), **f)
         dL_dscales = torch.zeros(P, 3, **f) if use_cov else torch.empty(P, 3, **f)
         dL_drotations = torch.zeros(P, 4, **f) if use_cov else torch.empty(P, 4, **f)
         if P != 0:
@@ -208,6 +234,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
+        ctx.grad_sink = dict(_GRAD_SINK)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
@@ -234,7 +261,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise ex
         else:
             (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
-             grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(*args)
+             grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(*args, grad_out=ctx.grad_sink)
         # gradient order of DGR/diff_gaussian_rasterization/__init__.py:143-155
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
                 grad_cov3Ds_precomp, None)

@@ -206,13 +206,30 @@ class ViewShardedTrainer:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
     def step(self, cam, gt_image):
-        self.params.flat_grad.zero_()
-        pkg = render(self.params, cam, self.bg, self.rasterizer_cls, self.settings_cls, self.sh_degree)
-        loss = train_loss(pkg["render"], gt_image, self.lambda_dssim, self.fused_loss)
-        loss.backward()
+        """gaussian_splatting/train.py:86-128 for one view per rank.  Gradients are taken with torch.autograd.grad and
+        land in the flat gradient buffer: the two large ones (xyz, SH) are written there by the rasterizer backward itself
+        (grad_sink), the small ones are copied; nothing is zero-filled or accumulated."""
+        p = self.params
+        leaves = [p.params[k] for k in p.NAMES]
+        sinks = {}
+        if p.flat.is_cuda:
+            from .diff_gaussian_rasterization import grad_sink
+            sinks = dict(means3D=p.params["xyz"].grad, shs=p.params["features"].grad)
+            ctxm = grad_sink(**sinks)
+        else:
+            import contextlib
+            ctxm = contextlib.nullcontext()
+        with ctxm:
+            pkg = render(p, cam, self.bg, self.rasterizer_cls, self.settings_cls, self.sh_degree)
+            loss = train_loss(pkg["render"], gt_image, self.lambda_dssim, self.fused_loss)
+            grads = torch.autograd.grad(loss, leaves)
+        with torch.no_grad():
+            for leaf, g in zip(leaves, grads):
+                if g.data_ptr() != leaf.grad.data_ptr():
+                    leaf.grad.copy_(g)
         if self.world > 1:
             # the only collective on the path: sum of the per-view parameter gradients (then mean over views)
-            dist.all_reduce(self.params.flat_grad, op=dist.ReduceOp.SUM)
-            self.params.flat_grad.mul_(1.0 / self.world)
+            dist.all_reduce(p.flat_grad, op=dist.ReduceOp.SUM)
+            p.flat_grad.mul_(1.0 / self.world)
         self.opt.step()
         return loss.detach(), pkg
