@@ -1,0 +1,59 @@
+"""Host side of the k-NN helpers (C ABI: sgr_dist2, sgr_knn in include/sugar_raster.h).
+
+  distCUDA2(points[P,3]) -> float[P]         simple-knn/spatial.cu:15-26 (mean squared distance to the 3 nearest others)
+  knn_points(p1[1,N,3], p2[1,M,3], K)        the call shape SuGaR uses from pytorch3d.ops
+                                             (sugar_scene/sugar_model.py:49,235,1028,1342): returns (dists[1,N,K] squared,
+                                             ascending; idx[1,N,K] int64; None)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+
+from . import _lib
+
+
+class _KNN(NamedTuple):
+    dists: torch.Tensor
+    idx: torch.Tensor
+    knn: Optional[torch.Tensor]
+
+
+def _check(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: the HIP k-NN needs tensors on a ROCm device; there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32")
+    return t.contiguous()
+
+
+def distCUDA2(points: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    points = _check(points, "points")
+    P = points.shape[0]
+    out = torch.zeros(P, dtype=torch.float32, device=points.device)  # spatial.cu:19 (full 0.0)
+    if P:
+        with torch.cuda.device(points.device):
+            rc = lib.sgr_dist2(P, C.c_void_p(points.data_ptr()), C.c_void_p(out.data_ptr()),
+                               C.c_void_p(torch.cuda.current_stream(points.device).cuda_stream))
+        if rc < 0:
+            raise RuntimeError(f"sgr_dist2 failed ({rc})")
+    return out
+
+
+def knn_points(p1: torch.Tensor, p2: torch.Tensor, K: int = 1, **_unused) -> _KNN:
+    lib = _lib.load()
+    if p1.dim() != 3 or p2.dim() != 3 or p1.shape[0] != 1 or p2.shape[0] != 1 or p1.shape[2] != 3 or p2.shape[2] != 3:
+        raise RuntimeError("knn_points: expected p1[1,N,3], p2[1,M,3] (the shapes SuGaR uses)")
+    q, r = _check(p1[0], "p1"), _check(p2[0], "p2")
+    N, M = q.shape[0], r.shape[0]
+    d = torch.empty(N, K, dtype=torch.float32, device=q.device)
+    i = torch.empty(N, K, dtype=torch.int64, device=q.device)
+    with torch.cuda.device(q.device):
+        rc = lib.sgr_knn(N, C.c_void_p(q.data_ptr()), M, C.c_void_p(r.data_ptr()), int(K), C.c_void_p(d.data_ptr()),
+                         C.c_void_p(i.data_ptr()), C.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
+    if rc < 0:
+        raise RuntimeError(f"sgr_knn failed ({rc}); supported K: 1,2,3,4,8,16,32")
+    return _KNN(d[None], i[None], None)
