@@ -17,13 +17,43 @@
 namespace {
 
 #define BATCH 256
+#define LOG2E 1.4426950408889634f
+
+// Which of the tile's four 16x4 pixel strips (one per wave) can a Gaussian contribute to?  A pair contributes only if
+// power <= 0 and opacity * exp(power) >= 1/255 (forward.cu:336-345), i.e. inside the ellipse q(d) <= 2*ln(255*opacity)
+// with q the conic form.  The ellipse's axis-aligned bounding box (inflated by 0.1 % + 0.01 px against rounding) is tested
+// against each strip.  Skipping an entry for a strip is therefore exact: no pixel of that strip would have passed the
+// reference's tests.  Degenerate conics fall back to "all strips".
+__device__ __forceinline__ uint32_t strip_hit_mask(float gxc, float gyc, float cx, float cy, float cz, float op, float x0,
+                                                   float y0)
+{
+    if (op < 1.0f / 255.0f) return 0u;  // alpha <= opacity < 1/255 everywhere
+    const float det = cx * cz - cy * cy;
+    if (!(det > 0.f) || !(cx > 0.f) || !(cz > 0.f)) return 0xFu;
+    const float tau2 = 2.0f * __logf(255.0f * op);
+    const float inv = tau2 / det;
+    const float hx = sqrtf(inv * cz) * 1.001f + 0.01f;
+    const float hy = sqrtf(inv * cx) * 1.001f + 0.01f;
+    if (!(gxc - hx <= x0 + 15.0f && gxc + hx >= x0)) return 0u;
+    uint32_t m = 0u;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const float ys = y0 + 4.0f * w;
+        if (gyc - hy <= ys + 3.0f && gyc + hy >= ys) m |= 1u << w;
+    }
+    return m;
+}
 
 struct StageFwd {
-    float4 a[BATCH];  // x, y, conic.x, conic.y
-    float4 b[BATCH];  // conic.z, opacity, r, g
-    float c[BATCH];   // b
+    float4 a[BATCH];      // x, y, -0.5*conic.x*log2e, -conic.y*log2e
+    float4 b[BATCH];      // -0.5*conic.z*log2e, opacity, r, g
+    float c[BATCH];       // b
+    uint32_t hit[BATCH];  // strip_hit_mask
 };
 
+// Forward blend.  The workgroup stages 256 list entries at a time (one 48-B record gather per thread) together with each
+// entry's strip mask; every wave then walks ONLY the entries that can touch its strip, in list order, and stops as soon as
+// its own 64 pixels are done.  Conic terms are pre-scaled by log2(e) at staging so a pair costs one v_exp_f32.
 __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const uint32_t* __restrict__ tile_start,
                                                    const uint32_t* __restrict__ point_list,
                                                    const GeomRec* __restrict__ rec, const float* __restrict__ bg,
@@ -38,8 +68,9 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x;
-    const int wave = tid >> 6;
-    const int px = tx * SGR_TILE_X + (tid & 15), py = ty * SGR_TILE_Y + (tid >> 4);
+    const int wave = tid >> 6, lane = tid & 63;
+    const int x0 = tx * SGR_TILE_X, y0 = ty * SGR_TILE_Y;
+    const int px = x0 + (tid & 15), py = y0 + (tid >> 4);
     const bool inside = px < W && py < H;
     const float pixfx = (float)px, pixfy = (float)py;
     const uint32_t r0 = tile_start[tile], r1 = tile_start[tile + 1];
@@ -47,38 +78,58 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
 
     bool done = !inside;
     float T = 1.0f;
-    uint32_t contributor = 0, last_contributor = 0;
+    uint32_t last_contributor = 0, done_pos = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
 
     for (int base = 0; base < total; base += BATCH) {
         // workgroup vote: stop when every pixel is done (forward.cu:309-311)
-        const unsigned long long m = __ballot(done);
-        if ((tid & 63) == 0) s_done[wave] = (m == ~0ull);
+        const bool wave_done = __ballot(!done) == 0ull;
+        if (lane == 0) s_done[wave] = wave_done;
         __syncthreads();
         if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;
         const int nb = min(BATCH, total - base);
+        uint32_t hit = 0u;
         if (tid < nb) {
             const uint32_t id = point_list[r0 + base + tid];
             const float4* rp = reinterpret_cast<const float4*>(rec + id);
             const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
-            st.a[tid] = v0; st.b[tid] = v1; st.c[tid] = v2.x;
+            hit = strip_hit_mask(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)x0, (float)y0);
+            st.a[tid] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
+            st.b[tid] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v1.z, v1.w);
+            st.c[tid] = v2.x;
         }
+        st.hit[tid] = hit;
         __syncthreads();
-        for (int j = 0; !done && j < nb; j++) {
-            contributor++;
-            const float4 a = st.a[j];
-            const float4 b = st.b[j];
-            const float dx = a.x - pixfx, dy = a.y - pixfy;
-            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-            if (power > 0.0f) continue;
-            const float alpha = fminf(0.99f, b.y * __expf(power));
-            if (alpha < 1.0f / 255.0f) continue;
-            const float test_T = T * (1.0f - alpha);
-            if (test_T < 0.0001f) { done = true; continue; }
-            const float w = alpha * T;
-            C0 += b.z * w; C1 += b.w * w; C2 += st.c[j] * w;
-            T = test_T;
-            last_contributor = contributor;
+        if (wave_done) continue;  // this wave's pixels are finished; it only helps staging
+        bool all_done = false;
+        for (int c0 = 0; c0 < nb && !all_done; c0 += 64) {
+            unsigned long long bits = __ballot((st.hit[c0 + lane] >> wave) & 1u);
+            while (bits) {
+                const int j = c0 + __builtin_ctzll(bits);
+                bits &= bits - 1;
+                if (!done) {
+                    const float4 a = st.a[j];
+                    const float4 b = st.b[j];
+                    const float dx = a.x - pixfx, dy = a.y - pixfy;
+                    const float power2 = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;  // log2(e) * power
+                    if (!(power2 > 0.0f)) {
+                        const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power2));
+                        if (!(alpha < 1.0f / 255.0f)) {
+                            const float test_T = T * (1.0f - alpha);
+                            if (test_T < 0.0001f) {
+                                done = true;
+                                done_pos = (uint32_t)(base + j + 1);
+                            } else {
+                                const float w = alpha * T;
+                                C0 += b.z * w; C1 += b.w * w; C2 += st.c[j] * w;
+                                T = test_T;
+                                last_contributor = (uint32_t)(base + j + 1);
+                            }
+                        }
+                    }
+                }
+                if (__ballot(!done) == 0ull) { all_done = true; break; }
+            }
         }
     }
     if (inside) {
@@ -93,10 +144,11 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
     // deepest contributor of the tile, consumed by the backward
     uint32_t mc = inside ? last_contributor : 0u;
     for (int o = 32; o > 0; o >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, o));
-    // furthest list position any pixel looked at (R_f of the roofline accounting)
-    uint32_t wk = inside ? contributor : 0u;
+    // furthest list position any pixel examined (R_f of the roofline accounting): the entry that
+    // finished the pixel, or the whole list for a pixel that never saturated
+    uint32_t wk = inside ? (done ? done_pos : (uint32_t)total) : 0u;
     for (int o = 32; o > 0; o >>= 1) wk = max(wk, (uint32_t)__shfl_xor((int)wk, o));
-    if ((tid & 63) == 0) { s_maxc[wave] = mc; s_walk[wave] = wk; }
+    if (lane == 0) { s_maxc[wave] = mc; s_walk[wave] = wk; }
     __syncthreads();
     if (tid == 0) {
         tile_maxc[tile] = max(max(s_maxc[0], s_maxc[1]), max(s_maxc[2], s_maxc[3]));
@@ -133,6 +185,7 @@ struct __attribute__((aligned(16))) BwdShared {
     float4 b[BWD_BATCH];                  // conic.z, opacity, r, g
     float c[BWD_BATCH];                   // b
     uint32_t id[BWD_BATCH];
+    uint32_t hit[BWD_BATCH];              // strip_hit_mask: which waves' strips the entry can touch
     float part[BWD_BATCH][12];            // per-workgroup sums of the current batch
     float gpix[3][256];                   // dL_dpix of the tile's pixels, [channel][wave*64 + lane]
     float2 zw[4][BWD_SUB * ZW_STRIDE];    // wave-private (Z, Wt) panels
@@ -186,19 +239,27 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
 
     for (int base = 0; base < total; base += BWD_BATCH) {
         const int nb = min(BWD_BATCH, total - base);
-        if (tid < nb) {
-            const uint32_t id = point_list[r0 + (uint32_t)(total - 1 - base - tid)];
-            const float4* rp = reinterpret_cast<const float4*>(rec + id);
-            const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
-            sh.a[tid] = v0; sh.b[tid] = v1; sh.c[tid] = v2.x; sh.id[tid] = id;
+        if (tid < BWD_BATCH) {
+            uint32_t hit = 0u;
+            if (tid < nb) {
+                const uint32_t id = point_list[r0 + (uint32_t)(total - 1 - base - tid)];
+                const float4* rp = reinterpret_cast<const float4*>(rec + id);
+                const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
+                sh.a[tid] = v0; sh.b[tid] = v1; sh.c[tid] = v2.x; sh.id[tid] = id;
+                hit = strip_hit_mask(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)x0, (float)y0);
+            }
+            sh.hit[tid] = hit;
         }
         __syncthreads();
-        for (int sb = 0; sb < nb; sb += BWD_SUB) {
-            const int ns = min(BWD_SUB, nb - sb);
+        // entries of this batch that can touch this wave's strip, walked in list order in groups of <= 16 panel rows
+        unsigned long long bits = __ballot((sh.hit[lane] >> wave) & 1u);
+        while (bits) {
             // ---------------- phase A: lane = pixel
-            uint32_t gmask = 0;  // wave-uniform: Gaussians of this sub-batch that touch the wave's strip
-            for (int g = 0; g < ns; g++) {
-                const int j = sb + g;
+            int rows = 0;   // wave-uniform: panel rows in use
+            int myj = 0;    // phase-B role: batch index of the Gaussian in panel row bg_g
+            while (bits && rows < BWD_SUB) {
+                const int j = __builtin_ctzll(bits);
+                bits &= bits - 1;
                 const int pos = total - base - j;  // 1-based list position of this entry
                 const float4 a = sh.a[j];
                 const float4 b = sh.b[j];
@@ -208,7 +269,6 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
                 const float alpha = fminf(0.99f, b.y * G);
                 const bool active = (pos <= last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
                 if (__ballot(active) == 0ull) continue;  // wave-uniform
-                gmask |= 1u << g;
                 float Z = 0.f, Wt = 0.f;
                 if (active) {
                     T = T / (1.f - alpha);
@@ -223,16 +283,18 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
                     dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
                     Z = G * dL_dalpha;
                 }
-                zw[g * ZW_STRIDE + lane] = make_float2(Z, Wt);
+                zw[rows * ZW_STRIDE + lane] = make_float2(Z, Wt);
+                if (bg_g == rows) myj = j;
+                rows++;
             }
-            if (gmask == 0) continue;  // wave-uniform
+            if (rows == 0) continue;  // wave-uniform (bits is now 0)
             // the panel is exchanged between lanes of ONE wave: LDS operations of a wave execute in order, so a
             // wave-scope fence (compiler ordering) is all that is needed, no workgroup barrier
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // ---------------- phase B: lane = (Gaussian bg_g, row bq)
-            if ((gmask >> bg_g) & 1u) {
-                const float4 a = sh.a[sb + bg_g];
+            // ---------------- phase B: lane = (panel row bg_g, pixel row bq)
+            if (bg_g < rows) {
+                const float4 a = sh.a[myj];
                 const float dyr = a.y - rowy;
                 float s0 = 0.f, sx = 0.f, sxx = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
                 const float2* row = zw + bg_g * ZW_STRIDE + bq * 16;
@@ -252,7 +314,7 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
                     o[v] += __shfl_xor(o[v], 32);
                 }
                 if (bq == 0) {
-                    float* dst = sh.part[sb + bg_g];
+                    float* dst = sh.part[myj];
 #pragma unroll
                     for (int v = 0; v < 9; v++) atomicAdd(&dst[v], o[v]);
                 }
