@@ -106,7 +106,8 @@ size_t sgr_binning_point_list_offset(int64_t R);        /* uint32[R]: Gaussian i
  * the Gaussians, 4 blend forward, 5 blend backward, 6 preprocess backward.  sgr_profile_read synchronises the recorded events, returns the summed
  * milliseconds and launch counts per stage since the last read, and clears the record. */
 #define SGR_N_STAGES 7
-void sgr_profile_enable(int on);
+void sgr_profile_enable(int stage_mask); /* bit s set: record events around stage s (0 disables; each event pair costs
+                                            several microseconds of GPU pipeline, so time only what is being measured) */
 int sgr_profile_read(double* ms_sum, int64_t* count, int n_stages);
 
 /* ---- k-NN helpers sharing the Gaussian position buffer ------------------------------------------

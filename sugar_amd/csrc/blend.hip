@@ -48,12 +48,15 @@ struct StageFwd {
     float4 a[BATCH];      // x, y, -0.5*conic.x*log2e, -conic.y*log2e
     float4 b[BATCH];      // -0.5*conic.z*log2e, opacity, r, g
     float c[BATCH];       // b
-    uint32_t hit[BATCH];  // strip_hit_mask
+    uint8_t list[4][BATCH];  // per strip (wave): staged indices of the entries that can touch it, in list order
+    uint32_t cnt[4][4];   // [staging wave][strip] hit counts
 };
 
-// Forward blend.  The workgroup stages 256 list entries at a time (one 48-B record gather per thread) together with each
-// entry's strip mask; every wave then walks ONLY the entries that can touch its strip, in list order, and stops as soon as
-// its own 64 pixels are done.  Conic terms are pre-scaled by log2(e) at staging so a pair costs one v_exp_f32.
+// Forward blend.  The workgroup stages 256 list entries at a time (one 48-B record gather per thread), computes each
+// entry's strip mask and compacts, per strip, the indices of the entries that can touch it.  Every wave then walks ONLY
+// its own compacted list, in list order, with a branch-free body (the skip tests of forward.cu:336-351 become lane
+// predicates), and stops as soon as its own 64 pixels are done.  Conic terms are pre-scaled by log2(e) at staging so a
+// pair costs one v_exp_f32.
 __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const uint32_t* __restrict__ tile_start,
                                                    const uint32_t* __restrict__ point_list,
                                                    const GeomRec* __restrict__ rec, const float* __restrict__ bg,
@@ -75,6 +78,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
     const float pixfx = (float)px, pixfy = (float)py;
     const uint32_t r0 = tile_start[tile], r1 = tile_start[tile + 1];
     const int total = (int)(r1 - r0);
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     bool done = !inside;
     float T = 1.0f;
@@ -98,38 +102,46 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
             st.b[tid] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v1.z, v1.w);
             st.c[tid] = v2.x;
         }
-        st.hit[tid] = hit;
+        unsigned long long bal[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) bal[w] = __ballot((hit >> w) & 1u);
+        if (lane == 0) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) st.cnt[wave][w] = (uint32_t)__popcll(bal[w]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if ((hit >> w) & 1u) {
+                uint32_t pos = (uint32_t)__popcll(bal[w] & lt_mask);
+                for (int c = 0; c < wave; c++) pos += st.cnt[c][w];
+                st.list[w][pos] = (uint8_t)tid;
+            }
+        }
         __syncthreads();
         if (wave_done) continue;  // this wave's pixels are finished; it only helps staging
-        bool all_done = false;
-        for (int c0 = 0; c0 < nb && !all_done; c0 += 64) {
-            unsigned long long bits = __ballot((st.hit[c0 + lane] >> wave) & 1u);
-            while (bits) {
-                const int j = c0 + __builtin_ctzll(bits);
-                bits &= bits - 1;
-                if (!done) {
-                    const float4 a = st.a[j];
-                    const float4 b = st.b[j];
-                    const float dx = a.x - pixfx, dy = a.y - pixfy;
-                    const float power2 = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;  // log2(e) * power
-                    if (!(power2 > 0.0f)) {
-                        const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power2));
-                        if (!(alpha < 1.0f / 255.0f)) {
-                            const float test_T = T * (1.0f - alpha);
-                            if (test_T < 0.0001f) {
-                                done = true;
-                                done_pos = (uint32_t)(base + j + 1);
-                            } else {
-                                const float w = alpha * T;
-                                C0 += b.z * w; C1 += b.w * w; C2 += st.c[j] * w;
-                                T = test_T;
-                                last_contributor = (uint32_t)(base + j + 1);
-                            }
-                        }
-                    }
-                }
-                if (__ballot(!done) == 0ull) { all_done = true; break; }
-            }
+        const int n_mine = __builtin_amdgcn_readfirstlane(
+            (int)(st.cnt[0][wave] + st.cnt[1][wave] + st.cnt[2][wave] + st.cnt[3][wave]));
+        for (int k = 0; k < n_mine; k++) {
+            const int j = __builtin_amdgcn_readfirstlane((int)st.list[wave][k]);  // wave-uniform: keep it scalar
+            const float4 a = st.a[j];
+            const float4 b = st.b[j];
+            const float cb = st.c[j];
+            const uint32_t pos = (uint32_t)(base + j + 1);
+            const float dx = a.x - pixfx, dy = a.y - pixfy;
+            const float power2 = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;  // log2(e) * power
+            const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power2));
+            const bool ok = !done && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
+            const float test_T = T * (1.0f - alpha);
+            const bool stop = ok && (test_T < 0.0001f);
+            const bool upd = ok && !stop;
+            const float w = upd ? alpha * T : 0.0f;
+            C0 += b.z * w; C1 += b.w * w; C2 += cb * w;
+            T = upd ? test_T : T;
+            last_contributor = upd ? pos : last_contributor;
+            done_pos = stop ? pos : done_pos;
+            done = done || stop;
+            if (__ballot(!done) == 0ull) break;
         }
     }
     if (inside) {

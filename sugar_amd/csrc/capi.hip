@@ -43,7 +43,7 @@ thread_local Pinned g_pinned;
 
 // ---- optional per-stage timing with HIP events on the caller's stream (bench.py's roofline leg) ----------
 struct Prof {
-    bool on = false;
+    unsigned mask = 0;  // bit s set: time stage s
     struct Rec { int stage; hipEvent_t a, b; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -62,7 +62,7 @@ struct StageTimer {
     hipStream_t s; int stage; hipEvent_t a = nullptr, b = nullptr; bool live = false;
     StageTimer(hipStream_t s_, int stage_) : s(s_), stage(stage_)
     {
-        if (g_prof.on) {
+        if (g_prof.mask & (1u << stage_)) {
             std::lock_guard<std::mutex> lk(g_prof_mu);
             if (g_prof.recs.size() < 65536) {
                 a = g_prof.get(); b = g_prof.get();
@@ -101,7 +101,7 @@ size_t sgr_img_tile_maxc_offset(int w, int h) { return sgr_img_layout(w, h).tile
 size_t sgr_img_tile_walked_offset(int w, int h) { return sgr_img_layout(w, h).tile_walked; }
 size_t sgr_binning_point_list_offset(int64_t R) { return sgr_bin_layout(R).point_list; }
 
-void sgr_profile_enable(int on) { g_prof.on = on != 0; }
+void sgr_profile_enable(int stage_mask) { g_prof.mask = (unsigned)stage_mask; }
 
 int sgr_profile_read(double* ms_sum, int64_t* count, int n_stages)
 {
