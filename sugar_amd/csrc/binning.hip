@@ -188,27 +188,66 @@ __global__ void __launch_bounds__(64) k_bin_ordered(int P, int gx, int gy, int p
             }
         }
         unsigned long long todo = __ballot(n > 0);
-        while (todo) {  // one Gaussian at a time, in sorted order
-            const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
-            todo &= todo - 1;
-            const int jn = __builtin_amdgcn_readlane(n, j);
-            const int jw = __builtin_amdgcn_readlane(w, j);
-            const int jx = __builtin_amdgcn_readlane(minx, j);
-            const int jy = __builtin_amdgcn_readlane(miny, j);
-            const uint32_t jid = (uint32_t)__builtin_amdgcn_readlane(id, j);
-            const float inv_w = 1.0f / (float)jw;
-            for (int k = lane; k < jn; k += 64) {
-                const int ty = (int)(((float)k + 0.5f) * inv_w);
-                const int tx = k - ty * jw;
-                const int t = (jy + ty) * gx + jx + tx;
-                if (SCATTER) {
-                    const uint32_t slot = atomicAdd(&cnt[t], 1u);
-                    point_list[slot] = jid;
+        while (todo) {  // Gaussians in sorted order, four per step to keep several LDS atomics in flight
+            int jn[4], jw[4], jx[4], jy[4];
+            uint32_t jid[4];
+            bool big = false;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (todo) {
+                    const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+                    todo &= todo - 1;
+                    jn[u] = __builtin_amdgcn_readlane(n, j);
+                    jw[u] = __builtin_amdgcn_readlane(w, j);
+                    jx[u] = __builtin_amdgcn_readlane(minx, j);
+                    jy[u] = __builtin_amdgcn_readlane(miny, j);
+                    jid[u] = (uint32_t)__builtin_amdgcn_readlane(id, j);
+                    big = big || jn[u] > 64;
                 } else {
-                    atomicAdd(&cnt[t], 1u);
+                    jn[u] = 0; jw[u] = 1; jx[u] = 0; jy[u] = 0; jid[u] = 0u;
                 }
             }
-            // a Gaussian's tiles are distinct, but the NEXT Gaussian may hit the same tile: keep the walk ordered
+            if (!big) {
+                // every rectangle fits in one pass of 64 lanes: issue the (ordered) LDS atomics back to back, then the
+                // stores; LDS operations of one wave execute in program order, so tile slots are still handed out in
+                // depth order
+                uint32_t slot[4];
+                int tt[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int ty = (int)(((float)lane + 0.5f) * (1.0f / (float)jw[u]));
+                    tt[u] = (jy[u] + ty) * gx + jx[u] + (lane - ty * jw[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (lane < jn[u]) {
+                        if (SCATTER) slot[u] = atomicAdd(&cnt[tt[u]], 1u);
+                        else atomicAdd(&cnt[tt[u]], 1u);
+                    }
+                }
+                if (SCATTER) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (lane < jn[u]) point_list[slot[u]] = jid[u];
+                }
+            } else {
+                // a rectangle larger than 64 tiles: strictly one Gaussian at a time
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const float inv_w = 1.0f / (float)jw[u];
+                    for (int k = lane; k < jn[u]; k += 64) {
+                        const int ty = (int)(((float)k + 0.5f) * inv_w);
+                        const int t = (jy[u] + ty) * gx + jx[u] + (k - ty * jw[u]);
+                        if (SCATTER) {
+                            const uint32_t sl = atomicAdd(&cnt[t], 1u);
+                            point_list[sl] = jid[u];
+                        } else {
+                            atomicAdd(&cnt[t], 1u);
+                        }
+                    }
+                    if (SCATTER) WAVE_FENCE();
+                }
+            }
             if (SCATTER) WAVE_FENCE();
         }
     }
