@@ -10,9 +10,10 @@
 //
 //   gsort      : stable LSD radix sort (4 x 8-bit passes) of (depth_bits, gaussian_id) over the P Gaussians.  Culled
 //                Gaussians carry key 0xFFFFFFFF and sink to the end.  Ties keep ascending id.
-//   bin_count  : a persistent grid of single-wave workgroups; workgroup b owns a contiguous slice of the sorted order and
-//                a private histogram over all T tiles in LDS.  The wave takes its Gaussians ONE AT A TIME, in order, and
-//                spreads that Gaussian's tile rectangle over its 64 lanes (LDS atomics on distinct tiles).
+//   bin_count  : a persistent grid; workgroup b owns a contiguous slice of the sorted order and a private histogram over
+//                all T tiles in LDS.  Each of its four waves owns a horizontal band of tile rows and walks the slice's
+//                Gaussians IN ORDER, spreading the part of a Gaussian's tile rectangle that lies in its band over its 64
+//                lanes (LDS atomics on distinct tiles); a tile is only ever touched by one wave.
 //   hist_scan  : column-wise exclusive scan over b of blk_hist[b][t] (in place) + per-tile totals
 //   tile_scan  : exclusive scan of the totals -> tile_start[T+1] (the ranges), R, largest tile count
 //   bin_scatter: same walk as bin_count; slot = tile_start[t] + blk_hist[b][t] + (running LDS counter) and the Gaussian id
@@ -152,28 +153,34 @@ __global__ void __launch_bounds__(64) k_rs_scatter(int n, const uint32_t* __rest
 // Ordered binning (count and scatter share one walk).
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool SCATTER, bool LDS_COUNTERS>
-__global__ void __launch_bounds__(64) k_bin_ordered(int P, int gx, int gy, int per_block, const uint32_t* __restrict__ order,
-                                                    const GeomRec* __restrict__ rec, const uint32_t* __restrict__ tile_start,
-                                                    uint32_t* __restrict__ blk_hist, uint32_t* __restrict__ point_list)
+__global__ void __launch_bounds__(256) k_bin_ordered(int P, int gx, int gy, int per_block, const uint32_t* __restrict__ order,
+                                                     const GeomRec* __restrict__ rec, const uint32_t* __restrict__ tile_start,
+                                                     uint32_t* __restrict__ blk_hist, uint32_t* __restrict__ point_list)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_lds[];
     const int T = gx * gy;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t* row = blk_hist + (size_t)blockIdx.x * T;
     // counters: LDS when the tile grid fits, otherwise this workgroup's private row of blk_hist in global memory
     uint32_t* cnt = LDS_COUNTERS ? s_lds : row;
     if (SCATTER) {
-        for (int t = lane; t < T; t += 64) cnt[t] = tile_start[t] + row[t];
+        for (int t = tid; t < T; t += 256) cnt[t] = tile_start[t] + row[t];
     } else {
-        for (int t = lane; t < T; t += 64) cnt[t] = 0u;
+        for (int t = tid; t < T; t += 256) cnt[t] = 0u;
     }
     if (!LDS_COUNTERS) __threadfence_block();
-    WAVE_FENCE();
+    __syncthreads();
+    // The workgroup's four waves walk the SAME slice of the depth order, each owning a horizontal band of tile rows: a
+    // tile belongs to exactly one wave, which sees the slice's Gaussians strictly in order, so per-tile order is kept
+    // while four waves per workgroup (sixteen per CU) hide each other's latencies.
+    const int band_rows = (gy + 3) / 4;
+    const int band_y0 = wave * band_rows, band_y1 = min(gy, band_y0 + band_rows);
     const int begin = blockIdx.x * per_block;
     const int end = min(P, begin + per_block);
     for (int base = begin; base < end; base += 64) {
         const int s = base + lane;
         int id = 0, minx = 0, miny = 0, w = 1, n = 0;
+        float inv_w = 1.0f;
         if (s < end) {
             id = (int)order[s];
             const float4* rp = reinterpret_cast<const float4*>(rec + id);
@@ -183,13 +190,17 @@ __global__ void __launch_bounds__(64) k_bin_ordered(int P, int gx, int gy, int p
                 const float4 r0 = rp[0];
                 int maxx, maxy;
                 sgr_get_rect(r0.x, r0.y, radius, gx, gy, minx, miny, maxx, maxy);
+                miny = max(miny, band_y0);
+                maxy = min(maxy, band_y1);
                 w = maxx - minx;
-                n = w * (maxy - miny);
+                n = (maxy > miny) ? w * (maxy - miny) : 0;
+                inv_w = __builtin_amdgcn_rcpf((float)w);  // k / w below is exact for k < 2^20 with a 1-ulp reciprocal
             }
         }
         unsigned long long todo = __ballot(n > 0);
         while (todo) {  // Gaussians in sorted order, four per step to keep several LDS atomics in flight
             int jn[4], jw[4], jx[4], jy[4];
+            float jinv[4];
             uint32_t jid[4];
             bool big = false;
 #pragma unroll
@@ -201,10 +212,11 @@ __global__ void __launch_bounds__(64) k_bin_ordered(int P, int gx, int gy, int p
                     jw[u] = __builtin_amdgcn_readlane(w, j);
                     jx[u] = __builtin_amdgcn_readlane(minx, j);
                     jy[u] = __builtin_amdgcn_readlane(miny, j);
+                    jinv[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_w), j));
                     jid[u] = (uint32_t)__builtin_amdgcn_readlane(id, j);
                     big = big || jn[u] > 64;
                 } else {
-                    jn[u] = 0; jw[u] = 1; jx[u] = 0; jy[u] = 0; jid[u] = 0u;
+                    jn[u] = 0; jw[u] = 1; jx[u] = 0; jy[u] = 0; jid[u] = 0u; jinv[u] = 1.0f;
                 }
             }
             if (!big) {
@@ -215,7 +227,7 @@ __global__ void __launch_bounds__(64) k_bin_ordered(int P, int gx, int gy, int p
                 int tt[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const int ty = (int)(((float)lane + 0.5f) * (1.0f / (float)jw[u]));
+                    const int ty = (int)(((float)lane + 0.5f) * jinv[u]);
                     tt[u] = (jy[u] + ty) * gx + jx[u] + (lane - ty * jw[u]);
                 }
 #pragma unroll
@@ -234,9 +246,8 @@ __global__ void __launch_bounds__(64) k_bin_ordered(int P, int gx, int gy, int p
                 // a rectangle larger than 64 tiles: strictly one Gaussian at a time
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const float inv_w = 1.0f / (float)jw[u];
                     for (int k = lane; k < jn[u]; k += 64) {
-                        const int ty = (int)(((float)k + 0.5f) * inv_w);
+                        const int ty = (int)(((float)k + 0.5f) * jinv[u]);
                         const int t = (jy[u] + ty) * gx + jx[u] + (k - ty * jw[u]);
                         if (SCATTER) {
                             const uint32_t sl = atomicAdd(&cnt[t], 1u);
@@ -252,8 +263,8 @@ __global__ void __launch_bounds__(64) k_bin_ordered(int P, int gx, int gy, int p
         }
     }
     if (!SCATTER && LDS_COUNTERS) {
-        WAVE_FENCE();
-        for (int t = lane; t < T; t += 64) row[t] = cnt[t];
+        __syncthreads();
+        for (int t = tid; t < T; t += 256) row[t] = cnt[t];
     }
 }
 
@@ -324,10 +335,10 @@ void launch_bin(int P, int gx, int gy, int n_blocks, int per_block, bool lds, co
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             configured = bytes;
         }
-        hipLaunchKernelGGL((k_bin_ordered<SCATTER, true>), dim3(n_blocks), dim3(64), bytes, s, P, gx, gy, per_block, order, rec,
+        hipLaunchKernelGGL((k_bin_ordered<SCATTER, true>), dim3(n_blocks), dim3(256), bytes, s, P, gx, gy, per_block, order, rec,
                            tile_start, blk_hist, point_list);
     } else {
-        hipLaunchKernelGGL((k_bin_ordered<SCATTER, false>), dim3(n_blocks), dim3(64), 0, s, P, gx, gy, per_block, order, rec,
+        hipLaunchKernelGGL((k_bin_ordered<SCATTER, false>), dim3(n_blocks), dim3(256), 0, s, P, gx, gy, per_block, order, rec,
                            tile_start, blk_hist, point_list);
     }
 }

@@ -199,8 +199,8 @@ struct __attribute__((aligned(16))) BwdShared {
     uint32_t id[BWD_BATCH];
     uint32_t hit[BWD_BATCH];              // strip_hit_mask: which waves' strips the entry can touch
     float part[BWD_BATCH][12];            // per-workgroup sums of the current batch
-    float gpix[3][256];                   // dL_dpix of the tile's pixels, [channel][wave*64 + lane]
-    float2 zw[4][BWD_SUB * ZW_STRIDE];    // wave-private (Z, Wt) panels
+    float2 zw[4][BWD_SUB * ZW_STRIDE];    // wave-private (Z, Wt) panels; before the walk starts the same memory carries
+                                          // dL_dpix of the tile once (gpix view below): 39 KB total -> 4 workgroups per CU
 };
 
 __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const uint32_t* __restrict__ tile_start,
@@ -237,15 +237,17 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
 
     // phase-B lane role and the dL_dpix of its 16-pixel row, kept in registers for the whole kernel
     const int bg_g = lane & 15, bq = lane >> 4;
-    sh.gpix[0][tid] = g0; sh.gpix[1][tid] = g1; sh.gpix[2][tid] = g2;
+    float* gpix = reinterpret_cast<float*>(&sh.zw[0][0]);  // [3][256], one-time exchange through the panel memory
+    gpix[tid] = g0; gpix[256 + tid] = g1; gpix[512 + tid] = g2;
     for (int i = tid; i < BWD_BATCH * 12; i += 256) (&sh.part[0][0])[i] = 0.f;
     __syncthreads();
     float rg0[16], rg1[16], rg2[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const int p = wave * 64 + bq * 16 + i;
-        rg0[i] = sh.gpix[0][p]; rg1[i] = sh.gpix[1][p]; rg2[i] = sh.gpix[2][p];
+        rg0[i] = gpix[p]; rg1[i] = gpix[256 + p]; rg2[i] = gpix[512 + p];
     }
+    __syncthreads();  // the panels are written from here on
     const float rowy = (float)(y0 + wave * 4 + bq);
     float2* zw = sh.zw[wave];
 
