@@ -10,14 +10,15 @@
 //
 //   gsort      : stable LSD radix sort (4 x 8-bit passes) of (depth_bits, gaussian_id) over the P Gaussians.  Culled
 //                Gaussians carry key 0xFFFFFFFF and sink to the end.  Ties keep ascending id.
-//   bin_count  : a persistent grid; workgroup b owns a contiguous slice of the sorted order and a private histogram over
-//                all T tiles in LDS.  Each of its four waves owns a horizontal band of tile rows and walks the slice's
-//                Gaussians IN ORDER, spreading the part of a Gaussian's tile rectangle that lies in its band over its 64
-//                lanes (LDS atomics on distinct tiles); a tile is only ever touched by one wave.
-//   hist_scan  : column-wise exclusive scan over b of blk_hist[b][t] (in place) + per-tile totals
+//   pack_rects : tile rectangles of the Gaussians in sorted order, 8 bytes each (the walks below stream them)
+//   bin_count  : workgroup (slice, band) owns a contiguous slice of the sorted order and one of eight bands of tile rows,
+//                with a private histogram of the band's tiles in LDS.  Each of its four waves owns a sub-band and walks
+//                the slice's Gaussians IN ORDER, spreading the part of a Gaussian's rectangle that lies in its rows over
+//                its 64 lanes (LDS atomics on distinct tiles); a tile is only ever touched by one wave.
+//   hist_scan  : column-wise exclusive scan over the slices of blk_hist[slice][t] (in place) + per-tile totals
 //   tile_scan  : exclusive scan of the totals -> tile_start[T+1] (the ranges), R, largest tile count
-//   bin_scatter: same walk as bin_count; slot = tile_start[t] + blk_hist[b][t] + (running LDS counter) and the Gaussian id
-//                goes straight into point_list.  Slices are ordered, a wave processes its slice sequentially, and one
+//   bin_scatter: same walk as bin_count; slot = tile_start[t] + blk_hist[slice][t] + (running LDS counter) and the Gaussian
+//                id goes straight into point_list.  Slices are ordered, a wave processes its slice sequentially, and one
 //                Gaussian never hits a tile twice, so the per-tile order is exactly the sorted order.
 //
 // Order contract: the reference's stable radix sort orders a tile's list by depth bits, ties by ascending Gaussian index
@@ -152,119 +153,147 @@ __global__ void __launch_bounds__(64) k_rs_scatter(int n, const uint32_t* __rest
 // ---------------------------------------------------------------------------------------------------------------------
 // Ordered binning (count and scatter share one walk).
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool SCATTER, bool LDS_COUNTERS>
-__global__ void __launch_bounds__(256) k_bin_ordered(int P, int gx, int gy, int per_block, const uint32_t* __restrict__ order,
-                                                     const GeomRec* __restrict__ rec, const uint32_t* __restrict__ tile_start,
+// Tile rectangles in sorted order, packed {minx | miny << 16, w | h << 16} (w == 0: culled), so the ordered walks stream
+// 8 contiguous bytes per Gaussian instead of chasing order[] -> rec[] through two dependent random loads.
+__global__ void __launch_bounds__(256) k_pack_rects(int P, int gx, int gy, const uint32_t* __restrict__ order,
+                                                    const GeomRec* __restrict__ rec, uint2* __restrict__ rects)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= P) return;
+    const uint32_t id = order[s];
+    const float4* rp = reinterpret_cast<const float4*>(rec + id);
+    const float4 r2 = rp[2];
+    const int radius = __float_as_int(r2.z);
+    uint2 out = make_uint2(0u, 0u);
+    if (radius > 0) {
+        const float4 r0 = rp[0];
+        int minx, miny, maxx, maxy;
+        sgr_get_rect(r0.x, r0.y, radius, gx, gy, minx, miny, maxx, maxy);
+        out.x = (uint32_t)minx | ((uint32_t)miny << 16);
+        out.y = (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16);
+    }
+    rects[s] = out;
+}
+
+// Workgroup (slice, band): `slice` = a contiguous piece of the depth order, `band` = blockIdx % 8 = one of eight groups of
+// tile rows.  On MI355X consecutive workgroups are dispatched round-robin over the 8 XCDs, so all writes to a given tile's
+// list come from ONE XCD and merge in its L2 instead of leaving it as 4-byte partial-line writes from eight L2s (measured
+// 7.8x write amplification without this).  Correctness does not depend on the placement.  Inside the workgroup each of the
+// four waves owns a sub-band of rows and walks the slice IN ORDER: a tile is only ever touched by one wave, which hands
+// out its slots in depth order.
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) k_bin_ordered(int P, int gx, int gy, int per_slice, const uint32_t* __restrict__ order,
+                                                     const uint2* __restrict__ rects, const uint32_t* __restrict__ tile_start,
                                                      uint32_t* __restrict__ blk_hist, uint32_t* __restrict__ point_list)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_lds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];  // counters of this band's tiles
     const int T = gx * gy;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t* row = blk_hist + (size_t)blockIdx.x * T;
-    // counters: LDS when the tile grid fits, otherwise this workgroup's private row of blk_hist in global memory
-    uint32_t* cnt = LDS_COUNTERS ? s_lds : row;
+    const int band = blockIdx.x & 7, slice = blockIdx.x >> 3;
+    const int band_rows = (gy + 7) / 8;
+    const int by0 = band * band_rows, by1 = min(gy, by0 + band_rows);
+    if (by0 >= by1) return;
+    const int t0 = by0 * gx, nt = (by1 - by0) * gx;  // this band's tiles: [t0, t0 + nt)
+    uint32_t* row = blk_hist + (size_t)slice * T + t0;
     if (SCATTER) {
-        for (int t = tid; t < T; t += 256) cnt[t] = tile_start[t] + row[t];
+        for (int t = tid; t < nt; t += 256) s_cnt[t] = tile_start[t0 + t] + row[t];
     } else {
-        for (int t = tid; t < T; t += 256) cnt[t] = 0u;
+        for (int t = tid; t < nt; t += 256) s_cnt[t] = 0u;
     }
-    if (!LDS_COUNTERS) __threadfence_block();
     __syncthreads();
-    // The workgroup's four waves walk the SAME slice of the depth order, each owning a horizontal band of tile rows: a
-    // tile belongs to exactly one wave, which sees the slice's Gaussians strictly in order, so per-tile order is kept
-    // while four waves per workgroup (sixteen per CU) hide each other's latencies.
-    const int band_rows = (gy + 3) / 4;
-    const int band_y0 = wave * band_rows, band_y1 = min(gy, band_y0 + band_rows);
-    const int begin = blockIdx.x * per_block;
-    const int end = min(P, begin + per_block);
-    for (int base = begin; base < end; base += 64) {
-        const int s = base + lane;
-        int id = 0, minx = 0, miny = 0, w = 1, n = 0;
-        float inv_w = 1.0f;
-        if (s < end) {
-            id = (int)order[s];
-            const float4* rp = reinterpret_cast<const float4*>(rec + id);
-            const float4 r2 = rp[2];
-            const int radius = __float_as_int(r2.z);
-            if (radius > 0) {
-                const float4 r0 = rp[0];
-                int maxx, maxy;
-                sgr_get_rect(r0.x, r0.y, radius, gx, gy, minx, miny, maxx, maxy);
-                miny = max(miny, band_y0);
-                maxy = min(maxy, band_y1);
-                w = maxx - minx;
-                n = (maxy > miny) ? w * (maxy - miny) : 0;
-                inv_w = __builtin_amdgcn_rcpf((float)w);  // k / w below is exact for k < 2^20 with a 1-ulp reciprocal
-            }
-        }
-        unsigned long long todo = __ballot(n > 0);
-        while (todo) {  // Gaussians in sorted order, four per step to keep several LDS atomics in flight
-            int jn[4], jw[4], jx[4], jy[4];
-            float jinv[4];
-            uint32_t jid[4];
-            bool big = false;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (todo) {
-                    const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
-                    todo &= todo - 1;
-                    jn[u] = __builtin_amdgcn_readlane(n, j);
-                    jw[u] = __builtin_amdgcn_readlane(w, j);
-                    jx[u] = __builtin_amdgcn_readlane(minx, j);
-                    jy[u] = __builtin_amdgcn_readlane(miny, j);
-                    jinv[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_w), j));
-                    jid[u] = (uint32_t)__builtin_amdgcn_readlane(id, j);
-                    big = big || jn[u] > 64;
+    const int sub_rows = (by1 - by0 + 3) / 4;
+    const int wy0 = by0 + wave * sub_rows, wy1 = min(by1, wy0 + sub_rows);
+    const int begin = slice * per_slice;
+    const int end = min(P, begin + per_slice);
+    if (wy0 < wy1) {
+        for (int base = begin; base < end; base += 64) {
+            const int s = base + lane;
+            int id = 0, minx = 0, miny = 0, w = 1, n = 0;
+            float inv_w = 1.0f;
+            if (s < end) {
+                const uint2 r = rects[s];
+                w = (int)(r.y & 0xFFFFu);
+                if (w > 0) {
+                    minx = (int)(r.x & 0xFFFFu);
+                    const int y0 = (int)(r.x >> 16), y1 = y0 + (int)(r.y >> 16);
+                    miny = max(y0, wy0);
+                    const int maxy = min(y1, wy1);
+                    n = (maxy > miny) ? w * (maxy - miny) : 0;
+                    if (SCATTER && n > 0) id = (int)order[s];
+                    inv_w = __builtin_amdgcn_rcpf((float)w);  // k / w below is exact for k < 2^20 with a 1-ulp reciprocal
                 } else {
-                    jn[u] = 0; jw[u] = 1; jx[u] = 0; jy[u] = 0; jid[u] = 0u; jinv[u] = 1.0f;
+                    w = 1;
                 }
             }
-            if (!big) {
-                // every rectangle fits in one pass of 64 lanes: issue the (ordered) LDS atomics back to back, then the
-                // stores; LDS operations of one wave execute in program order, so tile slots are still handed out in
-                // depth order
-                uint32_t slot[4];
-                int tt[4];
+            unsigned long long todo = __ballot(n > 0);
+            while (todo) {  // Gaussians in sorted order, four per step to keep several LDS atomics in flight
+                int jn[4], jw[4], jx[4], jy[4];
+                float jinv[4];
+                uint32_t jid[4];
+                bool big = false;
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const int ty = (int)(((float)lane + 0.5f) * jinv[u]);
-                    tt[u] = (jy[u] + ty) * gx + jx[u] + (lane - ty * jw[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (lane < jn[u]) {
-                        if (SCATTER) slot[u] = atomicAdd(&cnt[tt[u]], 1u);
-                        else atomicAdd(&cnt[tt[u]], 1u);
+                    if (todo) {
+                        const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+                        todo &= todo - 1;
+                        jn[u] = __builtin_amdgcn_readlane(n, j);
+                        jw[u] = __builtin_amdgcn_readlane(w, j);
+                        jx[u] = __builtin_amdgcn_readlane(minx, j);
+                        jy[u] = __builtin_amdgcn_readlane(miny, j);
+                        jinv[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_w), j));
+                        jid[u] = SCATTER ? (uint32_t)__builtin_amdgcn_readlane(id, j) : 0u;
+                        big = big || jn[u] > 64;
+                    } else {
+                        jn[u] = 0; jw[u] = 1; jx[u] = 0; jy[u] = by0; jid[u] = 0u; jinv[u] = 1.0f;
                     }
                 }
-                if (SCATTER) {
+                if (!big) {
+                    // every rectangle fits in one pass of 64 lanes: issue the (ordered) LDS atomics back to back, then
+                    // the stores; LDS operations of one wave execute in program order, so tile slots are still handed
+                    // out in depth order
+                    uint32_t slot[4];
+                    int tt[4];
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        if (lane < jn[u]) point_list[slot[u]] = jid[u];
-                }
-            } else {
-                // a rectangle larger than 64 tiles: strictly one Gaussian at a time
+                    for (int u = 0; u < 4; u++) {
+                        const int ty = (int)(((float)lane + 0.5f) * jinv[u]);
+                        tt[u] = (jy[u] - by0 + ty) * gx + jx[u] + (lane - ty * jw[u]);
+                    }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    for (int k = lane; k < jn[u]; k += 64) {
-                        const int ty = (int)(((float)k + 0.5f) * jinv[u]);
-                        const int t = (jy[u] + ty) * gx + jx[u] + (k - ty * jw[u]);
-                        if (SCATTER) {
-                            const uint32_t sl = atomicAdd(&cnt[t], 1u);
-                            point_list[sl] = jid[u];
-                        } else {
-                            atomicAdd(&cnt[t], 1u);
+                    for (int u = 0; u < 4; u++) {
+                        if (lane < jn[u]) {
+                            if (SCATTER) slot[u] = atomicAdd(&s_cnt[tt[u]], 1u);
+                            else atomicAdd(&s_cnt[tt[u]], 1u);
                         }
                     }
-                    if (SCATTER) WAVE_FENCE();
+                    if (SCATTER) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (lane < jn[u]) point_list[slot[u]] = jid[u];
+                    }
+                } else {
+                    // a rectangle larger than 64 tiles: strictly one Gaussian at a time
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        for (int k = lane; k < jn[u]; k += 64) {
+                            const int ty = (int)(((float)k + 0.5f) * jinv[u]);
+                            const int t = (jy[u] - by0 + ty) * gx + jx[u] + (k - ty * jw[u]);
+                            if (SCATTER) {
+                                const uint32_t sl = atomicAdd(&s_cnt[t], 1u);
+                                point_list[sl] = jid[u];
+                            } else {
+                                atomicAdd(&s_cnt[t], 1u);
+                            }
+                        }
+                        if (SCATTER) WAVE_FENCE();
+                    }
                 }
+                if (SCATTER) WAVE_FENCE();
             }
-            if (SCATTER) WAVE_FENCE();
         }
     }
-    if (!SCATTER && LDS_COUNTERS) {
+    if (!SCATTER) {
         __syncthreads();
-        for (int t = tid; t < T; t += 256) row[t] = cnt[t];
+        for (int t = tid; t < nt; t += 256) row[t] = s_cnt[t];
     }
 }
 
@@ -324,28 +353,30 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __res
 }
 
 template <bool SCATTER>
-void launch_bin(int P, int gx, int gy, int n_blocks, int per_block, bool lds, const uint32_t* order, const GeomRec* rec,
+void launch_bin(int P, int gx, int gy, int n_slices, int per_slice, const uint32_t* order, const uint2* rects,
                 const uint32_t* tile_start, uint32_t* blk_hist, uint32_t* point_list, hipStream_t s)
 {
-    const size_t bytes = (size_t)gx * gy * 4;
-    if (lds) {
-        static size_t configured = 0;
-        if (bytes > configured) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_ordered<SCATTER, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-            configured = bytes;
-        }
-        hipLaunchKernelGGL((k_bin_ordered<SCATTER, true>), dim3(n_blocks), dim3(256), bytes, s, P, gx, gy, per_block, order, rec,
-                           tile_start, blk_hist, point_list);
-    } else {
-        hipLaunchKernelGGL((k_bin_ordered<SCATTER, false>), dim3(n_blocks), dim3(256), 0, s, P, gx, gy, per_block, order, rec,
-                           tile_start, blk_hist, point_list);
+    const size_t bytes = (size_t)((gy + 7) / 8) * gx * 4;
+    static size_t configured = 0;
+    if (bytes > configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_ordered<SCATTER>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        configured = bytes;
     }
+    hipLaunchKernelGGL((k_bin_ordered<SCATTER>), dim3(n_slices * 8), dim3(256), bytes, s, P, gx, gy, per_slice, order, rects,
+                       tile_start, blk_hist, point_list);
 }
 
 }  // namespace
 
 size_t sgr_sort_scratch_bytes(int P)
+{
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    const size_t chunks = (n + RS_ITEMS - 1) / RS_ITEMS;
+    return sgr_align(n * 4) * 4 + sgr_align(chunks * 256 * 4) + 1024 + sgr_align(n * 8);  // + packed rectangles
+}
+
+size_t sgr_sort_rects_offset(int P)
 {
     const size_t n = (size_t)(P > 0 ? P : 1);
     const size_t chunks = (n + RS_ITEMS - 1) / RS_ITEMS;
@@ -378,17 +409,22 @@ void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_
     *order_out = vals_a;  // pass 0 -> b, 1 -> a, 2 -> b, 3 -> a
 }
 
-void sgr_launch_bin_count(int P, int gx, int gy, int n_blocks, int per_block, bool lds, const uint32_t* order,
-                          const GeomRec* rec, uint32_t* blk_hist, hipStream_t s)
+void sgr_launch_pack_rects(int P, int gx, int gy, const uint32_t* order, const GeomRec* rec, uint2* rects, hipStream_t s)
 {
-    launch_bin<false>(P, gx, gy, n_blocks, per_block, lds, order, rec, nullptr, blk_hist, nullptr, s);
+    if (P <= 0) return;
+    hipLaunchKernelGGL(k_pack_rects, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, gy, order, rec, rects);
 }
 
-void sgr_launch_bin_scatter(int P, int gx, int gy, int n_blocks, int per_block, bool lds, const uint32_t* order,
-                            const GeomRec* rec, const uint32_t* tile_start, uint32_t* blk_hist, uint32_t* point_list,
-                            hipStream_t s)
+void sgr_launch_bin_count(int P, int gx, int gy, int n_slices, int per_slice, const uint32_t* order, const uint2* rects,
+                          uint32_t* blk_hist, hipStream_t s)
 {
-    launch_bin<true>(P, gx, gy, n_blocks, per_block, lds, order, rec, tile_start, blk_hist, point_list, s);
+    launch_bin<false>(P, gx, gy, n_slices, per_slice, order, rects, nullptr, blk_hist, nullptr, s);
+}
+
+void sgr_launch_bin_scatter(int P, int gx, int gy, int n_slices, int per_slice, const uint32_t* order, const uint2* rects,
+                            const uint32_t* tile_start, uint32_t* blk_hist, uint32_t* point_list, hipStream_t s)
+{
+    launch_bin<true>(P, gx, gy, n_slices, per_slice, order, rects, tile_start, blk_hist, point_list, s);
 }
 
 void sgr_launch_hist_scan(int T, int n_blocks, uint32_t* blk_hist, uint32_t* tile_count, hipStream_t s)

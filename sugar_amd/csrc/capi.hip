@@ -150,6 +150,8 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     if (!cov3D_precomp && (!scales || !rotations)) return fail(SGR_E_INVALID, "need scales+rotations or cov3D_precomp");
 
     const ImgLayout IL = sgr_img_layout(width, height);
+    if ((size_t)((IL.gy + 7) / 8) * IL.gx * 4 > 150 * 1024 || IL.gx > 65535 || IL.gy > 65535)
+        return fail(SGR_E_INVALID, "image too large: a band of tile rows (gy/8 x gx counters) must fit in 150 KB of LDS");
     char* geom = geom_alloc(geom_user, sgr_geom_bytes(P));
     char* img = img_alloc(img_user, IL.total);
     if (!geom || !img) return fail(SGR_E_ALLOC, "geometry/image scratch allocation failed");
@@ -165,7 +167,8 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
 
     uint32_t* blk_hist = reinterpret_cast<uint32_t*>(img + IL.blk_hist);
     char* sort_scratch = geom + sgr_geom_sort_offset(P);
-    const int per_block = (((P + IL.n_blocks - 1) / IL.n_blocks + 63) / 64) * 64;
+    const int per_block = (((P + IL.n_blocks - 1) / IL.n_blocks + 63) / 64) * 64;  // Gaussians per slice
+    uint2* rects = reinterpret_cast<uint2*>(sort_scratch + sgr_sort_rects_offset(P));
 
     PreprocessArgs pa;
     pa.P = P; pa.D = D; pa.M = shs ? M : 0;
@@ -186,7 +189,8 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
 
     {
         StageTimer t(s, SGR_STAGE_SCAN);
-        sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, IL.lds_counters, order, rec, blk_hist, s);
+        sgr_launch_pack_rects(P, IL.gx, IL.gy, order, rec, rects, s);
+        sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, blk_hist, s);
         sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
         sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, s);
     }
@@ -204,8 +208,7 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
 
     if (R > 0) {
         StageTimer t(s, SGR_STAGE_SCATTER);
-        sgr_launch_bin_scatter(P, IL.gx, IL.gy, IL.n_blocks, per_block, IL.lds_counters, order, rec, tile_start, blk_hist,
-                               point_list, s);
+        sgr_launch_bin_scatter(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, tile_start, blk_hist, point_list, s);
     }
     STAGE_CHECK("bin_scatter");
     {

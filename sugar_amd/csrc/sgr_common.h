@@ -8,7 +8,7 @@
 #define SGR_TILE_Y 16  // BLOCK_Y, DGR/cuda_rasterizer/config.h:17
 #define SGR_TILE_PIX 256
 #define SGR_NUM_CUS 256              // MI355X
-#define SGR_BIN_LDS_MAX (150 * 1024) // LDS budget per CU for the binning histograms (160 KB per CU)
+#define SGR_BIN_SLICES 256           // slices of the depth order; x 8 tile-row bands = 2048 workgroups (8 per CU)
 
 // ---- private scratch layouts -----------------------------------------------------------------
 // geom  : [ GeomRec rec[P] | acc f32[P][12] | sort scratch ]   48 B / Gaussian record (AoS: one gather = 1-2 lines),
@@ -30,12 +30,12 @@ static inline size_t sgr_align(size_t x, size_t a = 256) { return (x + a - 1) / 
 static inline size_t sgr_geom_acc_offset(int P) { return sgr_align((size_t)(P > 0 ? P : 1) * 48); }
 size_t sgr_sort_scratch_bytes(int P);  // binning.hip
 static inline size_t sgr_geom_sort_offset(int P) { return sgr_geom_acc_offset(P) + sgr_align((size_t)(P > 0 ? P : 1) * 48); }
+size_t sgr_sort_rects_offset(int P);    // binning.hip: offset of the packed rectangles inside the sort scratch
 static inline size_t sgr_geom_total(int P) { return sgr_geom_sort_offset(P) + sgr_sort_scratch_bytes(P); }
 
 struct ImgLayout {
     size_t final_T, n_contrib, tile_start, tile_cursor, tile_maxc, tile_walked, header, blk_hist, total;
-    int n_blocks;      // persistent single-wave binning grid
-    bool lds_counters; // the per-workgroup tile histogram fits in LDS (else: the workgroup's blk_hist row in global memory)
+    int n_blocks;      // slices of the depth order in the ordered binning (8 band workgroups each)
     int gx, gy, T;
 };
 static inline ImgLayout sgr_img_layout(int W, int H)
@@ -52,13 +52,7 @@ static inline ImgLayout sgr_img_layout(int W, int H)
     L.tile_maxc = off;   off = sgr_align(off + (size_t)L.T * 4);
     L.tile_walked = off; off = sgr_align(off + (size_t)L.T * 4);
     L.header = off;      off = sgr_align(off + 64);
-    L.lds_counters = (size_t)L.T * 4 <= SGR_BIN_LDS_MAX;
-    {   // single-wave workgroups per CU: bounded by LDS (one T-entry histogram each), at most 8
-        size_t per_cu = L.lds_counters ? SGR_BIN_LDS_MAX / ((size_t)L.T * 4) : 2;
-        if (per_cu > 8) per_cu = 8;
-        if (per_cu < 1) per_cu = 1;
-        L.n_blocks = (int)(SGR_NUM_CUS * per_cu);
-    }
+    L.n_blocks = SGR_BIN_SLICES;
     L.blk_hist = off;    off = sgr_align(off + (size_t)L.n_blocks * L.T * 4);
     L.total = off;
     return L;
@@ -109,11 +103,11 @@ struct PreprocessBwdArgs {
 void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
 
 void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_out, hipStream_t s);
-void sgr_launch_bin_count(int P, int gx, int gy, int n_blocks, int per_block, bool lds, const uint32_t* order,
-                          const GeomRec* rec, uint32_t* blk_hist, hipStream_t s);
-void sgr_launch_bin_scatter(int P, int gx, int gy, int n_blocks, int per_block, bool lds, const uint32_t* order,
-                            const GeomRec* rec, const uint32_t* tile_start, uint32_t* blk_hist, uint32_t* point_list,
-                            hipStream_t s);
+void sgr_launch_pack_rects(int P, int gx, int gy, const uint32_t* order, const GeomRec* rec, uint2* rects, hipStream_t s);
+void sgr_launch_bin_count(int P, int gx, int gy, int n_slices, int per_slice, const uint32_t* order, const uint2* rects,
+                          uint32_t* blk_hist, hipStream_t s);
+void sgr_launch_bin_scatter(int P, int gx, int gy, int n_slices, int per_slice, const uint32_t* order, const uint2* rects,
+                            const uint32_t* tile_start, uint32_t* blk_hist, uint32_t* point_list, hipStream_t s);
 void sgr_launch_hist_scan(int T, int n_blocks, uint32_t* blk_hist, uint32_t* tile_count, hipStream_t s);
 void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* header, hipStream_t s);
 
