@@ -11,14 +11,13 @@
 //   gsort      : stable LSD radix sort (4 x 8-bit passes) of (depth_bits, gaussian_id) over the P Gaussians.  Culled
 //                Gaussians carry key 0xFFFFFFFF and sink to the end.  Ties keep ascending id.
 //   pack_rects : tile rectangles of the Gaussians in sorted order, 8 bytes each (the walks below stream them)
-//   bin_count  : workgroup (slice, band) owns a contiguous slice of the sorted order and one of eight bands of tile rows,
-//                with a private histogram of the band's tiles in LDS.  Each of its four waves owns a sub-band and walks
-//                the slice's Gaussians IN ORDER, spreading the part of a Gaussian's rectangle that lies in its rows over
-//                its 64 lanes (LDS atomics on distinct tiles); a tile is only ever touched by one wave.
+//   bin_count  : workgroup b owns a contiguous slice of the sorted order and a private histogram over all T tiles in LDS;
+//                one lane per Gaussian (counting needs no order).
 //   hist_scan  : column-wise exclusive scan over the slices of blk_hist[slice][t] (in place) + per-tile totals
 //   tile_scan  : exclusive scan of the totals -> tile_start[T+1] (the ranges), R, largest tile count
-//   bin_scatter: same walk as bin_count; slot = tile_start[t] + blk_hist[slice][t] + (running LDS counter) and the Gaussian
-//                id goes straight into point_list.  Slices are ordered, a wave processes its slice sequentially, and one
+//   bin_scatter: ONE wave per slice takes the slice's Gaussians in order and spreads each rectangle over its 64 lanes;
+//                slot = tile_start[t] + blk_hist[slice][t] + (running LDS counter, returning atomic) and the Gaussian id
+//                goes straight into point_list.  Slices are ordered, a wave processes its slice sequentially, and one
 //                Gaussian never hits a tile twice, so the per-tile order is exactly the sorted order.
 //
 // Order contract: the reference's stable radix sort orders a tile's list by depth bits, ties by ascending Gaussian index
@@ -175,125 +174,112 @@ __global__ void __launch_bounds__(256) k_pack_rects(int P, int gx, int gy, const
     rects[s] = out;
 }
 
-// Workgroup (slice, band): `slice` = a contiguous piece of the depth order, `band` = blockIdx % 8 = one of eight groups of
-// tile rows.  On MI355X consecutive workgroups are dispatched round-robin over the 8 XCDs, so all writes to a given tile's
-// list come from ONE XCD and merge in its L2 instead of leaving it as 4-byte partial-line writes from eight L2s (measured
-// 7.8x write amplification without this).  Correctness does not depend on the placement.  Inside the workgroup each of the
-// four waves owns a sub-band of rows and walks the slice IN ORDER: a tile is only ever touched by one wave, which hands
-// out its slots in depth order.
-template <bool SCATTER>
-__global__ void __launch_bounds__(256) k_bin_ordered(int P, int gx, int gy, int per_slice, const uint32_t* __restrict__ order,
-                                                     const uint2* __restrict__ rects, const uint32_t* __restrict__ tile_start,
-                                                     uint32_t* __restrict__ blk_hist, uint32_t* __restrict__ point_list)
+// Counting needs no order: workgroup b histograms the tiles of its slice of the depth order with one lane per Gaussian
+// (LDS atomics), 16 waves per CU.
+__global__ void __launch_bounds__(256) k_bin_count(int P, int gx, int gy, int per_slice, const uint2* __restrict__ rects,
+                                                   uint32_t* __restrict__ blk_hist)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];  // counters of this band's tiles
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];
     const int T = gx * gy;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int band = blockIdx.x & 7, slice = blockIdx.x >> 3;
-    const int band_rows = (gy + 7) / 8;
-    const int by0 = band * band_rows, by1 = min(gy, by0 + band_rows);
-    if (by0 >= by1) return;
-    const int t0 = by0 * gx, nt = (by1 - by0) * gx;  // this band's tiles: [t0, t0 + nt)
-    uint32_t* row = blk_hist + (size_t)slice * T + t0;
-    if (SCATTER) {
-        for (int t = tid; t < nt; t += 256) s_cnt[t] = tile_start[t0 + t] + row[t];
-    } else {
-        for (int t = tid; t < nt; t += 256) s_cnt[t] = 0u;
-    }
+    const int tid = threadIdx.x;
+    for (int t = tid; t < T; t += 256) s_cnt[t] = 0u;
     __syncthreads();
-    const int sub_rows = (by1 - by0 + 3) / 4;
-    const int wy0 = by0 + wave * sub_rows, wy1 = min(by1, wy0 + sub_rows);
-    const int begin = slice * per_slice;
+    const int begin = blockIdx.x * per_slice;
     const int end = min(P, begin + per_slice);
-    if (wy0 < wy1) {
-        for (int base = begin; base < end; base += 64) {
-            const int s = base + lane;
-            int id = 0, minx = 0, miny = 0, w = 1, n = 0;
-            float inv_w = 1.0f;
-            if (s < end) {
-                const uint2 r = rects[s];
-                w = (int)(r.y & 0xFFFFu);
-                if (w > 0) {
-                    minx = (int)(r.x & 0xFFFFu);
-                    const int y0 = (int)(r.x >> 16), y1 = y0 + (int)(r.y >> 16);
-                    miny = max(y0, wy0);
-                    const int maxy = min(y1, wy1);
-                    n = (maxy > miny) ? w * (maxy - miny) : 0;
-                    if (SCATTER && n > 0) id = (int)order[s];
-                    inv_w = __builtin_amdgcn_rcpf((float)w);  // k / w below is exact for k < 2^20 with a 1-ulp reciprocal
-                } else {
-                    w = 1;
-                }
-            }
-            unsigned long long todo = __ballot(n > 0);
-            while (todo) {  // Gaussians in sorted order, four per step to keep several LDS atomics in flight
-                int jn[4], jw[4], jx[4], jy[4];
-                float jinv[4];
-                uint32_t jid[4];
-                bool big = false;
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (todo) {
-                        const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
-                        todo &= todo - 1;
-                        jn[u] = __builtin_amdgcn_readlane(n, j);
-                        jw[u] = __builtin_amdgcn_readlane(w, j);
-                        jx[u] = __builtin_amdgcn_readlane(minx, j);
-                        jy[u] = __builtin_amdgcn_readlane(miny, j);
-                        jinv[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_w), j));
-                        jid[u] = SCATTER ? (uint32_t)__builtin_amdgcn_readlane(id, j) : 0u;
-                        big = big || jn[u] > 64;
-                    } else {
-                        jn[u] = 0; jw[u] = 1; jx[u] = 0; jy[u] = by0; jid[u] = 0u; jinv[u] = 1.0f;
-                    }
-                }
-                if (!big) {
-                    // every rectangle fits in one pass of 64 lanes: issue the (ordered) LDS atomics back to back, then
-                    // the stores; LDS operations of one wave execute in program order, so tile slots are still handed
-                    // out in depth order
-                    uint32_t slot[4];
-                    int tt[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int ty = (int)(((float)lane + 0.5f) * jinv[u]);
-                        tt[u] = (jy[u] - by0 + ty) * gx + jx[u] + (lane - ty * jw[u]);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (lane < jn[u]) {
-                            if (SCATTER) slot[u] = atomicAdd(&s_cnt[tt[u]], 1u);
-                            else atomicAdd(&s_cnt[tt[u]], 1u);
-                        }
-                    }
-                    if (SCATTER) {
-#pragma unroll
-                        for (int u = 0; u < 4; u++)
-                            if (lane < jn[u]) point_list[slot[u]] = jid[u];
-                    }
-                } else {
-                    // a rectangle larger than 64 tiles: strictly one Gaussian at a time
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        for (int k = lane; k < jn[u]; k += 64) {
-                            const int ty = (int)(((float)k + 0.5f) * jinv[u]);
-                            const int t = (jy[u] - by0 + ty) * gx + jx[u] + (k - ty * jw[u]);
-                            if (SCATTER) {
-                                const uint32_t sl = atomicAdd(&s_cnt[t], 1u);
-                                point_list[sl] = jid[u];
-                            } else {
-                                atomicAdd(&s_cnt[t], 1u);
-                            }
-                        }
-                        if (SCATTER) WAVE_FENCE();
-                    }
-                }
-                if (SCATTER) WAVE_FENCE();
-            }
+    for (int s = begin + tid; s < end; s += 256) {
+        const uint2 r = rects[s];
+        const int w = (int)(r.y & 0xFFFFu), h = (int)(r.y >> 16);
+        const int minx = (int)(r.x & 0xFFFFu), miny = (int)(r.x >> 16);
+        for (int y = 0; y < h; y++) {
+            uint32_t* rowp = s_cnt + (miny + y) * gx + minx;
+            for (int x = 0; x < w; x++) atomicAdd(&rowp[x], 1u);
         }
     }
-    if (!SCATTER) {
-        __syncthreads();
-        for (int t = tid; t < nt; t += 256) row[t] = s_cnt[t];
+    __syncthreads();
+    uint32_t* row = blk_hist + (size_t)blockIdx.x * T;
+    for (int t = tid; t < T; t += 256) row[t] = s_cnt[t];
+}
+
+// The scatter must hand out a tile's slots in depth order: ONE wave per slice takes the slice's Gaussians in order and
+// spreads each rectangle over its 64 lanes (returning LDS atomics on distinct tiles); four Gaussians are in flight per
+// step (LDS operations of one wave execute in program order, so the order of the atomics is the order of the Gaussians).
+__global__ void __launch_bounds__(64) k_bin_scatter(int P, int gx, int gy, int per_slice, const uint32_t* __restrict__ order,
+                                                    const uint2* __restrict__ rects, const uint32_t* __restrict__ tile_start,
+                                                    const uint32_t* __restrict__ blk_hist, uint32_t* __restrict__ point_list)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];
+    const int T = gx * gy;
+    const int lane = threadIdx.x;
+    const uint32_t* row = blk_hist + (size_t)blockIdx.x * T;
+    for (int t = lane; t < T; t += 64) s_cnt[t] = tile_start[t] + row[t];
+    WAVE_FENCE();
+    const int begin = blockIdx.x * per_slice;
+    const int end = min(P, begin + per_slice);
+    for (int base = begin; base < end; base += 64) {
+        const int s = base + lane;
+        int id = 0, t0 = 0, w = 1, n = 0;
+        float inv_w = 1.0f;
+        if (s < end) {
+            const uint2 r = rects[s];
+            const int rw = (int)(r.y & 0xFFFFu);
+            if (rw > 0) {
+                w = rw;
+                n = rw * (int)(r.y >> 16);
+                t0 = (int)(r.x >> 16) * gx + (int)(r.x & 0xFFFFu);
+                id = (int)order[s];
+                inv_w = __builtin_amdgcn_rcpf((float)rw);  // k / w below is exact for k < 2^20 with a 1-ulp reciprocal
+            }
+        }
+        unsigned long long todo = __ballot(n > 0);
+        while (todo) {
+            int jn[4], jw[4], jt[4];
+            float jinv[4];
+            uint32_t jid[4];
+            bool big = false;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (todo) {
+                    const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+                    todo &= todo - 1;
+                    jn[u] = __builtin_amdgcn_readlane(n, j);
+                    jw[u] = __builtin_amdgcn_readlane(w, j);
+                    jt[u] = __builtin_amdgcn_readlane(t0, j);
+                    jinv[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_w), j));
+                    jid[u] = (uint32_t)__builtin_amdgcn_readlane(id, j);
+                    big = big || jn[u] > 64;
+                } else {
+                    jn[u] = 0; jw[u] = 1; jt[u] = 0; jid[u] = 0u; jinv[u] = 1.0f;
+                }
+            }
+            if (!big) {
+                uint32_t slot[4];
+                int tt[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int ty = (int)(((float)lane + 0.5f) * jinv[u]);
+                    tt[u] = jt[u] + ty * gx + (lane - ty * jw[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (lane < jn[u]) slot[u] = atomicAdd(&s_cnt[tt[u]], 1u);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (lane < jn[u]) point_list[slot[u]] = jid[u];
+            } else {
+                // a rectangle larger than 64 tiles: strictly one Gaussian at a time
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    for (int k = lane; k < jn[u]; k += 64) {
+                        const int ty = (int)(((float)k + 0.5f) * jinv[u]);
+                        const int t = jt[u] + ty * gx + (k - ty * jw[u]);
+                        const uint32_t sl = atomicAdd(&s_cnt[t], 1u);
+                        point_list[sl] = jid[u];
+                    }
+                    WAVE_FENCE();
+                }
+            }
+            WAVE_FENCE();
+        }
     }
 }
 
@@ -352,21 +338,6 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __res
     }
 }
 
-template <bool SCATTER>
-void launch_bin(int P, int gx, int gy, int n_slices, int per_slice, const uint32_t* order, const uint2* rects,
-                const uint32_t* tile_start, uint32_t* blk_hist, uint32_t* point_list, hipStream_t s)
-{
-    const size_t bytes = (size_t)((gy + 7) / 8) * gx * 4;
-    static size_t configured = 0;
-    if (bytes > configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_ordered<SCATTER>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        configured = bytes;
-    }
-    hipLaunchKernelGGL((k_bin_ordered<SCATTER>), dim3(n_slices * 8), dim3(256), bytes, s, P, gx, gy, per_slice, order, rects,
-                       tile_start, blk_hist, point_list);
-}
-
 }  // namespace
 
 size_t sgr_sort_scratch_bytes(int P)
@@ -415,16 +386,32 @@ void sgr_launch_pack_rects(int P, int gx, int gy, const uint32_t* order, const G
     hipLaunchKernelGGL(k_pack_rects, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, gy, order, rec, rects);
 }
 
+static void set_lds_limit(const void* fn, size_t bytes, size_t& configured)
+{
+    if (bytes > configured) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        configured = bytes;
+    }
+}
+
 void sgr_launch_bin_count(int P, int gx, int gy, int n_slices, int per_slice, const uint32_t* order, const uint2* rects,
                           uint32_t* blk_hist, hipStream_t s)
 {
-    launch_bin<false>(P, gx, gy, n_slices, per_slice, order, rects, nullptr, blk_hist, nullptr, s);
+    (void)order;
+    static size_t configured = 0;
+    const size_t bytes = (size_t)gx * gy * 4;
+    set_lds_limit(reinterpret_cast<const void*>(&k_bin_count), bytes, configured);
+    hipLaunchKernelGGL(k_bin_count, dim3(n_slices), dim3(256), bytes, s, P, gx, gy, per_slice, rects, blk_hist);
 }
 
 void sgr_launch_bin_scatter(int P, int gx, int gy, int n_slices, int per_slice, const uint32_t* order, const uint2* rects,
                             const uint32_t* tile_start, uint32_t* blk_hist, uint32_t* point_list, hipStream_t s)
 {
-    launch_bin<true>(P, gx, gy, n_slices, per_slice, order, rects, tile_start, blk_hist, point_list, s);
+    static size_t configured = 0;
+    const size_t bytes = (size_t)gx * gy * 4;
+    set_lds_limit(reinterpret_cast<const void*>(&k_bin_scatter), bytes, configured);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(n_slices), dim3(64), bytes, s, P, gx, gy, per_slice, order, rects, tile_start, blk_hist,
+                       point_list);
 }
 
 void sgr_launch_hist_scan(int T, int n_blocks, uint32_t* blk_hist, uint32_t* tile_count, hipStream_t s)

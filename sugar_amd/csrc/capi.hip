@@ -150,8 +150,8 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     if (!cov3D_precomp && (!scales || !rotations)) return fail(SGR_E_INVALID, "need scales+rotations or cov3D_precomp");
 
     const ImgLayout IL = sgr_img_layout(width, height);
-    if ((size_t)((IL.gy + 7) / 8) * IL.gx * 4 > 150 * 1024 || IL.gx > 65535 || IL.gy > 65535)
-        return fail(SGR_E_INVALID, "image too large: a band of tile rows (gy/8 x gx counters) must fit in 150 KB of LDS");
+    if ((size_t)IL.T * 4 > 150 * 1024 || IL.gx > 65535 || IL.gy > 65535)
+        return fail(SGR_E_INVALID, "image too large: one counter per tile must fit in 150 KB of LDS (about 38 000 tiles)");
     char* geom = geom_alloc(geom_user, sgr_geom_bytes(P));
     char* img = img_alloc(img_user, IL.total);
     if (!geom || !img) return fail(SGR_E_ALLOC, "geometry/image scratch allocation failed");

@@ -8,7 +8,7 @@
 #define SGR_TILE_Y 16  // BLOCK_Y, DGR/cuda_rasterizer/config.h:17
 #define SGR_TILE_PIX 256
 #define SGR_NUM_CUS 256              // MI355X
-#define SGR_BIN_SLICES 256           // slices of the depth order; x 8 tile-row bands = 2048 workgroups (8 per CU)
+#define SGR_BIN_SLICES 1024          // slices of the depth order in the ordered binning (one T-entry LDS histogram each)
 
 // ---- private scratch layouts -----------------------------------------------------------------
 // geom  : [ GeomRec rec[P] | acc f32[P][12] | sort scratch ]   48 B / Gaussian record (AoS: one gather = 1-2 lines),
@@ -35,7 +35,7 @@ static inline size_t sgr_geom_total(int P) { return sgr_geom_sort_offset(P) + sg
 
 struct ImgLayout {
     size_t final_T, n_contrib, tile_start, tile_cursor, tile_maxc, tile_walked, header, blk_hist, total;
-    int n_blocks;      // slices of the depth order in the ordered binning (8 band workgroups each)
+    int n_blocks;      // slices of the depth order in the ordered binning
     int gx, gy, T;
 };
 static inline ImgLayout sgr_img_layout(int W, int H)

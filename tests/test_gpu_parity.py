@@ -208,14 +208,12 @@ def test_knn_and_dist2_match_oracle():
     assert (i.cpu().numpy() == ii).mean() > 0.999 and np.array_equal(i[:, 0].cpu().numpy(), np.arange(3000))
 
 
-def test_large_tile_grid():
-    """39 200 tiles (3200x3136): 20 KB of LDS counters per tile-row band; rows not divisible by the 8 bands / 4 waves."""
+def test_large_tile_grid_4k():
+    """BASELINE config-5 image size (3840x2160 = 32 400 tiles, 127 KB of LDS tile counters per workgroup)."""
     scene = syn.make_scene(3000, 33, 0.02, 0.2)
-    cam = syn.orbit_cameras(3200, 3136)[1]
-    _check(scene, cam, torch.zeros(3), grads=False)
+    _check(scene, syn.orbit_cameras(3840, 2160)[1], torch.zeros(3), grads=False)
 
 
-def test_tiny_image_fewer_tile_rows_than_bands():
-    """2 tile rows: six of the eight row bands are empty."""
+def test_tiny_image():
     scene = syn.make_scene(2000, 34, 0.02, 0.2)
     _check(scene, syn.orbit_cameras(100, 20)[0], torch.tensor([0.5, 0.1, 0.9]))
