@@ -285,7 +285,10 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
                 if (__ballot(active) == 0ull) continue;  // wave-uniform
                 float Z = 0.f, Wt = 0.f;
                 if (active) {
-                    T = T / (1.f - alpha);
+                    // 1/(1-alpha) with the hardware reciprocal (1 ulp): the reference's two IEEE divisions
+                    // (backward.cu:503,534) cost ~24 instructions per pair; 1-alpha >= 0.01, so no range issue
+                    const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                    T = T * inv_1ma;
                     Wt = alpha * T;
                     const float c0 = b.z, c1 = b.w, c2 = sh.c[j];
                     acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = c0;
@@ -294,7 +297,7 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
                     float dL_dalpha = (c0 - acc0) * g0 + (c1 - acc1) * g1 + (c2 - acc2) * g2;
                     dL_dalpha *= T;
                     last_alpha = alpha;
-                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                    dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
                     Z = G * dL_dalpha;
                 }
                 zw[rows * ZW_STRIDE + lane] = make_float2(Z, Wt);
