@@ -85,13 +85,6 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
     uint32_t last_contributor = 0, done_pos = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
 
-    // software prefetch: the record gather of batch b+1 is issued before batch b is walked, so its (two dependent) memory
-    // latencies overlap with compute instead of stalling the whole workgroup at the staging barrier
-    float4 pf0 = make_float4(0.f, 0.f, 0.f, 0.f), pf1 = pf0, pf2 = pf0;
-    if (tid < total) {
-        const float4* rp = reinterpret_cast<const float4*>(rec + point_list[r0 + tid]);
-        pf0 = rp[0]; pf1 = rp[1]; pf2 = rp[2];
-    }
     for (int base = 0; base < total; base += BATCH) {
         // workgroup vote: stop when every pixel is done (forward.cu:309-311)
         const bool wave_done = __ballot(!done) == 0ull;
@@ -101,15 +94,13 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
         const int nb = min(BATCH, total - base);
         uint32_t hit = 0u;
         if (tid < nb) {
-            const float4 v0 = pf0, v1 = pf1, v2 = pf2;
+            const uint32_t id = point_list[r0 + base + tid];
+            const float4* rp = reinterpret_cast<const float4*>(rec + id);
+            const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
             hit = strip_hit_mask(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)x0, (float)y0);
             st.a[tid] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
             st.b[tid] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v1.z, v1.w);
             st.c[tid] = v2.x;
-        }
-        if (base + BATCH + tid < total) {
-            const float4* rp = reinterpret_cast<const float4*>(rec + point_list[r0 + base + BATCH + tid]);
-            pf0 = rp[0]; pf1 = rp[1]; pf2 = rp[2];
         }
         unsigned long long bal[4];
 #pragma unroll
@@ -260,29 +251,18 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
     const float rowy = (float)(y0 + wave * 4 + bq);
     float2* zw = sh.zw[wave];
 
-    // software prefetch of the next batch's records (first wave only: 64 entries per batch), as in the forward
-    float4 pf0 = make_float4(0.f, 0.f, 0.f, 0.f), pf1 = pf0, pf2 = pf0;
-    uint32_t pf_id = 0u;
-    if (tid < BWD_BATCH && tid < total) {
-        pf_id = point_list[r0 + (uint32_t)(total - 1 - tid)];
-        const float4* rp = reinterpret_cast<const float4*>(rec + pf_id);
-        pf0 = rp[0]; pf1 = rp[1]; pf2 = rp[2];
-    }
     for (int base = 0; base < total; base += BWD_BATCH) {
         const int nb = min(BWD_BATCH, total - base);
         if (tid < BWD_BATCH) {
             uint32_t hit = 0u;
             if (tid < nb) {
-                const float4 v0 = pf0, v1 = pf1, v2 = pf2;
-                sh.a[tid] = v0; sh.b[tid] = v1; sh.c[tid] = v2.x; sh.id[tid] = pf_id;
+                const uint32_t id = point_list[r0 + (uint32_t)(total - 1 - base - tid)];
+                const float4* rp = reinterpret_cast<const float4*>(rec + id);
+                const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
+                sh.a[tid] = v0; sh.b[tid] = v1; sh.c[tid] = v2.x; sh.id[tid] = id;
                 hit = strip_hit_mask(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)x0, (float)y0);
             }
             sh.hit[tid] = hit;
-            if (base + BWD_BATCH + tid < total) {
-                pf_id = point_list[r0 + (uint32_t)(total - 1 - base - BWD_BATCH - tid)];
-                const float4* rp = reinterpret_cast<const float4*>(rec + pf_id);
-                pf0 = rp[0]; pf1 = rp[1]; pf2 = rp[2];
-            }
         }
         __syncthreads();
         // entries of this batch that can touch this wave's strip, walked in list order in groups of <= 16 panel rows
