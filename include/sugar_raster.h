@@ -145,6 +145,33 @@ int sgr_adam_step(long long n, float* params, const float* grads, float* exp_avg
                   const long long* seg_begin, const long long* seg_end, const float* seg_lr_a, const float* seg_lr_b,
                   const int* seg_period, const int* seg_split, float beta1, float beta2, float eps, int step, void* stream);
 
+/* ---- SuGaR density field and level-set surface sampler (share the Gaussian buffers) --------------
+ * B_g = R_g diag(1 / max(s_g, 1e-8)) is SuGaR's get_covariance(return_full_matrix=True, return_sqrt=True,
+ * inverse_scales=True) (sugar_scene/sugar_model.py:730-736), row-major [P,3,3]; nbr_idx is the int64 [N,K] k-NN index
+ * table (knn_idx[gaussian_idx]); strengths is [P] (SuGaR's [P,1]).
+ *
+ * sgr_density_field_forward: sugar_model.py:1270-1276 (get_field_values) -- neighbor_opacities[N,K] (may be NULL) and
+ *   density[N] = sum over the K neighbours of  f * strength * exp(-0.5 * clamp(|B^T (x - mu)|^2, 0, 1e8)).
+ *   (The `density >= 1 -> density / (density.detach() + 1e-12)` step of :1277-1281 is left to the caller.)
+ * sgr_density_field_backward: gradients of  sum(dL_dopacities * opacities) + sum(dL_ddensity * density):
+ *   dL_dx[N,3] is written; dL_dcenters[P,3], dL_dinv_scaled_rot[P,9], dL_dstrengths[P] are ACCUMULATED into (zero them).
+ * sgr_level_set_points: sugar_model.py:1971-2079 (compute_level_surface_points_from_camera_fast) for N unprojected
+ *   pixels: n_range samples in +-range_size * gaussian_std[nbr_idx[n,0]] along normalize(p - cam_center), densities
+ *   (normalised where >= 1), per level (HOST array, <= 8) the first crossing with linear interpolation and the normal
+ *   -normalize(grad density).  Outputs are level-major: valid[L,N] (0 = the reference's empty_pixels), points[L,N,3],
+ *   normals[L,N,3] (may be NULL); rows with valid == 0 are zero. */
+int sgr_density_field_forward(int N, int K, const float* x, const int64_t* nbr_idx, const float* centers,
+                              const float* inv_scaled_rot, const float* strengths, float density_factor,
+                              float* neighbor_opacities, float* density, void* stream);
+int sgr_density_field_backward(int N, int K, const float* x, const int64_t* nbr_idx, const float* centers,
+                               const float* inv_scaled_rot, const float* strengths, float density_factor,
+                               const float* dL_dopacities, const float* dL_ddensity, float* dL_dx, float* dL_dcenters,
+                               float* dL_dinv_scaled_rot, float* dL_dstrengths, void* stream);
+int sgr_level_set_points(int N, int K, const float* world_points, const int64_t* nbr_idx, const float* cam_center,
+                         const float* centers, const float* inv_scaled_rot, const float* strengths,
+                         const float* gaussian_std, int n_levels, const float* levels_host, int n_range, float range_size,
+                         float density_factor, uint8_t* valid, float* points, float* normals, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,69 @@
+"""PyTorch restatement of SuGaR's density field and level-set sampler -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+sugar_scene/sugar_model.py cannot be imported here (pytorch3d / open3d are absent), so the relevant lines are restated with
+the same tensor expressions (PARITY UNPINNED by reference tests: the reference has none).  Line numbers refer to
+/root/reference/sugar_scene/sugar_model.py.
+"""
+import torch
+
+
+def density_field(x, closest_gaussians_idx, gaussian_centers, gaussian_inv_scaled_rotation, gaussian_strengths,
+                  density_factor=1.0):
+    """:1266-1276"""
+    closest_gaussian_centers = gaussian_centers[closest_gaussians_idx]
+    closest_gaussian_inv_scaled_rotation = gaussian_inv_scaled_rotation[closest_gaussians_idx]
+    closest_gaussian_strengths = gaussian_strengths[closest_gaussians_idx]
+    shift = (x[:, None] - closest_gaussian_centers)
+    warped_shift = closest_gaussian_inv_scaled_rotation.transpose(-1, -2) @ shift[..., None]
+    neighbor_opacities = (warped_shift[..., 0] * warped_shift[..., 0]).sum(dim=-1).clamp(min=0., max=1e8)
+    neighbor_opacities = density_factor * closest_gaussian_strengths[..., 0] * torch.exp(-1. / 2 * neighbor_opacities)
+    densities = neighbor_opacities.sum(dim=-1)
+    return neighbor_opacities, densities
+
+
+def level_set_points(all_world_points, closest_gaussians_idx, camera_center, gaussian_centers, gaussian_inv_scaled_rotation,
+                     gaussian_strengths, gaussian_standard_deviations, surface_levels=(0.1, 0.3, 0.5), n_points_in_range=21,
+                     range_size=3., density_factor=1.):
+    """:1971-2079 with compute_intersection_for_flat_gaussian=False, compute_flat_normals=False, return_normals=True"""
+    knn = closest_gaussians_idx.shape[1]
+    points_stds = gaussian_standard_deviations[closest_gaussians_idx[..., 0]]
+    points_range = torch.linspace(-range_size, range_size, n_points_in_range).to(all_world_points.device).view(1, -1, 1)
+    points_range = points_range * points_stds[..., None, None].expand(-1, n_points_in_range, 1)
+    camera_to_samples = torch.nn.functional.normalize(all_world_points - camera_center, dim=-1)
+    samples = (all_world_points[:, None, :] + points_range * camera_to_samples[:, None, :]).view(-1, 3)
+    samples_closest_gaussians_idx = closest_gaussians_idx[:, None, :].expand(-1, n_points_in_range, -1).reshape(-1, knn)
+    neighbor_opacities, pass_densities = density_field(samples, samples_closest_gaussians_idx, gaussian_centers,
+                                                       gaussian_inv_scaled_rotation, gaussian_strengths, density_factor)
+    pass_density_mask = pass_densities >= 1.
+    pass_densities[pass_density_mask] = pass_densities[pass_density_mask] / (pass_densities[pass_density_mask].detach() + 1e-12)
+    densities = pass_densities.reshape(-1, n_points_in_range)
+    all_outputs = {}
+    for surface_level in surface_levels:
+        outputs = {}
+        under_level = (densities - surface_level < 0)
+        above_level = (densities - surface_level > 0)
+        _, first_point_above_level = above_level.max(dim=-1, keepdim=True)
+        empty_pixels = ~under_level[..., 0] + (first_point_above_level[..., 0] == 0)
+        valid_densities = densities[~empty_pixels]
+        valid_range = points_range[~empty_pixels][..., 0]
+        valid_first_point_above_level = first_point_above_level[~empty_pixels]
+        first_value_above_level = valid_densities.gather(dim=-1, index=valid_first_point_above_level).view(-1)
+        value_before_level = valid_densities.gather(dim=-1, index=valid_first_point_above_level - 1).view(-1)
+        first_t_above_level = valid_range.gather(dim=-1, index=valid_first_point_above_level).view(-1)
+        t_before_level = valid_range.gather(dim=-1, index=valid_first_point_above_level - 1).view(-1)
+        intersection_t = (surface_level - value_before_level) / (first_value_above_level - value_before_level) * (first_t_above_level - t_before_level) + t_before_level
+        intersection_points = (all_world_points[~empty_pixels] + intersection_t[:, None] * camera_to_samples[~empty_pixels])
+        outputs['intersection_points'] = intersection_points
+        outputs['valid'] = ~empty_pixels
+        points_closest_gaussians_idx = closest_gaussians_idx[~empty_pixels]
+        closest_gaussian_centers = gaussian_centers[points_closest_gaussians_idx]
+        closest_gaussian_inv_scaled_rotation = gaussian_inv_scaled_rotation[points_closest_gaussians_idx]
+        closest_gaussian_strengths = gaussian_strengths[points_closest_gaussians_idx]
+        shift = (intersection_points[:, None] - closest_gaussian_centers)
+        warped_shift = closest_gaussian_inv_scaled_rotation.transpose(-1, -2) @ shift[..., None]
+        nop = (warped_shift[..., 0] * warped_shift[..., 0]).sum(dim=-1).clamp(min=0., max=1e8)
+        nop = density_factor * closest_gaussian_strengths[..., 0] * torch.exp(-1. / 2 * nop)
+        density_grad = (nop[..., None] * (closest_gaussian_inv_scaled_rotation @ warped_shift)[..., 0]).sum(dim=-2)
+        outputs['normals'] = -torch.nn.functional.normalize(density_grad, dim=-1)
+        all_outputs[surface_level] = outputs
+    return all_outputs

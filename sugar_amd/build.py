@@ -27,6 +27,7 @@ SOURCES = {
     "knn.hip": ["-ffp-contract=off"],
     "loss.hip": [],
     "adam.hip": [],
+    "field.hip": [],
     "capi.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

@@ -1,0 +1,245 @@
+// field.hip -- SuGaR's Gaussian density field and level-set surface sampler as fused gfx950 kernels that read the same
+// per-Gaussian buffers as the reference's PyTorch code (centres, inverse-scaled rotations, strengths, k-NN indices).
+//
+//   density field : sugar_scene/sugar_model.py:1270-1281 (get_field_values) and :1998-2009 (the sampler's copy):
+//                     w = B_g^T (x - mu_g);  o_g = f * strength_g * exp(-0.5 * clamp(|w|^2, 0, 1e8));  density = sum_g o_g
+//                   with B_g = R_g diag(1 / max(s_g, 1e-8))  (get_covariance(return_full_matrix, return_sqrt, inverse_scales),
+//                   :730-736).  The reference materialises [N,16,3,3] and [N,16,3,1] temporaries per call; here one lane
+//                   owns one sample and walks its 16 neighbours.
+//   backward      : gradients of sum(g_op * o) + sum(g_den * density) w.r.t. x, mu, B, strength (autograd of the above).
+//   level sets    : sugar_scene/sugar_model.py:1971-2079 (compute_level_surface_points_from_camera_fast): 21 samples along
+//                   the pixel's ray in +-3 sigma of the front Gaussian, density at each (normalised where >= 1), first
+//                   crossing per level with linear interpolation, normal = -normalize(grad density) at the crossing.
+//                   One lane per pixel; a_g = B_g^T (p - mu_g) and b_g = B_g^T dir are formed once per neighbour, so a
+//                   sample costs 3 FMAs + |.|^2 + one exp per neighbour instead of a 3x3 product.
+#include "../../include/sugar_raster.h"
+#include "sgr_common.h"
+
+namespace {
+
+struct GaussNbr {
+    float mx, my, mz;
+    float B[9];  // row-major 3x3: B[3*i + j]
+    float s;
+};
+
+__device__ __forceinline__ GaussNbr load_nbr(long long g, const float* __restrict__ centers, const float* __restrict__ B,
+                                             const float* __restrict__ strengths)
+{
+    GaussNbr n;
+    n.mx = centers[3 * g]; n.my = centers[3 * g + 1]; n.mz = centers[3 * g + 2];
+#pragma unroll
+    for (int i = 0; i < 9; i++) n.B[i] = B[9 * g + i];
+    n.s = strengths[g];
+    return n;
+}
+
+// w = B^T d  (w_j = sum_i B[i][j] d_i)
+__device__ __forceinline__ void bt_mul(const float* Bm, float dx, float dy, float dz, float& w0, float& w1, float& w2)
+{
+    w0 = Bm[0] * dx + Bm[3] * dy + Bm[6] * dz;
+    w1 = Bm[1] * dx + Bm[4] * dy + Bm[7] * dz;
+    w2 = Bm[2] * dx + Bm[5] * dy + Bm[8] * dz;
+}
+
+__global__ void __launch_bounds__(256) k_density_fwd(int N, int K, const float* __restrict__ x, const long long* __restrict__ nbr,
+                                                     const float* __restrict__ centers, const float* __restrict__ B,
+                                                     const float* __restrict__ strengths, float factor,
+                                                     float* __restrict__ opac, float* __restrict__ density)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float px = x[3 * (size_t)n], py = x[3 * (size_t)n + 1], pz = x[3 * (size_t)n + 2];
+    float sum = 0.f;
+    for (int k = 0; k < K; k++) {
+        const GaussNbr g = load_nbr(nbr[(size_t)n * K + k], centers, B, strengths);
+        float w0, w1, w2;
+        bt_mul(g.B, px - g.mx, py - g.my, pz - g.mz, w0, w1, w2);
+        const float q = fminf(fmaxf(w0 * w0 + w1 * w1 + w2 * w2, 0.f), 1e8f);
+        const float o = factor * g.s * __expf(-0.5f * q);
+        if (opac) opac[(size_t)n * K + k] = o;
+        sum += o;
+    }
+    density[n] = sum;
+}
+
+__global__ void __launch_bounds__(256) k_density_bwd(int N, int K, const float* __restrict__ x, const long long* __restrict__ nbr,
+                                                     const float* __restrict__ centers, const float* __restrict__ B,
+                                                     const float* __restrict__ strengths, float factor,
+                                                     const float* __restrict__ g_opac, const float* __restrict__ g_den,
+                                                     float* __restrict__ dx_out, float* __restrict__ dcenters,
+                                                     float* __restrict__ dB, float* __restrict__ dstrengths)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float px = x[3 * (size_t)n], py = x[3 * (size_t)n + 1], pz = x[3 * (size_t)n + 2];
+    const float gd = g_den ? g_den[n] : 0.f;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int k = 0; k < K; k++) {
+        const long long gi = nbr[(size_t)n * K + k];
+        const GaussNbr g = load_nbr(gi, centers, B, strengths);
+        const float dx = px - g.mx, dy = py - g.my, dz = pz - g.mz;
+        float w0, w1, w2;
+        bt_mul(g.B, dx, dy, dz, w0, w1, w2);
+        const float q_raw = w0 * w0 + w1 * w1 + w2 * w2;
+        const float q = fminf(fmaxf(q_raw, 0.f), 1e8f);
+        const float e = __expf(-0.5f * q);
+        const float go = (g_opac ? g_opac[(size_t)n * K + k] : 0.f) + gd;  // dL/do
+        atomicAdd(&dstrengths[gi], go * factor * e);
+        // d o / d q = -0.5 o inside the clamp range, 0 outside (torch.clamp gradient)
+        const float dq = (q_raw > 0.f && q_raw < 1e8f) ? -0.5f * factor * g.s * e * go : 0.f;
+        const float dw0 = 2.f * w0 * dq, dw1 = 2.f * w1 * dq, dw2 = 2.f * w2 * dq;
+        // d = x - mu;  w_j = sum_i B[i][j] d_i  ->  dL/dd_i = sum_j B[i][j] dw_j ;  dL/dB[i][j] = d_i dw_j
+        const float dd0 = g.B[0] * dw0 + g.B[1] * dw1 + g.B[2] * dw2;
+        const float dd1 = g.B[3] * dw0 + g.B[4] * dw1 + g.B[5] * dw2;
+        const float dd2 = g.B[6] * dw0 + g.B[7] * dw1 + g.B[8] * dw2;
+        ax += dd0; ay += dd1; az += dd2;
+        if (dq != 0.f) {
+            atomicAdd(&dcenters[3 * gi], -dd0); atomicAdd(&dcenters[3 * gi + 1], -dd1); atomicAdd(&dcenters[3 * gi + 2], -dd2);
+            float* b = dB + 9 * gi;
+            atomicAdd(&b[0], dx * dw0); atomicAdd(&b[1], dx * dw1); atomicAdd(&b[2], dx * dw2);
+            atomicAdd(&b[3], dy * dw0); atomicAdd(&b[4], dy * dw1); atomicAdd(&b[5], dy * dw2);
+            atomicAdd(&b[6], dz * dw0); atomicAdd(&b[7], dz * dw1); atomicAdd(&b[8], dz * dw2);
+        }
+    }
+    if (dx_out) { dx_out[3 * (size_t)n] = ax; dx_out[3 * (size_t)n + 1] = ay; dx_out[3 * (size_t)n + 2] = az; }
+}
+
+#define LS_MAX_RANGE 32
+#define LS_MAX_LEVELS 8
+struct LevelArgs { int n; float v[LS_MAX_LEVELS]; };
+
+__global__ void __launch_bounds__(128) k_level_set(int N, int K, const float* __restrict__ world_points,
+                                                   const long long* __restrict__ nbr, const float* __restrict__ cam_center,
+                                                   const float* __restrict__ centers, const float* __restrict__ B,
+                                                   const float* __restrict__ strengths, const float* __restrict__ gaussian_std,
+                                                   LevelArgs levels, int n_range, float range_size, float factor,
+                                                   uint8_t* __restrict__ valid, float* __restrict__ points, float* __restrict__ normals)
+{
+    const int n = blockIdx.x * 128 + threadIdx.x;
+    if (n >= N) return;
+    const float wx = world_points[3 * (size_t)n], wy = world_points[3 * (size_t)n + 1], wz = world_points[3 * (size_t)n + 2];
+    // camera_to_samples = normalize(p - camera_center)  (:1978); F.normalize divides by max(|v|, 1e-12)
+    float dirx = wx - cam_center[0], diry = wy - cam_center[1], dirz = wz - cam_center[2];
+    const float dn = fmaxf(sqrtf(dirx * dirx + diry * diry + dirz * dirz), 1e-12f);
+    dirx /= dn; diry /= dn; dirz /= dn;
+    const long long* my_nbr = nbr + (size_t)n * K;
+    const float sigma = gaussian_std[my_nbr[0]];  // points_stds (:1973)
+    // points_range = linspace(-range, range, n_range) * sigma  (:1976-1977); torch.linspace: start + i * step
+    const float step = n_range > 1 ? (2.f * range_size) / (float)(n_range - 1) : 0.f;
+    float dens[LS_MAX_RANGE];
+#pragma unroll
+    for (int i = 0; i < LS_MAX_RANGE; i++) dens[i] = 0.f;
+    for (int k = 0; k < K; k++) {
+        const GaussNbr g = load_nbr(my_nbr[k], centers, B, strengths);
+        float a0, a1, a2, b0, b1, b2;
+        bt_mul(g.B, wx - g.mx, wy - g.my, wz - g.mz, a0, a1, a2);
+        bt_mul(g.B, dirx, diry, dirz, b0, b1, b2);
+        const float fs = factor * g.s;
+#pragma unroll
+        for (int i = 0; i < LS_MAX_RANGE; i++) {
+            if (i < n_range) {
+                const float t = (-range_size + (float)i * step) * sigma;
+                const float w0 = a0 + t * b0, w1 = a1 + t * b1, w2 = a2 + t * b2;
+                const float q = fminf(fmaxf(w0 * w0 + w1 * w1 + w2 * w2, 0.f), 1e8f);
+                dens[i] += fs * __expf(-0.5f * q);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LS_MAX_RANGE; i++)
+        if (dens[i] >= 1.f) dens[i] = dens[i] / (dens[i] + 1e-12f);  // :2007-2008
+    for (int l = 0; l < levels.n; l++) {
+        const float L = levels.v[l];
+        // first sample above the level (argmax of a boolean row: 0 when none is above), :2019-2020
+        int first = 0;
+        float d_first = 0.f, d_prev = 0.f;
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < LS_MAX_RANGE; i++) {
+            if (i < n_range && !found && (dens[i] - L > 0.f)) {
+                found = true; first = i; d_first = dens[i];
+                d_prev = (i > 0) ? dens[i - 1] : 0.f;
+            }
+        }
+        const bool under0 = (dens[0] - L < 0.f);
+        const bool empty = (!under0) || (first == 0);  // :2021
+        const size_t o = (size_t)l * N + n;
+        valid[o] = empty ? 0 : 1;
+        float ix = 0.f, iy = 0.f, iz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+        if (!empty) {
+            const float t_first = (-range_size + (float)first * step) * sigma;
+            const float t_prev = (-range_size + (float)(first - 1) * step) * sigma;
+            const float t = (L - d_prev) / (d_first - d_prev) * (t_first - t_prev) + t_prev;  // :2035
+            ix = wx + t * dirx; iy = wy + t * diry; iz = wz + t * dirz;                    // :2036
+            if (normals) {
+                float gx = 0.f, gy = 0.f, gz = 0.f;  // density_grad = sum_g o_g * B_g w_g  (:2069)
+                for (int k = 0; k < K; k++) {
+                    const GaussNbr g = load_nbr(my_nbr[k], centers, B, strengths);
+                    float w0, w1, w2;
+                    bt_mul(g.B, ix - g.mx, iy - g.my, iz - g.mz, w0, w1, w2);
+                    const float q = fminf(fmaxf(w0 * w0 + w1 * w1 + w2 * w2, 0.f), 1e8f);
+                    const float oo = factor * g.s * __expf(-0.5f * q);
+                    gx += oo * (g.B[0] * w0 + g.B[1] * w1 + g.B[2] * w2);
+                    gy += oo * (g.B[3] * w0 + g.B[4] * w1 + g.B[5] * w2);
+                    gz += oo * (g.B[6] * w0 + g.B[7] * w1 + g.B[8] * w2);
+                }
+                const float gn = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);
+                nx = -gx / gn; ny = -gy / gn; nz = -gz / gn;  // :2078
+            }
+        }
+        points[3 * o] = ix; points[3 * o + 1] = iy; points[3 * o + 2] = iz;
+        if (normals) { normals[3 * o] = nx; normals[3 * o + 1] = ny; normals[3 * o + 2] = nz; }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sgr_density_field_forward(int N, int K, const float* x, const int64_t* nbr_idx, const float* centers,
+                              const float* inv_scaled_rot, const float* strengths, float density_factor,
+                              float* neighbor_opacities, float* density, void* stream)
+{
+    if (N <= 0) return 0;
+    if (K <= 0 || !x || !nbr_idx || !centers || !inv_scaled_rot || !strengths || !density) return SGR_E_INVALID;
+    hipLaunchKernelGGL(k_density_fwd, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, K, x,
+                       reinterpret_cast<const long long*>(nbr_idx), centers, inv_scaled_rot, strengths, density_factor,
+                       neighbor_opacities, density);
+    return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
+}
+
+int sgr_density_field_backward(int N, int K, const float* x, const int64_t* nbr_idx, const float* centers,
+                               const float* inv_scaled_rot, const float* strengths, float density_factor,
+                               const float* dL_dopacities, const float* dL_ddensity, float* dL_dx, float* dL_dcenters,
+                               float* dL_dinv_scaled_rot, float* dL_dstrengths, void* stream)
+{
+    if (N <= 0) return 0;
+    if (K <= 0 || !x || !nbr_idx || !centers || !inv_scaled_rot || !strengths || !dL_dcenters || !dL_dinv_scaled_rot ||
+        !dL_dstrengths || (!dL_dopacities && !dL_ddensity))
+        return SGR_E_INVALID;
+    hipLaunchKernelGGL(k_density_bwd, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, K, x,
+                       reinterpret_cast<const long long*>(nbr_idx), centers, inv_scaled_rot, strengths, density_factor,
+                       dL_dopacities, dL_ddensity, dL_dx, dL_dcenters, dL_dinv_scaled_rot, dL_dstrengths);
+    return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
+}
+
+int sgr_level_set_points(int N, int K, const float* world_points, const int64_t* nbr_idx, const float* cam_center,
+                         const float* centers, const float* inv_scaled_rot, const float* strengths,
+                         const float* gaussian_std, int n_levels, const float* levels_host, int n_range, float range_size,
+                         float density_factor, uint8_t* valid, float* points, float* normals, void* stream)
+{
+    if (N <= 0) return 0;
+    if (K <= 0 || n_levels <= 0 || n_levels > LS_MAX_LEVELS || n_range < 2 || n_range > LS_MAX_RANGE || !world_points ||
+        !nbr_idx || !cam_center || !centers || !inv_scaled_rot || !strengths || !gaussian_std || !levels_host || !valid || !points)
+        return SGR_E_INVALID;
+    LevelArgs la;
+    la.n = n_levels;
+    for (int i = 0; i < LS_MAX_LEVELS; i++) la.v[i] = i < n_levels ? levels_host[i] : 0.f;
+    hipLaunchKernelGGL(k_level_set, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, N, K, world_points,
+                       reinterpret_cast<const long long*>(nbr_idx), cam_center, centers, inv_scaled_rot, strengths, gaussian_std,
+                       la, n_range, range_size, density_factor, valid, points, normals);
+    return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
+}
+
+}  // extern "C"

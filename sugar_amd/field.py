@@ -1,0 +1,105 @@
+"""Host side of SuGaR's density field and level-set sampler (C ABI: sgr_density_field_*, sgr_level_set_points).
+
+`density_field(x, nbr_idx, centers, inv_scaled_rot, strengths)` is the differentiable core of
+SuGaR.get_field_values (sugar_scene/sugar_model.py:1247-1281); `level_set_points(...)` is the per-pixel part of
+SuGaR.compute_level_surface_points_from_camera_fast (:1971-2079).  Both read the same tensors SuGaR already holds
+(`self.points`, `self.get_covariance(return_full_matrix=True, return_sqrt=True, inverse_scales=True)`, `self.strengths`,
+`self.knn_idx`).  GPU tensors only; the HIP library must be built.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _prep(x, nbr_idx, centers, B, strengths):
+    if not x.is_cuda:
+        raise RuntimeError("the HIP density field needs tensors on a ROCm device; there is no CPU fallback")
+    P = centers.shape[0]
+    return (x.contiguous().float(), nbr_idx.contiguous().to(torch.int64), centers.contiguous().float(),
+            B.reshape(P, 9).contiguous().float(), strengths.reshape(P).contiguous().float())
+
+
+class _DensityField(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, nbr_idx, centers, inv_scaled_rot, strengths, density_factor):
+        lib = _lib.load()
+        xs, nb, ce, Bm, st = _prep(x, nbr_idx, centers, inv_scaled_rot, strengths)
+        N, K = nb.shape
+        dev = xs.device
+        opac = torch.empty(N, K, device=dev)
+        dens = torch.empty(N, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.sgr_density_field_forward(N, K, _p(xs), _p(nb), _p(ce), _p(Bm), _p(st), float(density_factor), _p(opac),
+                                               _p(dens), _stream(dev))
+        if rc < 0:
+            raise RuntimeError(f"sgr_density_field_forward failed ({rc})")
+        ctx.save_for_backward(xs, nb, ce, Bm, st)
+        ctx.factor = float(density_factor)
+        ctx.shapes = (inv_scaled_rot.shape, strengths.shape)
+        return opac, dens
+
+    @staticmethod
+    def backward(ctx, g_opac, g_dens):
+        lib = _lib.load()
+        xs, nb, ce, Bm, st = ctx.saved_tensors
+        N, K = nb.shape
+        dev = xs.device
+        P = ce.shape[0]
+        dx = torch.empty(N, 3, device=dev)
+        dce = torch.zeros(P, 3, device=dev); dB = torch.zeros(P, 9, device=dev); dst = torch.zeros(P, device=dev)
+        go = g_opac.contiguous().float() if g_opac is not None else None
+        gd = g_dens.contiguous().float() if g_dens is not None else None
+        with torch.cuda.device(dev):
+            rc = lib.sgr_density_field_backward(N, K, _p(xs), _p(nb), _p(ce), _p(Bm), _p(st), ctx.factor, _p(go), _p(gd), _p(dx),
+                                                _p(dce), _p(dB), _p(dst), _stream(dev))
+        if rc < 0:
+            raise RuntimeError(f"sgr_density_field_backward failed ({rc})")
+        Bshape, sshape = ctx.shapes
+        return dx, None, dce, dB.reshape(Bshape), dst.reshape(sshape), None
+
+
+def density_field(x, nbr_idx, centers, inv_scaled_rot, strengths, density_factor: float = 1.0):
+    """Returns (neighbor_opacities[N,K], densities[N]) exactly as sugar_model.py:1270-1276, differentiable w.r.t. x,
+    centers, inv_scaled_rot and strengths."""
+    return _DensityField.apply(x, nbr_idx, centers, inv_scaled_rot, strengths, density_factor)
+
+
+def level_set_points(world_points, nbr_idx, cam_center, centers, inv_scaled_rot, strengths, gaussian_std,
+                     surface_levels=(0.1, 0.3, 0.5), n_points_in_range: int = 21, range_size: float = 3.0,
+                     density_factor: float = 1.0, return_normals: bool = True):
+    """Per level: dict(valid=bool[N], intersection_points=[n_valid,3], normals=[n_valid,3]) -- the `outputs` of
+    sugar_model.py:2013-2081 (rows where the reference's empty_pixels is False)."""
+    lib = _lib.load()
+    wp, nb, ce, Bm, st = _prep(world_points, nbr_idx, centers, inv_scaled_rot, strengths)
+    dev = wp.device
+    N, K = nb.shape
+    L = len(surface_levels)
+    cam = cam_center.reshape(3).contiguous().float().to(dev)
+    gstd = gaussian_std.reshape(-1).contiguous().float()
+    valid = torch.empty(L, N, dtype=torch.uint8, device=dev)
+    pts = torch.empty(L, N, 3, device=dev)
+    nrm = torch.empty(L, N, 3, device=dev) if return_normals else None
+    lv = (C.c_float * L)(*[float(v) for v in surface_levels])
+    with torch.cuda.device(dev):
+        rc = lib.sgr_level_set_points(N, K, _p(wp), _p(nb), _p(cam), _p(ce), _p(Bm), _p(st), _p(gstd), L, lv,
+                                      int(n_points_in_range), float(range_size), float(density_factor), _p(valid), _p(pts),
+                                      _p(nrm), _stream(dev))
+    if rc < 0:
+        raise RuntimeError(f"sgr_level_set_points failed ({rc})")
+    out = {}
+    for i, level in enumerate(surface_levels):
+        m = valid[i].bool()
+        out[level] = dict(valid=m, intersection_points=pts[i][m], normals=(nrm[i][m] if return_normals else None))
+    return out
