@@ -121,6 +121,13 @@ int sgr_profile_read(double* ms_sum, int64_t* count, int n_stages);
  *   comes first with distance 0. */
 int sgr_dist2(int P, const float* points, float* meanDists, void* stream);
 int sgr_knn(int N, const float* query, int M, const float* ref, int K, float* dists, int64_t* idx, void* stream);
+/* Same results (values AND indices) through an exact uniform-grid search, O(N) instead of O(N*M): the reference set is
+ * counting-sorted into ~6-point cells and each query walks rings of cells until its K-th best distance is covered.
+ * `scratch`: sgr_knn_grid_scratch_bytes(M) bytes of device memory.  No host synchronisation. */
+size_t sgr_knn_grid_scratch_bytes(int M);
+int sgr_knn_grid(int N, const float* query, int M, const float* ref, int K, float* dists, int64_t* idx, char* scratch,
+                 void* stream);
+int sgr_dist2_grid(int P, const float* points, float* meanDists, char* scratch, void* stream);
 
 /* ---- fused photometric loss of the train step ---------------------------------------------------
  * loss = (1 - lambda) * mean|img - gt| + lambda * (1 - mean(SSIM(img, gt))), window 11, sigma 1.5, zero padding:

@@ -44,6 +44,9 @@ SIGNATURES = {
     "sgr_level_set_points": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "sgr_dist2": (_i, [_i, _vp, _vp, _vp]),
     "sgr_knn": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "sgr_knn_grid_scratch_bytes": (_sz, [_i]),
+    "sgr_knn_grid": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "sgr_dist2_grid": (_i, [_i, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

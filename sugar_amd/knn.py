@@ -29,21 +29,29 @@ def _check(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
-def distCUDA2(points: torch.Tensor) -> torch.Tensor:
+GRID_THRESHOLD = 4096  # below this the exhaustive LDS-tiled kernel is as fast; both give identical results
+
+
+def distCUDA2(points: torch.Tensor, method: str = "auto") -> torch.Tensor:
     lib = _lib.load()
     points = _check(points, "points")
     P = points.shape[0]
     out = torch.zeros(P, dtype=torch.float32, device=points.device)  # spatial.cu:19 (full 0.0)
     if P:
         with torch.cuda.device(points.device):
-            rc = lib.sgr_dist2(P, C.c_void_p(points.data_ptr()), C.c_void_p(out.data_ptr()),
-                               C.c_void_p(torch.cuda.current_stream(points.device).cuda_stream))
+            stream = C.c_void_p(torch.cuda.current_stream(points.device).cuda_stream)
+            if method == "grid" or (method == "auto" and P >= GRID_THRESHOLD):
+                scratch = torch.empty(lib.sgr_knn_grid_scratch_bytes(P), dtype=torch.uint8, device=points.device)
+                rc = lib.sgr_dist2_grid(P, C.c_void_p(points.data_ptr()), C.c_void_p(out.data_ptr()),
+                                        C.c_void_p(scratch.data_ptr()), stream)
+            else:
+                rc = lib.sgr_dist2(P, C.c_void_p(points.data_ptr()), C.c_void_p(out.data_ptr()), stream)
         if rc < 0:
             raise RuntimeError(f"sgr_dist2 failed ({rc})")
     return out
 
 
-def knn_points(p1: torch.Tensor, p2: torch.Tensor, K: int = 1, **_unused) -> _KNN:
+def knn_points(p1: torch.Tensor, p2: torch.Tensor, K: int = 1, method: str = "auto", **_unused) -> _KNN:
     lib = _lib.load()
     if p1.dim() != 3 or p2.dim() != 3 or p1.shape[0] != 1 or p2.shape[0] != 1 or p1.shape[2] != 3 or p2.shape[2] != 3:
         raise RuntimeError("knn_points: expected p1[1,N,3], p2[1,M,3] (the shapes SuGaR uses)")
@@ -52,8 +60,14 @@ def knn_points(p1: torch.Tensor, p2: torch.Tensor, K: int = 1, **_unused) -> _KN
     d = torch.empty(N, K, dtype=torch.float32, device=q.device)
     i = torch.empty(N, K, dtype=torch.int64, device=q.device)
     with torch.cuda.device(q.device):
-        rc = lib.sgr_knn(N, C.c_void_p(q.data_ptr()), M, C.c_void_p(r.data_ptr()), int(K), C.c_void_p(d.data_ptr()),
-                         C.c_void_p(i.data_ptr()), C.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
+        stream = C.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
+        if method == "grid" or (method == "auto" and M >= GRID_THRESHOLD):
+            scratch = torch.empty(lib.sgr_knn_grid_scratch_bytes(M), dtype=torch.uint8, device=q.device)
+            rc = lib.sgr_knn_grid(N, C.c_void_p(q.data_ptr()), M, C.c_void_p(r.data_ptr()), int(K), C.c_void_p(d.data_ptr()),
+                                  C.c_void_p(i.data_ptr()), C.c_void_p(scratch.data_ptr()), stream)
+        else:
+            rc = lib.sgr_knn(N, C.c_void_p(q.data_ptr()), M, C.c_void_p(r.data_ptr()), int(K), C.c_void_p(d.data_ptr()),
+                             C.c_void_p(i.data_ptr()), stream)
     if rc < 0:
         raise RuntimeError(f"sgr_knn failed ({rc}); supported K: 1,2,3,4,8,16,32")
     return _KNN(d[None], i[None], None)

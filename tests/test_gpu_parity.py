@@ -217,3 +217,29 @@ def test_large_tile_grid_4k():
 def test_tiny_image():
     scene = syn.make_scene(2000, 34, 0.02, 0.2)
     _check(scene, syn.orbit_cameras(100, 20)[0], torch.tensor([0.5, 0.1, 0.9]))
+
+
+@pytest.mark.parametrize("dist", ["uniform", "clustered"])
+def test_grid_knn_is_identical_to_exhaustive(dist):
+    """sgr_knn_grid / sgr_dist2_grid return the same values AND indices as the exhaustive kernels (ties on index)."""
+    from sugar_amd.knn import knn_points, distCUDA2
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    P = 30000
+    if dist == "uniform":
+        pts = torch.rand(P, 3, generator=g) * 2 - 1
+    else:  # dense clusters, duplicates and far outliers stretching the bounding box
+        c = torch.randn(20, 3, generator=g)
+        pts = c[torch.randint(0, 20, (P,), generator=g)] + 0.01 * torch.randn(P, 3, generator=g)
+        pts[:50] = pts[50:100]
+        pts[100] = torch.tensor([40.0, -35.0, 22.0])
+    p = pts.to(dev)
+    for K in (1, 4, 16):
+        a = knn_points(p[None], p[None], K=K, method="brute")
+        b = knn_points(p[None], p[None], K=K, method="grid")
+        assert torch.equal(a.dists, b.dists) and torch.equal(a.idx, b.idx)
+    q = (torch.rand(5000, 3, generator=g) * 3 - 1.5).to(dev)  # queries outside the reference bounding box too
+    a = knn_points(q[None], p[None], K=8, method="brute")
+    b = knn_points(q[None], p[None], K=8, method="grid")
+    assert torch.equal(a.dists, b.dists) and torch.equal(a.idx, b.idx)
+    assert torch.equal(distCUDA2(p, method="brute"), distCUDA2(p, method="grid"))
