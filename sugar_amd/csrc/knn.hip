@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256) k_knn(int N, const float* __restrict__ qu
     float bd[K];
     int bi[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) { bd[k] = 3.402823466e+38f; bi[k] = -1; }
+    for (int k = 0; k < K; k++) { bd[k] = 3.402823466e+38f; bi[k] = 0x7FFFFFFF; }
     for (int base = 0; base < M; base += KNN_TILE) {
         const int nt = min(KNN_TILE, M - base);
         __syncthreads();
@@ -45,8 +45,9 @@ __global__ void __launch_bounds__(256) k_knn(int N, const float* __restrict__ qu
             if (!(d < bd[K - 1])) continue;
             int id = gi;
 #pragma unroll
-            for (int k = 0; k < K; k++) {  // insertion into the ascending list (strict <: earlier index wins ties)
-                if (d < bd[k]) {
+            for (int k = 0; k < K; k++) {  // insertion ordered on (distance, index): the lower index wins ties, and a
+                                           // displaced entry keeps its place relative to equal-distance successors
+                if (d < bd[k] || (d == bd[k] && id < bi[k])) {
                     const float td = bd[k]; const int ti = bi[k];
                     bd[k] = d; bi[k] = id; d = td; id = ti;
                 }
@@ -58,7 +59,7 @@ __global__ void __launch_bounds__(256) k_knn(int N, const float* __restrict__ qu
         out_mean[q] = (bd[0] + bd[1] + bd[2]) / 3.0f;  // simple_knn.cu:182
     } else {
 #pragma unroll
-        for (int k = 0; k < K; k++) { out_d[(size_t)q * K + k] = bd[k]; out_i[(size_t)q * K + k] = (int64_t)bi[k]; }
+        for (int k = 0; k < K; k++) { out_d[(size_t)q * K + k] = bd[k]; out_i[(size_t)q * K + k] = (bi[k] == 0x7FFFFFFF) ? -1 : (int64_t)bi[k]; }
     }
 }
 
@@ -266,7 +267,7 @@ __global__ void __launch_bounds__(128) k_grid_query(int N, const float* __restri
             }
         // every point outside rings 0..r is at least r*h away (conservatively ignoring the offset inside the own cell)
         const float reach = (float)r * g.h;
-        if (bd[K - 1] <= reach * reach) break;
+        if (bd[K - 1] < reach * reach) break;
         if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == G - 1 && y1 == G - 1 && z1 == G - 1) break;  // whole grid searched
     }
     if (out_mean) {
