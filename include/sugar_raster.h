@@ -66,7 +66,10 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user,
  *     dL_dopacity[P], dL_dcolor[P*3], dL_dmean3D[P*3], dL_dcov3D[P*6], dL_dsh[P*M*3],
  *     dL_dscale[P*3], dL_drot[P*4].
  *   Every output row is fully written by this call (rows of culled Gaussians are set to zero), so the
- *   caller does NOT need to pre-zero them; pre-zeroed buffers (rasterize_points.cu:151-159) work too. */
+ *   caller does NOT need to pre-zero them; pre-zeroed buffers (rasterize_points.cu:151-159) work too.
+ *   Compact SH mode: with shs given and dL_dsh == NULL no SH gradient is written and dL_dcolor receives the colour
+ *   gradients masked by the forward's clamp flags (the dL_dRGB of backward.cu:31-34); sgr_sh_grad_from_views rebuilds
+ *   the SH gradient, summed over any number of views, from those 3 floats per Gaussian and view. */
 int sgr_backward(int P, int D, int M, int64_t R,
                  const float* background, int width, int height,
                  const float* means3D, const float* shs, const float* colors_precomp,
@@ -78,6 +81,13 @@ int sgr_backward(int P, int D, int M, int64_t R,
                  float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                  int debug, void* stream);
+
+/* SH gradient from per-view masked colour gradients (view-sharded training exchanges 12 B per Gaussian and view instead
+ * of 12*M B):  dL_dsh[P*M*3] = sum_v basis(normalize(means3D - campos_all[v])) (x) dcolor_all[v][P*3]   (the per-view
+ * computeColorFromSH backward, backward.cu:47-97, summed over the n_views views).  campos_all[n_views*3] and
+ * dcolor_all[n_views*P*3] are device arrays. */
+int sgr_sh_grad_from_views(int P, int n_views, int D, int M, const float* means3D, const float* campos_all,
+                           const float* dcolor_all, float* dL_dsh, void* stream);
 
 /* Rasterizer::markVisible, DGR/cuda_rasterizer/rasterizer.h:24-29 / rasterizer_impl.cu:141-153.
  * present[P] is one byte per Gaussian (bool). */
@@ -147,10 +157,12 @@ int sgr_l1_ssim_backward(int channels, int width, int height, const float* img, 
  * gaussian_splatting/scene/gaussian_model.py:152-166.  n (multiple of 4) floats in params / grads / exp_avg / exp_avg_sq;
  * the learning rate of element i is given by up to 8 segments k (HOST arrays): for seg_begin[k] <= i < seg_end[k] it is
  * seg_lr_a[k] when (i - seg_begin[k]) % seg_period[k] < seg_split[k], else seg_lr_b[k]; elements in no segment keep
- * lr 0 (their moments still update).  `step` is the 1-based step count used for bias correction. */
+ * lr 0 (their moments still update).  `step` is the 1-based step count used for bias correction; gradients are
+ * multiplied by `grad_scale` on the fly (1/world_size after a SUM all-reduce, so the mean needs no extra pass). */
 int sgr_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n_seg,
                   const long long* seg_begin, const long long* seg_end, const float* seg_lr_a, const float* seg_lr_b,
-                  const int* seg_period, const int* seg_split, float beta1, float beta2, float eps, int step, void* stream);
+                  const int* seg_period, const int* seg_split, float beta1, float beta2, float eps, int step,
+                  float grad_scale, void* stream);
 
 /* ---- SuGaR density field and level-set surface sampler (share the Gaussian buffers) --------------
  * B_g = R_g diag(1 / max(s_g, 1e-8)) is SuGaR's get_covariance(return_full_matrix=True, return_sqrt=True,

@@ -33,10 +33,11 @@ __device__ __forceinline__ float lr_of(const AdamSegs& sg, long long i)
 
 __global__ void __launch_bounds__(256) k_adam(long long n4, float4* __restrict__ p, const float4* __restrict__ g,
                                               float4* __restrict__ m, float4* __restrict__ v, AdamSegs sg, float b1, float b2,
-                                              float eps, float bc1, float bc2_sqrt)
+                                              float eps, float bc1, float bc2_sqrt, float grad_scale)
 {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        const float4 gg = g[i];
+        float4 gg = g[i];
+        gg.x *= grad_scale; gg.y *= grad_scale; gg.z *= grad_scale; gg.w *= grad_scale;
         float4 pp = p[i], mm = m[i], vv = v[i];
         float* pf = reinterpret_cast<float*>(&pp);
         float* mf = reinterpret_cast<float*>(&mm);
@@ -59,7 +60,7 @@ __global__ void __launch_bounds__(256) k_adam(long long n4, float4* __restrict__
 extern "C" int sgr_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n_seg,
                              const long long* seg_begin, const long long* seg_end, const float* seg_lr_a,
                              const float* seg_lr_b, const int* seg_period, const int* seg_split, float beta1, float beta2,
-                             float eps, int step, void* stream)
+                             float eps, int step, float grad_scale, void* stream)
 {
     if (n <= 0) return 0;
     if (!params || !grads || !exp_avg || !exp_avg_sq || n_seg < 0 || n_seg > ADAM_MAX_SEG || step < 1 || (n & 3)) return SGR_E_INVALID;
@@ -77,6 +78,6 @@ extern "C" int sgr_adam_step(long long n, float* params, const float* grads, flo
     const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n4, reinterpret_cast<float4*>(params),
                        reinterpret_cast<const float4*>(grads), reinterpret_cast<float4*>(exp_avg),
-                       reinterpret_cast<float4*>(exp_avg_sq), sg, beta1, beta2, eps, bc1, bc2_sqrt);
+                       reinterpret_cast<float4*>(exp_avg_sq), sg, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }

@@ -235,7 +235,8 @@ int sgr_backward(int P, int D, int M, int64_t R, const float* background, int wi
     if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
         return fail(SGR_E_INVALID, "null gradient output");
     const bool use_sh = shs && !colors_precomp;
-    if (use_sh && !dL_dsh) return fail(SGR_E_INVALID, "dL_dsh required with SHs");
+    // use_sh with dL_dsh == NULL selects the compact mode: dL_dcolor receives the clamp-masked colour gradients and no
+    // SH gradient is materialised (see sgr_sh_grad_from_views)
     if (!cov3D_precomp && (!dL_dscale || !dL_drot)) return fail(SGR_E_INVALID, "dL_dscale/dL_drot required");
 
     const ImgLayout IL = sgr_img_layout(width, height);
@@ -272,6 +273,18 @@ int sgr_backward(int P, int D, int M, int64_t R, const float* background, int wi
     pb.dL_dscale = cov3D_precomp ? nullptr : dL_dscale; pb.dL_drot = cov3D_precomp ? nullptr : dL_drot;
     { StageTimer t(s, SGR_STAGE_PREPROCESS_BWD); sgr_launch_preprocess_bwd(pb, s); }
     STAGE_CHECK("preprocess_bwd");
+    return 0;
+}
+
+int sgr_sh_grad_from_views(int P, int n_views, int D, int M, const float* means3D, const float* campos_all,
+                           const float* dcolor_all, float* dL_dsh, void* stream)
+{
+    if (P <= 0) return 0;
+    if (n_views <= 0 || D < 0 || D > 3 || M < (D + 1) * (D + 1) || M > 16 || !means3D || !campos_all || !dcolor_all || !dL_dsh)
+        return fail(SGR_E_INVALID, "sgr_sh_grad_from_views: bad arguments");
+    sgr_launch_sh_grad_from_views(P, n_views, D, M, means3D, campos_all, dcolor_all, dL_dsh, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SGR_E_HIP, std::string("sh_grad_from_views: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -438,8 +438,16 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
             float oz = (-vv.x * vv.z * dL_ddir[0] - vv.y * vv.z * dL_ddir[1] + (sum2 - vv.z * vv.z) * dL_ddir[2]) * invsum32;
             dmean[0] += ox; dmean[1] += oy; dmean[2] += oz;
         }
-        float* dst = a.dL_dsh + (size_t)idx * n_sh;
-        if (n_sh == 48 && ((uintptr_t)dst & 15) == 0) {
+        if (!a.dL_dsh) {
+            // compact mode (view-sharded training): the SH gradient is the outer product basis(dir) x (masked dL/dRGB), so
+            // only the 3 masked colour gradients leave this kernel; sgr_sh_grad_from_views rebuilds sum over views later
+            a.dL_dcolor[i3] = ((clamped >> 0) & 1u) ? 0.f : dcol[0];
+            a.dL_dcolor[i3 + 1] = ((clamped >> 1) & 1u) ? 0.f : dcol[1];
+            a.dL_dcolor[i3 + 2] = ((clamped >> 2) & 1u) ? 0.f : dcol[2];
+        }
+        float* dst = a.dL_dsh ? a.dL_dsh + (size_t)idx * n_sh : nullptr;
+        if (!dst) {
+        } else if (n_sh == 48 && ((uintptr_t)dst & 15) == 0) {
             float4* d4 = reinterpret_cast<float4*>(dst);
 #pragma unroll
             for (int i = 0; i < 12; i++) { float4 o = {dsh[4 * i], dsh[4 * i + 1], dsh[4 * i + 2], dsh[4 * i + 3]}; d4[i] = o; }
@@ -491,6 +499,61 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
     for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
 }
 
+// dL/dsh[k][c] = sum over views v of  basis_k(dir_v) * g_v[c]   with dir_v = normalize(mean - campos_v) and g_v the
+// clamp-masked dL/dRGB of view v -- exactly the per-view SH backward (backward.cu:47-97) summed over views, but the views
+// exchange 3 floats per Gaussian instead of 3*M.  dirs use the same arithmetic as the forward (glm::length, division).
+__global__ void __launch_bounds__(256) k_sh_grad_from_views(int P, int V, int D, int M, const float* __restrict__ means3D,
+                                                            const float* __restrict__ campos, const float* __restrict__ dcolor,
+                                                            float* __restrict__ dL_dsh)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const size_t i3 = 3 * (size_t)idx;
+    const float mx = means3D[i3], my = means3D[i3 + 1], mz = means3D[i3 + 2];
+    float acc[48];
+#pragma unroll
+    for (int k = 0; k < 48; k++) acc[k] = 0.f;
+    for (int v = 0; v < V; v++) {
+        const float* g = dcolor + ((size_t)v * P + idx) * 3;
+        const float g0 = g[0], g1 = g[1], g2 = g[2];
+        if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;  // culled or fully clamped in this view
+        float dx = mx - campos[3 * v], dy = my - campos[3 * v + 1], dz = mz - campos[3 * v + 2];
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float x = dx / len, y = dy / len, z = dz / len;
+        float b[16];
+        b[0] = SH_C0;
+        if (D > 0) {
+            b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x;
+            if (D > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                b[4] = SH_C2[0] * xy; b[5] = SH_C2[1] * yz; b[6] = SH_C2[2] * (2.f * zz - xx - yy);
+                b[7] = SH_C2[3] * xz; b[8] = SH_C2[4] * (xx - yy);
+                if (D > 2) {
+                    b[9] = SH_C3[0] * y * (3.f * xx - yy); b[10] = SH_C3[1] * xy * z;
+                    b[11] = SH_C3[2] * y * (4.f * zz - xx - yy); b[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                    b[13] = SH_C3[4] * x * (4.f * zz - xx - yy); b[14] = SH_C3[5] * z * (xx - yy);
+                    b[15] = SH_C3[6] * x * (xx - 3.f * yy);
+                }
+            }
+        }
+        const int nb = (D + 1) * (D + 1);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (k < nb) { acc[3 * k] += b[k] * g0; acc[3 * k + 1] += b[k] * g1; acc[3 * k + 2] += b[k] * g2; }
+        }
+    }
+    const int n_sh = 3 * M;
+    float* dst = dL_dsh + (size_t)idx * n_sh;
+    if (n_sh == 48 && ((uintptr_t)dst & 15) == 0) {
+        float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+        for (int i = 0; i < 12; i++) { float4 o = {acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]}; d4[i] = o; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 48; i++) if (i < n_sh) dst[i] = acc[i];
+    }
+}
+
 }  // namespace
 
 void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s)
@@ -509,4 +572,11 @@ void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
 {
     if (a.P <= 0) return;
     hipLaunchKernelGGL(k_preprocess_bwd, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+}
+
+void sgr_launch_sh_grad_from_views(int P, int V, int D, int M, const float* means3D, const float* campos, const float* dcolor,
+                                   float* dL_dsh, hipStream_t s)
+{
+    if (P <= 0) return;
+    hipLaunchKernelGGL(k_sh_grad_from_views, dim3((P + 255) / 256), dim3(256), 0, s, P, V, D, M, means3D, campos, dcolor, dL_dsh);
 }

@@ -101,6 +101,8 @@ struct PreprocessBwdArgs {
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
 };
 void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
+void sgr_launch_sh_grad_from_views(int P, int V, int D, int M, const float* means3D, const float* campos, const float* dcolor,
+                                   float* dL_dsh, hipStream_t s);
 
 void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_out, hipStream_t s);
 void sgr_launch_pack_rects(int P, int gx, int gy, const uint32_t* order, const GeomRec* rec, uint2* rects, hipStream_t s);

@@ -25,6 +25,9 @@ from .. import _lib
 # backward of every rasterizer call made in the block writes dL/dmeans3D and dL/dshs straight into the given buffers and
 # returns those buffers as the gradients, instead of allocating fresh tensors.  The train step points them at its flat
 # gradient buffer, so the 192 MB SH gradient is produced in place and never copied or accumulated.
+# `grad_sink(compact_sh=True, out=holder)` selects the compact SH mode of sgr_backward: no SH gradient is produced (the
+# autograd gradient of `shs` is None) and holder["masked_colors"] receives the clamp-masked dL/dRGB [P,3] from which
+# sugar_amd.train_step rebuilds the SH gradient summed over all views (sgr_sh_grad_from_views).
 _GRAD_SINK: dict = {}
 
 
@@ -161,7 +164,8 @@ class _CModule:
         dL_dconic = torch.empty(P, 2, 2, **f)
         dL_dopacity = torch.empty(P, 1, **f)
         dL_dcov3D = torch.empty(P, 6, **f)
-        dL_dsh = _sink_or_empty(grad_out, "shs", (P, M, 3), **f)
+        compact_sh = bool(grad_out and grad_out.get("compact_sh")) and M > 0
+        dL_dsh = None if compact_sh else _sink_or_empty(grad_out, "shs", (P, M, 3), **f)
         dL_dscales = torch.zeros(P, 3, **f) if use_cov else torch.empty(P, 3, **f)
         dL_drotations = torch.zeros(P, 4, **f) if use_cov else torch.empty(P, 4, **f)
         if P != 0:
@@ -182,6 +186,8 @@ class _CModule:
                     C.c_void_p(stream))
             if rc < 0:
                 raise RuntimeError(f"sgr_backward failed ({rc}): {_lib.last_error()}")
+        if compact_sh and isinstance(grad_out.get("out"), dict):
+            grad_out["out"]["masked_colors"] = dL_dcolors
         return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
     @staticmethod

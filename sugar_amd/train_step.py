@@ -81,7 +81,7 @@ class GaussianParams:
     streaming kernel.  The SH coefficients are ONE [P,M,3] tensor (the layout the rasterizer consumes); the reference keeps
     f_dc / f_rest apart and torch.cat()s them every step (gaussian_model.py:108-111: 192 MB of copies per step at 1M)."""
 
-    NAMES = ("xyz", "features", "opacity", "scaling", "rotation")
+    NAMES = ("xyz", "opacity", "scaling", "rotation", "features")  # the SH tensor last: everything else is one prefix
     # arguments/__init__.py:74-83 (position lr at its initial value; f_rest runs at feature_lr / 20, gaussian_model.py:158)
     LRS = dict(xyz=0.00016, features=0.0025, opacity=0.05, scaling=0.005, rotation=0.001)
     REST_LR = 0.0025 / 20.0
@@ -98,6 +98,7 @@ class GaussianParams:
             offs[k] = off
             off += (sizes[k] + 63) // 64 * 64
         self.offsets, self.sizes = offs, sizes
+        self.n_small = offs["features"]  # flat[:n_small] = xyz | opacity | scaling | rotation (11 floats per Gaussian)
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
         self.flat_grad = torch.zeros(off, dtype=torch.float32, device=device)
         self.params = {}
@@ -165,14 +166,14 @@ class FlatAdam:
                      (C.c_int * n)(*[s[4] for s in segs]), (C.c_int * n)(*[s[5] for s in segs]))
         self._n = n
 
-    def step(self):
+    def step(self, grad_scale: float = 1.0):
         C, p = self._C, self.params
         self.t += 1
         dev = p.flat.device
         with torch.cuda.device(dev):
             rc = self._lib.sgr_adam_step(p.flat.numel(), C.c_void_p(p.flat.data_ptr()), C.c_void_p(p.flat_grad.data_ptr()),
                                          C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()), self._n,
-                                         *self._seg, self.betas[0], self.betas[1], self.eps, self.t,
+                                         *self._seg, self.betas[0], self.betas[1], self.eps, self.t, float(grad_scale),
                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         if rc < 0:
             raise RuntimeError(f"sgr_adam_step failed ({rc})")
@@ -193,43 +194,102 @@ def render(params: GaussianParams, cam, bg, rasterizer_cls, settings_cls, sh_deg
     return dict(render=image, viewspace_points=screenspace_points, visibility_filter=radii > 0, radii=radii)
 
 
+def sh_grad_from_views(means3D, campos_all, dcolor_all, sh_degree, out):
+    """out[P,M,3] = sum over views of basis(normalize(means3D - campos_v)) (x) dcolor_all[v]  (HIP: sgr_sh_grad_from_views)"""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    if not means3D.is_cuda:
+        raise RuntimeError("sh_grad_from_views needs tensors on a ROCm device; there is no CPU fallback")
+    V, P = dcolor_all.shape[0], means3D.shape[0]
+    M = out.shape[1]
+    dev = means3D.device
+    with torch.cuda.device(dev):
+        rc = lib.sgr_sh_grad_from_views(P, V, int(sh_degree), M, C.c_void_p(means3D.contiguous().data_ptr()),
+                                        C.c_void_p(campos_all.contiguous().data_ptr()),
+                                        C.c_void_p(dcolor_all.contiguous().data_ptr()), C.c_void_p(out.data_ptr()),
+                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc < 0:
+        raise RuntimeError(f"sgr_sh_grad_from_views failed ({rc})")
+    return out
+
+
 class ViewShardedTrainer:
-    """One optimisation step over a batch of `world_size` views, one view per rank."""
+    """One optimisation step over a batch of `world_size` views, one view per rank.
+
+    Gradient exchange (world > 1).  The SH gradient of a view is the outer product  basis(view direction) (x) masked dL/dRGB
+    (backward.cu:47-97), so instead of all-reducing 59 floats per Gaussian (236 MB at 1M: the ring is xGMI-link bound), the
+    ranks all-gather the 3 masked colour gradients per Gaussian and view plus the camera centres, all-reduce the 11
+    remaining floats, and every rank rebuilds  sum_v basis_v (x) g_v  locally (`compact_sh`): 3*V + 11 floats per Gaussian
+    on the wire instead of 59."""
 
     def __init__(self, params: GaussianParams, rasterizer_cls, settings_cls, bg, sh_degree=3, lambda_dssim=0.2,
-                 fused_loss=True):
+                 fused_loss=True, compact_sh=None, sh_grad_fn=None, grad_sink_cm=None):
         self.fused_loss = fused_loss
         self.params = params
         self.opt = params.make_optimizer()
         self.rasterizer_cls, self.settings_cls = rasterizer_cls, settings_cls
         self.bg, self.sh_degree, self.lambda_dssim = bg, sh_degree, lambda_dssim
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.compact_sh = (self.world > 1 and params.flat.is_cuda) if compact_sh is None else bool(compact_sh)
+        self.sh_grad_fn = sh_grad_fn or sh_grad_from_views
+        if grad_sink_cm is None and params.flat.is_cuda:
+            from .diff_gaussian_rasterization import grad_sink as grad_sink_cm
+        self.grad_sink_cm = grad_sink_cm  # context manager factory honoured by the rasterizer's backward (None: plain autograd)
 
     def step(self, cam, gt_image):
         """gaussian_splatting/train.py:86-128 for one view per rank.  Gradients are taken with torch.autograd.grad and
-        land in the flat gradient buffer: the two large ones (xyz, SH) are written there by the rasterizer backward itself
-        (grad_sink), the small ones are copied; nothing is zero-filled or accumulated."""
+        land in the flat gradient buffer: the large ones are written there by the rasterizer backward itself (grad_sink),
+        the small ones are copied; nothing is zero-filled or accumulated."""
+        import contextlib
         p = self.params
-        leaves = [p.params[k] for k in p.NAMES]
-        sinks = {}
-        if p.flat.is_cuda:
-            from .diff_gaussian_rasterization import grad_sink
-            sinks = dict(means3D=p.params["xyz"].grad, shs=p.params["features"].grad)
-            ctxm = grad_sink(**sinks)
+        names = list(p.NAMES)
+        leaves = [p.params[k] for k in names]
+        holder = {}
+        if self.grad_sink_cm is not None:
+            sinks = dict(means3D=p.params["xyz"].grad)
+            if self.compact_sh:
+                sinks.update(compact_sh=True, out=holder)
+            else:
+                sinks.update(shs=p.params["features"].grad)
+            ctxm = self.grad_sink_cm(**sinks)
         else:
-            import contextlib
             ctxm = contextlib.nullcontext()
         with ctxm:
             pkg = render(p, cam, self.bg, self.rasterizer_cls, self.settings_cls, self.sh_degree)
             loss = train_loss(pkg["render"], gt_image, self.lambda_dssim, self.fused_loss)
-            grads = torch.autograd.grad(loss, leaves)
+            grads = torch.autograd.grad(loss, leaves, allow_unused=True)
         with torch.no_grad():
-            for leaf, g in zip(leaves, grads):
-                if g.data_ptr() != leaf.grad.data_ptr():
+            for name, leaf, g in zip(names, leaves, grads):
+                if g is None:
+                    if not (self.compact_sh and name == "features"):
+                        leaf.grad.zero_()
+                elif g.data_ptr() != leaf.grad.data_ptr():
                     leaf.grad.copy_(g)
-        if self.world > 1:
-            # the only collective on the path: sum of the per-view parameter gradients (then mean over views)
-            dist.all_reduce(p.flat_grad, op=dist.ReduceOp.SUM)
-            p.flat_grad.mul_(1.0 / self.world)
-        self.opt.step()
+            if self.compact_sh:
+                if "masked_colors" not in holder:
+                    raise RuntimeError("compact_sh: the rasterizer backward did not deliver the masked colour gradients")
+                g_rgb = holder["masked_colors"].contiguous()
+                campos = cam.campos.reshape(1, 3).to(g_rgb.dtype).contiguous()
+                if self.world > 1:
+                    P_ = g_rgb.shape[0]
+                    all_rgb = torch.empty(self.world * P_, 3, dtype=g_rgb.dtype, device=g_rgb.device)  # rank-major concat
+                    all_cam = torch.empty(self.world, 3, dtype=g_rgb.dtype, device=g_rgb.device)
+                    dist.all_gather_into_tensor(all_rgb, g_rgb)
+                    dist.all_gather_into_tensor(all_cam, campos)
+                    all_rgb = all_rgb.view(self.world, P_, 3)
+                    dist.all_reduce(p.flat_grad[: p.n_small], op=dist.ReduceOp.SUM)
+                else:
+                    all_rgb, all_cam = g_rgb[None], campos
+                self.sh_grad_fn(p.params["xyz"].detach(), all_cam, all_rgb, self.sh_degree, p.params["features"].grad)
+            elif self.world > 1:
+                # plain path: one flat all-reduce of all 59 floats per Gaussian
+                dist.all_reduce(p.flat_grad, op=dist.ReduceOp.SUM)
+        scale = 1.0 / self.world
+        if isinstance(self.opt, FlatAdam):
+            self.opt.step(grad_scale=scale)  # the mean over views is folded into the optimiser kernel
+        else:
+            if self.world > 1:
+                p.flat_grad.mul_(scale)
+            self.opt.step()
         return loss.detach(), pkg

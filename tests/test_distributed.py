@@ -30,12 +30,13 @@ def _setup():
     return orast, scene, cams, gts
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, compact):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     orast, scene, cams, gts = _setup()
     params = GaussianParams(scene, torch.device("cpu"))
-    tr = ViewShardedTrainer(params, orast.GaussianRasterizer, orast.GaussianRasterizationSettings, torch.zeros(3))
+    kw = dict(compact_sh=True, sh_grad_fn=orast.sh_grad_from_views_torch, grad_sink_cm=orast.grad_sink) if compact else {}
+    tr = ViewShardedTrainer(params, orast.GaussianRasterizer, orast.GaussianRasterizationSettings, torch.zeros(3), **kw)
     for s in range(STEPS):
         k = (s * world + rank) % len(cams)
         tr.step(cams[k], gts[k])
@@ -43,9 +44,15 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_view_sharded_step_matches_sequential_accumulation(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("compact", [False, True], ids=["flat_allreduce", "compact_sh_exchange"])
+def test_view_sharded_step_matches_sequential_accumulation(tmp_path, compact):
+    """Both gradient exchanges (one flat all-reduce of 59 floats/Gaussian; all-gather of 3 masked colour gradients per view
+    + all-reduce of the other 11 + local SH reconstruction) must equal single-process accumulation of the same views."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), compact), nprocs=world, join=True)
     flats = [np.load(tmp_path / f"flat_{r}.npy") for r in range(world)]
     assert np.array_equal(flats[0], flats[1]), "replicas diverged"
     # single-process reference: accumulate the same views, mean gradient, one Adam step per batch
@@ -67,7 +74,7 @@ def test_view_sharded_step_matches_sequential_accumulation(tmp_path):
 def test_flat_parameter_views_and_grads_alias():
     scene = syn.make_scene(10, 1, 0.01, 0.1)
     p = GaussianParams(scene, torch.device("cpu"))
-    assert sum(v.numel() for v in p.params.values()) == 10 * 59
+    assert sum(v.numel() for v in p.params.values()) == 10 * 59 and p.n_small == p.offsets["features"]
     assert p.params["features"].shape == (10, 16, 3)
     p.params["xyz"].grad.fill_(3.0)
     assert float(p.flat_grad.sum()) == 3.0 * 30
