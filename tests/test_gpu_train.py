@@ -44,7 +44,7 @@ def test_compact_sh_mode_rebuilds_the_sh_gradient_over_views():
     out = torch.empty_like(ref)
     sh_grad_from_views(scene.means3D.to(dev), torch.stack(campos), torch.stack(masked), 3, out)
     err = float((out - ref).norm() / ref.norm())
-    assert err < 1e-6, err
+    assert err < 2e-5, err  # two independent backward runs (atomic ordering) + float summation order
     assert float(ref.abs().max()) > 0
 
 
