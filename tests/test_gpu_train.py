@@ -38,7 +38,8 @@ def test_compact_sh_mode_rebuilds_the_sh_gradient_over_views():
         gc, holder = _render_grads(scene, cam, bg, g, compact=True)
         assert gc[1] is None and "masked_colors" in holder
         for a, b in zip([gr[0], gr[2], gr[3], gr[4]], [gc[0], gc[2], gc[3], gc[4]]):
-            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)  # the other gradients do not depend on the mode
+            # the other gradients do not depend on the mode; two backward runs differ only by atomic ordering
+            assert float((a - b).norm() / a.norm()) < 1e-5
         full.append(gr[1]); masked.append(holder["masked_colors"]); campos.append(cam.campos.to(dev))
     ref = full[0] + full[1] + full[2]
     out = torch.empty_like(ref)
