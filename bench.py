@@ -7,7 +7,8 @@
 
 One "step" = rasterizer forward (SH degree 3, scale/rotation in-rasterizer) -> 0.8*L1 + 0.2*(1-SSIM) -> backward ->
 Adam over 59 floats/Gaussian, on synthetic data resident in HBM.  With N ranks every rank
-renders its own view of the same replica and the parameter gradients are summed by one RCCL all-reduce
+renders its own view of the same replica; the ranks exchange 3 masked colour gradients per Gaussian and view (all-gather)
+plus the 11 non-SH gradient floats per Gaussian (all-reduce) over RCCL and rebuild the summed SH gradient locally
 ("weak" scaling: one view per GPU per step; value = views/s over all ranks).
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
@@ -165,7 +166,9 @@ def main():
                 "workload": f"{args.workload}: {P} Gaussians @ {W}x{H}, SH degree 3, 3DGS train step "
                             "(raster fwd -> 0.8 L1 + 0.2 DSSIM -> bwd -> Adam, 59 floats/Gaussian), 8 orbit cameras cycled",
                 "views_per_step": world,
-                "parallelism": f"view-sharded dp{world}, one flat RCCL all-reduce of parameter grads",
+                "parallelism": (f"view-sharded dp{world}: all-gather of 3 masked colour grads per Gaussian and view + all-reduce of "
+                                "the 11 non-SH floats per Gaussian (RCCL), SH gradient rebuilt locally" if trainer.compact_sh
+                                else f"view-sharded dp{world}, single process, no collective"),
                 "instances_per_view": R, "instances_walked_fwd": R_f, "instances_walked_bwd": R_b,
             },
             "ms_fwd_bwd": sum(stages.values()),

@@ -191,6 +191,19 @@ int sgr_level_set_points(int N, int K, const float* world_points, const int64_t*
                          const float* gaussian_std, int n_levels, const float* levels_host, int n_range, float range_size,
                          float density_factor, uint8_t* valid, float* points, float* normals, void* stream);
 
+/* ---- SuGaR.get_points_rgb, sugar_scene/sugar_model.py:839-883 (with sugar_utils/spherical_harmonics.py:117-172) -----
+ * colors[P,3] = clamp_min(eval_sh(D, sh, dir) + 0.5, 0),  dir = F.normalize(positions - camera_centers) when positions is
+ * given (camera_centers[n_centers,3], n_centers = 1 or P), else directions[P,3] as they are.  sh is [P,M,3] (the
+ * rasterizer's layout; rows may be a view of a wider tensor: M = row stride in coefficients), D = sh_levels - 1 <= 3 and
+ * the first (D+1)^2 coefficients are used.
+ * Backward: dL_dsh[P,M,3] (all M rows written, zeros beyond the used ones), dL_dpositions[P,3] (positions mode) or
+ * dL_ddirections[P,3] (directions mode); each may be NULL.  The clamp mask is recomputed. */
+int sgr_sh_to_rgb_forward(int P, int D, int M, const float* sh, const float* positions, const float* camera_centers,
+                          int n_centers, const float* directions, float* colors, void* stream);
+int sgr_sh_to_rgb_backward(int P, int D, int M, const float* sh, const float* positions, const float* camera_centers,
+                           int n_centers, const float* directions, const float* dL_dcolors, float* dL_dsh,
+                           float* dL_dpositions, float* dL_ddirections, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

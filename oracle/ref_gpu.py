@@ -2,7 +2,7 @@
 
 The library is the REFERENCE rasterizer itself (DGR/cuda_rasterizer/*.cu, compiled unmodified by hipcc for gfx950 by
 oracle/ref_build/build_ref.sh).  It exists only on a GPU; the -m gpu tests use it to pin parity against "the reference
-run here", and scripts/ab_reference.py uses it as the A/B timing baseline.  It cannot be a cpu_baseline.
+run here", and tests/ab_reference.py uses it as the A/B timing baseline.  It cannot be a cpu_baseline.
 
 The reference's private scratch layout (GeometryState / ImageState / BinningState, rasterizer_impl.h:21-66 and
 rasterizer_impl.cu:155-194) is decoded here so that the depth-sorted tile lists and ranges can be compared exactly:

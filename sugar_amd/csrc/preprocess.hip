@@ -16,6 +16,7 @@
 // blend kernels gather later is emitted as ONE 48-byte record (GeomRec), so a gather touches one or two
 // 128-B lines instead of the reference's three separate arrays; cov3D is recomputed in the backward
 // instead of being stored (24 B/Gaussian of HBM traffic each way for ~40 flops).
+#include "../../include/sugar_raster.h"
 #include "sgr_common.h"
 
 namespace {
@@ -161,6 +162,53 @@ __device__ __forceinline__ void load_sh(const float* shs, size_t idx, int M, flo
     } else {
 #pragma unroll
         for (int i = 0; i < MAXC; i++) sh[i] = (i < n) ? src[i] : 0.0f;
+    }
+}
+
+// computeColorFromSH backward for one Gaussian (backward.cu:47-137): dsh[k][c] = basis_k(dir) * masked dL/dRGB[c] and the
+// gradient w.r.t. the (normalised) view direction.  `clamped` bit c set = channel c was clamped to 0 by the forward.
+__device__ __forceinline__ void sh_backward(const int deg, const float* sh, const float* dcol, const uint32_t clamped,
+                                            const float x, const float y, const float z, float* dsh, float* dL_ddir)
+{
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#define SH(k) sh[3 * (k) + c]
+#define DSH(k) dsh[3 * (k) + c]
+        float dL_dRGB = dcol[c] * (((clamped >> c) & 1u) ? 0.0f : 1.0f);
+        float dRGBdx = 0, dRGBdy = 0, dRGBdz = 0;
+        DSH(0) = SH_C0 * dL_dRGB;
+        if (deg > 0) {
+            DSH(1) = (-SH_C1 * y) * dL_dRGB; DSH(2) = (SH_C1 * z) * dL_dRGB; DSH(3) = (-SH_C1 * x) * dL_dRGB;
+            dRGBdx = -SH_C1 * SH(3); dRGBdy = -SH_C1 * SH(1); dRGBdz = SH_C1 * SH(2);
+            if (deg > 1) {
+                float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                DSH(4) = (SH_C2[0] * xy) * dL_dRGB; DSH(5) = (SH_C2[1] * yz) * dL_dRGB;
+                DSH(6) = (SH_C2[2] * (2.f * zz - xx - yy)) * dL_dRGB; DSH(7) = (SH_C2[3] * xz) * dL_dRGB;
+                DSH(8) = (SH_C2[4] * (xx - yy)) * dL_dRGB;
+                dRGBdx += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8);
+                dRGBdy += SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) + SH_C2[4] * 2.f * -y * SH(8);
+                dRGBdz += SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7);
+                if (deg > 2) {
+                    DSH(9) = (SH_C3[0] * y * (3.f * xx - yy)) * dL_dRGB; DSH(10) = (SH_C3[1] * xy * z) * dL_dRGB;
+                    DSH(11) = (SH_C3[2] * y * (4.f * zz - xx - yy)) * dL_dRGB;
+                    DSH(12) = (SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * dL_dRGB;
+                    DSH(13) = (SH_C3[4] * x * (4.f * zz - xx - yy)) * dL_dRGB;
+                    DSH(14) = (SH_C3[5] * z * (xx - yy)) * dL_dRGB; DSH(15) = (SH_C3[6] * x * (xx - 3.f * yy)) * dL_dRGB;
+                    dRGBdx += (SH_C3[0] * SH(9) * 3.f * 2.f * xy + SH_C3[1] * SH(10) * yz + SH_C3[2] * SH(11) * -2.f * xy +
+                               SH_C3[3] * SH(12) * -3.f * 2.f * xz + SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                               SH_C3[5] * SH(14) * 2.f * xz + SH_C3[6] * SH(15) * 3.f * (xx - yy));
+                    dRGBdy += (SH_C3[0] * SH(9) * 3.f * (xx - yy) + SH_C3[1] * SH(10) * xz +
+                               SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * SH(12) * -3.f * 2.f * yz +
+                               SH_C3[4] * SH(13) * -2.f * xy + SH_C3[5] * SH(14) * -2.f * yz + SH_C3[6] * SH(15) * -3.f * 2.f * xy);
+                    dRGBdz += (SH_C3[1] * SH(10) * xy + SH_C3[2] * SH(11) * 4.f * 2.f * yz +
+                               SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * SH(13) * 4.f * 2.f * xz +
+                               SH_C3[5] * SH(14) * (xx - yy));
+                }
+            }
+        }
+#undef SH
+#undef DSH
+        dL_ddir[0] += dRGBdx * dL_dRGB; dL_ddir[1] += dRGBdy * dL_dRGB; dL_ddir[2] += dRGBdz * dL_dRGB;
     }
 }
 
@@ -388,46 +436,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
         const uint32_t clamped = rp->clamped;
         const int deg = a.D;
         float dL_ddir[3] = {0, 0, 0};
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-#define SH(k) sh[3 * (k) + c]
-#define DSH(k) dsh[3 * (k) + c]
-            float dL_dRGB = dcol[c] * (((clamped >> c) & 1u) ? 0.0f : 1.0f);
-            float dRGBdx = 0, dRGBdy = 0, dRGBdz = 0;
-            DSH(0) = SH_C0 * dL_dRGB;
-            if (deg > 0) {
-                DSH(1) = (-SH_C1 * y) * dL_dRGB; DSH(2) = (SH_C1 * z) * dL_dRGB; DSH(3) = (-SH_C1 * x) * dL_dRGB;
-                dRGBdx = -SH_C1 * SH(3); dRGBdy = -SH_C1 * SH(1); dRGBdz = SH_C1 * SH(2);
-                if (deg > 1) {
-                    float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    DSH(4) = (SH_C2[0] * xy) * dL_dRGB; DSH(5) = (SH_C2[1] * yz) * dL_dRGB;
-                    DSH(6) = (SH_C2[2] * (2.f * zz - xx - yy)) * dL_dRGB; DSH(7) = (SH_C2[3] * xz) * dL_dRGB;
-                    DSH(8) = (SH_C2[4] * (xx - yy)) * dL_dRGB;
-                    dRGBdx += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8);
-                    dRGBdy += SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) + SH_C2[4] * 2.f * -y * SH(8);
-                    dRGBdz += SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7);
-                    if (deg > 2) {
-                        DSH(9) = (SH_C3[0] * y * (3.f * xx - yy)) * dL_dRGB; DSH(10) = (SH_C3[1] * xy * z) * dL_dRGB;
-                        DSH(11) = (SH_C3[2] * y * (4.f * zz - xx - yy)) * dL_dRGB;
-                        DSH(12) = (SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * dL_dRGB;
-                        DSH(13) = (SH_C3[4] * x * (4.f * zz - xx - yy)) * dL_dRGB;
-                        DSH(14) = (SH_C3[5] * z * (xx - yy)) * dL_dRGB; DSH(15) = (SH_C3[6] * x * (xx - 3.f * yy)) * dL_dRGB;
-                        dRGBdx += (SH_C3[0] * SH(9) * 3.f * 2.f * xy + SH_C3[1] * SH(10) * yz + SH_C3[2] * SH(11) * -2.f * xy +
-                                   SH_C3[3] * SH(12) * -3.f * 2.f * xz + SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
-                                   SH_C3[5] * SH(14) * 2.f * xz + SH_C3[6] * SH(15) * 3.f * (xx - yy));
-                        dRGBdy += (SH_C3[0] * SH(9) * 3.f * (xx - yy) + SH_C3[1] * SH(10) * xz +
-                                   SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * SH(12) * -3.f * 2.f * yz +
-                                   SH_C3[4] * SH(13) * -2.f * xy + SH_C3[5] * SH(14) * -2.f * yz + SH_C3[6] * SH(15) * -3.f * 2.f * xy);
-                        dRGBdz += (SH_C3[1] * SH(10) * xy + SH_C3[2] * SH(11) * 4.f * 2.f * yz +
-                                   SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * SH(13) * 4.f * 2.f * xz +
-                                   SH_C3[5] * SH(14) * (xx - yy));
-                    }
-                }
-            }
-#undef SH
-#undef DSH
-            dL_ddir[0] += dRGBdx * dL_dRGB; dL_ddir[1] += dRGBdy * dL_dRGB; dL_ddir[2] += dRGBdz * dL_dRGB;
-        }
+        sh_backward(deg, sh, dcol, clamped, x, y, z, dsh, dL_ddir);
         // dnormvdv, auxiliary.h:107-117
         {
             V3 vv = dir_orig;
@@ -554,6 +563,104 @@ __global__ void __launch_bounds__(256) k_sh_grad_from_views(int P, int V, int D,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// SuGaR.get_points_rgb (sugar_scene/sugar_model.py:839-883): colours = clamp_min(eval_sh(levels-1, sh, dir) + 0.5, 0) with
+// dir = F.normalize(positions - camera_centers) (or given directions).  The reference spends ~30 elementwise launches and
+// their autograd twins on this every training step (it feeds `colors_precomp`); here it is one lane per point, forward
+// and backward, on the same SH basis code as the rasterizer.  sh rows have a stride of `M` coefficients; `n` are used.
+struct ShRgbArgs {
+    int P, D, M, n;            // D = sh_levels - 1, n = (D+1)^2
+    const float* sh;           // [P, M, 3]
+    const float* positions;    // [P, 3] or null (then `directions` is used as is)
+    const float* centers;      // [n_centers, 3], n_centers in {1, P}
+    int n_centers;
+    const float* directions;   // [P, 3] or null
+};
+
+__device__ __forceinline__ void sh_rgb_dir(const ShRgbArgs& a, int idx, float& x, float& y, float& z, float& vx, float& vy,
+                                           float& vz, float& len)
+{
+    const size_t i3 = 3 * (size_t)idx;
+    if (a.positions) {
+        const size_t c3 = a.n_centers == 1 ? 0 : i3;
+        vx = a.positions[i3] - a.centers[c3]; vy = a.positions[i3 + 1] - a.centers[c3 + 1]; vz = a.positions[i3 + 2] - a.centers[c3 + 2];
+        len = fmax_(sqrtf(vx * vx + vy * vy + vz * vz), 1e-12f);  // F.normalize: v / max(|v|, eps)
+        x = vx / len; y = vy / len; z = vz / len;
+    } else {
+        x = a.directions[i3]; y = a.directions[i3 + 1]; z = a.directions[i3 + 2];
+        vx = x; vy = y; vz = z; len = 1.f;
+    }
+}
+
+__device__ __forceinline__ void load_sh_n(const float* shs, size_t idx, int M, int n, float* sh)
+{
+    if (n == M) { load_sh<48>(shs, idx, M, sh); return; }
+    const float* src = shs + idx * (size_t)M * 3;
+#pragma unroll
+    for (int i = 0; i < 48; i++) sh[i] = (i < 3 * n) ? src[i] : 0.0f;
+}
+
+__global__ void __launch_bounds__(256) k_sh_to_rgb_fwd(ShRgbArgs a, float* __restrict__ colors)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.P) return;
+    float x, y, z, vx, vy, vz, len;
+    sh_rgb_dir(a, idx, x, y, z, vx, vy, vz, len);
+    float sh[48];
+    load_sh_n(a.sh, idx, a.M, a.n, sh);
+    const size_t i3 = 3 * (size_t)idx;
+    colors[i3] = fmax_(sh_channel(a.D, sh, 0, x, y, z), 0.0f);
+    colors[i3 + 1] = fmax_(sh_channel(a.D, sh, 1, x, y, z), 0.0f);
+    colors[i3 + 2] = fmax_(sh_channel(a.D, sh, 2, x, y, z), 0.0f);
+}
+
+// dL_dsh gets every one of the M rows (zeros beyond the n used ones: it is the gradient of the full coefficient tensor);
+// dL_dpositions / dL_ddirections are optional.
+__global__ void __launch_bounds__(256) k_sh_to_rgb_bwd(ShRgbArgs a, const float* __restrict__ dL_dcolors,
+                                                       float* __restrict__ dL_dsh, float* __restrict__ dL_dpositions,
+                                                       float* __restrict__ dL_ddirections)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.P) return;
+    float x, y, z, vx, vy, vz, len;
+    sh_rgb_dir(a, idx, x, y, z, vx, vy, vz, len);
+    float sh[48], dsh[48];
+    load_sh_n(a.sh, idx, a.M, a.n, sh);
+#pragma unroll
+    for (int k = 0; k < 48; k++) dsh[k] = 0.0f;
+    const size_t i3 = 3 * (size_t)idx;
+    const float dcol[3] = {dL_dcolors[i3], dL_dcolors[i3 + 1], dL_dcolors[i3 + 2]};
+    // torch.clamp_min passes the gradient where the input is >= the bound
+    const uint32_t clamped = (sh_channel(a.D, sh, 0, x, y, z) < 0.f ? 1u : 0u) | (sh_channel(a.D, sh, 1, x, y, z) < 0.f ? 2u : 0u) |
+                             (sh_channel(a.D, sh, 2, x, y, z) < 0.f ? 4u : 0u);
+    float dL_ddir[3] = {0, 0, 0};
+    sh_backward(a.D, sh, dcol, clamped, x, y, z, dsh, dL_ddir);
+    if (dL_dsh) {
+        float* dst = dL_dsh + (size_t)idx * a.M * 3;
+        const int n_sh = 3 * a.M;
+        if (n_sh == 48 && ((uintptr_t)dst & 15) == 0) {
+            float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+            for (int i = 0; i < 12; i++) { float4 o = {dsh[4 * i], dsh[4 * i + 1], dsh[4 * i + 2], dsh[4 * i + 3]}; d4[i] = o; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 48; i++) if (i < n_sh) dst[i] = dsh[i];
+        }
+    }
+    if (a.positions) {
+        if (dL_dpositions) {
+            // d normalize(v) / dv = (I - n n^T) / |v|   (|v| above the eps of F.normalize)
+            const float dot = x * dL_ddir[0] + y * dL_ddir[1] + z * dL_ddir[2];
+            const float inv = 1.0f / len;
+            dL_dpositions[i3] = (dL_ddir[0] - x * dot) * inv;
+            dL_dpositions[i3 + 1] = (dL_ddir[1] - y * dot) * inv;
+            dL_dpositions[i3 + 2] = (dL_ddir[2] - z * dot) * inv;
+        }
+    } else if (dL_ddirections) {
+        dL_ddirections[i3] = dL_ddir[0]; dL_ddirections[i3 + 1] = dL_ddir[1]; dL_ddirections[i3 + 2] = dL_ddir[2];
+    }
+}
+
 }  // namespace
 
 void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s)
@@ -579,4 +686,36 @@ void sgr_launch_sh_grad_from_views(int P, int V, int D, int M, const float* mean
 {
     if (P <= 0) return;
     hipLaunchKernelGGL(k_sh_grad_from_views, dim3((P + 255) / 256), dim3(256), 0, s, P, V, D, M, means3D, campos, dcolor, dL_dsh);
+}
+
+static int sh_rgb_args(ShRgbArgs& a, int P, int D, int M, const float* sh, const float* positions, const float* centers,
+                       int n_centers, const float* directions)
+{
+    if (D < 0 || D > 3 || M < (D + 1) * (D + 1) || M > 16 || !sh) return SGR_E_INVALID;
+    if (positions ? (!centers || (n_centers != 1 && n_centers != P)) : !directions) return SGR_E_INVALID;
+    a.P = P; a.D = D; a.M = M; a.n = (D + 1) * (D + 1); a.sh = sh; a.positions = positions; a.centers = centers;
+    a.n_centers = n_centers; a.directions = directions;
+    return 0;
+}
+
+extern "C" int sgr_sh_to_rgb_forward(int P, int D, int M, const float* sh, const float* positions, const float* camera_centers,
+                                     int n_centers, const float* directions, float* colors, void* stream)
+{
+    if (P <= 0) return 0;
+    ShRgbArgs a;
+    if (!colors || sh_rgb_args(a, P, D, M, sh, positions, camera_centers, n_centers, directions) < 0) return SGR_E_INVALID;
+    hipLaunchKernelGGL(k_sh_to_rgb_fwd, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, colors);
+    return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
+}
+
+extern "C" int sgr_sh_to_rgb_backward(int P, int D, int M, const float* sh, const float* positions, const float* camera_centers,
+                                      int n_centers, const float* directions, const float* dL_dcolors, float* dL_dsh,
+                                      float* dL_dpositions, float* dL_ddirections, void* stream)
+{
+    if (P <= 0) return 0;
+    ShRgbArgs a;
+    if (!dL_dcolors || sh_rgb_args(a, P, D, M, sh, positions, camera_centers, n_centers, directions) < 0) return SGR_E_INVALID;
+    hipLaunchKernelGGL(k_sh_to_rgb_bwd, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, dL_dcolors, dL_dsh,
+                       dL_dpositions, dL_ddirections);
+    return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }

@@ -1,6 +1,6 @@
 """A/B on the GPU box: the REFERENCE rasterizer (oracle/_ref, hipcc build of the unmodified CUDA sources) versus this
 repository's HIP rasterizer, same inputs, same MI355X.  Prints parity statistics (reference vs CPU oracle, reference vs
-product) and fwd / bwd timings.   python scripts/ab_reference.py [config ...]
+product) and fwd / bwd timings.   python tests/ab_reference.py [config ...]
 """
 import json, os, sys, time
 import numpy as np, torch

@@ -87,6 +87,26 @@ def main():
     out["loss_img"] = img.detach().numpy(); out["loss_gt"] = gt.numpy()
     out["loss_value"] = np.float32(loss.item()); out["loss_grad"] = img.grad.numpy()
     out["loss_l1"] = np.float32(lu.l1_loss(img, gt).item()); out["loss_ssim"] = np.float32(lu.ssim(img, gt).item())
+    # SuGaR.get_points_rgb (sugar_scene/sugar_model.py:862-881, restated: the class cannot be imported) on the reference's own
+    # eval_sh, forward and autograd gradients, for sh_levels 1..4 (own generator: the vectors above stay unchanged)
+    g2 = torch.Generator().manual_seed(4321)
+    Pc = 160
+    pos = (torch.rand(Pc, 3, generator=g2) * 2 - 1)
+    cam = torch.tensor([[1.7, 0.4, -2.2]])
+    shc = torch.randn(Pc, 16, 3, generator=g2) * 0.5
+    w = torch.randn(Pc, 3, generator=g2)
+    out["prgb_positions"] = pos.numpy(); out["prgb_camera_center"] = cam.numpy()
+    out["prgb_sh_coordinates"] = shc.numpy(); out["prgb_weights"] = w.numpy()
+    for sh_levels in (1, 2, 3, 4):
+        p_ = pos.clone().requires_grad_(True); s_ = shc.clone().requires_grad_(True)
+        render_directions = torch.nn.functional.normalize(p_ - cam, dim=-1)
+        sh_coordinates = s_[:, :sh_levels ** 2]
+        shs_view = sh_coordinates.transpose(-1, -2).view(-1, 3, sh_levels ** 2)
+        sh2rgb = sh_mod.eval_sh(sh_levels - 1, shs_view, render_directions)
+        colors = torch.clamp_min(sh2rgb + 0.5, 0.0).view(-1, 3)
+        (colors * w).sum().backward()
+        out[f"prgb_colors_l{sh_levels}"] = colors.detach().numpy()
+        out[f"prgb_dsh_l{sh_levels}"] = s_.grad.numpy(); out[f"prgb_dpos_l{sh_levels}"] = (p_.grad if p_.grad is not None else torch.zeros_like(pos)).numpy()
     np.savez(os.path.join(HERE, "reference_helpers.npz"), **out)
     print("wrote", os.path.join(HERE, "reference_helpers.npz"), {k: v.shape for k, v in out.items()})
 
