@@ -51,7 +51,12 @@ def distCUDA2(points: torch.Tensor, method: str = "auto") -> torch.Tensor:
     return out
 
 
-def knn_points(p1: torch.Tensor, p2: torch.Tensor, K: int = 1, method: str = "auto", **_unused) -> _KNN:
+def knn_points(p1: torch.Tensor, p2: torch.Tensor, lengths1=None, lengths2=None, norm: int = 2, K: int = 1, version: int = -1,
+               return_nn: bool = False, return_sorted: bool = True, method: str = "auto") -> _KNN:
+    """pytorch3d.ops.knn_points for the call shape SuGaR uses (one cloud per call, 3-D, squared L2, sorted).  The
+    remaining pytorch3d arguments are accepted for signature compatibility; unsupported values raise."""
+    if lengths1 is not None or lengths2 is not None or norm != 2:
+        raise NotImplementedError("knn_points: lengths1/lengths2/norm=1 are not supported by the HIP k-NN")
     lib = _lib.load()
     if p1.dim() != 3 or p2.dim() != 3 or p1.shape[0] != 1 or p2.shape[0] != 1 or p1.shape[2] != 3 or p2.shape[2] != 3:
         raise RuntimeError("knn_points: expected p1[1,N,3], p2[1,M,3] (the shapes SuGaR uses)")
@@ -70,4 +75,18 @@ def knn_points(p1: torch.Tensor, p2: torch.Tensor, K: int = 1, method: str = "au
                              C.c_void_p(i.data_ptr()), stream)
     if rc < 0:
         raise RuntimeError(f"sgr_knn failed ({rc}); supported K: 1,2,3,4,8,16,32")
-    return _KNN(d[None], i[None], None)
+    return _KNN(d[None], i[None], r[i][None] if return_nn else None)
+
+
+def knn_points_pytorch3d(original):
+    """Wrap an installed pytorch3d.ops.knn_points: SuGaR's call shape on a ROCm device goes to the HIP k-NN, anything else
+    (batched clouds, lengths, other dimensions, L1) to the original."""
+    def knn_points_dispatch(p1, p2, lengths1=None, lengths2=None, norm=2, K=1, version=-1, return_nn=False, return_sorted=True):
+        ok = (p1.is_cuda and p1.dim() == 3 and p2.dim() == 3 and p1.shape[0] == 1 and p2.shape[0] == 1 and p1.shape[2] == 3 and
+              p2.shape[2] == 3 and lengths1 is None and lengths2 is None and norm == 2 and K in (1, 2, 3, 4, 8, 16, 32) and
+              p1.dtype == torch.float32 and p2.dtype == torch.float32 and not (p1.requires_grad or p2.requires_grad))
+        if ok:
+            return knn_points(p1, p2, K=K, return_nn=return_nn)
+        return original(p1, p2, lengths1=lengths1, lengths2=lengths2, norm=norm, K=K, version=version, return_nn=return_nn,
+                        return_sorted=return_sorted)
+    return knn_points_dispatch

@@ -1,0 +1,41 @@
+"""Stand-ins for the third-party modules the reference imports next to the rasterizer.
+
+`install()` makes `from pytorch3d.ops import knn_points` (sugar_scene/sugar_model.py:7) resolve to the HIP k-NN of this
+package:
+  * pytorch3d is installed  -> its `ops.knn_points` is replaced by `sugar_amd.knn.knn_points` for the call shape SuGaR uses
+                               (everything else stays pytorch3d's own);
+  * pytorch3d is absent     -> the minimal `pytorch3d` package under this directory is put on `sys.path`: `ops.knn_points`,
+                               `ops.estimate_pointcloud_normals`, the quaternion helpers of `transforms` that SuGaR uses, and
+                               placeholders for the mesh classes (`renderer`, `structures`, `loss`) that raise on use --
+                               mesh rasterization / extraction is outside this package's scope.
+"""
+from __future__ import annotations
+
+import importlib
+import importlib.util
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def install() -> str:
+    """Returns "patched" (real pytorch3d found, knn_points redirected) or "shim" (stand-in package activated)."""
+    spec = None
+    try:
+        spec = importlib.util.find_spec("pytorch3d")
+    except (ImportError, ValueError):
+        spec = None
+    real = spec is not None and spec.origin is not None and not os.path.abspath(spec.origin).startswith(_HERE)
+    if real:
+        import pytorch3d.ops as p3d_ops
+        from ..knn import knn_points_pytorch3d
+        if not hasattr(p3d_ops, "_sugar_amd_original_knn_points"):
+            p3d_ops._sugar_amd_original_knn_points = p3d_ops.knn_points
+        p3d_ops.knn_points = knn_points_pytorch3d(p3d_ops._sugar_amd_original_knn_points)
+        return "patched"
+    if _HERE not in sys.path:
+        sys.path.insert(0, _HERE)
+    importlib.invalidate_caches()
+    importlib.import_module("pytorch3d")
+    return "shim"

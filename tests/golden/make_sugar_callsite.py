@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""Golden fixture from the UNMODIFIED reference caller: sugar_scene/sugar_model.py is imported from /root/reference (with
+the stand-in `pytorch3d` of sugar_amd.shims and this repository's `diff_gaussian_rasterization` / `simple_knn` packages on
+the path), a SuGaR model is built and `SuGaR.render_image_gaussian_rasterizer` (:2085-2294) is run on the CPU.  Test-only
+substitutions, none of which touch the reference's files:
+  * the rasterizer class seen by sugar_model is the CPU-oracle-backed stand-in (tests/oracle_rasterizer.py) wrapped in a
+    recorder, so the fixture holds exactly what SuGaR hands to the rasterizer boundary and what comes back;
+  * `knn_points` is an exact scipy cKDTree stand-in (the HIP k-NN has no CPU path);
+  * `Tensor.cuda()` is the identity (the caller hard-codes `.cuda()`, :2143-2150); `open3d` / `plyfile` are empty modules;
+  * the cameras are duck-typed (CamerasWrapper needs pytorch3d's camera classes, which are out of scope).
+The GPU test replays the recorded boundary inputs through the HIP rasterizer (tests/test_gpu_sugar_callsite.py); the CPU test
+re-runs this script's `run()` when /root/reference is present (tests/test_shims.py).
+
+    python tests/golden/make_sugar_callsite.py      -> tests/golden/sugar_callsite.npz
+"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("SUGAR_REFERENCE", "/root/reference")
+W, H, P = 200, 152, 3000
+
+
+def _import_reference_model():
+    for p in (os.path.join(REF, "gaussian_splatting"), REF, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from sugar_amd import shims
+    shims.install()
+    for name in ("open3d", "plyfile"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except ImportError:
+                m = types.ModuleType(name)
+                m.PlyData = m.PlyElement = object
+                sys.modules[name] = m
+    import sugar_scene.sugar_model as sm
+    assert os.path.abspath(sm.__file__).startswith(os.path.abspath(REF)), sm.__file__
+    return sm
+
+
+def _scipy_knn_points(p1, p2, K=1, **_):
+    from scipy.spatial import cKDTree
+    from sugar_amd.knn import _KNN
+    d, i = cKDTree(p2[0].detach().double().numpy()).query(p1[0].detach().double().numpy(), k=K)
+    d = np.asarray(d).reshape(p1.shape[1], K); i = np.asarray(i).reshape(p1.shape[1], K)
+    return _KNN(torch.as_tensor(d ** 2, dtype=torch.float32)[None], torch.as_tensor(i, dtype=torch.int64)[None], None)
+
+
+class _P3DCamera:
+    def __init__(self, center):
+        self.znear = torch.tensor([0.01]); self.zfar = torch.tensor([100.0])
+        self.K = torch.zeros(1, 4, 4)
+        self.K[0, 0, 0] = self.K[0, 1, 1] = 1.7
+        self._c = center
+
+    def get_camera_center(self):
+        return self._c.reshape(1, 3)
+
+
+class _P3DCameras(list):
+    @property
+    def K(self):
+        return torch.cat([c.K for c in self])
+
+
+class _Cameras:
+    """the attributes of CamerasWrapper that SuGaR.__init__ and the renderer read"""
+    def __init__(self, cams):
+        n = len(cams)
+        self.height = torch.tensor([cams[0].image_height] * n); self.width = torch.tensor([cams[0].image_width] * n)
+        fx = cams[0].image_width / (2.0 * cams[0].tanfovx); fy = cams[0].image_height / (2.0 * cams[0].tanfovy)
+        self.fx = torch.tensor([fx] * n); self.fy = torch.tensor([fy] * n)
+        c2ws = []
+        for c in cams:
+            w2c = c.viewmatrix.t().double().numpy()          # COLMAP-convention world-to-camera
+            c2w = np.linalg.inv(w2c)
+            c2w[:3, 1:3] *= -1                               # to the nerfstudio convention the caller expects (:2133-2134)
+            c2ws.append(torch.tensor(c2w[:3], dtype=torch.float32))
+        self.camera_to_worlds = torch.stack(c2ws)
+        self.p3d_cameras = _P3DCameras(_P3DCamera(c2w[:, 3].clone()) for c2w in self.camera_to_worlds)
+
+    def get_spatial_extent(self):
+        return 3.0
+
+
+class _Recorder:
+    """wraps the rasterizer class the caller instantiates; keeps the boundary tensors of every call"""
+    calls = []
+
+    def __init__(self, raster_settings):
+        from tests.oracle_rasterizer import GaussianRasterizer
+        self.inner = GaussianRasterizer(raster_settings)
+        self.settings = raster_settings
+
+    def __call__(self, **kw):
+        for k, v in list(kw.items()):
+            if torch.is_tensor(v) and v.requires_grad:
+                # an alias per input: its .grad is the gradient that crosses the boundary (a parameter such as the positions
+                # also receives gradient along other paths, e.g. through the view-dependent colours)
+                kw[k] = v.view_as(v)
+                kw[k].retain_grad()
+        image, radii = self.inner(**kw)
+        _Recorder.calls.append(dict(settings=self.settings, inputs=kw, image=image, radii=radii))
+        return image, radii
+
+
+def run():
+    """returns {name: np.ndarray}"""
+    sm = _import_reference_model()
+    from sugar_amd import synthetic as syn
+    torch.manual_seed(0)
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sm.knn_points = _scipy_knn_points
+    sm.GaussianRasterizer = _Recorder
+    _Recorder.calls = []
+    try:
+        cams = syn.orbit_cameras(W, H)
+        nerf = types.SimpleNamespace(device=torch.device("cpu"), training_cameras=_Cameras(cams))
+        g = torch.Generator().manual_seed(77)
+        pts = (torch.rand(P, 3, generator=g) * 2 - 1) * 0.7
+        cols = torch.rand(P, 3, generator=g)
+        model = sm.SuGaR(nerfmodel=nerf, points=pts, colors=cols, initialize=True, sh_levels=4, keep_track_of_knn=True,
+                         knn_to_track=16)
+        with torch.no_grad():  # a mid-training state: the initial one has identity rotations and isotropic scales
+            model._scales += 0.35 * torch.randn(P, 3, generator=g) + 0.6
+            model._quaternions += 0.8 * torch.randn(P, 4, generator=g)
+            model.all_densities += 2.0 * torch.randn(P, 1, generator=g) + 1.5
+            model._sh_coordinates_rest += 0.15 * torch.randn(P, 15, 3, generator=g)
+        wimg = torch.randn(H, W, 3, generator=g)
+        out = {"W": np.int32(W), "H": np.int32(H), "dL_dimage_hw3": wimg.numpy()}
+        bgs = [None, torch.tensor([1.0, 1.0, 1.0])]
+        for ci, (cam_idx, in_rast) in enumerate(((1, False), (5, True))):
+            model.zero_grad(set_to_none=True)
+            res = model.render_image_gaussian_rasterizer(camera_indices=cam_idx, bg_color=bgs[ci], sh_deg=3,
+                                                         compute_color_in_rasterizer=in_rast, return_2d_radii=True)
+            (res["image"] * wimg).sum().backward()
+            call = _Recorder.calls[-1]
+            s = call["settings"]
+            pre = f"c{ci}_"
+            out[pre + "tanfov"] = np.array([s.tanfovx, s.tanfovy], dtype=np.float64)
+            out[pre + "sh_degree"] = np.int32(s.sh_degree)
+            for k in ("bg", "viewmatrix", "projmatrix", "campos"):
+                out[pre + k] = getattr(s, k).detach().numpy().astype(np.float32)
+            for k, v in call["inputs"].items():
+                if v is None:
+                    continue
+                out[pre + "in_" + k] = v.detach().numpy()
+                if v.grad is not None:
+                    out[pre + "grad_" + k] = v.grad.detach().numpy()
+            assert np.array_equal(out[pre + "grad_means2D"], res["viewspace_points"].grad.numpy())
+            out[pre + "image_hw3"] = res["image"].detach().numpy()
+            out[pre + "radii"] = res["radii"].numpy()
+            # gradients on SuGaR's own parameters (through the caller's activations)
+            for name in ("_points", "_scales", "_quaternions", "all_densities", "_sh_coordinates_dc", "_sh_coordinates_rest"):
+                out[pre + "param_grad" + name] = getattr(model, name).grad.detach().numpy()
+        return out
+    finally:
+        torch.Tensor.cuda = real_cuda
+
+
+def main():
+    out = run()
+    path = os.path.join(HERE, "sugar_callsite.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
+    for k in sorted(out):
+        if "image" in k or "radii" in k:
+            print(" ", k, out[k].shape, float(np.asarray(out[k], dtype=np.float64).mean()))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
