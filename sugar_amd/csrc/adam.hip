@@ -21,37 +21,74 @@ struct AdamSegs {
     int period[ADAM_MAX_SEG], split[ADAM_MAX_SEG];
 };
 
-__device__ __forceinline__ float lr_of(const AdamSegs& sg, long long i)
+__device__ __forceinline__ int seg_of(const AdamSegs& sg, long long i)
 {
-    float lr = 0.f;
+    int k = -1;
 #pragma unroll
-    for (int k = 0; k < ADAM_MAX_SEG; k++)
-        if (k < sg.n && i >= sg.begin[k] && i < sg.end[k])
-            lr = ((int)((i - sg.begin[k]) % sg.period[k]) < sg.split[k]) ? sg.lr_a[k] : sg.lr_b[k];
-    return lr;
+    for (int j = 0; j < ADAM_MAX_SEG; j++)
+        if (j < sg.n && i >= sg.begin[j] && i < sg.end[j]) k = j;
+    return k;
 }
 
-__global__ void __launch_bounds__(256) k_adam(long long n4, float4* __restrict__ p, const float4* __restrict__ g,
-                                              float4* __restrict__ m, float4* __restrict__ v, AdamSegs sg, float b1, float b2,
+// Learning rates of the four elements 4*i4 .. 4*i4+3.  A float4 almost always lies inside one segment: one segment search
+// and ONE 32-bit remainder for the four elements (a per-element 64-bit '%' made this kernel ALU-bound).
+__device__ __forceinline__ void lr_of4(const AdamSegs& sg, long long e0, float* lr)
+{
+    const int k0 = seg_of(sg, e0), k3 = seg_of(sg, e0 + 3);
+    if (k0 == k3) {
+        if (k0 < 0) { lr[0] = lr[1] = lr[2] = lr[3] = 0.f; return; }
+        float la = 0.f, lb = 0.f; int period = 1, split = 1; long long begin = 0;
+#pragma unroll
+        for (int j = 0; j < ADAM_MAX_SEG; j++)
+            if (j == k0) { la = sg.lr_a[j]; lb = sg.lr_b[j]; period = sg.period[j]; split = sg.split[j]; begin = sg.begin[j]; }
+        if (la == lb) { lr[0] = lr[1] = lr[2] = lr[3] = la; return; }
+        const unsigned long long off = (unsigned long long)(e0 - begin);
+        unsigned r = (off >> 32) ? (unsigned)(off % (unsigned long long)period) : ((unsigned)off % (unsigned)period);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            lr[c] = (int)r < split ? la : lb;
+            r = (r + 1 == (unsigned)period) ? 0u : r + 1;
+        }
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {  // the float4 straddles a segment boundary (at most n_seg of them)
+        const int k = seg_of(sg, e0 + c);
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < ADAM_MAX_SEG; j++)
+            if (j == k) v = ((int)((e0 + c - sg.begin[j]) % sg.period[j]) < sg.split[j]) ? sg.lr_a[j] : sg.lr_b[j];
+        lr[c] = v;
+    }
+}
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) k_adam(long long n4, f4* __restrict__ p, const f4* __restrict__ g,
+                                              f4* __restrict__ m, f4* __restrict__ v, AdamSegs sg, float b1, float b2,
                                               float eps, float bc1, float bc2_sqrt, float grad_scale)
 {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        float4 gg = g[i];
-        gg.x *= grad_scale; gg.y *= grad_scale; gg.z *= grad_scale; gg.w *= grad_scale;
-        float4 pp = p[i], mm = m[i], vv = v[i];
+        // g, m and v are touched once per step: stream them past the caches (p is read again by the next forward)
+        f4 gg = __builtin_nontemporal_load(&g[i]);
+        gg *= grad_scale;
+        f4 pp = p[i], mm = __builtin_nontemporal_load(&m[i]), vv = __builtin_nontemporal_load(&v[i]);
         float* pf = reinterpret_cast<float*>(&pp);
         float* mf = reinterpret_cast<float*>(&mm);
         float* vf = reinterpret_cast<float*>(&vv);
         const float* gf = reinterpret_cast<const float*>(&gg);
+        float lr[4];
+        lr_of4(sg, 4 * i, lr);
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            const float lr = lr_of(sg, 4 * i + c);
             mf[c] = b1 * mf[c] + (1.f - b1) * gf[c];
             vf[c] = b2 * vf[c] + (1.f - b2) * gf[c] * gf[c];
             const float denom = sqrtf(vf[c]) / bc2_sqrt + eps;
-            pf[c] -= (lr / bc1) * (mf[c] / denom);
+            pf[c] -= (lr[c] / bc1) * (mf[c] / denom);
         }
-        p[i] = pp; m[i] = mm; v[i] = vv;
+        p[i] = pp;
+        __builtin_nontemporal_store(mm, &m[i]);
+        __builtin_nontemporal_store(vv, &v[i]);
     }
 }
 
@@ -76,8 +113,8 @@ extern "C" int sgr_adam_step(long long n, float* params, const float* grads, flo
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     const long long n4 = n / 4;
     const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n4, reinterpret_cast<float4*>(params),
-                       reinterpret_cast<const float4*>(grads), reinterpret_cast<float4*>(exp_avg),
-                       reinterpret_cast<float4*>(exp_avg_sq), sg, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale);
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n4, reinterpret_cast<f4*>(params),
+                       reinterpret_cast<const f4*>(grads), reinterpret_cast<f4*>(exp_avg),
+                       reinterpret_cast<f4*>(exp_avg_sq), sg, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }

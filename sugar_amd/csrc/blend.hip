@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
     const int last_contributor = inside ? (int)n_contrib[pix_id] : 0;
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (inside) { g0 = dL_dpix[pix_id]; g1 = dL_dpix[HW + pix_id]; g2 = dL_dpix[2 * HW + pix_id]; }
-    const float bg_dot_dpixel = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
+    const float neg_Tfinal_bg = -T_final * (bg[0] * g0 + bg[1] * g1 + bg[2] * g2);
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;  // accum_rec
     float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;     // last_color
     float last_alpha = 0.f;
@@ -259,7 +259,10 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
                 const uint32_t id = point_list[r0 + (uint32_t)(total - 1 - base - tid)];
                 const float4* rp = reinterpret_cast<const float4*>(rec + id);
                 const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
-                sh.a[tid] = v0; sh.b[tid] = v1; sh.c[tid] = v2.x; sh.id[tid] = id;
+                // conic pre-scaled by log2(e) (and the -1/2 folded in): a pair costs one v_exp_f32 and no extra multiplies
+                sh.a[tid] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
+                sh.b[tid] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v1.z, v1.w);
+                sh.c[tid] = v2.x; sh.id[tid] = id;
                 hit = strip_hit_mask(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)x0, (float)y0);
             }
             sh.hit[tid] = hit;
@@ -278,8 +281,8 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
                 const float4 a = sh.a[j];
                 const float4 b = sh.b[j];
                 const float dx = a.x - pixfx, dy = a.y - pixfy;
-                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                const float G = __expf(power);
+                const float power = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;  // log2(e) * power of backward.cu:489
+                const float G = __builtin_amdgcn_exp2f(power);
                 const float alpha = fminf(0.99f, b.y * G);
                 const bool active = (pos <= last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
                 if (__ballot(active) == 0ull) continue;  // wave-uniform
@@ -291,13 +294,13 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
                     T = T * inv_1ma;
                     Wt = alpha * T;
                     const float c0 = b.z, c1 = b.w, c2 = sh.c[j];
-                    acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = c0;
-                    acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = c1;
-                    acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = c2;
+                    // accum_rec = last_alpha * last_color + (1 - last_alpha) * accum_rec  (backward.cu:514-516)
+                    acc0 += last_alpha * (lc0 - acc0); lc0 = c0;
+                    acc1 += last_alpha * (lc1 - acc1); lc1 = c1;
+                    acc2 += last_alpha * (lc2 - acc2); lc2 = c2;
                     float dL_dalpha = (c0 - acc0) * g0 + (c1 - acc1) * g1 + (c2 - acc2) * g2;
-                    dL_dalpha *= T;
                     last_alpha = alpha;
-                    dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
+                    dL_dalpha = dL_dalpha * T + neg_Tfinal_bg * inv_1ma;  // backward.cu:523-529
                     Z = G * dL_dalpha;
                 }
                 zw[rows * ZW_STRIDE + lane] = make_float2(Z, Wt);
@@ -313,17 +316,18 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
             if (bg_g < rows) {
                 const float4 a = sh.a[myj];
                 const float dyr = a.y - rowy;
-                float s0 = 0.f, sx = 0.f, sxx = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
                 const float2* row = zw + bg_g * ZW_STRIDE + bq * 16;
                 const float xb = a.x - (float)x0;
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     const float2 v = row[i];
-                    const float dxi = xb - (float)i;
-                    const float zx = v.x * dxi;
-                    s0 += v.x; sx += zx; sxx += zx * dxi;
+                    s0 += v.x; s1 += v.x * (float)i; s2 += v.x * (float)(i * i);  // moments about the tile's left edge
                     k0 += v.y * rg0[i]; k1 += v.y * rg1[i]; k2 += v.y * rg2[i];
                 }
+                // sum Z (xb - i) and sum Z (xb - i)^2 from the raw moments
+                const float sx = xb * s0 - s1;
+                const float sxx = xb * (xb * s0 - 2.f * s1) + s2;
                 float o[9] = {k0, k1, k2, s0, sx, dyr * s0, sxx, dyr * sx, dyr * dyr * s0};
 #pragma unroll
                 for (int v = 0; v < 9; v++) {
