@@ -204,6 +204,16 @@ int sgr_sh_to_rgb_backward(int P, int D, int M, const float* sh, const float* po
                            int n_centers, const float* directions, const float* dL_dcolors, float* dL_dsh,
                            float* dL_dpositions, float* dL_ddirections, void* stream);
 
+/* ---- parameter activations of the train step, gaussian_splatting/scene/gaussian_model.py:92-117 ----------------------
+ * scales = exp(scaling_raw)[P,3], rotations = F.normalize(rotation_raw)[P,4] (v / max(|v|, 1e-12)), opacities =
+ * sigmoid(opacity_raw)[P,1]; the backward maps gradients w.r.t. the activated values onto the raw parameters (every
+ * output element is written).  rotation pointers must be 16-byte aligned. */
+int sgr_activations_forward(int P, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                            float* scales, float* rotations, float* opacities, void* stream);
+int sgr_activations_backward(int P, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                             const float* dL_dscales, const float* dL_drotations, const float* dL_dopacities,
+                             float* dL_dscaling_raw, float* dL_drotation_raw, float* dL_dopacity_raw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,8 @@ SIGNATURES = {
     "sgr_level_set_points": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "sgr_sh_to_rgb_forward": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "sgr_sh_to_rgb_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sgr_activations_forward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sgr_activations_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgr_dist2": (_i, [_i, _vp, _vp, _vp]),
     "sgr_knn": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "sgr_knn_grid_scratch_bytes": (_sz, [_i]),

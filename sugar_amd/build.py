@@ -27,6 +27,7 @@ SOURCES = {
     "knn.hip": ["-ffp-contract=off"],
     "loss.hip": [],
     "adam.hip": [],
+    "activations.hip": [],
     "field.hip": [],
     "capi.hip": [],
 }

@@ -75,6 +75,50 @@ def train_loss(image, gt, lambda_dssim=0.2, fused=True):
 
 
 # ---------------------------------------------------------------- parameters
+class _Activations(torch.autograd.Function):
+    """exp / normalize / sigmoid of the raw parameters (sgr_activations_forward / _backward).  `sinks` = three tensors the
+    backward writes the raw-parameter gradients into (and returns), or None to allocate."""
+
+    @staticmethod
+    def forward(ctx, scaling, rotation, opacity, sinks):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        if not scaling.is_cuda:
+            raise RuntimeError("the fused activations need tensors on a ROCm device; there is no CPU fallback")
+        P, dev = scaling.shape[0], scaling.device
+        scales, rots, opac = torch.empty_like(scaling), torch.empty_like(rotation), torch.empty_like(opacity)
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        with torch.cuda.device(dev):
+            rc = lib.sgr_activations_forward(P, vp(scaling), vp(rotation), vp(opacity), vp(scales), vp(rots), vp(opac),
+                                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc < 0:
+            raise RuntimeError(f"sgr_activations_forward failed ({rc})")
+        ctx.save_for_backward(scaling, rotation, opacity)
+        ctx.sinks = sinks
+        return scales, rots, opac
+
+    @staticmethod
+    def backward(ctx, g_scales, g_rots, g_opac):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        scaling, rotation, opacity = ctx.saved_tensors
+        P, dev = scaling.shape[0], scaling.device
+        gs = torch.zeros_like(scaling) if g_scales is None else g_scales.contiguous()
+        gr = torch.zeros_like(rotation) if g_rots is None else g_rots.contiguous()
+        go = torch.zeros_like(opacity) if g_opac is None else g_opac.contiguous()
+        ds, dr, do = ctx.sinks if ctx.sinks is not None else (torch.empty_like(scaling), torch.empty_like(rotation),
+                                                             torch.empty_like(opacity))
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        with torch.cuda.device(dev):
+            rc = lib.sgr_activations_backward(P, vp(scaling), vp(rotation), vp(opacity), vp(gs), vp(gr), vp(go), vp(ds), vp(dr),
+                                              vp(do), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc < 0:
+            raise RuntimeError(f"sgr_activations_backward failed ({rc})")
+        return ds, dr, do, None
+
+
 class GaussianParams:
     """Raw (pre-activation) 3DGS parameters, 59 floats per Gaussian at SH degree 3, stored as views of ONE flat buffer:
     the data-parallel gradient exchange is a single all-reduce of one contiguous tensor and the optimiser a single
@@ -115,9 +159,14 @@ class GaussianParams:
             self.params["scaling"].copy_(torch.log(scene.scales))
             self.params["rotation"].copy_(scene.rotations)
 
-    def activated(self):
-        """gaussian_model.py:92-117: exp / normalize / sigmoid"""
+    def activated(self, fused=None):
+        """gaussian_model.py:92-117: exp / normalize / sigmoid -- one HIP kernel each way on a ROCm device (the gradients
+        land directly in the flat gradient buffer), stock torch ops otherwise."""
         p = self.params
+        if self.flat.is_cuda if fused is None else fused:
+            scales, rotations, opacities = _Activations.apply(p["scaling"], p["rotation"], p["opacity"],
+                                                             (p["scaling"].grad, p["rotation"].grad, p["opacity"].grad))
+            return dict(means3D=p["xyz"], scales=scales, rotations=rotations, opacities=opacities, shs=p["features"])
         return dict(means3D=p["xyz"], scales=torch.exp(p["scaling"]), rotations=F.normalize(p["rotation"]),
                     opacities=torch.sigmoid(p["opacity"]), shs=p["features"])
 

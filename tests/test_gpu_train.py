@@ -71,3 +71,32 @@ def test_trainer_compact_and_flat_paths_agree():
     # Adam normalises tiny gradients to +-lr, so compare the update, not bit patterns
     assert float((flats[0] - flats[1]).abs().max()) < 2e-2 * float((flats[0] - start).abs().max())
     assert float((flats[0] - flats[1]).norm() / (flats[0] - start).norm()) < 1e-3
+
+
+def test_fused_activations_match_torch_ops():
+    """exp / F.normalize / sigmoid of the raw parameters (gaussian_model.py:92-117) and their autograd gradients"""
+    from sugar_amd.train_step import GaussianParams
+    dev = torch.device(DEV)
+    scene = syn.make_scene(50001, 4, 0.005, 0.2)  # odd count: the tail block is partial
+    ws = None
+    out = []
+    for fused in (False, True):
+        p = GaussianParams(scene, dev)
+        with torch.no_grad():
+            p.params["rotation"].mul_(3.7)            # un-normalised quaternions, as they are mid-training
+            p.params["rotation"][:7] = 0.0            # |v| < eps: F.normalize divides by the clamped 1e-12
+        a = p.activated(fused=fused)
+        if ws is None:
+            g = torch.Generator().manual_seed(0)
+            ws = {k: torch.randn(a[k].shape, generator=g).to(dev) for k in ("scales", "rotations", "opacities")}
+        loss = sum((a[k] * ws[k]).sum() for k in ws)
+        grads = torch.autograd.grad(loss, [p.params["scaling"], p.params["rotation"], p.params["opacity"]])
+        if fused:  # the gradients were written into the flat gradient buffer and returned as such
+            for gr, name in zip(grads, ("scaling", "rotation", "opacity")):
+                assert gr.data_ptr() == p.params[name].grad.data_ptr()
+        out.append(([a[k].detach().clone() for k in ("scales", "rotations", "opacities")], [x.clone() for x in grads]))
+    for x, y in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
+        assert torch.isfinite(y).all()
+        # (the seven zero quaternions give 1e12-sized gradients: compare them apart from the regular rows)
+        assert torch.allclose(x[:7], y[:7], rtol=2e-5, atol=1e-6 * float(x[:7].abs().max()))
+        assert torch.allclose(x[7:], y[7:], rtol=2e-5, atol=2e-6 * float(x[7:].abs().max())), float((x[7:] - y[7:]).abs().max())
