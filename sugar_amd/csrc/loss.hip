@@ -16,9 +16,11 @@
 
 namespace {
 
-#define LT 16          // output tile edge
+#define LT 32          // output tile edge
 #define LH 5           // window half width (window_size 11)
-#define LR (LT + 2 * LH)  // 26: staged region edge
+#define LR (LT + 2 * LH)  // 42: staged region edge
+#define LRP (LR + 1)      // padded row strides (bank spread)
+#define LTP (LT + 1)
 
 struct Win { float w[11]; };
 
@@ -27,13 +29,16 @@ __device__ __forceinline__ float ld_pad(const float* __restrict__ img, int W, in
     return (x >= 0 && x < W && y >= 0 && y < H) ? img[(size_t)y * W + x] : 0.0f;
 }
 
+// Register-blocked separable window: in the horizontal pass a thread produces 4 adjacent outputs of one staged row from
+// 14 staged values (products x^2, y^2, xy formed once per value); in the vertical pass a thread produces 4 vertically
+// adjacent pixels of one column from 14 rows.  A 32x32 tile re-reads 1.7x its pixels as halo (a 16x16 tile: 2.6x).
 __global__ void __launch_bounds__(256) k_l1_ssim_fwd(int W, int H, const float* __restrict__ X, const float* __restrict__ Y,
                                                      Win win, float* __restrict__ dm1, float* __restrict__ ds1,
                                                      float* __restrict__ ds12, float2* __restrict__ partial)
 {
-    __shared__ float sx[LR][LR + 1];
-    __shared__ float sy[LR][LR + 1];
-    __shared__ float hq[5][LR][LT + 1];
+    __shared__ float sx[LR][LRP];
+    __shared__ float sy[LR][LRP];
+    __shared__ float hq[5][LR][LTP];
     __shared__ float red[2][4];
     const int c = blockIdx.z;
     const size_t plane = (size_t)c * W * H;
@@ -47,47 +52,82 @@ __global__ void __launch_bounds__(256) k_l1_ssim_fwd(int W, int H, const float* 
         sy[r][cc] = ld_pad(y, W, H, x0 + cc - LH, y0 + r - LH);
     }
     __syncthreads();
-    // horizontal pass: LR rows x LT columns, five quantities
-    for (int i = tid; i < LR * LT; i += 256) {
-        const int r = i / LT, cc = i - r * LT;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+    // horizontal pass: LR rows x LT columns, five quantities; item = (row, group of 4 columns)
+    for (int i = tid; i < LR * (LT / 4); i += 256) {
+        const int r = i >> 3, c0 = (i & 7) * 4;
+        float a[4][5];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = win.w[k];
-            const float vx = sx[r][cc + k], vy = sy[r][cc + k];
-            a0 += w * vx; a1 += w * vy; a2 += w * vx * vx; a3 += w * vy * vy; a4 += w * vx * vy;
+        for (int o = 0; o < 4; o++)
+#pragma unroll
+            for (int q = 0; q < 5; q++) a[o][q] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 14; k++) {
+            const float vx = sx[r][c0 + k], vy = sy[r][c0 + k];
+            const float xx = vx * vx, yy = vy * vy, xy = vx * vy;
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                const int t = k - o;  // tap index of output o for staged value k
+                if (t >= 0 && t < 11) {
+                    const float w = win.w[t];
+                    a[o][0] += w * vx; a[o][1] += w * vy; a[o][2] += w * xx; a[o][3] += w * yy; a[o][4] += w * xy;
+                }
+            }
         }
-        hq[0][r][cc] = a0; hq[1][r][cc] = a1; hq[2][r][cc] = a2; hq[3][r][cc] = a3; hq[4][r][cc] = a4;
+#pragma unroll
+        for (int o = 0; o < 4; o++)
+#pragma unroll
+            for (int q = 0; q < 5; q++) hq[q][r][c0 + o] = a[o][q];
     }
     __syncthreads();
-    const int lx = tid & 15, ly = tid >> 4;
-    const int px = x0 + lx, py = y0 + ly;
+    // vertical pass: thread = (column lx, rows 4*lg .. 4*lg+3)
+    const int lx = tid & 31, lg = tid >> 5;
+    const int px = x0 + lx;
     float s_val = 0.f, l1_val = 0.f;
-    if (px < W && py < H) {
-        float mu1 = 0.f, mu2 = 0.f, ex2 = 0.f, ey2 = 0.f, exy = 0.f;
+    {
+        float v[4][5];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = win.w[k];
-            mu1 += w * hq[0][ly + k][lx]; mu2 += w * hq[1][ly + k][lx]; ex2 += w * hq[2][ly + k][lx];
-            ey2 += w * hq[3][ly + k][lx]; exy += w * hq[4][ly + k][lx];
+        for (int o = 0; o < 4; o++)
+#pragma unroll
+            for (int q = 0; q < 5; q++) v[o][q] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 14; k++) {
+            float h[5];
+#pragma unroll
+            for (int q = 0; q < 5; q++) h[q] = hq[q][4 * lg + k][lx];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                const int t = k - o;
+                if (t >= 0 && t < 11) {
+                    const float w = win.w[t];
+#pragma unroll
+                    for (int q = 0; q < 5; q++) v[o][q] += w * h[q];
+                }
+            }
         }
-        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float sig1 = ex2 - mu1_sq, sig2 = ey2 - mu2_sq, sig12 = exy - mu12;
-        const float A = 2.f * mu12 + C1, B = 2.f * sig12 + C2, Cc = mu1_sq + mu2_sq + C1, D = sig1 + sig2 + C2;
-        const float inv_cd = 1.0f / (Cc * D);
-        const float S = A * B * inv_cd;
-        const size_t o = plane + (size_t)py * W + px;
-        dm1[o] = 2.f * mu2 * (B - A) * inv_cd - 2.f * mu1 * S * (D - Cc) * inv_cd;
-        ds1[o] = -S / D;
-        ds12[o] = 2.f * A * inv_cd;
-        s_val = S;
-        l1_val = fabsf(sx[ly + LH][lx + LH] - sy[ly + LH][lx + LH]);
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            const int ly = 4 * lg + o, py = y0 + ly;
+            if (px < W && py < H) {
+                const float mu1 = v[o][0], mu2 = v[o][1], ex2 = v[o][2], ey2 = v[o][3], exy = v[o][4];
+                const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+                const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+                const float sig1 = ex2 - mu1_sq, sig2 = ey2 - mu2_sq, sig12 = exy - mu12;
+                const float A = 2.f * mu12 + C1, B = 2.f * sig12 + C2, Cc = mu1_sq + mu2_sq + C1, D = sig1 + sig2 + C2;
+                const float inv_cd = 1.0f / (Cc * D);
+                const float S = A * B * inv_cd;
+                const size_t oo = plane + (size_t)py * W + px;
+                dm1[oo] = 2.f * mu2 * (B - A) * inv_cd - 2.f * mu1 * S * (D - Cc) * inv_cd;
+                ds1[oo] = -S / D;
+                ds12[oo] = 2.f * A * inv_cd;
+                s_val += S;
+                l1_val += fabsf(sx[ly + LH][lx + LH] - sy[ly + LH][lx + LH]);
+            }
+        }
     }
     for (int o = 32; o > 0; o >>= 1) { s_val += __shfl_xor(s_val, o); l1_val += __shfl_xor(l1_val, o); }
     if ((tid & 63) == 0) { red[0][tid >> 6] = s_val; red[1][tid >> 6] = l1_val; }
     __syncthreads();
-    // one partial per workgroup; k_l1_ssim_finish adds them in double (24k same-address device atomics cost 0.5 ms)
+    // one partial per workgroup; k_l1_ssim_finish adds them in double (same-address device atomics cost 0.5 ms)
     if (tid == 0) {
         const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         partial[blk] = make_float2(red[0][0] + red[0][1] + red[0][2] + red[0][3], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
@@ -118,8 +158,8 @@ __global__ void __launch_bounds__(256) k_l1_ssim_bwd(int W, int H, const float* 
                                                      const float* __restrict__ ds12, const float* __restrict__ grad_loss,
                                                      float lambda, float inv_n, float* __restrict__ dX)
 {
-    __shared__ float sm[3][LR][LR + 1];
-    __shared__ float hq[3][LR][LT + 1];
+    __shared__ float sm[3][LR][LRP];
+    __shared__ float hq[3][LR][LTP];
     const int c = blockIdx.z;
     const size_t plane = (size_t)c * W * H;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
@@ -132,32 +172,50 @@ __global__ void __launch_bounds__(256) k_l1_ssim_bwd(int W, int H, const float* 
         sm[2][r][cc] = ld_pad(ds12 + plane, W, H, gx, gy);
     }
     __syncthreads();
-    for (int i = tid; i < LR * LT; i += 256) {
-        const int r = i / LT, cc = i - r * LT;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = tid; i < LR * (LT / 4); i += 256) {
+        const int r = i >> 3, c0 = (i & 7) * 4;
+        float a[4][3];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = win.w[k];
-            a0 += w * sm[0][r][cc + k]; a1 += w * sm[1][r][cc + k]; a2 += w * sm[2][r][cc + k];
+        for (int o = 0; o < 4; o++) { a[o][0] = 0.f; a[o][1] = 0.f; a[o][2] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 14; k++) {
+            const float v0 = sm[0][r][c0 + k], v1 = sm[1][r][c0 + k], v2 = sm[2][r][c0 + k];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                const int t = k - o;
+                if (t >= 0 && t < 11) { const float w = win.w[t]; a[o][0] += w * v0; a[o][1] += w * v1; a[o][2] += w * v2; }
+            }
         }
-        hq[0][r][cc] = a0; hq[1][r][cc] = a1; hq[2][r][cc] = a2;
+#pragma unroll
+        for (int o = 0; o < 4; o++) { hq[0][r][c0 + o] = a[o][0]; hq[1][r][c0 + o] = a[o][1]; hq[2][r][c0 + o] = a[o][2]; }
     }
     __syncthreads();
-    const int lx = tid & 15, ly = tid >> 4;
-    const int px = x0 + lx, py = y0 + ly;
-    if (px < W && py < H) {
-        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    const int lx = tid & 31, lg = tid >> 5;
+    const int px = x0 + lx;
+    float g[4][3];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = win.w[k];
-            g0 += w * hq[0][ly + k][lx]; g1 += w * hq[1][ly + k][lx]; g2 += w * hq[2][ly + k][lx];
+    for (int o = 0; o < 4; o++) { g[o][0] = 0.f; g[o][1] = 0.f; g[o][2] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        const float h0 = hq[0][4 * lg + k][lx], h1 = hq[1][4 * lg + k][lx], h2 = hq[2][4 * lg + k][lx];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            const int t = k - o;
+            if (t >= 0 && t < 11) { const float w = win.w[t]; g[o][0] += w * h0; g[o][1] += w * h1; g[o][2] += w * h2; }
         }
-        const size_t o = plane + (size_t)py * W + px;
-        const float xv = X[o], yv = Y[o];
-        const float d = xv - yv;
-        const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-        const float dssim = g0 + 2.f * xv * g1 + yv * g2;
-        dX[o] = grad_loss[0] * inv_n * ((1.f - lambda) * sgn - lambda * dssim);
+    }
+    const float gl = grad_loss[0] * inv_n;
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        const int py = y0 + 4 * lg + o;
+        if (px < W && py < H) {
+            const size_t oo = plane + (size_t)py * W + px;
+            const float xv = X[oo], yv = Y[oo];
+            const float d = xv - yv;
+            const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+            const float dssim = g[o][0] + 2.f * xv * g[o][1] + yv * g[o][2];
+            dX[oo] = gl * ((1.f - lambda) * sgn - lambda * dssim);
+        }
     }
 }
 
