@@ -20,26 +20,40 @@ namespace {
 #define LOG2E 1.4426950408889634f
 
 // Which of the tile's four 16x4 pixel strips (one per wave) can a Gaussian contribute to?  A pair contributes only if
-// power <= 0 and opacity * exp(power) >= 1/255 (forward.cu:336-345), i.e. inside the ellipse q(d) <= 2*ln(255*opacity)
-// with q the conic form.  The ellipse's axis-aligned bounding box (inflated by 0.1 % + 0.01 px against rounding) is tested
-// against each strip.  Skipping an entry for a strip is therefore exact: no pixel of that strip would have passed the
-// reference's tests.  Degenerate conics fall back to "all strips".
+// power <= 0 and opacity * exp(power) >= 1/255 (forward.cu:336-345), i.e. the pixel lies inside the ellipse
+//     q(d) = cx dx^2 + 2 cy dx dy + cz dy^2 <= tau^2 = 2 ln(255 opacity)        (d = pixel - centre).
+// The test is exact for the strip's rectangle: q is convex, so unless the centre lies in the rectangle its minimum over
+// the rectangle is attained on one of the four edges, where q is a 1-D parabola,
+//     q(dx, .) = (det/cz) dx^2 + cz (dy - dy*)^2,  dy* = -cy dx / cz      (and symmetrically for a horizontal edge),
+// minimised by clamping dy* to the edge.  tau^2 is inflated by 0.2 % + 1e-3 against rounding (at the threshold that is a
+// 1 % margin in alpha, the float evaluation of the pair differs from the exact one by ~1e-6).  Skipping an entry for a
+// strip is therefore exact: no pixel of that strip would have passed the reference's tests.  Elongated, diagonal
+// splats miss most of the strips of their bounding box.  Degenerate conics fall back to "all strips".
 __device__ __forceinline__ uint32_t strip_hit_mask(float gxc, float gyc, float cx, float cy, float cz, float op, float x0,
                                                    float y0)
 {
     if (op < 1.0f / 255.0f) return 0u;  // alpha <= opacity < 1/255 everywhere
     const float det = cx * cz - cy * cy;
     if (!(det > 0.f) || !(cx > 0.f) || !(cz > 0.f)) return 0xFu;
-    const float tau2 = 2.0f * __logf(255.0f * op);
-    const float inv = tau2 / det;
-    const float hx = sqrtf(inv * cz) * 1.001f + 0.01f;
-    const float hy = sqrtf(inv * cx) * 1.001f + 0.01f;
-    if (!(gxc - hx <= x0 + 15.0f && gxc + hx >= x0)) return 0u;
+    const float tau2 = 2.0f * __logf(255.0f * op) * 1.002f + 1e-3f;
+    const float icx = __builtin_amdgcn_rcpf(cx), icz = __builtin_amdgcn_rcpf(cz);
+    const float det_cz = det * icz, det_cx = det * icx;   // curvature left along an edge after minimising across it
+    const float kyx = -cy * icz, kxy = -cy * icx;         // dy* = kyx dx,  dx* = kxy dy
+    const float dxl = x0 - gxc, dxr = dxl + 15.0f;
+    const bool in_x = dxl <= 0.f && dxr >= 0.f;
+    const float sL = kyx * dxl, sR = kyx * dxr;           // optimal dy on the left / right edge
+    const float bL = det_cz * dxl * dxl, bR = det_cz * dxr * dxr;
     uint32_t m = 0u;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-        const float ys = y0 + 4.0f * w;
-        if (gyc - hy <= ys + 3.0f && gyc + hy >= ys) m |= 1u << w;
+        const float dyl = y0 + 4.0f * w - gyc, dyh = dyl + 3.0f;
+        float tL = fminf(fmaxf(sL, dyl), dyh) - sL, tR = fminf(fmaxf(sR, dyl), dyh) - sR;
+        float q = fminf(bL + cz * tL * tL, bR + cz * tR * tR);
+        const float sT = kxy * dyl, sB = kxy * dyh;       // optimal dx on the top / bottom edge
+        const float tT = fminf(fmaxf(sT, dxl), dxr) - sT, tB = fminf(fmaxf(sB, dxl), dxr) - sB;
+        q = fminf(q, fminf(det_cx * dyl * dyl + cx * tT * tT, det_cx * dyh * dyh + cx * tB * tB));
+        const bool inside = in_x && dyl <= 0.f && dyh >= 0.f;
+        if (inside || q <= tau2) m |= 1u << w;
     }
     return m;
 }
