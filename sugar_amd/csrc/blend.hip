@@ -14,6 +14,11 @@
 // recorded by the forward) instead of at the end of the tile's list.
 #include "sgr_common.h"
 
+#ifdef SGR_COUNT
+__device__ unsigned long long g_sgr_count[8];
+extern "C" void sgr_debug_counts(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sgr_count), sizeof(g_sgr_count)); unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_sgr_count), z, sizeof(z)); }
+#endif
+
 namespace {
 
 #define BATCH 256
@@ -56,6 +61,17 @@ __device__ __forceinline__ uint32_t strip_hit_mask(float gxc, float gyc, float c
         if (inside || q <= tau2) m |= 1u << w;
     }
     return m;
+}
+
+// x summed over the four 16-lane rows of the wave (lanes l, l+16, l+32, l+48), result in every lane: two gfx950 lane-swap
+// VALU ops instead of two ds_bpermute round trips through the LDS pipeline.
+__device__ __forceinline__ float sum_over_rows(float x)
+{
+    const uint32_t u = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // {r0,r0,r2,r2} , {r1,r1,r3,r3}
+    const uint32_t y = __float_as_uint(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+    auto q = __builtin_amdgcn_permlane32_swap(y, y, false, false);      // {lo,lo} , {hi,hi}
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
 struct StageFwd {
@@ -155,6 +171,21 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
             last_contributor = upd ? pos : last_contributor;
             done_pos = stop ? pos : done_pos;
             done = done || stop;
+#ifdef SGR_COUNT
+            {   // lanes that pass the tests, per 16-lane row (4x... here: 16x1 pixel rows) and per wave iteration
+                const unsigned long long okm = __ballot(ok);
+                if (lane == 0) {
+                    atomicAdd(&g_sgr_count[0], 1ull);                       // (entry, wave) iterations
+                    atomicAdd(&g_sgr_count[1], (unsigned long long)__popcll(okm));  // passing lanes
+                    int rows = ((okm & 0xFFFFull) != 0) + ((okm & 0xFFFF0000ull) != 0) + ((okm & 0xFFFF00000000ull) != 0) + ((okm >> 48) != 0);
+                    atomicAdd(&g_sgr_count[2], (unsigned long long)rows);   // 16x1 rows with a passing lane
+                    // 4x4 blocks with a passing lane: lane = (y&3)*16 + x -> block = x>>2
+                    int blocks = 0;
+                    for (int bq = 0; bq < 4; bq++) { unsigned long long m = 0xFull << (4 * bq); m = m | (m << 16) | (m << 32) | (m << 48); blocks += (okm & m) != 0; }
+                    atomicAdd(&g_sgr_count[3], (unsigned long long)blocks);
+                }
+            }
+#endif
             if (__ballot(!done) == 0ull) break;
         }
     }
@@ -344,10 +375,7 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
                 const float sxx = xb * (xb * s0 - 2.f * s1) + s2;
                 float o[9] = {k0, k1, k2, s0, sx, dyr * s0, sxx, dyr * sx, dyr * dyr * s0};
 #pragma unroll
-                for (int v = 0; v < 9; v++) {
-                    o[v] += __shfl_xor(o[v], 16);
-                    o[v] += __shfl_xor(o[v], 32);
-                }
+                for (int v = 0; v < 9; v++) o[v] = sum_over_rows(o[v]);
                 if (bq == 0) {
                     float* dst = sh.part[myj];
 #pragma unroll
