@@ -191,6 +191,13 @@ int sgr_level_set_points(int N, int K, const float* world_points, const int64_t*
                          const float* gaussian_std, int n_levels, const float* levels_host, int n_range, float range_size,
                          float density_factor, uint8_t* valid, float* points, float* normals, void* stream);
 
+/* ---- binning path selection (debug / tests) ------------------------------------------------------------------------
+ * mode 0 (default): two-level depth-ordered binning (super-tiles of 8x8 tiles, then tiles) with an automatic fall-back
+ * to mode 1 when the level-1 list would overflow; mode 1: single-level ordered scatter.  Both produce bit-identical lists
+ * and ranges.  sgr_set_binning_mode returns the previous mode; sgr_last_binning_mode the path the last forward took. */
+int sgr_set_binning_mode(int mode);
+int sgr_last_binning_mode(void);
+
 /* ---- SuGaR.get_points_rgb, sugar_scene/sugar_model.py:839-883 (with sugar_utils/spherical_harmonics.py:117-172) -----
  * colors[P,3] = clamp_min(eval_sh(D, sh, dir) + 0.5, 0),  dir = F.normalize(positions - camera_centers) when positions is
  * given (camera_centers[n_centers,3], n_centers = 1 or P), else directions[P,3] as they are.  sh is [P,M,3] (the

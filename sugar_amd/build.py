@@ -23,6 +23,7 @@ ARCH = "gfx950"
 SOURCES = {
     "preprocess.hip": ["-ffp-contract=off"],
     "binning.hip": ["-ffp-contract=off"],
+    "binning2.hip": ["-ffp-contract=off"],
     "blend.hip": ["-fno-slp-vectorize"] + os.environ.get("SGR_BLEND_DEFS", "").split(),  # the auto-formed v_pk_* pairs cost more v_mov shuffles than they save
     "knn.hip": ["-ffp-contract=off"],
     "loss.hip": [],

@@ -1,0 +1,423 @@
+// binning2.hip -- two-level depth-ordered tile binning for gfx950 (the default path; binning.hip's single-level scatter
+// stays as the fallback for scenes whose Gaussians cover more super-tiles than the level-1 list can hold).
+//
+// Same contract as binning.hip (DGR/cuda_rasterizer/rasterizer_impl.cu:70-138, 277-317 replaced): every tile's list holds
+// the Gaussians whose rectangle covers the tile, in (depth bits, id) order -- bit-identical lists and ranges.
+//
+// Why two levels.  The single-level scatter keeps one open write stream per (slice, tile): 1024 waves x 8160 tiles at
+// 1080p.  No cache can hold that many partially written lines, so the 74 MB of list entries cost ~570 MB of HBM writes
+// (rocprofv3 WRITE_SIZE) and the kernel is latency-bound with one wave per SIMD.  Here a Gaussian is first appended, in
+// depth order, to the lists of the 8x8-tile SUPER-TILES its rectangle touches (135 bins at 1080p, ~2 entries per
+// Gaussian: the ordered scatter is cheap and runs 2048 waves), and each super-tile list is then cut into chunks of 512
+// entries.  One wave per chunk walks its entries in order with lane = tile of the super-tile, tests rectangle vs tile and
+// appends the id to its own tile's list: 64 sequential write streams per wave, full lines, no atomics.
+//
+//   sup_count   : slice b of the depth order histograms its super-tiles in LDS (one lane per Gaussian)
+//   sup_hist_scan: exclusive scan over slices, per-super-tile totals
+//   sup_scan    : super-tile list starts, chunk table (chunk_base[s] = first chunk of super-tile s), capacity check
+//   sup_scatter : one wave per slice appends the sorted positions of its Gaussians to the super-tile lists, in order
+//   tile_pass<0>: per chunk, per tile of the super-tile: number of covering entries  -> cnt2[chunk][64]
+//   tile_scan2  : per super-tile, exclusive scan of cnt2 over its chunks (in place) -> per-tile totals
+//   tile_scan   : (binning.hip) ranges, R
+//   tile_pass<1>: per chunk, the same walk again, now storing ids at tile_start[t] + cnt2[chunk][t] + running count
+#include "sgr_device.h"
+
+namespace {
+
+#define LDS_ORDER()                          \
+    do {                                     \
+        asm volatile("" ::: "memory");       \
+        __builtin_amdgcn_wave_barrier();     \
+    } while (0)
+
+#define SGR_B2_MAXN 16  // super-tiles per Gaussian handled by the lane-parallel level-1 path
+
+#define WAVE_FENCE()                                          \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                      \
+    } while (0)
+
+// rectangle of a packed tile rectangle in super-tile units; returns false for a culled Gaussian
+__device__ __forceinline__ bool sup_rect(uint2 r, int& sx0, int& sy0, int& w1, int& h1)
+{
+    const int w = (int)(r.y & 0xFFFFu), h = (int)(r.y >> 16);
+    if (w == 0) return false;
+    const int minx = (int)(r.x & 0xFFFFu), miny = (int)(r.x >> 16);
+    sx0 = minx >> SGR_SUP_SHIFT; sy0 = miny >> SGR_SUP_SHIFT;
+    w1 = ((minx + w - 1) >> SGR_SUP_SHIFT) - sx0 + 1;
+    h1 = ((miny + h - 1) >> SGR_SUP_SHIFT) - sy0 + 1;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_sup_count(int P, int sgx, int T1, int per_slice, const uint2* __restrict__ rects,
+                                                   uint32_t* __restrict__ hist1)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];
+    const int tid = threadIdx.x;
+    for (int t = tid; t < T1; t += 256) s_cnt[t] = 0u;
+    __syncthreads();
+    const int begin = blockIdx.x * per_slice;
+    const int end = min(P, begin + per_slice);
+    for (int s = begin + tid; s < end; s += 256) {
+        int sx0, sy0, w1, h1;
+        if (!sup_rect(rects[s], sx0, sy0, w1, h1)) continue;
+        for (int y = 0; y < h1; y++)
+            for (int x = 0; x < w1; x++) atomicAdd(&s_cnt[(sy0 + y) * sgx + sx0 + x], 1u);
+    }
+    __syncthreads();
+    uint32_t* row = hist1 + (size_t)blockIdx.x * T1;
+    for (int t = tid; t < T1; t += 256) row[t] = s_cnt[t];
+}
+
+// one 1024-thread workgroup: list starts, chunk table, totals
+__global__ void __launch_bounds__(1024) k_sup_scan(int T1, uint32_t cap1, uint32_t chunk_cap, const uint32_t* __restrict__ sup_count,
+                                                   uint32_t* __restrict__ sup_start, uint32_t* __restrict__ chunk_base,
+                                                   uint32_t* __restrict__ chunk_sup, uint32_t* __restrict__ hdr)
+{
+    __shared__ uint32_t s_a[1024], s_b[1024];
+    const int tid = threadIdx.x;
+    const int per = (T1 + 1023) / 1024;
+    const int b = tid * per, e = min(T1, b + per);
+    uint32_t sa = 0, sb = 0;
+    for (int i = b; i < e; i++) { const uint32_t c = sup_count[i]; sa += c; sb += (c + SGR_B2_CHUNK - 1) / SGR_B2_CHUNK; }
+    s_a[tid] = sa; s_b[tid] = sb;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t va = (tid >= o) ? s_a[tid - o] : 0, vb = (tid >= o) ? s_b[tid - o] : 0;
+        __syncthreads();
+        s_a[tid] += va; s_b[tid] += vb;
+        __syncthreads();
+    }
+    uint32_t ra = s_a[tid] - sa, rb = s_b[tid] - sb;
+    for (int i = b; i < e; i++) {
+        const uint32_t c = sup_count[i];
+        sup_start[i] = ra; chunk_base[i] = rb;
+        const uint32_t nc = (c + SGR_B2_CHUNK - 1) / SGR_B2_CHUNK;
+        for (uint32_t k = 0; k < nc && rb + k < chunk_cap; k++) chunk_sup[rb + k] = (uint32_t)i;  // chunk -> super-tile
+        ra += c; rb += nc;
+    }
+    if (tid == 1023) {
+        const uint32_t R1 = s_a[1023], nch = s_b[1023];
+        sup_start[T1] = R1; chunk_base[T1] = nch;
+        hdr[SGR_B2_HDR_R1] = R1;
+        hdr[SGR_B2_HDR_CHUNKS] = nch;
+        hdr[SGR_B2_HDR_OVERFLOW] = (R1 > cap1 || nch > chunk_cap) ? 1u : 0u;
+    }
+}
+
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m)  // set bits of m in lanes below this one
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Ordered append to the super-tile lists: ONE wave per slice walks its Gaussians in depth order, 64 per step with one
+// lane per Gaussian.  The (Gaussian, super-tile) pairs of a step are laid out in LDS ordered by Gaussian (a rectangle
+// touches one to four super-tiles unless the splat is wider than 128 px), then taken 64 at a time: pairs with the same
+// super-tile find each other with one ballot per key bit, the first of them reserves the group's slots with ONE returning
+// LDS atomic and every pair stores at base + its rank.  (A step with a splat over more than SGR_B2_MAXN super-tiles is
+// taken one Gaussian at a time.)  Equal keys inside a batch are ranked by pair index = depth order,
+// batches are sequential: a super-tile's list comes out in depth order.  The entry is the Gaussian's position in the
+// depth order (rects[] and order[] are indexed by it).
+__global__ void __launch_bounds__(64) k_sup_scatter(int P, int sgx, int T1, int key_bits, int per_slice,
+                                                    const uint2* __restrict__ rects, const uint32_t* __restrict__ sup_start,
+                                                    const uint32_t* __restrict__ hist1, const uint32_t* __restrict__ hdr,
+                                                    uint32_t* __restrict__ L1)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];  // [T1] running slots, then [64 * SGR_B2_MAXN] pairs
+    if (hdr[SGR_B2_HDR_OVERFLOW]) return;
+    uint32_t* s_pair = s_cnt + T1;
+    const int lane = threadIdx.x;
+    const uint32_t* row = hist1 + (size_t)blockIdx.x * T1;
+    for (int t = lane; t < T1; t += 64) s_cnt[t] = sup_start[t] + row[t];
+    WAVE_FENCE();
+    const int begin = blockIdx.x * per_slice;
+    const int end = min(P, begin + per_slice);
+    for (int base = begin; base < end; base += 64) {
+        const int s = base + lane;
+        int t0 = 0, w = 1, n = 0;
+        if (s < end) {
+            int sx0, sy0, w1, h1;
+            if (sup_rect(rects[s], sx0, sy0, w1, h1)) { w = w1; n = w1 * h1; t0 = sy0 * sgx + sx0; }
+        }
+        if (__ballot(n > SGR_B2_MAXN) == 0ull) {
+            // exclusive prefix of n over the lanes: the pairs of this step, ordered by Gaussian
+            int incl = n;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int y = __shfl_up(incl, d);
+                if (lane >= d) incl += y;
+            }
+            const uint32_t off = (uint32_t)(incl - n);
+            const int m = __builtin_amdgcn_readlane(incl, 63);
+            const float inv_w = 1.0f / (float)w;
+            for (int p = 0; p < n; p++) {
+                const int ty = (int)(((float)p + 0.5f) * inv_w);  // p / w, exact for these sizes
+                s_pair[off + p] = ((uint32_t)(t0 + ty * sgx + (p - ty * w)) << 8) | (uint32_t)lane;
+            }
+            WAVE_FENCE();
+            for (int q = 0; q < m; q += 64) {
+                const bool on = q + lane < m;
+                const uint32_t v = on ? s_pair[q + lane] : 0u;
+                const uint32_t key = v >> 8;
+                unsigned long long mm = __ballot(on);
+                for (int b = 0; b < key_bits; b++) {
+                    const unsigned long long bb = __ballot(on && ((key >> b) & 1u));
+                    mm &= ((key >> b) & 1u) ? bb : ~bb;
+                }
+                const uint32_t rank = lanes_below(mm);
+                uint32_t slot = 0;
+                if (on && rank == 0) slot = atomicAdd(&s_cnt[key], (uint32_t)__popcll(mm));
+                const int leader = on ? (int)__builtin_ctzll(mm) : lane;
+                slot = (uint32_t)__shfl((int)slot, leader);
+                if (on) L1[slot + rank] = (uint32_t)base + (v & 0xFFu);
+                asm volatile("" ::: "memory");  // keep the batches' atomics in program order (compiler only)
+            }
+            WAVE_FENCE();  // s_pair is rewritten by the next step
+        } else {
+            // a huge splat: strictly one Gaussian at a time for this step
+            unsigned long long todo = __ballot(n > 0);
+            while (todo) {
+                const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+                todo &= todo - 1;
+                const int jn = __builtin_amdgcn_readlane(n, j), jw = __builtin_amdgcn_readlane(w, j);
+                const int jt = __builtin_amdgcn_readlane(t0, j);
+                for (int k = lane; k < jn; k += 64) {
+                    const int ty = k / jw;
+                    const uint32_t sl = atomicAdd(&s_cnt[jt + ty * sgx + (k - ty * jw)], 1u);
+                    L1[sl] = (uint32_t)(base + j);
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+    }
+}
+
+// One wave per chunk of a super-tile list (<= 512 entries = 8 batches of one entry per lane).  A lane turns the rectangle
+// of its entry into the 64-bit mask of the super-tile's 8 x 8 tiles it covers (a dozen instructions for 64 entries).
+// Then, per tile t, one ballot of bit t per batch gives the entries that cover it, in list order:
+//   WRITE = false: the popcounts are the tile's count for this chunk (kept in lane t of one register);
+//   WRITE = true : the covering lanes drop their ids into an LDS row at (running count + number of covering lanes below),
+//                  i.e. the row is the tile's list segment of this chunk, and the wave then copies it out 64 ids per
+//                  store instruction -- contiguous, coalesced, no atomics.  (One global store per (batch, tile) with ten
+//                  active lanes kept the CU's address unit busy for 24 cycles each: 4x the instructions.)
+__device__ __forceinline__ void tile_mask(uint2 r, int ox, int oy, uint32_t& lo, uint32_t& hi)
+{
+    const int minx = (int)(r.x & 0xFFFFu), miny = (int)(r.x >> 16);
+    const int x0 = max(minx - ox, 0), x1 = min(minx + (int)(r.y & 0xFFFFu) - ox, SGR_SUP);
+    const int y0 = max(miny - oy, 0), y1 = min(miny + (int)(r.y >> 16) - oy, SGR_SUP);
+    const uint32_t xb = ((1u << (x1 - x0)) - 1u) << x0;  // columns, 8 bits
+    const uint32_t yb = ((1u << (y1 - y0)) - 1u) << y0;  // rows, 8 bits
+    const uint32_t rows4 = xb * 0x01010101u;             // the column pattern in four rows
+    // row bit r -> byte r all ones: spread the four bits to the byte lsbs, then * 0xFF
+    lo = rows4 & ((((yb & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu);
+    hi = rows4 & ((((yb >> 4) * 0x00204081u) & 0x01010101u) * 0xFFu);
+}
+
+#define SGR_B2_BATCHES (SGR_B2_CHUNK / 64)
+
+template <bool WRITE>
+__global__ void __launch_bounds__(64) k_tile_pass(int gx, int gy, int sgx, int T1, const uint32_t* __restrict__ sup_start,
+                                                  const uint32_t* __restrict__ chunk_base, const uint32_t* __restrict__ chunk_sup,
+                                                  const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ L1,
+                                                  const uint2* __restrict__ rects,
+                                                  const uint32_t* __restrict__ order, uint32_t* __restrict__ cnt2,
+                                                  const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ point_list)
+{
+    __shared__ uint32_t s_row[WRITE ? SGR_B2_CHUNK : 1];
+    if (hdr[SGR_B2_HDR_OVERFLOW]) return;
+    const int lane = threadIdx.x;
+    const int n_chunks = (int)hdr[SGR_B2_HDR_CHUNKS];
+    for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const int sup = (int)chunk_sup[c];
+        const uint32_t e0 = sup_start[sup] + (uint32_t)(c - (int)chunk_base[sup]) * SGR_B2_CHUNK;
+        const int n = (int)min((uint32_t)SGR_B2_CHUNK, sup_start[sup + 1] - e0);
+        const int ox = (sup % sgx) * SGR_SUP, oy = (sup / sgx) * SGR_SUP;
+        if (!WRITE) {
+            uint32_t run = 0;  // lane t: entries of this chunk covering tile t
+            for (int b = 0; b < n; b += 64) {
+                uint32_t lo = 0u, hi = 0u;
+                if (b + lane < n) tile_mask(rects[L1[e0 + b + lane]], ox, oy, lo, hi);
+                uint32_t add = 0;
+#pragma unroll
+                for (int t = 0; t < 32; t++) {
+                    const unsigned long long M = __ballot((lo & (1u << t)) != 0u);
+                    add = (lane == t) ? (uint32_t)__popcll(M) : add;
+                }
+#pragma unroll
+                for (int t = 0; t < 32; t++) {
+                    const unsigned long long M = __ballot((hi & (1u << t)) != 0u);
+                    add = (lane == t + 32) ? (uint32_t)__popcll(M) : add;
+                }
+                run += add;
+            }
+            cnt2[(size_t)c * 64 + lane] = run;
+        } else {
+            uint32_t lo[SGR_B2_BATCHES], hi[SGR_B2_BATCHES], id[SGR_B2_BATCHES];
+#pragma unroll
+            for (int b = 0; b < SGR_B2_BATCHES; b++) {
+                lo[b] = 0u; hi[b] = 0u; id[b] = 0u;
+                if (b * 64 + lane < n) {
+                    const uint32_t i = L1[e0 + b * 64 + lane];
+                    tile_mask(rects[i], ox, oy, lo[b], hi[b]);
+                    id[b] = order[i];
+                }
+            }
+            // lane t: first slot of tile t's segment for this chunk
+            uint32_t base = 0;
+            {
+                const int tx = ox + (lane & (SGR_SUP - 1)), ty = oy + (lane >> SGR_SUP_SHIFT);
+                if (tx < gx && ty < gy) base = tile_start[ty * gx + tx] + cnt2[(size_t)c * 64 + lane];
+            }
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                for (int t = 0; t < 32; t++) {
+                    const uint32_t sel = 1u << t;
+                    uint32_t cnt = 0;  // wave-uniform
+#pragma unroll
+                    for (int b = 0; b < SGR_B2_BATCHES; b++) {
+                        const bool bit = ((half ? hi[b] : lo[b]) & sel) != 0u;
+                        const unsigned long long M = __ballot(bit);
+                        if (bit) s_row[cnt + lanes_below(M)] = id[b];
+                        cnt += (uint32_t)__popcll(M);
+                    }
+                    if (cnt) {
+                        // the LDS pipeline of a wave is in order: the row's writes land before these reads, and the reads
+                        // before the next tile's writes; only the compiler has to keep that order (a fence would drain
+                        // the stores)
+                        LDS_ORDER();
+                        const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)base, t + 32 * half);
+                        for (uint32_t j = lane; j < cnt; j += 64) point_list[dst + j] = s_row[j];
+                        LDS_ORDER();
+                    }
+                }
+            }
+        }
+    }
+}
+
+// per super-tile: exclusive scan of cnt2 over its chunks (lane = tile), totals to tile_count
+__global__ void __launch_bounds__(64) k_tile_scan2(int gx, int gy, int sgx, const uint32_t* __restrict__ chunk_base,
+                                                   const uint32_t* __restrict__ hdr, uint32_t* __restrict__ cnt2,
+                                                   uint32_t* __restrict__ tile_count)
+{
+    if (hdr[SGR_B2_HDR_OVERFLOW]) return;
+    const int sup = blockIdx.x, lane = threadIdx.x;
+    const int c0 = (int)chunk_base[sup], c1 = (int)chunk_base[sup + 1];
+    constexpr int UNROLL = 8;
+    uint32_t run = 0;
+    int c = c0;
+    for (; c + UNROLL <= c1; c += UNROLL) {
+        uint32_t v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) v[u] = cnt2[(size_t)(c + u) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) { cnt2[(size_t)(c + u) * 64 + lane] = run; run += v[u]; }
+    }
+    for (; c < c1; c++) { const uint32_t v = cnt2[(size_t)c * 64 + lane]; cnt2[(size_t)c * 64 + lane] = run; run += v; }
+    const int tx = (sup % sgx) * SGR_SUP + (lane & (SGR_SUP - 1));
+    const int ty = (sup / sgx) * SGR_SUP + (lane >> SGR_SUP_SHIFT);
+    if (tx < gx && ty < gy) tile_count[ty * gx + tx] = run;
+}
+
+// exclusive scan over the slices of hist1[slice][t] for one bin t per workgroup (the bins are few, the slices many:
+// binning.hip's lane-per-bin column walk would leave the chip idle)
+__global__ void __launch_bounds__(256) k_sup_hist_scan(int T1, int n_slices, uint32_t* __restrict__ hist1,
+                                                       uint32_t* __restrict__ sup_count)
+{
+    __shared__ uint32_t s_part[256];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int per = (n_slices + 255) / 256;
+    const int b = tid * per, e = min(n_slices, b + per);
+    uint32_t sum = 0;
+    for (int i = b; i < e; i++) sum += hist1[(size_t)i * T1 + t];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const uint32_t v = (tid >= o) ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - sum;
+    for (int i = b; i < e; i++) { const uint32_t v = hist1[(size_t)i * T1 + t]; hist1[(size_t)i * T1 + t] = run; run += v; }
+    if (tid == 255) sup_count[t] = s_part[255];
+}
+
+void set_lds_limit(const void* fn, size_t bytes, size_t& configured)
+{
+    if (bytes > 48 * 1024 && bytes > configured) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        configured = bytes;
+    }
+}
+
+}  // namespace
+
+Bin2Layout sgr_bin2_layout(int P, int gx, int gy)
+{
+    Bin2Layout L;
+    L.sgx = (gx + SGR_SUP - 1) / SGR_SUP;
+    L.sgy = (gy + SGR_SUP - 1) / SGR_SUP;
+    L.T1 = L.sgx * L.sgy;
+    const size_t cap = (size_t)(P > 0 ? P : 1) * 4 + 65536;  // level-1 entries: ~2 per Gaussian in practice
+    L.cap1 = cap > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)cap;
+    L.chunk_cap = L.cap1 / SGR_B2_CHUNK + (uint32_t)L.T1 + 1;
+    L.per_slice = (((P + SGR_B2_SLICES - 1) / SGR_B2_SLICES + 63) / 64) * 64;
+    if (L.per_slice < 64) L.per_slice = 64;
+    size_t off = 0;
+    L.hist1 = off;      off = sgr_align(off + (size_t)SGR_B2_SLICES * L.T1 * 4);
+    L.sup_count = off;  off = sgr_align(off + (size_t)L.T1 * 4);
+    L.sup_start = off;  off = sgr_align(off + (size_t)(L.T1 + 1) * 4);
+    L.chunk_base = off; off = sgr_align(off + (size_t)(L.T1 + 1) * 4);
+    L.hdr = off;        off = sgr_align(off + 64);
+    L.L1 = off;         off = sgr_align(off + (size_t)L.cap1 * 4);
+    L.cnt2 = off;       off = sgr_align(off + (size_t)L.chunk_cap * 64 * 4);
+    L.chunk_sup = off;  off = sgr_align(off + (size_t)L.chunk_cap * 4);
+    L.total = off;
+    return L;
+}
+
+// level 1 + the counting half of level 2: leaves tile_count[T] (consumed by sgr_launch_tile_scan) and the header
+void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scratch, const uint2* rects, uint32_t* tile_count,
+                           hipStream_t s)
+{
+    uint32_t* hist1 = reinterpret_cast<uint32_t*>(scratch + L.hist1);
+    uint32_t* sup_count = reinterpret_cast<uint32_t*>(scratch + L.sup_count);
+    uint32_t* sup_start = reinterpret_cast<uint32_t*>(scratch + L.sup_start);
+    uint32_t* chunk_base = reinterpret_cast<uint32_t*>(scratch + L.chunk_base);
+    uint32_t* hdr = reinterpret_cast<uint32_t*>(scratch + L.hdr);
+    uint32_t* L1 = reinterpret_cast<uint32_t*>(scratch + L.L1);
+    uint32_t* cnt2 = reinterpret_cast<uint32_t*>(scratch + L.cnt2);
+    uint32_t* chunk_sup = reinterpret_cast<uint32_t*>(scratch + L.chunk_sup);
+    static size_t conf_a = 0, conf_b = 0;
+    const size_t lds = (size_t)L.T1 * 4, lds_sc = lds + 64 * SGR_B2_MAXN * 4;
+    int key_bits = 1;
+    while ((1 << key_bits) < L.T1) key_bits++;
+    set_lds_limit(reinterpret_cast<const void*>(&k_sup_count), lds, conf_a);
+    set_lds_limit(reinterpret_cast<const void*>(&k_sup_scatter), lds_sc, conf_b);
+    hipLaunchKernelGGL(k_sup_count, dim3(SGR_B2_SLICES), dim3(256), lds, s, P, L.sgx, L.T1, L.per_slice, rects, hist1);
+    hipLaunchKernelGGL(k_sup_hist_scan, dim3(L.T1), dim3(256), 0, s, L.T1, SGR_B2_SLICES, hist1, sup_count);
+    hipLaunchKernelGGL(k_sup_scan, dim3(1), dim3(1024), 0, s, L.T1, L.cap1, L.chunk_cap, sup_count, sup_start, chunk_base,
+                       chunk_sup, hdr);
+    hipLaunchKernelGGL(k_sup_scatter, dim3(SGR_B2_SLICES), dim3(64), lds_sc, s, P, L.sgx, L.T1, key_bits, L.per_slice, rects,
+                       sup_start, hist1, hdr, L1);
+    const uint32_t grid = L.chunk_cap < 8192u ? L.chunk_cap : 8192u;  // the chunk count lives on the device: grid-stride
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_pass<false>), dim3(grid), dim3(64), 0, s, gx, gy, L.sgx, L.T1, sup_start, chunk_base,
+                       chunk_sup, hdr, L1, rects, (const uint32_t*)nullptr, cnt2, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_tile_scan2, dim3(L.T1), dim3(64), 0, s, gx, gy, L.sgx, chunk_base, hdr, cnt2, tile_count);
+}
+
+void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, uint32_t n_chunks, const uint2* rects,
+                           const uint32_t* order, const uint32_t* tile_start, uint32_t* point_list, hipStream_t s)
+{
+    if (n_chunks == 0) return;
+    const uint32_t* sup_start = reinterpret_cast<const uint32_t*>(scratch + L.sup_start);
+    const uint32_t* chunk_base = reinterpret_cast<const uint32_t*>(scratch + L.chunk_base);
+    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(scratch + L.hdr);
+    const uint32_t* L1 = reinterpret_cast<const uint32_t*>(scratch + L.L1);
+    uint32_t* cnt2 = reinterpret_cast<uint32_t*>(scratch + L.cnt2);
+    const uint32_t* chunk_sup = reinterpret_cast<const uint32_t*>(scratch + L.chunk_sup);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_pass<true>), dim3(n_chunks), dim3(64), 0, s, gx, gy, L.sgx, L.T1, sup_start,
+                       chunk_base, chunk_sup, hdr, L1, rects, order, cnt2, tile_start, point_list);
+}

@@ -85,9 +85,21 @@ struct StageTimer {
 
 }  // namespace
 
+static int g_binning_mode = 0;   // 0: two-level binning (binning2.hip) with automatic fallback, 1: single-level (binning.hip)
+static int g_last_binning = 0;   // which path the last forward took
+
 extern "C" {
 
 int sgr_abi_version(void) { return SGR_ABI_VERSION; }
+
+int sgr_set_binning_mode(int mode)
+{
+    const int old = g_binning_mode;
+    if (mode == 0 || mode == 1) g_binning_mode = mode;
+    return old;
+}
+
+int sgr_last_binning_mode(void) { return g_last_binning; }
 const char* sgr_last_error(void) { return g_err.c_str(); }
 
 size_t sgr_geom_bytes(int P) { return sgr_geom_total(P); }
@@ -152,8 +164,9 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     const ImgLayout IL = sgr_img_layout(width, height);
     if ((size_t)IL.T * 4 > 150 * 1024 || IL.gx > 65535 || IL.gy > 65535)
         return fail(SGR_E_INVALID, "image too large: one counter per tile must fit in 150 KB of LDS (about 38 000 tiles)");
+    const Bin2Layout B2 = sgr_bin2_layout(P, IL.gx, IL.gy);
     char* geom = geom_alloc(geom_user, sgr_geom_bytes(P));
-    char* img = img_alloc(img_user, IL.total);
+    char* img = img_alloc(img_user, IL.total + B2.total);  // [ image state | two-level binning scratch ]
     if (!geom || !img) return fail(SGR_E_ALLOC, "geometry/image scratch allocation failed");
 
     GeomRec* rec = reinterpret_cast<GeomRec*>(geom);
@@ -187,19 +200,36 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     { StageTimer t(s, SGR_STAGE_SORT); sgr_launch_gaussian_sort(P, sort_scratch, &order, s); }
     STAGE_CHECK("gaussian_sort");
 
+    char* bin2 = img + IL.total;
+    bool two_level = g_binning_mode == 0;
     {
         StageTimer t(s, SGR_STAGE_SCAN);
         sgr_launch_pack_rects(P, IL.gx, IL.gy, order, rec, rects, s);
-        sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, blk_hist, s);
-        sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
+        if (two_level) {
+            sgr_launch_bin2_count(P, IL.gx, IL.gy, B2, bin2, rects, tile_cursor, s);
+        } else {
+            sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, blk_hist, s);
+            sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
+        }
         sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, s);
     }
     STAGE_CHECK("bin_count");
 
     if (!g_pinned.p) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_pinned.p), 64, hipHostMallocDefault));
     HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 16, hipMemcpyDeviceToHost, s));
+    if (two_level) HIP_TRY(hipMemcpyAsync(g_pinned.p + 4, bin2 + B2.hdr, 16, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));  // the one host round trip of the forward (rasterizer_impl.cu:280-281)
+    if (two_level && g_pinned.p[4 + SGR_B2_HDR_OVERFLOW]) {
+        // more (Gaussian, super-tile) pairs than the level-1 list holds (huge splats): the single-level path has no such limit
+        two_level = false;
+        sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, blk_hist, s);
+        sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
+        sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, s);
+        HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     const int64_t R = (int64_t)g_pinned.p[SGR_HDR_R];
+    g_last_binning = two_level ? 0 : 1;
 
     const BinLayout BL = sgr_bin_layout(R);
     char* binning = binning_alloc(binning_user, BL.total);
@@ -208,7 +238,10 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
 
     if (R > 0) {
         StageTimer t(s, SGR_STAGE_SCATTER);
-        sgr_launch_bin_scatter(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, tile_start, blk_hist, point_list, s);
+        if (two_level)
+            sgr_launch_bin2_write(IL.gx, IL.gy, B2, bin2, g_pinned.p[4 + SGR_B2_HDR_CHUNKS], rects, order, tile_start, point_list, s);
+        else
+            sgr_launch_bin_scatter(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, tile_start, blk_hist, point_list, s);
     }
     STAGE_CHECK("bin_scatter");
     {

@@ -57,6 +57,25 @@ static inline ImgLayout sgr_img_layout(int W, int H)
     L.total = off;
     return L;
 }
+// two-level binning (binning2.hip): scratch appended to the img allocation
+#define SGR_SUP 8                // tiles per super-tile edge
+#define SGR_SUP_SHIFT 3
+#define SGR_B2_SLICES 2048       // slices of the depth order in the level-1 ordered scatter
+#define SGR_B2_CHUNK 512         // level-1 list entries per level-2 wave
+#define SGR_B2_HDR_R1 0          // level-1 entries (Gaussian x super-tile)
+#define SGR_B2_HDR_CHUNKS 1      // level-2 chunks
+#define SGR_B2_HDR_OVERFLOW 2    // 1: the level-1 list does not fit its capacity -> the caller falls back to binning.hip
+struct Bin2Layout {
+    size_t hist1, sup_count, sup_start, chunk_base, hdr, L1, cnt2, chunk_sup, total;
+    int sgx, sgy, T1, per_slice;
+    uint32_t cap1, chunk_cap;
+};
+Bin2Layout sgr_bin2_layout(int P, int gx, int gy);
+void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scratch, const uint2* rects, uint32_t* tile_count,
+                           hipStream_t s);
+void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, uint32_t n_chunks, const uint2* rects,
+                           const uint32_t* order, const uint32_t* tile_start, uint32_t* point_list, hipStream_t s);
+
 struct BinLayout { size_t point_list, total; };
 static inline BinLayout sgr_bin_layout(int64_t R)
 {

@@ -243,3 +243,46 @@ def test_grid_knn_is_identical_to_exhaustive(dist):
     b = knn_points(q[None], p[None], K=8, method="grid")
     assert torch.equal(a.dists, b.dists) and torch.equal(a.idx, b.idx)
     assert torch.equal(distCUDA2(p, method="brute"), distCUDA2(p, method="grid"))
+
+
+def _lists(scene, cam, bg):
+    from sugar_amd import _lib
+    h = pu.run_hip(scene, cam, bg)
+    return h, _lib.load().sgr_last_binning_mode()
+
+
+def test_two_level_and_single_level_binning_give_identical_lists():
+    """binning2.hip (super-tiles, then tiles) against binning.hip (single-level ordered scatter): same ranges, same lists,
+    same image -- at a size where every level-2 code path runs (several chunks per super-tile, partial border super-tiles)."""
+    from sugar_amd import _lib
+    lib = _lib.load()
+    scene = syn.make_scene(120000, 21, 0.004, 0.05)
+    cam = syn.orbit_cameras(1000, 600)[3]   # 63 x 38 tiles: the last super-tile column / row are partial
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    old = lib.sgr_set_binning_mode(0)
+    try:
+        a, mode_a = _lists(scene, cam, bg)
+        lib.sgr_set_binning_mode(1)
+        b, mode_b = _lists(scene, cam, bg)
+    finally:
+        lib.sgr_set_binning_mode(old)
+    assert (mode_a, mode_b) == (0, 1)
+    assert a["num_rendered"] == b["num_rendered"] and a["num_rendered"] > 1_000_000
+    assert np.array_equal(a["tile_start"], b["tile_start"])
+    assert np.array_equal(a["point_list"], b["point_list"])
+    assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["n_contrib"], b["n_contrib"])
+
+
+def test_level1_overflow_falls_back_to_single_level_binning():
+    """a few huge splats on a 4K grid touch more (Gaussian, super-tile) pairs than the level-1 list holds: the forward must
+    notice, take the single-level path and still match the oracle bit for bit"""
+    scene = syn.make_scene(3000, 22, 0.4, 0.9)
+    cam = syn.orbit_cameras(3840, 2160)[0]
+    bg = torch.zeros(3)
+    h, mode = _lists(scene, cam, bg)
+    assert mode == 1
+    o = pu.run_oracle(scene, cam, bg)
+    assert np.array_equal(h["radii"], o["radii"])
+    assert h["num_rendered"] == o["num_rendered"]
+    assert np.array_equal(np.diff(h["tile_start"]), o["ranges"][:, 1] - o["ranges"][:, 0])
+    assert np.array_equal(h["point_list"], o["point_list"])
