@@ -1,0 +1,78 @@
+"""On-disk formats (sugar_amd/io.py): the 3DGS PLY and cameras.json.  The camera matrices are pinned against golden values
+produced by the reference's own loader (tests/golden/make_cameras_golden.py: camera_to_JSON -> load_gs_cameras -> GSCamera);
+the PLY layout is restated from gaussian_model.py:177-256 (the reference needs `plyfile`, absent here: PARITY UNPINNED for
+the byte layout beyond the header/ordering rules asserted below)."""
+import json
+import math
+import os
+
+import numpy as np
+import torch
+
+from sugar_amd import io as sio
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "cameras_golden.npz"))
+
+
+def test_cameras_json_matches_the_reference_loader(tmp_path):
+    p = tmp_path / "cameras.json"
+    p.write_bytes(GOLD["json"].tobytes())
+    cams, names = sio.cameras_from_json(str(p))
+    assert names == list(GOLD["names"])  # sorted by image name
+    assert len(cams) == 6
+    for i, c in enumerate(cams):
+        assert (c.image_height, c.image_width) == tuple(GOLD["sizes"][i])
+        assert abs(c.tanfovx - math.tan(GOLD["fov"][i, 0] / 2)) < 1e-12 and abs(c.tanfovy - math.tan(GOLD["fov"][i, 1] / 2)) < 1e-12
+        assert torch.equal(c.viewmatrix, torch.tensor(GOLD["world_view"][i]))
+        assert torch.equal(c.projmatrix, torch.tensor(GOLD["full_proj"][i]))
+        assert torch.equal(c.campos, torch.tensor(GOLD["center"][i]))
+    # images larger than max_img_size were scaled down; the others were not
+    assert max(cams[0].image_width, cams[1].image_width) <= 1920 and {c.image_width for c in cams} == {1600, 1920}
+
+
+def test_camera_json_round_trip(tmp_path):
+    rng = np.random.default_rng(0)
+    q = rng.standard_normal(4); q /= np.linalg.norm(q)
+    r, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)],
+                  [2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)],
+                  [2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]])
+    T = rng.standard_normal(3)
+    e = sio.camera_to_json(3, "a", R, T, 1.0, 0.7, 640, 480)
+    p = tmp_path / "c.json"
+    p.write_text(json.dumps([e, dict(e, id=4), dict(e, img_name="0")]))
+    cams, names = sio.cameras_from_json(str(p))
+    assert names == ["0", "a"]  # the duplicate name keeps one camera
+    direct = sio.camera_from_RT(R, T, 1.0, 0.7, 640, 480)
+    assert torch.allclose(cams[1].viewmatrix, direct.viewmatrix, atol=1e-6) and torch.allclose(cams[1].projmatrix, direct.projmatrix, atol=1e-5)
+    # row-vector convention: a world point maps with p @ viewmatrix, and the camera centre maps to the origin
+    assert torch.allclose(torch.cat([direct.campos, torch.ones(1)]) @ direct.viewmatrix, torch.tensor([0.0, 0, 0, 1]), atol=1e-5)
+
+
+def test_gaussian_ply_round_trip_and_layout(tmp_path):
+    g = torch.Generator().manual_seed(0)
+    P, M = 257, 16
+    t = dict(xyz=torch.randn(P, 3, generator=g), features=torch.randn(P, M, 3, generator=g), opacity=torch.randn(P, 1, generator=g),
+             scaling=torch.randn(P, 3, generator=g), rotation=torch.randn(P, 4, generator=g))
+    path = str(tmp_path / "sub" / "point_cloud.ply")
+    sio.save_gaussian_ply(path, **t)
+    raw = open(path, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    lines = head.decode().splitlines()
+    assert lines[:3] == ["ply", "format binary_little_endian 1.0", f"element vertex {P}"]
+    props = [l.split()[2] for l in lines[3:]]
+    assert all(l.startswith("property float ") for l in lines[3:])
+    assert props == sio.gaussian_ply_attributes(M) and len(props) == 62     # 3+3+3+45+1+3+4 (gaussian_model.py:177-189)
+    rows = np.frombuffer(body, dtype="<f4").reshape(P, 62)
+    assert np.array_equal(rows[:, 0:3], t["xyz"].numpy()) and not rows[:, 3:6].any()       # normals are zeros
+    # f_rest is channel-major: f_rest_k = coefficient 1 + k % 15 of channel k // 15 (transpose(1, 2).flatten(1))
+    assert np.array_equal(rows[:, 9 + 0], t["features"][:, 1, 0].numpy())
+    assert np.array_equal(rows[:, 9 + 14], t["features"][:, 15, 0].numpy())
+    assert np.array_equal(rows[:, 9 + 15], t["features"][:, 1, 1].numpy())
+    assert np.array_equal(rows[:, 6:9], t["features"][:, 0, :].numpy())
+    back = sio.load_gaussian_ply(path)
+    for k in t:
+        assert back[k].dtype == torch.float32 and torch.equal(back[k], t[k]), k
+    # lower SH degree and reordered / extra properties are handled by name
+    sio.save_gaussian_ply(str(tmp_path / "d1.ply"), t["xyz"], t["features"][:, :4], t["opacity"], t["scaling"], t["rotation"])
+    assert sio.load_gaussian_ply(str(tmp_path / "d1.ply"))["features"].shape == (P, 4, 3)
