@@ -39,6 +39,12 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------------
 // Global stable radix sort of (u32 key, u32 value) pairs, 8 bits per pass.
 // ---------------------------------------------------------------------------------------------------------------------
+#define LDS_ORDER()                          \
+    do {                                     \
+        asm volatile("" ::: "memory");       \
+        __builtin_amdgcn_wave_barrier();     \
+    } while (0)
+
 #define RS_ITEMS 1024  // keys per workgroup chunk (one wave scatters a chunk: 16 keys per lane held in registers)
 
 // per-chunk digit histogram, written digit-major: hist[digit * n_chunks + chunk]
@@ -87,7 +93,8 @@ __global__ void __launch_bounds__(256) k_rs_scan_rows(int n_chunks, uint32_t* __
 __global__ void __launch_bounds__(64) k_rs_scatter(int n, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int shift,
                                                    int n_chunks, const uint32_t* __restrict__ hist,
-                                                   const uint32_t* __restrict__ totals)
+                                                   const uint32_t* __restrict__ totals, const uint2* __restrict__ aux_by_val,
+                                                   uint2* __restrict__ aux_out)
 {
     __shared__ uint32_t s_off[256];
     const int lane = threadIdx.x;
@@ -143,6 +150,7 @@ __global__ void __launch_bounds__(64) k_rs_scatter(int n, const uint32_t* __rest
             const uint32_t dst = off + rank;
             keys_out[dst] = key;
             vals_out[dst] = val;
+            if (aux_out) aux_out[dst] = aux_by_val[val];  // last pass: the tile rectangles in sorted order
             if (rank == 0) s_off[digit] = off + cnt;
         }
         WAVE_FENCE();
@@ -344,7 +352,13 @@ size_t sgr_sort_scratch_bytes(int P)
 {
     const size_t n = (size_t)(P > 0 ? P : 1);
     const size_t chunks = (n + RS_ITEMS - 1) / RS_ITEMS;
-    return sgr_align(n * 4) * 4 + sgr_align(chunks * 256 * 4) + 1024 + sgr_align(n * 8);  // + packed rectangles
+    return sgr_align(n * 4) * 4 + sgr_align(chunks * 256 * 4) + 1024 + 2 * sgr_align(n * 8);  // + packed rectangles (sorted, by id)
+}
+
+size_t sgr_sort_rect_by_id_offset(int P)
+{
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    return sgr_sort_rects_offset(P) + sgr_align(n * 8);
 }
 
 size_t sgr_sort_rects_offset(int P)
@@ -356,7 +370,8 @@ size_t sgr_sort_rects_offset(int P)
 
 // keys_a (the first array of sort_scratch) must hold the keys, written by the preprocess kernel; on return *order_out
 // points at the sorted Gaussian ids (inside sort_scratch).
-void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_out, hipStream_t s)
+void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_out, const uint2* rect_by_id, uint2* rects_sorted,
+                              hipStream_t s)
 {
     const size_t n = (size_t)P;
     const size_t arr = sgr_align(n * 4);
@@ -374,7 +389,8 @@ void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_
         const int shift = 8 * pass;
         hipLaunchKernelGGL(k_rs_hist, dim3(chunks), dim3(256), 0, s, P, kin, shift, chunks, hist);
         hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(256), 0, s, chunks, hist, totals);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(chunks), dim3(64), 0, s, P, kin, vin, kout, vout, shift, chunks, hist, totals);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(chunks), dim3(64), 0, s, P, kin, vin, kout, vout, shift, chunks, hist, totals,
+                           rect_by_id, pass == 3 ? rects_sorted : (uint2*)nullptr);
         kin = kout; vin = vout;
     }
     *order_out = vals_a;  // pass 0 -> b, 1 -> a, 2 -> b, 3 -> a

@@ -193,18 +193,18 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     pa.focal_x = width / (2.0f * tan_fovx);
     pa.gx = IL.gx; pa.gy = IL.gy;
     pa.radii = radii; pa.rec = rec; pa.sort_keys = reinterpret_cast<uint32_t*>(sort_scratch);
+    pa.rect_by_id = reinterpret_cast<uint2*>(sort_scratch + sgr_sort_rect_by_id_offset(P));
     { StageTimer t(s, SGR_STAGE_PREPROCESS); sgr_launch_preprocess_fwd(pa, s); }
     STAGE_CHECK("preprocess");
 
     const uint32_t* order = nullptr;
-    { StageTimer t(s, SGR_STAGE_SORT); sgr_launch_gaussian_sort(P, sort_scratch, &order, s); }
+    { StageTimer t(s, SGR_STAGE_SORT); sgr_launch_gaussian_sort(P, sort_scratch, &order, pa.rect_by_id, rects, s); }
     STAGE_CHECK("gaussian_sort");
 
     char* bin2 = img + IL.total;
     bool two_level = g_binning_mode == 0;
     {
         StageTimer t(s, SGR_STAGE_SCAN);
-        sgr_launch_pack_rects(P, IL.gx, IL.gy, order, rec, rects, s);
         if (two_level) {
             sgr_launch_bin2_count(P, IL.gx, IL.gy, B2, bin2, rects, tile_cursor, s);
         } else {

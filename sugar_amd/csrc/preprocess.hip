@@ -311,6 +311,13 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreprocessArgs a)
     if (idx >= a.P) return;
     int minx, miny, maxx, maxy;
     preprocess_one(a, idx, minx, miny, maxx, maxy);
+    // tile rectangle {minx | miny << 16, w | h << 16} (w == 0: culled); the last depth-sort pass carries it along
+    uint2 r = make_uint2(0u, 0u);
+    if (maxx > minx && maxy > miny) {
+        r.x = (uint32_t)minx | ((uint32_t)miny << 16);
+        r.y = (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16);
+    }
+    a.rect_by_id[idx] = r;
 }
 
 // ---------------------------------------------------------------------------------------------

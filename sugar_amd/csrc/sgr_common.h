@@ -105,6 +105,7 @@ struct PreprocessArgs {
     int gx, gy;
     int* radii; GeomRec* rec;
     uint32_t* sort_keys;  // [P] depth bits of visible Gaussians, 0xFFFFFFFF for culled ones (input of the depth sort)
+    uint2* rect_by_id;    // [P] packed tile rectangle of every Gaussian (w == 0: culled)
 };
 void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 void sgr_launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
@@ -123,7 +124,9 @@ void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
 void sgr_launch_sh_grad_from_views(int P, int V, int D, int M, const float* means3D, const float* campos, const float* dcolor,
                                    float* dL_dsh, hipStream_t s);
 
-void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_out, hipStream_t s);
+void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_out, const uint2* rect_by_id, uint2* rects_sorted,
+                              hipStream_t s);
+size_t sgr_sort_rect_by_id_offset(int P);  // binning.hip: the by-id rectangles written by the preprocess kernel
 void sgr_launch_pack_rects(int P, int gx, int gy, const uint32_t* order, const GeomRec* rec, uint2* rects, hipStream_t s);
 void sgr_launch_bin_count(int P, int gx, int gy, int n_slices, int per_slice, const uint32_t* order, const uint2* rects,
                           uint32_t* blk_hist, hipStream_t s);
