@@ -89,6 +89,14 @@ int sgr_backward(int P, int D, int M, int64_t R,
 int sgr_sh_grad_from_views(int P, int n_views, int D, int M, const float* means3D, const float* campos_all,
                            const float* dcolor_all, float* dL_dsh, void* stream);
 
+/* The same sum consumed on the spot: one Adam step (the update of sgr_adam_step, learning rate lr_dc for the three DC
+ * values of a Gaussian and lr_rest for the others, gaussian_model.py:157-158) on sh_params[P*M*3] with its moment buffers;
+ * the 48-float SH gradient is never written to memory.  means3D must be the values the views were rendered with (call
+ * this before the positions are updated). */
+int sgr_sh_adam_from_views(int P, int n_views, int D, int M, const float* means3D, const float* campos_all,
+                           const float* dcolor_all, float* sh_params, float* exp_avg, float* exp_avg_sq, float lr_dc,
+                           float lr_rest, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+
 /* Rasterizer::markVisible, DGR/cuda_rasterizer/rasterizer.h:24-29 / rasterizer_impl.cu:141-153.
  * present[P] is one byte per Gaussian (bool). */
 int sgr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -321,4 +321,21 @@ int sgr_sh_grad_from_views(int P, int n_views, int D, int M, const float* means3
     return 0;
 }
 
+int sgr_sh_adam_from_views(int P, int n_views, int D, int M, const float* means3D, const float* campos_all,
+                           const float* dcolor_all, float* sh_params, float* exp_avg, float* exp_avg_sq, float lr_dc,
+                           float lr_rest, float beta1, float beta2, float eps, int step, float grad_scale, void* stream)
+{
+    if (P <= 0) return 0;
+    if (n_views <= 0 || D < 0 || D > 3 || M < (D + 1) * (D + 1) || M > 16 || step < 1 || !means3D || !campos_all || !dcolor_all ||
+        !sh_params || !exp_avg || !exp_avg_sq)
+        return fail(SGR_E_INVALID, "sgr_sh_adam_from_views: bad argument");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    sgr_launch_sh_adam_from_views(P, n_views, D, M, means3D, campos_all, dcolor_all, sh_params, exp_avg, exp_avg_sq, lr_dc, lr_rest,
+                                  beta1, beta2, eps, bc1, bc2_sqrt, grad_scale, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SGR_E_HIP, std::string("sh_adam_from_views: ") + hipGetErrorString(e));
+    return 0;
+}
+
 }  // extern "C"

@@ -518,15 +518,12 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
 // dL/dsh[k][c] = sum over views v of  basis_k(dir_v) * g_v[c]   with dir_v = normalize(mean - campos_v) and g_v the
 // clamp-masked dL/dRGB of view v -- exactly the per-view SH backward (backward.cu:47-97) summed over views, but the views
 // exchange 3 floats per Gaussian instead of 3*M.  dirs use the same arithmetic as the forward (glm::length, division).
-__global__ void __launch_bounds__(256) k_sh_grad_from_views(int P, int V, int D, int M, const float* __restrict__ means3D,
-                                                            const float* __restrict__ campos, const float* __restrict__ dcolor,
-                                                            float* __restrict__ dL_dsh)
+__device__ __forceinline__ void sh_grad_sum_over_views(int idx, int P, int V, int D, const float* __restrict__ means3D,
+                                                       const float* __restrict__ campos, const float* __restrict__ dcolor,
+                                                       float* acc)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
     const size_t i3 = 3 * (size_t)idx;
     const float mx = means3D[i3], my = means3D[i3 + 1], mz = means3D[i3 + 2];
-    float acc[48];
 #pragma unroll
     for (int k = 0; k < 48; k++) acc[k] = 0.f;
     for (int v = 0; v < V; v++) {
@@ -558,6 +555,16 @@ __global__ void __launch_bounds__(256) k_sh_grad_from_views(int P, int V, int D,
             if (k < nb) { acc[3 * k] += b[k] * g0; acc[3 * k + 1] += b[k] * g1; acc[3 * k + 2] += b[k] * g2; }
         }
     }
+}
+
+__global__ void __launch_bounds__(256) k_sh_grad_from_views(int P, int V, int D, int M, const float* __restrict__ means3D,
+                                                            const float* __restrict__ campos, const float* __restrict__ dcolor,
+                                                            float* __restrict__ dL_dsh)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    float acc[48];
+    sh_grad_sum_over_views(idx, P, V, D, means3D, campos, dcolor, acc);
     const int n_sh = 3 * M;
     float* dst = dL_dsh + (size_t)idx * n_sh;
     if (n_sh == 48 && ((uintptr_t)dst & 15) == 0) {
@@ -567,6 +574,85 @@ __global__ void __launch_bounds__(256) k_sh_grad_from_views(int P, int V, int D,
     } else {
 #pragma unroll
         for (int i = 0; i < 48; i++) if (i < n_sh) dst[i] = acc[i];
+    }
+}
+
+// The same sum, consumed on the spot: Adam on the Gaussian's SH coefficients (adam.hip's update, lr_dc for the three DC
+// values and lr_rest for the others: gaussian_model.py:157-158) without ever writing the 48-float gradient to memory.
+struct ShAdamArgs {
+    float lr_dc, lr_rest, b1, b2, eps, bc1, bc2_sqrt, grad_scale;
+};
+
+// One wave per 64 Gaussians.  Phase 1: lane = Gaussian, the 48 sums in registers, dropped into an LDS panel (row stride 52
+// floats: conflict-free for 16-byte accesses).  Phase 2: the wave walks the 64 x 48 floats of parameters and moments as
+// one contiguous stream, one float4 per lane and step (a lane-per-Gaussian walk touches 64 cache lines per instruction
+// and ran at 2 TB/s).
+#define SHA_STRIDE 52
+__global__ void __launch_bounds__(64) k_sh_adam_from_views(int P, int V, int D, int M, const float* __restrict__ means3D,
+                                                           const float* __restrict__ campos, const float* __restrict__ dcolor,
+                                                           float* __restrict__ sh, float* __restrict__ exp_avg,
+                                                           float* __restrict__ exp_avg_sq, ShAdamArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float s_g[64 * SHA_STRIDE];
+    const int lane = threadIdx.x;
+    const int g0 = blockIdx.x * 64;
+    const int idx = g0 + lane;
+    {
+        float acc[48];
+        if (idx < P) sh_grad_sum_over_views(idx, P, V, D, means3D, campos, dcolor, acc);
+        else {
+#pragma unroll
+            for (int k = 0; k < 48; k++) acc[k] = 0.f;
+        }
+        float4* row = reinterpret_cast<float4*>(s_g + lane * SHA_STRIDE);
+#pragma unroll
+        for (int i = 0; i < 12; i++) row[i] = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int n_sh = 3 * M;
+    const int live = min(64, P - g0);
+    auto upd = [&](int c, float g, float& p, float& m, float& v) {
+        g *= a.grad_scale;
+        m = a.b1 * m + (1.f - a.b1) * g;
+        v = a.b2 * v + (1.f - a.b2) * g * g;
+        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+        p -= ((c < 3 ? a.lr_dc : a.lr_rest) / a.bc1) * (m / denom);
+    };
+    const size_t base = (size_t)g0 * n_sh;
+    if (n_sh == 48 && ((((uintptr_t)sh | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0)) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4* p4 = reinterpret_cast<f4*>(sh + base);
+        f4* m4 = reinterpret_cast<f4*>(exp_avg + base);
+        f4* v4 = reinterpret_cast<f4*>(exp_avg_sq + base);
+        const int n4 = live * 12;
+#pragma unroll
+        for (int st = 0; st < 12; st++) {
+            const int e4 = st * 64 + lane;  // float4 index inside the wave's 64 x 48 block
+            if (e4 < n4) {
+                const int g = e4 / 12, c4 = e4 - g * 12;
+                const float4 gr = *reinterpret_cast<const float4*>(s_g + g * SHA_STRIDE + 4 * c4);
+                // the moments are touched once per step: stream them past the caches, the parameters are read again by
+                // the next forward and should stay in the last-level cache
+                const f4 pv = p4[e4], mv = __builtin_nontemporal_load(&m4[e4]), vv = __builtin_nontemporal_load(&v4[e4]);
+                float p[4] = {pv.x, pv.y, pv.z, pv.w}, m[4] = {mv.x, mv.y, mv.z, mv.w}, v[4] = {vv.x, vv.y, vv.z, vv.w};
+                const float gq[4] = {gr.x, gr.y, gr.z, gr.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) upd(4 * c4 + k, gq[k], p[k], m[k], v[k]);
+                const f4 po = {p[0], p[1], p[2], p[3]}, mo = {m[0], m[1], m[2], m[3]}, vo = {v[0], v[1], v[2], v[3]};
+                p4[e4] = po;
+                __builtin_nontemporal_store(mo, &m4[e4]);
+                __builtin_nontemporal_store(vo, &v4[e4]);
+            }
+        }
+    } else {
+        const int n = live * n_sh;
+        for (int e = lane; e < n; e += 64) {
+            const int g = e / n_sh, c = e - g * n_sh;
+            float p = sh[base + e], m = exp_avg[base + e], v = exp_avg_sq[base + e];
+            upd(c, s_g[g * SHA_STRIDE + c], p, m, v);
+            sh[base + e] = p; exp_avg[base + e] = m; exp_avg_sq[base + e] = v;
+        }
     }
 }
 
@@ -686,6 +772,15 @@ void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
 {
     if (a.P <= 0) return;
     hipLaunchKernelGGL(k_preprocess_bwd, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+}
+
+void sgr_launch_sh_adam_from_views(int P, int V, int D, int M, const float* means3D, const float* campos, const float* dcolor,
+                                   float* sh, float* exp_avg, float* exp_avg_sq, float lr_dc, float lr_rest, float b1, float b2,
+                                   float eps, float bc1, float bc2_sqrt, float grad_scale, hipStream_t s)
+{
+    ShAdamArgs a = {lr_dc, lr_rest, b1, b2, eps, bc1, bc2_sqrt, grad_scale};
+    hipLaunchKernelGGL(k_sh_adam_from_views, dim3((P + 63) / 64), dim3(64), 0, s, P, V, D, M, means3D, campos, dcolor, sh,
+                       exp_avg, exp_avg_sq, a);
 }
 
 void sgr_launch_sh_grad_from_views(int P, int V, int D, int M, const float* means3D, const float* campos, const float* dcolor,

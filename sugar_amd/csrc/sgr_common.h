@@ -124,6 +124,10 @@ void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
 void sgr_launch_sh_grad_from_views(int P, int V, int D, int M, const float* means3D, const float* campos, const float* dcolor,
                                    float* dL_dsh, hipStream_t s);
 
+void sgr_launch_sh_adam_from_views(int P, int V, int D, int M, const float* means3D, const float* campos, const float* dcolor,
+                                   float* sh, float* exp_avg, float* exp_avg_sq, float lr_dc, float lr_rest, float b1, float b2,
+                                   float eps, float bc1, float bc2_sqrt, float grad_scale, hipStream_t s);
+
 void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_out, const uint2* rect_by_id, uint2* rects_sorted,
                               hipStream_t s);
 size_t sgr_sort_rect_by_id_offset(int P);  // binning.hip: the by-id rectangles written by the preprocess kernel

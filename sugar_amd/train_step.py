@@ -209,21 +209,40 @@ class FlatAdam:
                 segs.append((b, e, params.LRS[k], params.REST_LR, 3 * params.M, 3))
             else:
                 segs.append((b, e, params.LRS[k], params.LRS[k], 1, 1))
-        n = len(segs)
-        self._seg = ((C.c_longlong * n)(*[s[0] for s in segs]), (C.c_longlong * n)(*[s[1] for s in segs]),
-                     (C.c_float * n)(*[s[2] for s in segs]), (C.c_float * n)(*[s[3] for s in segs]),
-                     (C.c_int * n)(*[s[4] for s in segs]), (C.c_int * n)(*[s[5] for s in segs]))
-        self._n = n
+        self._seg, self._n = self._pack(segs)
+        self._seg_small, self._n_small = self._pack(segs[:-1])  # everything but the SH tensor (the last segment)
 
-    def step(self, grad_scale: float = 1.0):
+    def _pack(self, segs):
+        C = self._C
+        n = len(segs)
+        return ((C.c_longlong * n)(*[s[0] for s in segs]), (C.c_longlong * n)(*[s[1] for s in segs]),
+                (C.c_float * n)(*[s[2] for s in segs]), (C.c_float * n)(*[s[3] for s in segs]),
+                (C.c_int * n)(*[s[4] for s in segs]), (C.c_int * n)(*[s[5] for s in segs])), n
+
+    def step(self, grad_scale: float = 1.0, sh_views=None):
+        """One Adam step over the flat buffer.  With `sh_views = (means3D, campos_all[V,3], masked_colors[V,P,3], sh_degree)`
+        the SH tensor is updated by sgr_sh_adam_from_views straight from the per-view colour gradients (its 48-float gradient
+        is never materialised) and the flat kernel covers the other 11 floats per Gaussian only."""
         C, p = self._C, self.params
         self.t += 1
         dev = p.flat.device
+        vp = lambda t: C.c_void_p(t.data_ptr())
         with torch.cuda.device(dev):
-            rc = self._lib.sgr_adam_step(p.flat.numel(), C.c_void_p(p.flat.data_ptr()), C.c_void_p(p.flat_grad.data_ptr()),
-                                         C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()), self._n,
-                                         *self._seg, self.betas[0], self.betas[1], self.eps, self.t, float(grad_scale),
-                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            n_flat, seg, n_seg = p.flat.numel(), self._seg, self._n
+            if sh_views is not None:
+                means3D, campos_all, dcolor_all, sh_degree = sh_views
+                off = p.offsets["features"]
+                rc = self._lib.sgr_sh_adam_from_views(
+                    p.P, int(dcolor_all.shape[0]), int(sh_degree), p.M, vp(means3D), vp(campos_all.contiguous()),
+                    vp(dcolor_all.contiguous()), C.c_void_p(p.flat.data_ptr() + 4 * off),
+                    C.c_void_p(self.exp_avg.data_ptr() + 4 * off), C.c_void_p(self.exp_avg_sq.data_ptr() + 4 * off),
+                    p.LRS["features"], p.REST_LR, self.betas[0], self.betas[1], self.eps, self.t, float(grad_scale), stream)
+                if rc < 0:
+                    raise RuntimeError(f"sgr_sh_adam_from_views failed ({rc})")
+                n_flat, seg, n_seg = p.n_small, self._seg_small, self._n_small  # positions are updated after they were read
+            rc = self._lib.sgr_adam_step(n_flat, vp(p.flat), vp(p.flat_grad), vp(self.exp_avg), vp(self.exp_avg_sq), n_seg,
+                                         *seg, self.betas[0], self.betas[1], self.eps, self.t, float(grad_scale), stream)
         if rc < 0:
             raise RuntimeError(f"sgr_adam_step failed ({rc})")
 
@@ -273,15 +292,18 @@ class ViewShardedTrainer:
     on the wire instead of 59."""
 
     def __init__(self, params: GaussianParams, rasterizer_cls, settings_cls, bg, sh_degree=3, lambda_dssim=0.2,
-                 fused_loss=True, compact_sh=None, sh_grad_fn=None, grad_sink_cm=None):
+                 fused_loss=True, compact_sh=None, sh_grad_fn=None, grad_sink_cm=None, fused_sh_adam=None):
         self.fused_loss = fused_loss
         self.params = params
         self.opt = params.make_optimizer()
         self.rasterizer_cls, self.settings_cls = rasterizer_cls, settings_cls
         self.bg, self.sh_degree, self.lambda_dssim = bg, sh_degree, lambda_dssim
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.compact_sh = (self.world > 1 and params.flat.is_cuda) if compact_sh is None else bool(compact_sh)
+        self.compact_sh = params.flat.is_cuda if compact_sh is None else bool(compact_sh)
         self.sh_grad_fn = sh_grad_fn or sh_grad_from_views
+        # compact mode on a ROCm device: the SH gradient is consumed by the optimiser kernel itself
+        self.fused_sh_adam = (self.compact_sh and isinstance(self.opt, FlatAdam) and sh_grad_fn is None) if fused_sh_adam is None \
+            else bool(fused_sh_adam)
         if grad_sink_cm is None and params.flat.is_cuda:
             from .diff_gaussian_rasterization import grad_sink as grad_sink_cm
         self.grad_sink_cm = grad_sink_cm  # context manager factory honoured by the rasterizer's backward (None: plain autograd)
@@ -308,6 +330,7 @@ class ViewShardedTrainer:
             pkg = render(p, cam, self.bg, self.rasterizer_cls, self.settings_cls, self.sh_degree)
             loss = train_loss(pkg["render"], gt_image, self.lambda_dssim, self.fused_loss)
             grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+        sh_views = None
         with torch.no_grad():
             for name, leaf, g in zip(names, leaves, grads):
                 if g is None:
@@ -330,13 +353,16 @@ class ViewShardedTrainer:
                     dist.all_reduce(p.flat_grad[: p.n_small], op=dist.ReduceOp.SUM)
                 else:
                     all_rgb, all_cam = g_rgb[None], campos
-                self.sh_grad_fn(p.params["xyz"].detach(), all_cam, all_rgb, self.sh_degree, p.params["features"].grad)
+                if self.fused_sh_adam:
+                    sh_views = (p.params["xyz"].detach(), all_cam, all_rgb, self.sh_degree)
+                else:
+                    self.sh_grad_fn(p.params["xyz"].detach(), all_cam, all_rgb, self.sh_degree, p.params["features"].grad)
             elif self.world > 1:
                 # plain path: one flat all-reduce of all 59 floats per Gaussian
                 dist.all_reduce(p.flat_grad, op=dist.ReduceOp.SUM)
         scale = 1.0 / self.world
         if isinstance(self.opt, FlatAdam):
-            self.opt.step(grad_scale=scale)  # the mean over views is folded into the optimiser kernel
+            self.opt.step(grad_scale=scale, sh_views=sh_views)  # the mean over views is folded into the optimiser kernels
         else:
             if self.world > 1:
                 p.flat_grad.mul_(scale)

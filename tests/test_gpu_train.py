@@ -58,10 +58,12 @@ def test_trainer_compact_and_flat_paths_agree():
             for c in syn.orbit_cameras(400, 240)]
     gts = [torch.rand(3, 240, 400, generator=torch.Generator().manual_seed(i)).to(dev) for i in range(3)]
     flats = []
-    for compact in (False, True):
+    # flat SH gradient | compact exchange + SH gradient rebuilt | compact exchange + SH gradient consumed inside the Adam kernel
+    for compact, fused in ((False, False), (True, False), (True, True)):
         p = GaussianParams(scene, dev)
         tr = ViewShardedTrainer(p, GaussianRasterizer, GaussianRasterizationSettings, torch.zeros(3, device=dev),
-                                compact_sh=compact)
+                                compact_sh=compact, fused_sh_adam=fused)
+        assert tr.fused_sh_adam == fused
         for i in range(3):
             loss, _ = tr.step(cams[i], gts[i])
             assert torch.isfinite(loss)
@@ -69,8 +71,11 @@ def test_trainer_compact_and_flat_paths_agree():
     start = GaussianParams(scene, dev).flat
     assert float((flats[0] - start).abs().max()) > 1e-4
     # Adam normalises tiny gradients to +-lr, so compare the update, not bit patterns
-    assert float((flats[0] - flats[1]).abs().max()) < 2e-2 * float((flats[0] - start).abs().max())
-    assert float((flats[0] - flats[1]).norm() / (flats[0] - start).norm()) < 1e-3
+    for other in flats[1:]:
+        assert float((flats[0] - other).abs().max()) < 2e-2 * float((flats[0] - start).abs().max())
+        assert float((flats[0] - other).norm() / (flats[0] - start).norm()) < 1e-3
+    tr = ViewShardedTrainer(GaussianParams(scene, dev), GaussianRasterizer, GaussianRasterizationSettings, torch.zeros(3, device=dev))
+    assert tr.compact_sh and tr.fused_sh_adam  # the defaults on a ROCm device
 
 
 def test_fused_activations_match_torch_ops():
