@@ -276,8 +276,9 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (inside) { g0 = dL_dpix[pix_id]; g1 = dL_dpix[HW + pix_id]; g2 = dL_dpix[2 * HW + pix_id]; }
     const float neg_Tfinal_bg = -T_final * (bg[0] * g0 + bg[1] * g1 + bg[2] * g2);
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;  // accum_rec
-    float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;     // last_color
+    // accum_rec and last_color of backward.cu:514-516 only ever meet dL_dpixel in a dot product: the recurrence is carried
+    // for the scalars  accum_rec . dL_dpixel  and  last_color . dL_dpixel  (6 instead of 12 instructions per pair)
+    float acc_g = 0.f, lc_g = 0.f;
     float last_alpha = 0.f;
 
     // phase-B lane role and the dL_dpix of its 16-pixel row, kept in registers for the whole kernel
@@ -340,10 +341,9 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
                     Wt = alpha * T;
                     const float c0 = b.z, c1 = b.w, c2 = sh.c[j];
                     // accum_rec = last_alpha * last_color + (1 - last_alpha) * accum_rec  (backward.cu:514-516)
-                    acc0 += last_alpha * (lc0 - acc0); lc0 = c0;
-                    acc1 += last_alpha * (lc1 - acc1); lc1 = c1;
-                    acc2 += last_alpha * (lc2 - acc2); lc2 = c2;
-                    float dL_dalpha = (c0 - acc0) * g0 + (c1 - acc1) * g1 + (c2 - acc2) * g2;
+                    acc_g += last_alpha * (lc_g - acc_g);
+                    lc_g = c0 * g0 + c1 * g1 + c2 * g2;
+                    float dL_dalpha = lc_g - acc_g;
                     last_alpha = alpha;
                     dL_dalpha = dL_dalpha * T + neg_Tfinal_bg * inv_1ma;  // backward.cu:523-529
                     Z = G * dL_dalpha;
