@@ -112,7 +112,8 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
 
     bool done = !inside;
     float T = 1.0f;
-    uint32_t last_contributor = 0, done_pos = 0;
+    uint32_t last_contributor = 0;
+    uint32_t wave_walked = (uint32_t)total;  // list position at which this wave's last pixel finished (whole list: never)
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
 
     for (int base = 0; base < total; base += BATCH) {
@@ -169,7 +170,6 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
             C0 += b.z * w; C1 += b.w * w; C2 += cb * w;
             T = upd ? test_T : T;
             last_contributor = upd ? pos : last_contributor;
-            done_pos = stop ? pos : done_pos;
             done = done || stop;
 #ifdef SGR_COUNT
             {   // lanes that pass the tests, per 16-lane row (4x... here: 16x1 pixel rows) and per wave iteration
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
                 }
             }
 #endif
-            if (__ballot(!done) == 0ull) break;
+            if (__ballot(!done) == 0ull) { wave_walked = pos; break; }
         }
     }
     if (inside) {
@@ -202,9 +202,8 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
     uint32_t mc = inside ? last_contributor : 0u;
     for (int o = 32; o > 0; o >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, o));
     // furthest list position any pixel examined (R_f of the roofline accounting): the entry that
-    // finished the pixel, or the whole list for a pixel that never saturated
-    uint32_t wk = inside ? (done ? done_pos : (uint32_t)total) : 0u;
-    for (int o = 32; o > 0; o >>= 1) wk = max(wk, (uint32_t)__shfl_xor((int)wk, o));
+    // finished the wave's last pixel, or the whole list for a wave with a pixel that never saturated
+    uint32_t wk = __ballot(inside) ? wave_walked : 0u;
     if (lane == 0) { s_maxc[wave] = mc; s_walk[wave] = wk; }
     __syncthreads();
     if (tid == 0) {
