@@ -8,7 +8,8 @@
 One "step" = rasterizer forward (SH degree 3, scale/rotation in-rasterizer) -> 0.8*L1 + 0.2*(1-SSIM) -> backward ->
 Adam over 59 floats/Gaussian, on synthetic data resident in HBM.  With N ranks every rank
 renders its own view of the same replica; the ranks exchange 3 masked colour gradients per Gaussian and view (all-gather)
-plus the 11 non-SH gradient floats per Gaussian (all-reduce) over RCCL and rebuild the summed SH gradient locally
+plus the 11 non-SH gradient floats per Gaussian (all-reduce) over RCCL; the SH gradient is summed over the views inside
+the Adam kernel of every rank
 ("weak" scaling: one view per GPU per step; value = views/s over all ranks).
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
@@ -55,11 +56,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP rasterizer has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; SGR_BENCH_BACKEND=gloo with fewer GPUs than ranks is a functional rehearsal only (ranks share a GPU)
+    backend = os.environ.get("SGR_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if world > n_dev and backend == "nccl":
+        raise SystemExit(f"bench.py: {world} ranks but {n_dev} GPUs; RCCL needs one GPU per rank")
+    local_dev = local_rank % n_dev
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -167,7 +177,8 @@ def main():
                             "(raster fwd -> 0.8 L1 + 0.2 DSSIM -> bwd -> Adam, 59 floats/Gaussian), 8 orbit cameras cycled",
                 "views_per_step": world,
                 "parallelism": (f"view-sharded dp{world}: all-gather of 3 masked colour grads per Gaussian and view + all-reduce of "
-                                "the 11 non-SH floats per Gaussian (RCCL), SH gradient rebuilt locally" if trainer.compact_sh
+                                "the 11 non-SH floats per Gaussian (RCCL), SH gradient summed over views inside the Adam kernel"
+                                if trainer.compact_sh and world > 1 else f"view-sharded dp{world}" if world > 1
                                 else f"view-sharded dp{world}, single process, no collective"),
                 "instances_per_view": R, "instances_walked_fwd": R_f, "instances_walked_bwd": R_b,
             },
