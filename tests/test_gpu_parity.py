@@ -152,11 +152,13 @@ def test_non_default_stream():
     assert np.array_equal(ref["color"], out["color"])
 
 
-def test_full_size_properties_config2():
-    """BASELINE config 2 at full size (300k Gaussians, 800x800): size-independent properties instead of the oracle:
-    every tile list is sorted by (depth, index), lists hold exactly the Gaussians whose rectangle covers the tile,
-    R = sum of rectangle areas, T in [0,1], colour bounded, backward finite and zero for culled Gaussians."""
-    scene, cams, bg = syn.make_config("config2")
+@pytest.mark.parametrize("config", ["config2", "metric"])
+def test_full_size_properties(config):
+    """BASELINE config 2 (300k Gaussians, 800x800) and the metric case (1M Gaussians, 1920x1080) at full size:
+    size-independent properties instead of the oracle: every tile list is sorted by (depth, index), lists hold exactly the
+    Gaussians whose rectangle covers the tile, R = sum of rectangle areas, T in [0,1], colour bounded, backward finite and
+    zero for culled Gaussians."""
+    scene, cams, bg = syn.make_config(config)
     cam = cams[0]
     H, W = cam.image_height, cam.image_width
     g = np.random.default_rng(0).standard_normal((3, H, W)).astype(np.float32)
@@ -173,8 +175,9 @@ def test_full_size_properties_config2():
     radii = hp["radii"].astype(np.float32)
     gx, gy = (W + 15) // 16, (H + 15) // 16
     x, y = rec[:, 0], rec[:, 1]
-    minx = np.clip(np.trunc((x - radii) / np.float32(16)), 0, gx); maxx = np.clip(np.trunc((x + radii + np.float32(15)) / np.float32(16)), 0, gx)
-    miny = np.clip(np.trunc((y - radii) / np.float32(16)), 0, gy); maxy = np.clip(np.trunc((y + radii + np.float32(15)) / np.float32(16)), 0, gy)
+    f16, f1 = np.float32(16), np.float32(1)  # getRect, auxiliary.h:46-56: (p + r + BLOCK - 1) / BLOCK, evaluated left to right
+    minx = np.clip(np.trunc((x - radii) / f16), 0, gx); maxx = np.clip(np.trunc((((x + radii) + f16) - f1) / f16), 0, gx)
+    miny = np.clip(np.trunc((y - radii) / f16), 0, gy); maxy = np.clip(np.trunc((((y + radii) + f16) - f1) / f16), 0, gy)
     area = ((maxx - minx) * (maxy - miny)).astype(np.int64) * (hp["radii"] > 0)
     assert np.array_equal(np.bincount(pl, minlength=len(radii)), area)
     txs, tys = tile_of % gx, tile_of // gx
