@@ -153,7 +153,7 @@ class _CModule:
         dev = means3D.device
         P = means3D.size(0)
         H, W = dL_dout_color.size(1), dL_dout_color.size(2)
-        M = sh.size(1) if sh.numel() != 0 else 0
+        M = sh.size(1) if sh.dim() == 3 else 0  # (the reference takes 0 for an empty tensor and then fails in autograd when P == 0)
         f = dict(dtype=torch.float32, device=dev)
         use_cov = cov3D_precomp.numel() != 0
         # Every row of these is written by sgr_backward, so no 300 MB of zero-fill per call

@@ -289,3 +289,26 @@ def test_level1_overflow_falls_back_to_single_level_binning():
     assert h["num_rendered"] == o["num_rendered"]
     assert np.array_equal(np.diff(h["tile_start"]), o["ranges"][:, 1] - o["ranges"][:, 0])
     assert np.array_equal(h["point_list"], o["point_list"])
+
+
+@pytest.mark.parametrize("P", [1, 2, 63, 64, 65, 511, 513, 1023, 1025, 2049])
+def test_counts_around_the_chunk_boundaries(P):
+    """Gaussian counts around the 64-lane, 512-entry and 1024-key chunk sizes of the sort and binning kernels"""
+    scene = syn.make_scene(P, 100 + P, 0.02, 0.25)
+    _check(scene, syn.orbit_cameras(176, 144)[P % 8], torch.tensor([0.3, 0.2, 0.1]))
+
+
+def test_empty_input_short_circuits_like_the_reference():
+    """P == 0 never reaches the core (rasterize_points.cu:68-69,81): the image stays at its torch::full(0.0) initial value
+    (NOT the background), radii are empty"""
+    from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device("cuda:0")
+    cam = syn.orbit_cameras(64, 48)[0]
+    bg = torch.tensor([0.25, 0.5, 0.75], device=dev)
+    st = GaussianRasterizationSettings(48, 64, cam.tanfovx, cam.tanfovy, bg, 1.0, cam.viewmatrix.to(dev), cam.projmatrix.to(dev), 3,
+                                       cam.campos.to(dev), False, False)
+    e = lambda *s: torch.zeros(*s, device=dev, requires_grad=True)
+    color, radii = GaussianRasterizer(st)(e(0, 3), e(0, 3), e(0, 1), shs=e(0, 16, 3), scales=e(0, 3), rotations=e(0, 4))
+    assert color.shape == (3, 48, 64) and radii.shape == (0,)
+    assert torch.equal(color, torch.zeros(3, 48, 64, device=dev))
+    color.sum().backward()  # and the backward of the empty call runs
