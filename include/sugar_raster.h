@@ -194,6 +194,14 @@ int sgr_density_field_backward(int N, int K, const float* x, const int64_t* nbr_
                                const float* inv_scaled_rot, const float* strengths, float density_factor,
                                const float* dL_dopacities, const float* dL_ddensity, float* dL_dx, float* dL_dcenters,
                                float* dL_dinv_scaled_rot, float* dL_dstrengths, void* stream);
+/* The same gradients without float atomics: every pair takes one integer atomic for its rank among the pairs that reference
+ * the same Gaussian, the pairs are laid out per Gaussian and summed in registers.  P = number of Gaussians; the three
+ * per-Gaussian outputs are WRITTEN (every row, no zero-fill needed); scratch of sgr_density_field_backward_scratch_bytes. */
+size_t sgr_density_field_backward_scratch_bytes(int N, int K, int P);
+int sgr_density_field_backward_gather(int N, int K, int P, const float* x, const int64_t* nbr_idx, const float* centers,
+                                      const float* inv_scaled_rot, const float* strengths, float density_factor,
+                                      const float* dL_dopacities, const float* dL_ddensity, float* dL_dx, float* dL_dcenters,
+                                      float* dL_dinv_scaled_rot, float* dL_dstrengths, char* scratch, void* stream);
 int sgr_level_set_points(int N, int K, const float* world_points, const int64_t* nbr_idx, const float* cam_center,
                          const float* centers, const float* inv_scaled_rot, const float* strengths,
                          const float* gaussian_std, int n_levels, const float* levels_host, int n_range, float range_size,

@@ -105,6 +105,149 @@ __global__ void __launch_bounds__(256) k_density_bwd(int N, int K, const float* 
     if (dx_out) { dx_out[3 * (size_t)n] = ax; dx_out[3 * (size_t)n + 1] = ay; dx_out[3 * (size_t)n + 2] = az; }
 }
 
+// ---- gather formulation of the backward ---------------------------------------------------------------------------
+// The kernel above spends 13 float atomics per (sample, neighbour) pair (208 M at 1M x 16: ~10 ms, L2 atomic rate).  Here a
+// pair costs ONE returning integer atomic (its rank in the list of pairs that reference the same Gaussian); after a scan the
+// pairs are laid out per Gaussian and a lane per Gaussian sums its pairs in registers and writes its 13 outputs once.
+__global__ void __launch_bounds__(256) k_density_bwd_rank(int N, int K, const float* __restrict__ x, const long long* __restrict__ nbr,
+                                                          const float* __restrict__ centers, const float* __restrict__ B,
+                                                          const float* __restrict__ strengths, float factor,
+                                                          const float* __restrict__ g_opac, const float* __restrict__ g_den,
+                                                          float* __restrict__ dx_out, uint32_t* __restrict__ cnt,
+                                                          uint32_t* __restrict__ rank)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float px = x[3 * (size_t)n], py = x[3 * (size_t)n + 1], pz = x[3 * (size_t)n + 2];
+    const float gd = g_den ? g_den[n] : 0.f;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int k = 0; k < K; k++) {
+        const size_t p = (size_t)n * K + k;
+        const long long gi = nbr[p];
+        rank[p] = atomicAdd(&cnt[gi], 1u);
+        if (dx_out) {
+            const GaussNbr g = load_nbr(gi, centers, B, strengths);
+            float w0, w1, w2;
+            bt_mul(g.B, px - g.mx, py - g.my, pz - g.mz, w0, w1, w2);
+            const float q_raw = w0 * w0 + w1 * w1 + w2 * w2;
+            const float e = __expf(-0.5f * fminf(fmaxf(q_raw, 0.f), 1e8f));
+            const float go = (g_opac ? g_opac[p] : 0.f) + gd;
+            const float dq = (q_raw > 0.f && q_raw < 1e8f) ? -0.5f * factor * g.s * e * go : 0.f;
+            const float dw0 = 2.f * w0 * dq, dw1 = 2.f * w1 * dq, dw2 = 2.f * w2 * dq;
+            ax += g.B[0] * dw0 + g.B[1] * dw1 + g.B[2] * dw2;
+            ay += g.B[3] * dw0 + g.B[4] * dw1 + g.B[5] * dw2;
+            az += g.B[6] * dw0 + g.B[7] * dw1 + g.B[8] * dw2;
+        }
+    }
+    if (dx_out) { dx_out[3 * (size_t)n] = ax; dx_out[3 * (size_t)n + 1] = ay; dx_out[3 * (size_t)n + 2] = az; }
+}
+
+// exclusive scan of cnt[0..n) into start[0..n], start[n] = total: block sums, scan of the block sums, block-local scans
+#define FSCAN_BLOCK 2048  // elements per 256-thread workgroup (8 per thread)
+__global__ void __launch_bounds__(256) k_fscan_sums(int n, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ block_sums)
+{
+    __shared__ uint32_t s_w[4];
+    const int base = blockIdx.x * FSCAN_BLOCK + threadIdx.x * 8;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) sum += (base + i < n) ? cnt[base + i] : 0u;
+    for (int o = 32; o > 0; o >>= 1) sum += (uint32_t)__shfl_xor((int)sum, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ void __launch_bounds__(1024) k_fscan_top(int n_blocks, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ total)
+{
+    __shared__ uint32_t s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n_blocks + 1023) / 1024;
+    const int b = tid * per, e = min(n_blocks, b + per);
+    uint32_t sum = 0;
+    for (int i = b; i < e; i++) sum += block_sums[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = (tid >= o) ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - sum;
+    for (int i = b; i < e; i++) { const uint32_t v = block_sums[i]; block_sums[i] = run; run += v; }
+    if (tid == 1023) *total = s_part[1023];
+}
+
+__global__ void __launch_bounds__(256) k_fscan_apply(int n, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ block_sums,
+                                                     uint32_t* __restrict__ start)
+{
+    __shared__ uint32_t s_w[4];
+    const int base = blockIdx.x * FSCAN_BLOCK + threadIdx.x * 8;
+    uint32_t v[8], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { v[i] = (base + i < n) ? cnt[base + i] : 0u; sum += v[i]; }
+    uint32_t incl = sum;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += y; }
+    if (lane == 63) s_w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t run = block_sums[blockIdx.x] + incl - sum;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += s_w[w];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { if (base + i < n) start[base + i] = run; run += v[i]; }
+}
+
+__global__ void __launch_bounds__(256) k_density_bwd_fill(long long NK, const long long* __restrict__ nbr,
+                                                          const uint32_t* __restrict__ start, const uint32_t* __restrict__ rank,
+                                                          uint32_t* __restrict__ pair_list)
+{
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= NK) return;
+    pair_list[start[nbr[p]] + rank[p]] = (uint32_t)p;
+}
+
+__global__ void __launch_bounds__(256) k_density_bwd_gather(int P, int K, const float* __restrict__ x,
+                                                            const float* __restrict__ centers, const float* __restrict__ B,
+                                                            const float* __restrict__ strengths, float factor,
+                                                            const float* __restrict__ g_opac, const float* __restrict__ g_den,
+                                                            const uint32_t* __restrict__ start,
+                                                            const uint32_t* __restrict__ pair_list, float* __restrict__ dcenters,
+                                                            float* __restrict__ dB, float* __restrict__ dstrengths)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= P) return;
+    const GaussNbr g = load_nbr(t, centers, B, strengths);
+    float dc0 = 0.f, dc1 = 0.f, dc2 = 0.f, ds = 0.f;
+    float b[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) b[i] = 0.f;
+    const uint32_t e0 = start[t], e1 = start[t + 1];
+    for (uint32_t e = e0; e < e1; e++) {
+        const uint32_t p = pair_list[e];
+        const uint32_t n = p / (uint32_t)K;
+        const float dx = x[3 * (size_t)n] - g.mx, dy = x[3 * (size_t)n + 1] - g.my, dz = x[3 * (size_t)n + 2] - g.mz;
+        float w0, w1, w2;
+        bt_mul(g.B, dx, dy, dz, w0, w1, w2);
+        const float q_raw = w0 * w0 + w1 * w1 + w2 * w2;
+        const float ex = __expf(-0.5f * fminf(fmaxf(q_raw, 0.f), 1e8f));
+        const float go = (g_opac ? g_opac[p] : 0.f) + (g_den ? g_den[n] : 0.f);
+        ds += go * factor * ex;
+        const float dq = (q_raw > 0.f && q_raw < 1e8f) ? -0.5f * factor * g.s * ex * go : 0.f;
+        const float dw0 = 2.f * w0 * dq, dw1 = 2.f * w1 * dq, dw2 = 2.f * w2 * dq;
+        dc0 -= g.B[0] * dw0 + g.B[1] * dw1 + g.B[2] * dw2;
+        dc1 -= g.B[3] * dw0 + g.B[4] * dw1 + g.B[5] * dw2;
+        dc2 -= g.B[6] * dw0 + g.B[7] * dw1 + g.B[8] * dw2;
+        b[0] += dx * dw0; b[1] += dx * dw1; b[2] += dx * dw2;
+        b[3] += dy * dw0; b[4] += dy * dw1; b[5] += dy * dw2;
+        b[6] += dz * dw0; b[7] += dz * dw1; b[8] += dz * dw2;
+    }
+    dcenters[3 * (size_t)t] = dc0; dcenters[3 * (size_t)t + 1] = dc1; dcenters[3 * (size_t)t + 2] = dc2;
+#pragma unroll
+    for (int i = 0; i < 9; i++) dB[9 * (size_t)t + i] = b[i];
+    dstrengths[t] = ds;
+}
+
 #define LS_MAX_RANGE 32
 #define LS_MAX_LEVELS 8
 struct LevelArgs { int n; float v[LS_MAX_LEVELS]; };
@@ -221,6 +364,49 @@ int sgr_density_field_backward(int N, int K, const float* x, const int64_t* nbr_
     hipLaunchKernelGGL(k_density_bwd, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, K, x,
                        reinterpret_cast<const long long*>(nbr_idx), centers, inv_scaled_rot, strengths, density_factor,
                        dL_dopacities, dL_ddensity, dL_dx, dL_dcenters, dL_dinv_scaled_rot, dL_dstrengths);
+    return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
+}
+
+size_t sgr_density_field_backward_scratch_bytes(int N, int K, int P)
+{
+    const size_t nk = (size_t)(N > 0 ? N : 0) * (size_t)(K > 0 ? K : 0), p = (size_t)(P > 0 ? P : 0);
+    const size_t blocks = (p + FSCAN_BLOCK - 1) / FSCAN_BLOCK + 1;
+    return sgr_align((p + 1) * 4) * 2 + sgr_align(blocks * 4) + 2 * sgr_align(nk * 4);  // cnt | start | block sums | rank | pair_list
+}
+
+int sgr_density_field_backward_gather(int N, int K, int P, const float* x, const int64_t* nbr_idx, const float* centers,
+                                      const float* inv_scaled_rot, const float* strengths, float density_factor,
+                                      const float* dL_dopacities, const float* dL_ddensity, float* dL_dx, float* dL_dcenters,
+                                      float* dL_dinv_scaled_rot, float* dL_dstrengths, char* scratch, void* stream)
+{
+    if (P <= 0) return 0;
+    if (N < 0 || K <= 0 || (N > 0 && (!x || !nbr_idx)) || !centers || !inv_scaled_rot || !strengths || !dL_dcenters ||
+        !dL_dinv_scaled_rot || !dL_dstrengths || !scratch || (!dL_dopacities && !dL_ddensity) || (size_t)N * K > 0xFFFFFFFFull)
+        return SGR_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nk = (size_t)N * K, pa = sgr_align(((size_t)P + 1) * 4);
+    const int n_blocks = (P + FSCAN_BLOCK - 1) / FSCAN_BLOCK;
+    const size_t ba = sgr_align(((size_t)n_blocks + 1) * 4);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(scratch);
+    uint32_t* start = reinterpret_cast<uint32_t*>(scratch + pa);
+    uint32_t* block_sums = reinterpret_cast<uint32_t*>(scratch + 2 * pa);
+    uint32_t* rank = reinterpret_cast<uint32_t*>(scratch + 2 * pa + ba);
+    uint32_t* pair_list = reinterpret_cast<uint32_t*>(scratch + 2 * pa + ba + sgr_align(nk * 4));
+    const long long* nbr = reinterpret_cast<const long long*>(nbr_idx);
+    if (hipMemsetAsync(cnt, 0, ((size_t)P + 1) * 4, s) != hipSuccess) return SGR_E_HIP;
+    if (N > 0) {
+        hipLaunchKernelGGL(k_density_bwd_rank, dim3((N + 255) / 256), dim3(256), 0, s, N, K, x, nbr, centers, inv_scaled_rot,
+                           strengths, density_factor, dL_dopacities, dL_ddensity, dL_dx, cnt, rank);
+    }
+    hipLaunchKernelGGL(k_fscan_sums, dim3(n_blocks), dim3(256), 0, s, P, cnt, block_sums);
+    hipLaunchKernelGGL(k_fscan_top, dim3(1), dim3(1024), 0, s, n_blocks, block_sums, start + P);
+    hipLaunchKernelGGL(k_fscan_apply, dim3(n_blocks), dim3(256), 0, s, P, cnt, block_sums, start);
+    if (N > 0) {
+        hipLaunchKernelGGL(k_density_bwd_fill, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, (long long)nk, nbr, start, rank,
+                           pair_list);
+    }
+    hipLaunchKernelGGL(k_density_bwd_gather, dim3((P + 255) / 256), dim3(256), 0, s, P, K, x, centers, inv_scaled_rot, strengths,
+                       density_factor, dL_dopacities, dL_ddensity, start, pair_list, dL_dcenters, dL_dinv_scaled_rot, dL_dstrengths);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 

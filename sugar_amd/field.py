@@ -32,6 +32,8 @@ def _prep(x, nbr_idx, centers, B, strengths):
 
 
 class _DensityField(torch.autograd.Function):
+    use_gather = True  # False: the 13-float-atomics-per-pair kernel (kept for comparison)
+
     @staticmethod
     def forward(ctx, x, nbr_idx, centers, inv_scaled_rot, strengths, density_factor):
         lib = _lib.load()
@@ -58,12 +60,20 @@ class _DensityField(torch.autograd.Function):
         dev = xs.device
         P = ce.shape[0]
         dx = torch.empty(N, 3, device=dev)
-        dce = torch.zeros(P, 3, device=dev); dB = torch.zeros(P, 9, device=dev); dst = torch.zeros(P, device=dev)
         go = g_opac.contiguous().float() if g_opac is not None else None
         gd = g_dens.contiguous().float() if g_dens is not None else None
-        with torch.cuda.device(dev):
-            rc = lib.sgr_density_field_backward(N, K, _p(xs), _p(nb), _p(ce), _p(Bm), _p(st), ctx.factor, _p(go), _p(gd), _p(dx),
-                                                _p(dce), _p(dB), _p(dst), _stream(dev))
+        if _DensityField.use_gather:
+            # one integer atomic per pair + a per-Gaussian gather (every output row is written)
+            dce = torch.empty(P, 3, device=dev); dB = torch.empty(P, 9, device=dev); dst = torch.empty(P, device=dev)
+            scratch = torch.empty(lib.sgr_density_field_backward_scratch_bytes(N, K, P), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.sgr_density_field_backward_gather(N, K, P, _p(xs), _p(nb), _p(ce), _p(Bm), _p(st), ctx.factor, _p(go), _p(gd),
+                                                           _p(dx), _p(dce), _p(dB), _p(dst), _p(scratch), _stream(dev))
+        else:
+            dce = torch.zeros(P, 3, device=dev); dB = torch.zeros(P, 9, device=dev); dst = torch.zeros(P, device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.sgr_density_field_backward(N, K, _p(xs), _p(nb), _p(ce), _p(Bm), _p(st), ctx.factor, _p(go), _p(gd), _p(dx),
+                                                    _p(dce), _p(dB), _p(dst), _stream(dev))
         if rc < 0:
             raise RuntimeError(f"sgr_density_field_backward failed ({rc})")
         Bshape, sshape = ctx.shapes

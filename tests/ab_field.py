@@ -68,11 +68,20 @@ def main():
             return fn(x, nb, pts, B, strengths, 1.0)
 
     say("inputs")
+    def atomics_variant(fn):
+        from sugar_amd import field as F
+        F._DensityField.use_gather = False
+        try:
+            return fn()
+        finally:
+            F._DensityField.use_gather = True
+
     a = run(density_field); say("hip density"); b = run(ref.density_field); say("torch density")
     rel = lambda u, v: float((u - v).norm() / v.norm())
     out["density_field"] = {
         "hip_fwd_ms": timed(lambda: fwd_only(density_field)), "torch_fwd_ms": timed(lambda: fwd_only(ref.density_field)),
-        "hip_fwd_bwd_ms": timed(lambda: run(density_field)), "torch_fwd_bwd_ms": timed(lambda: run(ref.density_field)),
+        "hip_fwd_bwd_ms": timed(lambda: run(density_field)), "hip_fwd_bwd_atomics_ms": atomics_variant(lambda: timed(lambda: run(density_field))),
+        "torch_fwd_bwd_ms": timed(lambda: run(ref.density_field)),
         "rel_err": {n: rel(u, v) for n, u, v in zip(["opac", "dens", "dx", "dcenters", "dB", "dstrengths"], a, b)},
         "algorithmic_bytes_fwd": N * (12 + K * 8 + K * 52 + K * 4 + 4),
     }
