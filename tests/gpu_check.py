@@ -1,5 +1,5 @@
 """Developer check on the GPU box: prints parity statistics HIP vs CPU oracle and rough timings.
-    python scripts/gpu_check.py [--big]
+    python tests/gpu_check.py [--big]
 """
 import os, sys, time, json
 import numpy as np, torch
