@@ -85,16 +85,18 @@ int sgr_backward(int P, int D, int M, int64_t R,
 /* SH gradient from per-view masked colour gradients (view-sharded training exchanges 12 B per Gaussian and view instead
  * of 12*M B):  dL_dsh[P*M*3] = sum_v basis(normalize(means3D - campos_all[v])) (x) dcolor_all[v][P*3]   (the per-view
  * computeColorFromSH backward, backward.cu:47-97, summed over the n_views views).  campos_all[n_views*3] and
- * dcolor_all[n_views*P*3] are device arrays. */
+ * dcolor_all[n_views*P*3] are device arrays; view_stride = rows between consecutive views in dcolor_all (0 = P: dense;
+ * the all-gather buffer of the trainer carries one extra row per view). */
 int sgr_sh_grad_from_views(int P, int n_views, int D, int M, const float* means3D, const float* campos_all,
-                           const float* dcolor_all, float* dL_dsh, void* stream);
+                           const float* dcolor_all, int64_t view_stride, float* dL_dsh, void* stream);
 
 /* The same sum consumed on the spot: one Adam step (the update of sgr_adam_step, learning rate lr_dc for the three DC
  * values of a Gaussian and lr_rest for the others, gaussian_model.py:157-158) on sh_params[P*M*3] with its moment buffers;
  * the 48-float SH gradient is never written to memory.  means3D must be the values the views were rendered with (call
  * this before the positions are updated). */
 int sgr_sh_adam_from_views(int P, int n_views, int D, int M, const float* means3D, const float* campos_all,
-                           const float* dcolor_all, float* sh_params, float* exp_avg, float* exp_avg_sq, float lr_dc,
+                           const float* dcolor_all, int64_t view_stride, float* sh_params, float* exp_avg, float* exp_avg_sq,
+                           float lr_dc,
                            float lr_rest, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
 
 /* Rasterizer::markVisible, DGR/cuda_rasterizer/rasterizer.h:24-29 / rasterizer_impl.cu:141-153.

@@ -310,19 +310,21 @@ int sgr_backward(int P, int D, int M, int64_t R, const float* background, int wi
 }
 
 int sgr_sh_grad_from_views(int P, int n_views, int D, int M, const float* means3D, const float* campos_all,
-                           const float* dcolor_all, float* dL_dsh, void* stream)
+                           const float* dcolor_all, int64_t view_stride, float* dL_dsh, void* stream)
 {
     if (P <= 0) return 0;
     if (n_views <= 0 || D < 0 || D > 3 || M < (D + 1) * (D + 1) || M > 16 || !means3D || !campos_all || !dcolor_all || !dL_dsh)
         return fail(SGR_E_INVALID, "sgr_sh_grad_from_views: bad arguments");
-    sgr_launch_sh_grad_from_views(P, n_views, D, M, means3D, campos_all, dcolor_all, dL_dsh, (hipStream_t)stream);
+    if (view_stride != 0 && view_stride < P) return fail(SGR_E_INVALID, "sgr_sh_grad_from_views: view_stride < P");
+    sgr_launch_sh_grad_from_views(P, n_views, D, M, (size_t)(view_stride ? view_stride : P), means3D, campos_all, dcolor_all, dL_dsh,
+                                  (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SGR_E_HIP, std::string("sh_grad_from_views: ") + hipGetErrorString(e));
     return 0;
 }
 
 int sgr_sh_adam_from_views(int P, int n_views, int D, int M, const float* means3D, const float* campos_all,
-                           const float* dcolor_all, float* sh_params, float* exp_avg, float* exp_avg_sq, float lr_dc,
+                           const float* dcolor_all, int64_t view_stride, float* sh_params, float* exp_avg, float* exp_avg_sq, float lr_dc,
                            float lr_rest, float beta1, float beta2, float eps, int step, float grad_scale, void* stream)
 {
     if (P <= 0) return 0;
@@ -331,7 +333,8 @@ int sgr_sh_adam_from_views(int P, int n_views, int D, int M, const float* means3
         return fail(SGR_E_INVALID, "sgr_sh_adam_from_views: bad argument");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
-    sgr_launch_sh_adam_from_views(P, n_views, D, M, means3D, campos_all, dcolor_all, sh_params, exp_avg, exp_avg_sq, lr_dc, lr_rest,
+    if (view_stride != 0 && view_stride < P) return fail(SGR_E_INVALID, "sgr_sh_adam_from_views: view_stride < P");
+    sgr_launch_sh_adam_from_views(P, n_views, D, M, (size_t)(view_stride ? view_stride : P), means3D, campos_all, dcolor_all, sh_params, exp_avg, exp_avg_sq, lr_dc, lr_rest,
                                   beta1, beta2, eps, bc1, bc2_sqrt, grad_scale, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SGR_E_HIP, std::string("sh_adam_from_views: ") + hipGetErrorString(e));

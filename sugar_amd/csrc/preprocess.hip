@@ -518,7 +518,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
 // dL/dsh[k][c] = sum over views v of  basis_k(dir_v) * g_v[c]   with dir_v = normalize(mean - campos_v) and g_v the
 // clamp-masked dL/dRGB of view v -- exactly the per-view SH backward (backward.cu:47-97) summed over views, but the views
 // exchange 3 floats per Gaussian instead of 3*M.  dirs use the same arithmetic as the forward (glm::length, division).
-__device__ __forceinline__ void sh_grad_sum_over_views(int idx, int P, int V, int D, const float* __restrict__ means3D,
+__device__ __forceinline__ void sh_grad_sum_over_views(int idx, size_t P, int V, int D, const float* __restrict__ means3D,
                                                        const float* __restrict__ campos, const float* __restrict__ dcolor,
                                                        float* acc)
 {
@@ -557,14 +557,15 @@ __device__ __forceinline__ void sh_grad_sum_over_views(int idx, int P, int V, in
     }
 }
 
-__global__ void __launch_bounds__(256) k_sh_grad_from_views(int P, int V, int D, int M, const float* __restrict__ means3D,
+__global__ void __launch_bounds__(256) k_sh_grad_from_views(int P, int V, int D, int M, size_t vstride,
+                                                            const float* __restrict__ means3D,
                                                             const float* __restrict__ campos, const float* __restrict__ dcolor,
                                                             float* __restrict__ dL_dsh)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P) return;
     float acc[48];
-    sh_grad_sum_over_views(idx, P, V, D, means3D, campos, dcolor, acc);
+    sh_grad_sum_over_views(idx, vstride, V, D, means3D, campos, dcolor, acc);
     const int n_sh = 3 * M;
     float* dst = dL_dsh + (size_t)idx * n_sh;
     if (n_sh == 48 && ((uintptr_t)dst & 15) == 0) {
@@ -588,7 +589,8 @@ struct ShAdamArgs {
 // one contiguous stream, one float4 per lane and step (a lane-per-Gaussian walk touches 64 cache lines per instruction
 // and ran at 2 TB/s).
 #define SHA_STRIDE 52
-__global__ void __launch_bounds__(64) k_sh_adam_from_views(int P, int V, int D, int M, const float* __restrict__ means3D,
+__global__ void __launch_bounds__(64) k_sh_adam_from_views(int P, int V, int D, int M, size_t vstride,
+                                                           const float* __restrict__ means3D,
                                                            const float* __restrict__ campos, const float* __restrict__ dcolor,
                                                            float* __restrict__ sh, float* __restrict__ exp_avg,
                                                            float* __restrict__ exp_avg_sq, ShAdamArgs a)
@@ -599,7 +601,7 @@ __global__ void __launch_bounds__(64) k_sh_adam_from_views(int P, int V, int D, 
     const int idx = g0 + lane;
     {
         float acc[48];
-        if (idx < P) sh_grad_sum_over_views(idx, P, V, D, means3D, campos, dcolor, acc);
+        if (idx < P) sh_grad_sum_over_views(idx, vstride, V, D, means3D, campos, dcolor, acc);
         else {
 #pragma unroll
             for (int k = 0; k < 48; k++) acc[k] = 0.f;
@@ -774,20 +776,20 @@ void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
     hipLaunchKernelGGL(k_preprocess_bwd, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
 }
 
-void sgr_launch_sh_adam_from_views(int P, int V, int D, int M, const float* means3D, const float* campos, const float* dcolor,
-                                   float* sh, float* exp_avg, float* exp_avg_sq, float lr_dc, float lr_rest, float b1, float b2,
+void sgr_launch_sh_adam_from_views(int P, int V, int D, int M, size_t vstride, const float* means3D, const float* campos,
+                                   const float* dcolor, float* sh, float* exp_avg, float* exp_avg_sq, float lr_dc, float lr_rest, float b1, float b2,
                                    float eps, float bc1, float bc2_sqrt, float grad_scale, hipStream_t s)
 {
     ShAdamArgs a = {lr_dc, lr_rest, b1, b2, eps, bc1, bc2_sqrt, grad_scale};
-    hipLaunchKernelGGL(k_sh_adam_from_views, dim3((P + 63) / 64), dim3(64), 0, s, P, V, D, M, means3D, campos, dcolor, sh,
+    hipLaunchKernelGGL(k_sh_adam_from_views, dim3((P + 63) / 64), dim3(64), 0, s, P, V, D, M, vstride, means3D, campos, dcolor, sh,
                        exp_avg, exp_avg_sq, a);
 }
 
-void sgr_launch_sh_grad_from_views(int P, int V, int D, int M, const float* means3D, const float* campos, const float* dcolor,
-                                   float* dL_dsh, hipStream_t s)
+void sgr_launch_sh_grad_from_views(int P, int V, int D, int M, size_t vstride, const float* means3D, const float* campos,
+                                   const float* dcolor, float* dL_dsh, hipStream_t s)
 {
-    if (P <= 0) return;
-    hipLaunchKernelGGL(k_sh_grad_from_views, dim3((P + 255) / 256), dim3(256), 0, s, P, V, D, M, means3D, campos, dcolor, dL_dsh);
+    hipLaunchKernelGGL(k_sh_grad_from_views, dim3((P + 255) / 256), dim3(256), 0, s, P, V, D, M, vstride, means3D, campos, dcolor,
+                       dL_dsh);
 }
 
 static int sh_rgb_args(ShRgbArgs& a, int P, int D, int M, const float* sh, const float* positions, const float* centers,

@@ -121,11 +121,11 @@ struct PreprocessBwdArgs {
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
 };
 void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
-void sgr_launch_sh_grad_from_views(int P, int V, int D, int M, const float* means3D, const float* campos, const float* dcolor,
-                                   float* dL_dsh, hipStream_t s);
+void sgr_launch_sh_grad_from_views(int P, int V, int D, int M, size_t vstride, const float* means3D, const float* campos,
+                                   const float* dcolor, float* dL_dsh, hipStream_t s);
 
-void sgr_launch_sh_adam_from_views(int P, int V, int D, int M, const float* means3D, const float* campos, const float* dcolor,
-                                   float* sh, float* exp_avg, float* exp_avg_sq, float lr_dc, float lr_rest, float b1, float b2,
+void sgr_launch_sh_adam_from_views(int P, int V, int D, int M, size_t vstride, const float* means3D, const float* campos,
+                                   const float* dcolor, float* sh, float* exp_avg, float* exp_avg_sq, float lr_dc, float lr_rest, float b1, float b2,
                                    float eps, float bc1, float bc2_sqrt, float grad_scale, hipStream_t s);
 
 void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_out, const uint2* rect_by_id, uint2* rects_sorted,

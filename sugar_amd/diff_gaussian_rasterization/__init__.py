@@ -160,7 +160,7 @@ class _CModule:
         # (the reference allocates nine torch::zeros, rasterize_points.cu:151-159).
         dL_dmeans3D = _sink_or_empty(grad_out, "means3D", (P, 3), **f)
         dL_dmeans2D = torch.empty(P, 3, **f)
-        dL_dcolors = torch.empty(P, 3, **f)
+        dL_dcolors = _sink_or_empty(grad_out, "colors", (P, 3), **f)
         dL_dconic = torch.empty(P, 2, 2, **f)
         dL_dopacity = torch.empty(P, 1, **f)
         dL_dcov3D = torch.empty(P, 6, **f)

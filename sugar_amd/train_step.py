@@ -233,9 +233,10 @@ class FlatAdam:
             if sh_views is not None:
                 means3D, campos_all, dcolor_all, sh_degree = sh_views
                 off = p.offsets["features"]
+                dcol, vstride = _view_rows(dcolor_all)
                 rc = self._lib.sgr_sh_adam_from_views(
                     p.P, int(dcolor_all.shape[0]), int(sh_degree), p.M, vp(means3D), vp(campos_all.contiguous()),
-                    vp(dcolor_all.contiguous()), C.c_void_p(p.flat.data_ptr() + 4 * off),
+                    vp(dcol), int(vstride), C.c_void_p(p.flat.data_ptr() + 4 * off),
                     C.c_void_p(self.exp_avg.data_ptr() + 4 * off), C.c_void_p(self.exp_avg_sq.data_ptr() + 4 * off),
                     p.LRS["features"], p.REST_LR, self.betas[0], self.betas[1], self.eps, self.t, float(grad_scale), stream)
                 if rc < 0:
@@ -262,6 +263,15 @@ def render(params: GaussianParams, cam, bg, rasterizer_cls, settings_cls, sh_deg
     return dict(render=image, viewspace_points=screenspace_points, visibility_filter=radii > 0, radii=radii)
 
 
+def _view_rows(dcolor_all):
+    """(tensor, rows between views) for a [V,P,3] tensor that is dense or a row-slice of a dense [V,P+k,3] buffer"""
+    V, P = dcolor_all.shape[0], dcolor_all.shape[1]
+    st = dcolor_all.stride()
+    if st[2] == 1 and st[1] == 3 and (V == 1 or (st[0] % 3 == 0 and st[0] // 3 >= P)):
+        return dcolor_all, (st[0] // 3 if V > 1 else P)
+    return dcolor_all.contiguous(), P
+
+
 def sh_grad_from_views(means3D, campos_all, dcolor_all, sh_degree, out):
     """out[P,M,3] = sum over views of basis(normalize(means3D - campos_v)) (x) dcolor_all[v]  (HIP: sgr_sh_grad_from_views)"""
     import ctypes as C
@@ -273,9 +283,10 @@ def sh_grad_from_views(means3D, campos_all, dcolor_all, sh_degree, out):
     M = out.shape[1]
     dev = means3D.device
     with torch.cuda.device(dev):
+        dcol, vstride = _view_rows(dcolor_all)
         rc = lib.sgr_sh_grad_from_views(P, V, int(sh_degree), M, C.c_void_p(means3D.contiguous().data_ptr()),
                                         C.c_void_p(campos_all.contiguous().data_ptr()),
-                                        C.c_void_p(dcolor_all.contiguous().data_ptr()), C.c_void_p(out.data_ptr()),
+                                        C.c_void_p(dcol.data_ptr()), int(vstride), C.c_void_p(out.data_ptr()),
                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     if rc < 0:
         raise RuntimeError(f"sgr_sh_grad_from_views failed ({rc})")
@@ -307,6 +318,7 @@ class ViewShardedTrainer:
         if grad_sink_cm is None and params.flat.is_cuda:
             from .diff_gaussian_rasterization import grad_sink as grad_sink_cm
         self.grad_sink_cm = grad_sink_cm  # context manager factory honoured by the rasterizer's backward (None: plain autograd)
+        self._send = self._recv = None    # all-gather buffers of the compact exchange
 
     def step(self, cam, gt_image):
         """gaussian_splatting/train.py:86-128 for one view per rank.  Gradients are taken with torch.autograd.grad and
@@ -321,6 +333,12 @@ class ViewShardedTrainer:
             sinks = dict(means3D=p.params["xyz"].grad)
             if self.compact_sh:
                 sinks.update(compact_sh=True, out=holder)
+                if self.world > 1:
+                    # the masked colour gradients land in the send buffer of the all-gather, followed by the camera centre
+                    if self._send is None:
+                        self._send = torch.empty(p.P + 1, 3, dtype=torch.float32, device=p.flat.device)
+                        self._recv = torch.empty(self.world * (p.P + 1), 3, dtype=torch.float32, device=p.flat.device)
+                    sinks.update(colors=self._send[: p.P])
             else:
                 sinks.update(shs=p.params["features"].grad)
             ctxm = self.grad_sink_cm(**sinks)
@@ -345,11 +363,15 @@ class ViewShardedTrainer:
                 campos = cam.campos.reshape(1, 3).to(g_rgb.dtype).contiguous()
                 if self.world > 1:
                     P_ = g_rgb.shape[0]
-                    all_rgb = torch.empty(self.world * P_, 3, dtype=g_rgb.dtype, device=g_rgb.device)  # rank-major concat
-                    all_cam = torch.empty(self.world, 3, dtype=g_rgb.dtype, device=g_rgb.device)
-                    dist.all_gather_into_tensor(all_rgb, g_rgb)
-                    dist.all_gather_into_tensor(all_cam, campos)
-                    all_rgb = all_rgb.view(self.world, P_, 3)
+                    if self._send is None or g_rgb.device != self._send.device:  # (a rasterizer that ignored the sink)
+                        self._send = torch.empty(P_ + 1, 3, dtype=g_rgb.dtype, device=g_rgb.device)
+                        self._recv = torch.empty(self.world * (P_ + 1), 3, dtype=g_rgb.dtype, device=g_rgb.device)
+                    if g_rgb.data_ptr() != self._send.data_ptr():
+                        self._send[:P_].copy_(g_rgb)
+                    self._send[P_:].copy_(campos)
+                    dist.all_gather_into_tensor(self._recv, self._send)  # one collective: colours and camera centres
+                    blocks = self._recv.view(self.world, P_ + 1, 3)
+                    all_rgb, all_cam = blocks[:, :P_], blocks[:, P_].contiguous()
                     dist.all_reduce(p.flat_grad[: p.n_small], op=dist.ReduceOp.SUM)
                 else:
                     all_rgb, all_cam = g_rgb[None], campos

@@ -105,3 +105,19 @@ def test_fused_activations_match_torch_ops():
         # (the seven zero quaternions give 1e12-sized gradients: compare them apart from the regular rows)
         assert torch.allclose(x[:7], y[:7], rtol=2e-5, atol=1e-6 * float(x[:7].abs().max()))
         assert torch.allclose(x[7:], y[7:], rtol=2e-5, atol=2e-6 * float(x[7:].abs().max())), float((x[7:] - y[7:]).abs().max())
+
+
+def test_view_stride_of_the_gathered_buffer():
+    """the all-gather buffer holds P + 1 rows per rank (colours, then the camera centre): the kernels read it in place"""
+    from sugar_amd.train_step import sh_grad_from_views, _view_rows
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(5)
+    P, V = 7001, 3
+    means = torch.randn(P, 3, generator=g).to(dev)
+    buf = torch.randn(V, P + 1, 3, generator=g).to(dev)
+    cams = buf[:, P].contiguous()
+    view = buf[:, :P]
+    assert not view.is_contiguous() and _view_rows(view)[1] == P + 1
+    a = sh_grad_from_views(means, cams, view, 3, torch.empty(P, 16, 3, device=dev))
+    b = sh_grad_from_views(means, cams, view.contiguous(), 3, torch.empty(P, 16, 3, device=dev))
+    assert torch.equal(a, b) and float(a.abs().max()) > 0
