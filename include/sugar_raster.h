@@ -104,7 +104,9 @@ int sgr_sh_adam_from_views(int P, int n_views, int D, int M, const float* means3
 int sgr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);
 
-/* Scratch sizes (bytes) for a given problem; the callbacks are asked for exactly these. */
+/* Scratch sizes (bytes) for a given problem.  The geometry and binning callbacks are asked for exactly these; the image
+ * callback is asked for sgr_img_bytes(width, height) PLUS the scratch of the two-level binning (which also depends on P),
+ * appended after the image state -- the offsets below stay valid. */
 size_t sgr_geom_bytes(int P);
 size_t sgr_img_bytes(int width, int height);
 size_t sgr_binning_bytes(int64_t R);

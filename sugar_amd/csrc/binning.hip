@@ -8,9 +8,12 @@
 // by sorting the P GAUSSIANS by depth once and then binning them into tiles IN THAT ORDER with a stable counting sort,
 // so every tile's list comes out depth-sorted and no per-instance sort exists at all:
 //
+// (This file holds the depth sort and the SINGLE-LEVEL binning, which is the fallback path; the default two-level binning
+//  lives in binning2.hip.)
 //   gsort      : stable LSD radix sort (4 x 8-bit passes) of (depth_bits, gaussian_id) over the P Gaussians.  Culled
 //                Gaussians carry key 0xFFFFFFFF and sink to the end.  Ties keep ascending id.
-//   pack_rects : tile rectangles of the Gaussians in sorted order, 8 bytes each (the walks below stream them)
+//                The last pass also carries each Gaussian's packed tile rectangle (8 bytes, written by the preprocess
+//                kernel) into sorted order: the walks below stream it.
 //   bin_count  : workgroup b owns a contiguous slice of the sorted order and a private histogram over all T tiles in LDS;
 //                one lane per Gaussian (counting needs no order).
 //   hist_scan  : column-wise exclusive scan over the slices of blk_hist[slice][t] (in place) + per-tile totals
@@ -162,26 +165,6 @@ __global__ void __launch_bounds__(64) k_rs_scatter(int n, const uint32_t* __rest
 // ---------------------------------------------------------------------------------------------------------------------
 // Tile rectangles in sorted order, packed {minx | miny << 16, w | h << 16} (w == 0: culled), so the ordered walks stream
 // 8 contiguous bytes per Gaussian instead of chasing order[] -> rec[] through two dependent random loads.
-__global__ void __launch_bounds__(256) k_pack_rects(int P, int gx, int gy, const uint32_t* __restrict__ order,
-                                                    const GeomRec* __restrict__ rec, uint2* __restrict__ rects)
-{
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= P) return;
-    const uint32_t id = order[s];
-    const float4* rp = reinterpret_cast<const float4*>(rec + id);
-    const float4 r2 = rp[2];
-    const int radius = __float_as_int(r2.z);
-    uint2 out = make_uint2(0u, 0u);
-    if (radius > 0) {
-        const float4 r0 = rp[0];
-        int minx, miny, maxx, maxy;
-        sgr_get_rect(r0.x, r0.y, radius, gx, gy, minx, miny, maxx, maxy);
-        out.x = (uint32_t)minx | ((uint32_t)miny << 16);
-        out.y = (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16);
-    }
-    rects[s] = out;
-}
-
 // Counting needs no order: workgroup b histograms the tiles of its slice of the depth order with one lane per Gaussian
 // (LDS atomics), 16 waves per CU.
 __global__ void __launch_bounds__(256) k_bin_count(int P, int gx, int gy, int per_slice, const uint2* __restrict__ rects,
@@ -394,12 +377,6 @@ void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_
         kin = kout; vin = vout;
     }
     *order_out = vals_a;  // pass 0 -> b, 1 -> a, 2 -> b, 3 -> a
-}
-
-void sgr_launch_pack_rects(int P, int gx, int gy, const uint32_t* order, const GeomRec* rec, uint2* rects, hipStream_t s)
-{
-    if (P <= 0) return;
-    hipLaunchKernelGGL(k_pack_rects, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, gy, order, rec, rects);
 }
 
 static void set_lds_limit(const void* fn, size_t bytes, size_t& configured)

@@ -131,7 +131,6 @@ void sgr_launch_sh_adam_from_views(int P, int V, int D, int M, size_t vstride, c
 void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_out, const uint2* rect_by_id, uint2* rects_sorted,
                               hipStream_t s);
 size_t sgr_sort_rect_by_id_offset(int P);  // binning.hip: the by-id rectangles written by the preprocess kernel
-void sgr_launch_pack_rects(int P, int gx, int gy, const uint32_t* order, const GeomRec* rec, uint2* rects, hipStream_t s);
 void sgr_launch_bin_count(int P, int gx, int gy, int n_slices, int per_slice, const uint32_t* order, const uint2* rects,
                           uint32_t* blk_hist, hipStream_t s);
 void sgr_launch_bin_scatter(int P, int gx, int gy, int n_slices, int per_slice, const uint32_t* order, const uint2* rects,
