@@ -3,7 +3,9 @@
 // Replaces renderCUDA forward  DGR/cuda_rasterizer/forward.cu:261-374
 //      and renderCUDA backward DGR/cuda_rasterizer/backward.cu:399-557.
 //
-// One 256-thread workgroup (4 wave64) per 16x16 tile; lane l of wave w owns pixel (x = l & 15, y = 4w + (l >> 4)).
+// One 256-thread workgroup (4 wave64) per 16x16 tile.  Forward: wave w owns the 8x8 pixel block (w & 1, w >> 1), lane l its
+// pixel (l & 7, l >> 3); backward: wave w owns the 16x4 strip of rows 4w.., lane l pixel (l & 15, l >> 4) (its phase B walks
+// rows of 16 pixels).
 // The tile's depth-sorted Gaussian list is staged through LDS in batches: each thread gathers ONE 48-byte
 // GeomRec (three dwordx4 loads from one or two cache lines) and the whole workgroup then walks the batch
 // with uniform-address (broadcast, conflict-free) LDS reads.
@@ -63,6 +65,35 @@ __device__ __forceinline__ uint32_t strip_hit_mask(float gxc, float gyc, float c
     return m;
 }
 
+// The same test for the forward's wave shape: four 8 x 8 pixel blocks in a 2 x 2 arrangement (bit w: block (w & 1, w >> 1)).
+// A square block is touched by ~10 % fewer splats than a 16 x 4 strip of the same area.
+__device__ __forceinline__ uint32_t block_hit_mask(float gxc, float gyc, float cx, float cy, float cz, float op, float x0,
+                                                   float y0)
+{
+    if (op < 1.0f / 255.0f) return 0u;
+    const float det = cx * cz - cy * cy;
+    if (!(det > 0.f) || !(cx > 0.f) || !(cz > 0.f)) return 0xFu;
+    const float tau2 = 2.0f * __logf(255.0f * op) * 1.002f + 1e-3f;
+    const float icx = __builtin_amdgcn_rcpf(cx), icz = __builtin_amdgcn_rcpf(cz);
+    const float det_cz = det * icz, det_cx = det * icx;
+    const float kyx = -cy * icz, kxy = -cy * icx;
+    uint32_t m = 0u;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const float dxl = x0 + 8.0f * (w & 1) - gxc, dxr = dxl + 7.0f;
+        const float dyl = y0 + 8.0f * (w >> 1) - gyc, dyh = dyl + 7.0f;
+        const float sL = kyx * dxl, sR = kyx * dxr;
+        const float tL = fminf(fmaxf(sL, dyl), dyh) - sL, tR = fminf(fmaxf(sR, dyl), dyh) - sR;
+        float q = fminf(det_cz * dxl * dxl + cz * tL * tL, det_cz * dxr * dxr + cz * tR * tR);
+        const float sT = kxy * dyl, sB = kxy * dyh;
+        const float tT = fminf(fmaxf(sT, dxl), dxr) - sT, tB = fminf(fmaxf(sB, dxl), dxr) - sB;
+        q = fminf(q, fminf(det_cx * dyl * dyl + cx * tT * tT, det_cx * dyh * dyh + cx * tB * tB));
+        const bool inside = dxl <= 0.f && dxr >= 0.f && dyl <= 0.f && dyh >= 0.f;
+        if (inside || q <= tau2) m |= 1u << w;
+    }
+    return m;
+}
+
 // x summed over the four 16-lane rows of the wave (lanes l, l+16, l+32, l+48), result in every lane: two gfx950 lane-swap
 // VALU ops instead of two ds_bpermute round trips through the LDS pipeline.
 __device__ __forceinline__ float sum_over_rows(float x)
@@ -103,7 +134,8 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int x0 = tx * SGR_TILE_X, y0 = ty * SGR_TILE_Y;
-    const int px = x0 + (tid & 15), py = y0 + (tid >> 4);
+    // wave w owns the 8 x 8 pixel block (w & 1, w >> 1) of the tile, lane l the pixel (l & 7, l >> 3) of it
+    const int px = x0 + 8 * (wave & 1) + (lane & 7), py = y0 + 8 * (wave >> 1) + (lane >> 3);
     const bool inside = px < W && py < H;
     const float pixfx = (float)px, pixfy = (float)py;
     const uint32_t r0 = tile_start[tile], r1 = tile_start[tile + 1];
@@ -128,7 +160,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
             const uint32_t id = point_list[r0 + base + tid];
             const float4* rp = reinterpret_cast<const float4*>(rec + id);
             const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
-            hit = strip_hit_mask(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)x0, (float)y0);
+            hit = block_hit_mask(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)x0, (float)y0);
             st.a[tid] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
             st.b[tid] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v1.z, v1.w);
             st.c[tid] = v2.x;
