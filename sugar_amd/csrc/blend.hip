@@ -204,16 +204,16 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
             last_contributor = upd ? pos : last_contributor;
             done = done || stop;
 #ifdef SGR_COUNT
-            {   // lanes that pass the tests, per 16-lane row (4x... here: 16x1 pixel rows) and per wave iteration
+            {   // lanes that pass the tests per wave iteration, and how many 8x2 row pairs / 4x4 sub-blocks hold one
                 const unsigned long long okm = __ballot(ok);
                 if (lane == 0) {
-                    atomicAdd(&g_sgr_count[0], 1ull);                       // (entry, wave) iterations
+                    atomicAdd(&g_sgr_count[0], 1ull);                               // (entry, wave) iterations
                     atomicAdd(&g_sgr_count[1], (unsigned long long)__popcll(okm));  // passing lanes
                     int rows = ((okm & 0xFFFFull) != 0) + ((okm & 0xFFFF0000ull) != 0) + ((okm & 0xFFFF00000000ull) != 0) + ((okm >> 48) != 0);
-                    atomicAdd(&g_sgr_count[2], (unsigned long long)rows);   // 16x1 rows with a passing lane
-                    // 4x4 blocks with a passing lane: lane = (y&3)*16 + x -> block = x>>2
-                    int blocks = 0;
-                    for (int bq = 0; bq < 4; bq++) { unsigned long long m = 0xFull << (4 * bq); m = m | (m << 16) | (m << 32) | (m << 48); blocks += (okm & m) != 0; }
+                    atomicAdd(&g_sgr_count[2], (unsigned long long)rows);
+                    // lane = 8 * y + x: sub-block (x >> 2, y >> 2)
+                    const unsigned long long m00 = 0x0F0F0F0Full, m10 = 0xF0F0F0F0ull;
+                    const int blocks = ((okm & m00) != 0) + ((okm & m10) != 0) + ((okm & (m00 << 32)) != 0) + ((okm & (m10 << 32)) != 0);
                     atomicAdd(&g_sgr_count[3], (unsigned long long)blocks);
                 }
             }

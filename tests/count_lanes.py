@@ -13,4 +13,4 @@ for name in ("metric", "config2"):
     torch.cuda.synchronize()
     lib.sgr_debug_counts(buf)
     it, ok, rows, blocks = buf[0], buf[1], buf[2], buf[3]
-    print(name, "wave-iterations", it, "ok lanes/iter", ok / it, "16x1 rows/iter", rows / it, "4x4 blocks/iter", blocks / it, flush=True)
+    print(name, "wave-iterations", it, "ok lanes/iter", ok / it, "8x2 row pairs/iter", rows / it, "4x4 blocks/iter", blocks / it, flush=True)
