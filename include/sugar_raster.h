@@ -82,6 +82,23 @@ int sgr_backward(int P, int D, int M, int64_t R,
                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                  int debug, void* stream);
 
+/* sgr_backward in two halves for the compact SH mode (shs given, dL_dsh == NULL), same arguments:
+ *   phase 1: accumulator reset + blend backward, then the clamp-masked colour gradients into dL_dcolor[P*3] -- they are
+ *            final here, so a view-sharded trainer can start their all-gather;
+ *   phase 2: the backward preprocess (every other output; dL_dcolor is not touched again);
+ *   phase 0: both, identical to sgr_backward. */
+int sgr_backward_phase(int phase, int P, int D, int M, int64_t R,
+                       const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* scales, float scale_modifier, const float* rotations,
+                       const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                       const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii,
+                       char* geom_buffer, char* binning_buffer, char* img_buffer,
+                       const float* dL_dpix,
+                       float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                       int debug, void* stream);
+
 /* SH gradient from per-view masked colour gradients (view-sharded training exchanges 12 B per Gaussian and view instead
  * of 12*M B):  dL_dsh[P*M*3] = sum_v basis(normalize(means3D - campos_all[v])) (x) dcolor_all[v][P*3]   (the per-view
  * computeColorFromSH backward, backward.cu:47-97, summed over the n_views views).  campos_all[n_views*3] and

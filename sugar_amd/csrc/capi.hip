@@ -253,16 +253,18 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     return R;
 }
 
-int sgr_backward(int P, int D, int M, int64_t R, const float* background, int width, int height, const float* means3D,
-                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                 const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer,
-                 char* binning_buffer, char* img_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
-                 float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                 float* dL_dscale, float* dL_drot, int debug, void* stream)
+// phase 0: everything; 1: the blend half (accumulator reset, blend backward, and in compact mode the masked colour
+// gradients into dL_dcolor); 2: the preprocess half (in compact mode dL_dcolor is left alone: phase 1 wrote it)
+static int backward_impl(int phase, int P, int D, int M, int64_t R, const float* background, int width, int height,
+                         const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                         float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                         const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, char* geom_buffer,
+                         char* binning_buffer, char* img_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                         float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                         float* dL_dscale, float* dL_drot, int debug, void* stream)
 {
-    (void)radii;  // the private geometry record carries the radius
     hipStream_t s = (hipStream_t)stream;
+    if (phase < 0 || phase > 2) return fail(SGR_E_INVALID, "phase must be 0, 1 or 2");
     if (P <= 0 || width <= 0 || height <= 0) return fail(SGR_E_INVALID, "P, width and height must be positive");
     if (!geom_buffer || !binning_buffer || !img_buffer || !dL_dpix) return fail(SGR_E_INVALID, "null scratch / dL_dpix");
     if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
@@ -270,7 +272,9 @@ int sgr_backward(int P, int D, int M, int64_t R, const float* background, int wi
     const bool use_sh = shs && !colors_precomp;
     // use_sh with dL_dsh == NULL selects the compact mode: dL_dcolor receives the clamp-masked colour gradients and no
     // SH gradient is materialised (see sgr_sh_grad_from_views)
+    const bool compact = use_sh && !dL_dsh;
     if (!cov3D_precomp && (!dL_dscale || !dL_drot)) return fail(SGR_E_INVALID, "dL_dscale/dL_drot required");
+    if (phase != 0 && !compact) return fail(SGR_E_INVALID, "the two-phase backward is for the compact SH mode");
 
     const ImgLayout IL = sgr_img_layout(width, height);
     const BinLayout BL = sgr_bin_layout(R);
@@ -283,13 +287,20 @@ int sgr_backward(int P, int D, int M, int64_t R, const float* background, int wi
 
     // the blend backward accumulates nine sums per Gaussian with atomics into the private acc[P][12] table
     float* acc = reinterpret_cast<float*>(geom_buffer + sgr_geom_acc_offset(P));
-    HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * 48, s));
-    if (R > 0) {
-        StageTimer t(s, SGR_STAGE_BLEND_BWD);
-        sgr_launch_blend_bwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
-                             tile_maxc, dL_dpix, acc, s);
+    if (phase != 2) {
+        HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * 48, s));
+        if (R > 0) {
+            StageTimer t(s, SGR_STAGE_BLEND_BWD);
+            sgr_launch_blend_bwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
+                                 tile_maxc, dL_dpix, acc, s);
+        }
+        STAGE_CHECK("blend_bwd");
+        if (phase == 1) {
+            sgr_launch_masked_colors(P, rec, acc, dL_dcolor, s);
+            STAGE_CHECK("masked_colors");
+            return 0;
+        }
     }
-    STAGE_CHECK("blend_bwd");
     PreprocessBwdArgs pb;
     pb.P = P; pb.D = D; pb.M = use_sh ? M : 0;
     pb.means3D = means3D; pb.shs = use_sh ? shs : nullptr;
@@ -301,12 +312,43 @@ int sgr_backward(int P, int D, int M, int64_t R, const float* background, int wi
     pb.focal_x = width / (2.0f * tan_fovx);
     pb.rec = rec;
     pb.acc = acc;
-    pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;
+    pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dopacity = dL_dopacity;
+    pb.dL_dcolor = phase == 2 ? nullptr : dL_dcolor;  // phase 2: already written (and possibly being sent) by phase 1
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_dsh = use_sh ? dL_dsh : nullptr;
     pb.dL_dscale = cov3D_precomp ? nullptr : dL_dscale; pb.dL_drot = cov3D_precomp ? nullptr : dL_drot;
     { StageTimer t(s, SGR_STAGE_PREPROCESS_BWD); sgr_launch_preprocess_bwd(pb, s); }
     STAGE_CHECK("preprocess_bwd");
     return 0;
+}
+
+int sgr_backward(int P, int D, int M, int64_t R, const float* background, int width, int height, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer,
+                 char* binning_buffer, char* img_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                 float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                 float* dL_dscale, float* dL_drot, int debug, void* stream)
+{
+    (void)radii;  // the private geometry record carries the radius
+    return backward_impl(0, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations,
+                         cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, geom_buffer, binning_buffer, img_buffer,
+                         dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
+                         debug, stream);
+}
+
+int sgr_backward_phase(int phase, int P, int D, int M, int64_t R, const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                       float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                       const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii,
+                       char* geom_buffer, char* binning_buffer, char* img_buffer, const float* dL_dpix, float* dL_dmean2D,
+                       float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                       float* dL_dscale, float* dL_drot, int debug, void* stream)
+{
+    (void)radii;
+    return backward_impl(phase, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier,
+                         rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, geom_buffer, binning_buffer,
+                         img_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
+                         dL_drot, debug, stream);
 }
 
 int sgr_sh_grad_from_views(int P, int n_views, int D, int M, const float* means3D, const float* campos_all,

@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
         a.dL_dmean2D[i3] = 0; a.dL_dmean2D[i3 + 1] = 0; a.dL_dmean2D[i3 + 2] = 0;
         { float4 z4 = {0, 0, 0, 0}; *reinterpret_cast<float4*>(a.dL_dconic + 4 * (size_t)idx) = z4; }
         a.dL_dopacity[idx] = 0;
-        a.dL_dcolor[i3] = 0; a.dL_dcolor[i3 + 1] = 0; a.dL_dcolor[i3 + 2] = 0;
+        if (a.dL_dcolor) { a.dL_dcolor[i3] = 0; a.dL_dcolor[i3 + 1] = 0; a.dL_dcolor[i3 + 2] = 0; }
         a.dL_dmean3D[i3] = 0; a.dL_dmean3D[i3 + 1] = 0; a.dL_dmean3D[i3 + 2] = 0;
         for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = 0;
         if (a.dL_dsh) for (int k = 0; k < n_sh; k++) a.dL_dsh[(size_t)idx * n_sh + k] = 0;
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
         float4 gc = {g0, g1, 0.f, g3};
         *reinterpret_cast<float4*>(a.dL_dconic + 4 * (size_t)idx) = gc;
         a.dL_dopacity[idx] = s0.w;
-        a.dL_dcolor[i3] = dcol[0]; a.dL_dcolor[i3 + 1] = dcol[1]; a.dL_dcolor[i3 + 2] = dcol[2];
+        if (a.dL_dcolor) { a.dL_dcolor[i3] = dcol[0]; a.dL_dcolor[i3 + 1] = dcol[1]; a.dL_dcolor[i3 + 2] = dcol[2]; }
     }
     // ---- K9, backward.cu:144-274
     {
@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
             float oz = (-vv.x * vv.z * dL_ddir[0] - vv.y * vv.z * dL_ddir[1] + (sum2 - vv.z * vv.z) * dL_ddir[2]) * invsum32;
             dmean[0] += ox; dmean[1] += oy; dmean[2] += oz;
         }
-        if (!a.dL_dsh) {
+        if (!a.dL_dsh && a.dL_dcolor) {
             // compact mode (view-sharded training): the SH gradient is the outer product basis(dir) x (masked dL/dRGB), so
             // only the 3 masked colour gradients leave this kernel; sgr_sh_grad_from_views rebuilds sum over views later
             a.dL_dcolor[i3] = ((clamped >> 0) & 1u) ? 0.f : dcol[0];
@@ -518,6 +518,23 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
 // dL/dsh[k][c] = sum over views v of  basis_k(dir_v) * g_v[c]   with dir_v = normalize(mean - campos_v) and g_v the
 // clamp-masked dL/dRGB of view v -- exactly the per-view SH backward (backward.cu:47-97) summed over views, but the views
 // exchange 3 floats per Gaussian instead of 3*M.  dirs use the same arithmetic as the forward (glm::length, division).
+// The clamp-masked colour gradients of the compact mode on their own: they only need the blend backward's sums, so a
+// trainer can start exchanging them while the backward preprocess is still running (sgr_backward_phase).
+__global__ void __launch_bounds__(256) k_masked_colors(int P, const GeomRec* __restrict__ rec, const float* __restrict__ acc,
+                                                       float* __restrict__ out)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const GeomRec* rp = rec + idx;
+    const size_t i3 = 3 * (size_t)idx;
+    if (!(rp->radius > 0)) { out[i3] = 0.f; out[i3 + 1] = 0.f; out[i3 + 2] = 0.f; return; }
+    const uint32_t clamped = rp->clamped;
+    const float4 s0 = *reinterpret_cast<const float4*>(acc + 12 * (size_t)idx);
+    out[i3] = (clamped & 1u) ? 0.f : s0.x;
+    out[i3 + 1] = (clamped & 2u) ? 0.f : s0.y;
+    out[i3 + 2] = (clamped & 4u) ? 0.f : s0.z;
+}
+
 __device__ __forceinline__ void sh_grad_sum_over_views(int idx, size_t P, int V, int D, const float* __restrict__ means3D,
                                                        const float* __restrict__ campos, const float* __restrict__ dcolor,
                                                        float* acc)
@@ -774,6 +791,11 @@ void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
 {
     if (a.P <= 0) return;
     hipLaunchKernelGGL(k_preprocess_bwd, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+}
+
+void sgr_launch_masked_colors(int P, const GeomRec* rec, const float* acc, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_masked_colors, dim3((P + 255) / 256), dim3(256), 0, s, P, rec, acc, out);
 }
 
 void sgr_launch_sh_adam_from_views(int P, int V, int D, int M, size_t vstride, const float* means3D, const float* campos,

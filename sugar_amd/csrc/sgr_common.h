@@ -121,6 +121,7 @@ struct PreprocessBwdArgs {
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
 };
 void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
+void sgr_launch_masked_colors(int P, const GeomRec* rec, const float* acc, float* out, hipStream_t s);
 void sgr_launch_sh_grad_from_views(int P, int V, int D, int M, size_t vstride, const float* means3D, const float* campos,
                                    const float* dcolor, float* dL_dsh, hipStream_t s);
 

@@ -176,14 +176,23 @@ class _CModule:
             cov3D_precomp = _dev_f32(cov3D_precomp, dev, "cov3D_precomp")
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream(dev).cuda_stream
-                rc = lib.sgr_backward(
-                    P, int(degree), int(M), int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
-                    _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix.contiguous()),
-                    _ptr(projmatrix.contiguous()), _ptr(campos.contiguous()), float(tan_fovx), float(tan_fovy), _ptr(radii),
-                    _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL),
-                    _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D),
-                    _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations), int(bool(debug)),
-                    C.c_void_p(stream))
+                args = (P, int(degree), int(M), int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
+                        _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix.contiguous()),
+                        _ptr(projmatrix.contiguous()), _ptr(campos.contiguous()), float(tan_fovx), float(tan_fovy), _ptr(radii),
+                        _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL),
+                        _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D),
+                        _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations), int(bool(debug)),
+                        C.c_void_p(stream))
+                on_colors = grad_out.get("on_colors") if (compact_sh and grad_out) else None
+                if on_colors is not None:
+                    # two halves: the masked colour gradients are final after the blend half, so the caller can start
+                    # exchanging them while the preprocess half runs
+                    rc = lib.sgr_backward_phase(1, *args)
+                    if rc >= 0:
+                        on_colors(dL_dcolors)
+                        rc = lib.sgr_backward_phase(2, *args)
+                else:
+                    rc = lib.sgr_backward(*args)
             if rc < 0:
                 raise RuntimeError(f"sgr_backward failed ({rc}): {_lib.last_error()}")
         if compact_sh and isinstance(grad_out.get("out"), dict):

@@ -319,6 +319,15 @@ class ViewShardedTrainer:
             from .diff_gaussian_rasterization import grad_sink as grad_sink_cm
         self.grad_sink_cm = grad_sink_cm  # context manager factory honoured by the rasterizer's backward (None: plain autograd)
         self._send = self._recv = None    # all-gather buffers of the compact exchange
+        self._work = None                 # the all-gather in flight
+
+    def _start_gather(self, colors):
+        """Called by the rasterizer backward between its two halves: the masked colour gradients (already in the send
+        buffer, followed by the camera centre) are final, the backward preprocess has not been launched yet -- the all-gather
+        runs on the communication stream next to it."""
+        if colors.data_ptr() != self._send.data_ptr():
+            self._send[: colors.shape[0]].copy_(colors)
+        self._work = dist.all_gather_into_tensor(self._recv, self._send, async_op=True)
 
     def step(self, cam, gt_image):
         """gaussian_splatting/train.py:86-128 for one view per rank.  Gradients are taken with torch.autograd.grad and
@@ -338,7 +347,9 @@ class ViewShardedTrainer:
                     if self._send is None:
                         self._send = torch.empty(p.P + 1, 3, dtype=torch.float32, device=p.flat.device)
                         self._recv = torch.empty(self.world * (p.P + 1), 3, dtype=torch.float32, device=p.flat.device)
-                    sinks.update(colors=self._send[: p.P])
+                    self._send[p.P:].copy_(cam.campos.reshape(1, 3))
+                    self._work = None
+                    sinks.update(colors=self._send[: p.P], on_colors=self._start_gather)
             else:
                 sinks.update(shs=p.params["features"].grad)
             ctxm = self.grad_sink_cm(**sinks)
@@ -366,10 +377,14 @@ class ViewShardedTrainer:
                     if self._send is None or g_rgb.device != self._send.device:  # (a rasterizer that ignored the sink)
                         self._send = torch.empty(P_ + 1, 3, dtype=g_rgb.dtype, device=g_rgb.device)
                         self._recv = torch.empty(self.world * (P_ + 1), 3, dtype=g_rgb.dtype, device=g_rgb.device)
-                    if g_rgb.data_ptr() != self._send.data_ptr():
-                        self._send[:P_].copy_(g_rgb)
-                    self._send[P_:].copy_(campos)
-                    dist.all_gather_into_tensor(self._recv, self._send)  # one collective: colours and camera centres
+                    if self._work is not None:
+                        self._work.wait()  # the all-gather was started from inside the rasterizer backward (_start_gather)
+                        self._work = None
+                    else:
+                        if g_rgb.data_ptr() != self._send.data_ptr():
+                            self._send[:P_].copy_(g_rgb)
+                        self._send[P_:].copy_(campos)
+                        dist.all_gather_into_tensor(self._recv, self._send)  # one collective: colours and camera centres
                     blocks = self._recv.view(self.world, P_ + 1, 3)
                     all_rgb, all_cam = blocks[:, :P_], blocks[:, P_].contiguous()
                     dist.all_reduce(p.flat_grad[: p.n_small], op=dist.ReduceOp.SUM)

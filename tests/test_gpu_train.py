@@ -121,3 +121,36 @@ def test_view_stride_of_the_gathered_buffer():
     a = sh_grad_from_views(means, cams, view, 3, torch.empty(P, 16, 3, device=dev))
     b = sh_grad_from_views(means, cams, view.contiguous(), 3, torch.empty(P, 16, 3, device=dev))
     assert torch.equal(a, b) and float(a.abs().max()) > 0
+
+
+def test_two_phase_backward_hands_over_final_colour_gradients():
+    """sgr_backward_phase: the masked colour gradients seen by the `on_colors` hook (between the blend half and the
+    preprocess half) are the final ones, and every other gradient equals the one-call backward's"""
+    from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, grad_sink
+    dev = torch.device(DEV)
+    scene = syn.make_scene(30000, 9, 0.01, 0.08)
+    cam = syn.orbit_cameras(320, 200)[2]
+    bg = torch.tensor([0.2, 0.3, 0.4])
+    g = torch.randn(3, 200, 320, generator=torch.Generator().manual_seed(3)).to(dev)
+    ref, holder_ref = _render_grads(scene, cam, bg, g, compact=True)
+    st = GaussianRasterizationSettings(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy, bg.to(dev), 1.0,
+                                       cam.viewmatrix.to(dev), cam.projmatrix.to(dev), 3, cam.campos.to(dev), False, False)
+    m = scene.means3D.to(dev).requires_grad_(True); sh = scene.shs.to(dev).requires_grad_(True)
+    op = scene.opacities.to(dev).requires_grad_(True); sc = scene.scales.to(dev).requires_grad_(True)
+    ro = scene.rotations.to(dev).requires_grad_(True)
+    seen, holder = [], {}
+    send = torch.full((scene.means3D.shape[0], 3), float("nan"), device=dev)
+
+    def on_colors(c):
+        assert c.data_ptr() == send.data_ptr()   # written straight into the caller's buffer
+        seen.append(c.clone())                   # a snapshot at hand-over time (stream-ordered)
+
+    with grad_sink(compact_sh=True, out=holder, colors=send, on_colors=on_colors):
+        color, _ = GaussianRasterizer(st)(m, torch.zeros_like(m, requires_grad=True), op, shs=sh, scales=sc, rotations=ro)
+        grads = torch.autograd.grad((color * g).sum(), [m, sh, op, sc, ro], allow_unused=True)
+    assert len(seen) == 1 and grads[1] is None
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    assert rel(seen[0], holder_ref["masked_colors"]) < 1e-5
+    assert torch.equal(seen[0], send) and torch.equal(holder["masked_colors"], send)  # the second half did not touch them
+    for a, b in zip([grads[0], grads[2], grads[3], grads[4]], [ref[0], ref[2], ref[3], ref[4]]):
+        assert rel(a, b) < 1e-5
