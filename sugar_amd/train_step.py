@@ -219,10 +219,11 @@ class FlatAdam:
                 (C.c_float * n)(*[s[2] for s in segs]), (C.c_float * n)(*[s[3] for s in segs]),
                 (C.c_int * n)(*[s[4] for s in segs]), (C.c_int * n)(*[s[5] for s in segs])), n
 
-    def step(self, grad_scale: float = 1.0, sh_views=None):
+    def step(self, grad_scale: float = 1.0, sh_views=None, before_small=None):
         """One Adam step over the flat buffer.  With `sh_views = (means3D, campos_all[V,3], masked_colors[V,P,3], sh_degree)`
         the SH tensor is updated by sgr_sh_adam_from_views straight from the per-view colour gradients (its 48-float gradient
-        is never materialised) and the flat kernel covers the other 11 floats per Gaussian only."""
+        is never materialised) and the flat kernel covers the other 11 floats per Gaussian only; `before_small` is called
+        between the two launches."""
         C, p = self._C, self.params
         self.t += 1
         dev = p.flat.device
@@ -242,6 +243,8 @@ class FlatAdam:
                 if rc < 0:
                     raise RuntimeError(f"sgr_sh_adam_from_views failed ({rc})")
                 n_flat, seg, n_seg = p.n_small, self._seg_small, self._n_small  # positions are updated after they were read
+                if before_small is not None:
+                    before_small()  # e.g. wait for the all-reduce of the small gradients, which ran next to the SH kernel
             rc = self._lib.sgr_adam_step(n_flat, vp(p.flat), vp(p.flat_grad), vp(self.exp_avg), vp(self.exp_avg_sq), n_seg,
                                          *seg, self.betas[0], self.betas[1], self.eps, self.t, float(grad_scale), stream)
         if rc < 0:
@@ -359,7 +362,7 @@ class ViewShardedTrainer:
             pkg = render(p, cam, self.bg, self.rasterizer_cls, self.settings_cls, self.sh_degree)
             loss = train_loss(pkg["render"], gt_image, self.lambda_dssim, self.fused_loss)
             grads = torch.autograd.grad(loss, leaves, allow_unused=True)
-        sh_views = None
+        sh_views = wait_small = None
         with torch.no_grad():
             for name, leaf, g in zip(names, leaves, grads):
                 if g is None:
@@ -387,7 +390,12 @@ class ViewShardedTrainer:
                         dist.all_gather_into_tensor(self._recv, self._send)  # one collective: colours and camera centres
                     blocks = self._recv.view(self.world, P_ + 1, 3)
                     all_rgb, all_cam = blocks[:, :P_], blocks[:, P_].contiguous()
-                    dist.all_reduce(p.flat_grad[: p.n_small], op=dist.ReduceOp.SUM)
+                    if self.fused_sh_adam:
+                        # the SH-Adam kernel needs the gathered colours only: the all-reduce of the 11 small floats runs next
+                        # to it and is waited for just before the flat Adam kernel
+                        wait_small = dist.all_reduce(p.flat_grad[: p.n_small], op=dist.ReduceOp.SUM, async_op=True).wait
+                    else:
+                        dist.all_reduce(p.flat_grad[: p.n_small], op=dist.ReduceOp.SUM)
                 else:
                     all_rgb, all_cam = g_rgb[None], campos
                 if self.fused_sh_adam:
@@ -399,7 +407,7 @@ class ViewShardedTrainer:
                 dist.all_reduce(p.flat_grad, op=dist.ReduceOp.SUM)
         scale = 1.0 / self.world
         if isinstance(self.opt, FlatAdam):
-            self.opt.step(grad_scale=scale, sh_views=sh_views)  # the mean over views is folded into the optimiser kernels
+            self.opt.step(grad_scale=scale, sh_views=sh_views, before_small=wait_small)  # (the mean over views is folded in)
         else:
             if self.world > 1:
                 p.flat_grad.mul_(scale)
