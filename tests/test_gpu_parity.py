@@ -312,3 +312,26 @@ def test_empty_input_short_circuits_like_the_reference():
     assert color.shape == (3, 48, 64) and radii.shape == (0,)
     assert torch.equal(color, torch.zeros(3, 48, 64, device=dev))
     color.sum().backward()  # and the backward of the empty call runs
+
+
+def test_backward_is_linear_in_the_pixel_gradient_at_full_size():
+    """size-independent property at the metric workload (1M Gaussians @ 1080p): the backward is linear in dL/dpixel, so
+    B(g1 + 2 g2) = B(g1) + 2 B(g2) for every gradient tensor (float-atomic summation order is the only difference)"""
+    from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device("cuda:0")
+    scene, cams, bg = syn.make_config("metric")
+    cam = cams[3]
+    H, W = cam.image_height, cam.image_width
+    st = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, bg.to(dev), 1.0, cam.viewmatrix.to(dev), cam.projmatrix.to(dev), 3,
+                                       cam.campos.to(dev), False, False)
+    leaves = [t.to(dev).requires_grad_(True) for t in (scene.means3D, scene.opacities, scene.shs, scene.scales, scene.rotations)]
+    m2 = torch.zeros_like(leaves[0], requires_grad=True)
+    color, _ = GaussianRasterizer(st)(leaves[0], m2, leaves[1], shs=leaves[2], scales=leaves[3], rotations=leaves[4])
+    gen = torch.Generator().manual_seed(11)
+    g1 = torch.randn(3, H, W, generator=gen).to(dev); g2 = torch.randn(3, H, W, generator=gen).to(dev)
+    B = lambda g: torch.autograd.grad(color, leaves + [m2], grad_outputs=g, retain_graph=True)
+    b1, b2, b12 = B(g1), B(g2), B(g1 + 2.0 * g2)
+    for a, b, c in zip(b1, b2, b12):
+        ref = a + 2.0 * b
+        assert torch.isfinite(c).all()
+        assert float((c - ref).norm() / ref.norm()) < 2e-5

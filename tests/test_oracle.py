@@ -184,3 +184,19 @@ def test_restated_loss_matches_reference_loss_utils():
     loss.backward()
     assert abs(float(loss) - float(GOLD["loss_value"])) < 1e-6
     np.testing.assert_allclose(img.grad.numpy(), GOLD["loss_grad"], rtol=1e-4, atol=1e-8)
+
+
+def test_oracle_backward_is_linear_in_the_pixel_gradient():
+    """B(a g1 + b g2) = a B(g1) + b B(g2): the property the GPU suite also checks at full size"""
+    scene = syn.make_scene(1500, 31, 0.02, 0.2)
+    cam = syn.orbit_cameras(96, 64)[2]
+    bg = torch.tensor([0.3, 0.1, 0.2])
+    st = pu.run_oracle(scene, cam, bg)
+    rng = np.random.default_rng(4)
+    g1 = rng.standard_normal((3, 64, 96)).astype(np.float32); g2 = rng.standard_normal((3, 64, 96)).astype(np.float32)
+    b1, b2, b12 = orc.backward(st, g1), orc.backward(st, g2), orc.backward(st, (g1 - 3.0 * g2).astype(np.float32))
+    for k in b1:
+        if b1[k] is None or not b1[k].size:
+            continue
+        ref = b1[k].astype(np.float64) - 3.0 * b2[k].astype(np.float64)
+        assert np.linalg.norm(b12[k] - ref) <= 2e-5 * max(np.linalg.norm(ref), 1e-30), k
