@@ -208,13 +208,18 @@ int sgr_adam_step(long long n, float* params, const float* grads, float* exp_avg
  *   (normalised where >= 1), per level (HOST array, <= 8) the first crossing with linear interpolation and the normal
  *   -normalize(grad density).  Outputs are level-major: valid[L,N] (0 = the reference's empty_pixels), points[L,N,3],
  *   normals[L,N,3] (may be NULL); rows with valid == 0 are zero. */
+/* Optional `packed` argument of the four functions below: [P][16] floats from sgr_pack_gaussians ({centre, strength,
+ * inverse-scaled rotation, pad}: one 64-byte record per Gaussian, four 16-byte loads per neighbour instead of thirteen scalar
+ * ones), or NULL to read the three arrays directly.  Must be 16-byte aligned. */
+int sgr_pack_gaussians(int P, const float* centers, const float* inv_scaled_rot, const float* strengths, float* packed,
+                       void* stream);
 int sgr_density_field_forward(int N, int K, const float* x, const int64_t* nbr_idx, const float* centers,
                               const float* inv_scaled_rot, const float* strengths, float density_factor,
-                              float* neighbor_opacities, float* density, void* stream);
+                              float* neighbor_opacities, float* density, const float* packed, void* stream);
 int sgr_density_field_backward(int N, int K, const float* x, const int64_t* nbr_idx, const float* centers,
                                const float* inv_scaled_rot, const float* strengths, float density_factor,
                                const float* dL_dopacities, const float* dL_ddensity, float* dL_dx, float* dL_dcenters,
-                               float* dL_dinv_scaled_rot, float* dL_dstrengths, void* stream);
+                               float* dL_dinv_scaled_rot, float* dL_dstrengths, const float* packed, void* stream);
 /* The same gradients without float atomics: every pair takes one integer atomic for its rank among the pairs that reference
  * the same Gaussian, the pairs are laid out per Gaussian and summed in registers.  P = number of Gaussians; the three
  * per-Gaussian outputs are WRITTEN (every row, no zero-fill needed); scratch of sgr_density_field_backward_scratch_bytes. */
@@ -222,11 +227,11 @@ size_t sgr_density_field_backward_scratch_bytes(int N, int K, int P);
 int sgr_density_field_backward_gather(int N, int K, int P, const float* x, const int64_t* nbr_idx, const float* centers,
                                       const float* inv_scaled_rot, const float* strengths, float density_factor,
                                       const float* dL_dopacities, const float* dL_ddensity, float* dL_dx, float* dL_dcenters,
-                                      float* dL_dinv_scaled_rot, float* dL_dstrengths, char* scratch, void* stream);
+                                      float* dL_dinv_scaled_rot, float* dL_dstrengths, char* scratch, const float* packed, void* stream);
 int sgr_level_set_points(int N, int K, const float* world_points, const int64_t* nbr_idx, const float* cam_center,
                          const float* centers, const float* inv_scaled_rot, const float* strengths,
                          const float* gaussian_std, int n_levels, const float* levels_host, int n_range, float range_size,
-                         float density_factor, uint8_t* valid, float* points, float* normals, void* stream);
+                         float density_factor, uint8_t* valid, float* points, float* normals, const float* packed, void* stream);
 
 /* ---- binning path selection (debug / tests) ------------------------------------------------------------------------
  * mode 0 (default): two-level depth-ordered binning (super-tiles of 8x8 tiles, then tiles) with an automatic fall-back

@@ -23,15 +23,38 @@ struct GaussNbr {
     float s;
 };
 
+// `packed` (optional): one 64-byte record per Gaussian {mu.xyz, strength, B[0..8], pad} written by k_pack_gaussians -- four
+// 16-byte loads from one cache line instead of thirteen scalar loads from three arrays.
 __device__ __forceinline__ GaussNbr load_nbr(long long g, const float* __restrict__ centers, const float* __restrict__ B,
-                                             const float* __restrict__ strengths)
+                                             const float* __restrict__ strengths, const float4* __restrict__ packed = nullptr)
 {
     GaussNbr n;
+    if (packed) {
+        const float4* r = packed + 4 * g;
+        const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+        n.mx = r0.x; n.my = r0.y; n.mz = r0.z; n.s = r0.w;
+        n.B[0] = r1.x; n.B[1] = r1.y; n.B[2] = r1.z; n.B[3] = r1.w;
+        n.B[4] = r2.x; n.B[5] = r2.y; n.B[6] = r2.z; n.B[7] = r2.w; n.B[8] = r3.x;
+        return n;
+    }
     n.mx = centers[3 * g]; n.my = centers[3 * g + 1]; n.mz = centers[3 * g + 2];
 #pragma unroll
     for (int i = 0; i < 9; i++) n.B[i] = B[9 * g + i];
     n.s = strengths[g];
     return n;
+}
+
+__global__ void __launch_bounds__(256) k_pack_gaussians(int P, const float* __restrict__ centers, const float* __restrict__ B,
+                                                        const float* __restrict__ strengths, float4* __restrict__ packed)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= P) return;
+    const GaussNbr n = load_nbr(g, centers, B, strengths);
+    float4* r = packed + 4 * (size_t)g;
+    r[0] = make_float4(n.mx, n.my, n.mz, n.s);
+    r[1] = make_float4(n.B[0], n.B[1], n.B[2], n.B[3]);
+    r[2] = make_float4(n.B[4], n.B[5], n.B[6], n.B[7]);
+    r[3] = make_float4(n.B[8], 0.f, 0.f, 0.f);
 }
 
 // w = B^T d  (w_j = sum_i B[i][j] d_i)
@@ -44,7 +67,7 @@ __device__ __forceinline__ void bt_mul(const float* Bm, float dx, float dy, floa
 
 __global__ void __launch_bounds__(256) k_density_fwd(int N, int K, const float* __restrict__ x, const long long* __restrict__ nbr,
                                                      const float* __restrict__ centers, const float* __restrict__ B,
-                                                     const float* __restrict__ strengths, float factor,
+                                                     const float* __restrict__ strengths, const float4* __restrict__ packed, float factor,
                                                      float* __restrict__ opac, float* __restrict__ density)
 {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -52,7 +75,7 @@ __global__ void __launch_bounds__(256) k_density_fwd(int N, int K, const float* 
     const float px = x[3 * (size_t)n], py = x[3 * (size_t)n + 1], pz = x[3 * (size_t)n + 2];
     float sum = 0.f;
     for (int k = 0; k < K; k++) {
-        const GaussNbr g = load_nbr(nbr[(size_t)n * K + k], centers, B, strengths);
+        const GaussNbr g = load_nbr(nbr[(size_t)n * K + k], centers, B, strengths, packed);
         float w0, w1, w2;
         bt_mul(g.B, px - g.mx, py - g.my, pz - g.mz, w0, w1, w2);
         const float q = fminf(fmaxf(w0 * w0 + w1 * w1 + w2 * w2, 0.f), 1e8f);
@@ -65,7 +88,7 @@ __global__ void __launch_bounds__(256) k_density_fwd(int N, int K, const float* 
 
 __global__ void __launch_bounds__(256) k_density_bwd(int N, int K, const float* __restrict__ x, const long long* __restrict__ nbr,
                                                      const float* __restrict__ centers, const float* __restrict__ B,
-                                                     const float* __restrict__ strengths, float factor,
+                                                     const float* __restrict__ strengths, const float4* __restrict__ packed, float factor,
                                                      const float* __restrict__ g_opac, const float* __restrict__ g_den,
                                                      float* __restrict__ dx_out, float* __restrict__ dcenters,
                                                      float* __restrict__ dB, float* __restrict__ dstrengths)
@@ -77,7 +100,7 @@ __global__ void __launch_bounds__(256) k_density_bwd(int N, int K, const float* 
     float ax = 0.f, ay = 0.f, az = 0.f;
     for (int k = 0; k < K; k++) {
         const long long gi = nbr[(size_t)n * K + k];
-        const GaussNbr g = load_nbr(gi, centers, B, strengths);
+        const GaussNbr g = load_nbr(gi, centers, B, strengths, packed);
         const float dx = px - g.mx, dy = py - g.my, dz = pz - g.mz;
         float w0, w1, w2;
         bt_mul(g.B, dx, dy, dz, w0, w1, w2);
@@ -111,7 +134,7 @@ __global__ void __launch_bounds__(256) k_density_bwd(int N, int K, const float* 
 // pairs are laid out per Gaussian and a lane per Gaussian sums its pairs in registers and writes its 13 outputs once.
 __global__ void __launch_bounds__(256) k_density_bwd_rank(int N, int K, const float* __restrict__ x, const long long* __restrict__ nbr,
                                                           const float* __restrict__ centers, const float* __restrict__ B,
-                                                          const float* __restrict__ strengths, float factor,
+                                                          const float* __restrict__ strengths, const float4* __restrict__ packed, float factor,
                                                           const float* __restrict__ g_opac, const float* __restrict__ g_den,
                                                           float* __restrict__ dx_out, uint32_t* __restrict__ cnt,
                                                           uint32_t* __restrict__ rank)
@@ -126,7 +149,7 @@ __global__ void __launch_bounds__(256) k_density_bwd_rank(int N, int K, const fl
         const long long gi = nbr[p];
         rank[p] = atomicAdd(&cnt[gi], 1u);
         if (dx_out) {
-            const GaussNbr g = load_nbr(gi, centers, B, strengths);
+            const GaussNbr g = load_nbr(gi, centers, B, strengths, packed);
             float w0, w1, w2;
             bt_mul(g.B, px - g.mx, py - g.my, pz - g.mz, w0, w1, w2);
             const float q_raw = w0 * w0 + w1 * w1 + w2 * w2;
@@ -209,7 +232,7 @@ __global__ void __launch_bounds__(256) k_density_bwd_fill(long long NK, const lo
 
 __global__ void __launch_bounds__(256) k_density_bwd_gather(int P, int K, const float* __restrict__ x,
                                                             const float* __restrict__ centers, const float* __restrict__ B,
-                                                            const float* __restrict__ strengths, float factor,
+                                                            const float* __restrict__ strengths, const float4* __restrict__ packed, float factor,
                                                             const float* __restrict__ g_opac, const float* __restrict__ g_den,
                                                             const uint32_t* __restrict__ start,
                                                             const uint32_t* __restrict__ pair_list, float* __restrict__ dcenters,
@@ -217,7 +240,7 @@ __global__ void __launch_bounds__(256) k_density_bwd_gather(int P, int K, const 
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= P) return;
-    const GaussNbr g = load_nbr(t, centers, B, strengths);
+    const GaussNbr g = load_nbr(t, centers, B, strengths, packed);
     float dc0 = 0.f, dc1 = 0.f, dc2 = 0.f, ds = 0.f;
     float b[9];
 #pragma unroll
@@ -255,7 +278,7 @@ struct LevelArgs { int n; float v[LS_MAX_LEVELS]; };
 __global__ void __launch_bounds__(128) k_level_set(int N, int K, const float* __restrict__ world_points,
                                                    const long long* __restrict__ nbr, const float* __restrict__ cam_center,
                                                    const float* __restrict__ centers, const float* __restrict__ B,
-                                                   const float* __restrict__ strengths, const float* __restrict__ gaussian_std,
+                                                   const float* __restrict__ strengths, const float4* __restrict__ packed, const float* __restrict__ gaussian_std,
                                                    LevelArgs levels, int n_range, float range_size, float factor,
                                                    uint8_t* __restrict__ valid, float* __restrict__ points, float* __restrict__ normals)
 {
@@ -274,7 +297,7 @@ __global__ void __launch_bounds__(128) k_level_set(int N, int K, const float* __
 #pragma unroll
     for (int i = 0; i < LS_MAX_RANGE; i++) dens[i] = 0.f;
     for (int k = 0; k < K; k++) {
-        const GaussNbr g = load_nbr(my_nbr[k], centers, B, strengths);
+        const GaussNbr g = load_nbr(my_nbr[k], centers, B, strengths, packed);
         float a0, a1, a2, b0, b1, b2;
         bt_mul(g.B, wx - g.mx, wy - g.my, wz - g.mz, a0, a1, a2);
         bt_mul(g.B, dirx, diry, dirz, b0, b1, b2);
@@ -318,7 +341,7 @@ __global__ void __launch_bounds__(128) k_level_set(int N, int K, const float* __
             if (normals) {
                 float gx = 0.f, gy = 0.f, gz = 0.f;  // density_grad = sum_g o_g * B_g w_g  (:2069)
                 for (int k = 0; k < K; k++) {
-                    const GaussNbr g = load_nbr(my_nbr[k], centers, B, strengths);
+                    const GaussNbr g = load_nbr(my_nbr[k], centers, B, strengths, packed);
                     float w0, w1, w2;
                     bt_mul(g.B, ix - g.mx, iy - g.my, iz - g.mz, w0, w1, w2);
                     const float q = fminf(fmaxf(w0 * w0 + w1 * w1 + w2 * w2, 0.f), 1e8f);
@@ -342,28 +365,37 @@ extern "C" {
 
 int sgr_density_field_forward(int N, int K, const float* x, const int64_t* nbr_idx, const float* centers,
                               const float* inv_scaled_rot, const float* strengths, float density_factor,
-                              float* neighbor_opacities, float* density, void* stream)
+                              float* neighbor_opacities, float* density, const float* packed, void* stream)
 {
     if (N <= 0) return 0;
     if (K <= 0 || !x || !nbr_idx || !centers || !inv_scaled_rot || !strengths || !density) return SGR_E_INVALID;
     hipLaunchKernelGGL(k_density_fwd, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, K, x,
-                       reinterpret_cast<const long long*>(nbr_idx), centers, inv_scaled_rot, strengths, density_factor,
-                       neighbor_opacities, density);
+                       reinterpret_cast<const long long*>(nbr_idx), centers, inv_scaled_rot, strengths, reinterpret_cast<const float4*>(packed),
+                       density_factor, neighbor_opacities, density);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 
 int sgr_density_field_backward(int N, int K, const float* x, const int64_t* nbr_idx, const float* centers,
                                const float* inv_scaled_rot, const float* strengths, float density_factor,
                                const float* dL_dopacities, const float* dL_ddensity, float* dL_dx, float* dL_dcenters,
-                               float* dL_dinv_scaled_rot, float* dL_dstrengths, void* stream)
+                               float* dL_dinv_scaled_rot, float* dL_dstrengths, const float* packed, void* stream)
 {
     if (N <= 0) return 0;
     if (K <= 0 || !x || !nbr_idx || !centers || !inv_scaled_rot || !strengths || !dL_dcenters || !dL_dinv_scaled_rot ||
         !dL_dstrengths || (!dL_dopacities && !dL_ddensity))
         return SGR_E_INVALID;
     hipLaunchKernelGGL(k_density_bwd, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, K, x,
-                       reinterpret_cast<const long long*>(nbr_idx), centers, inv_scaled_rot, strengths, density_factor,
-                       dL_dopacities, dL_ddensity, dL_dx, dL_dcenters, dL_dinv_scaled_rot, dL_dstrengths);
+                       reinterpret_cast<const long long*>(nbr_idx), centers, inv_scaled_rot, strengths, reinterpret_cast<const float4*>(packed),
+                       density_factor, dL_dopacities, dL_ddensity, dL_dx, dL_dcenters, dL_dinv_scaled_rot, dL_dstrengths);
+    return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
+}
+
+int sgr_pack_gaussians(int P, const float* centers, const float* inv_scaled_rot, const float* strengths, float* packed, void* stream)
+{
+    if (P <= 0) return 0;
+    if (!centers || !inv_scaled_rot || !strengths || !packed || ((uintptr_t)packed & 15)) return SGR_E_INVALID;
+    hipLaunchKernelGGL(k_pack_gaussians, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, centers, inv_scaled_rot,
+                       strengths, reinterpret_cast<float4*>(packed));
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 
@@ -377,7 +409,7 @@ size_t sgr_density_field_backward_scratch_bytes(int N, int K, int P)
 int sgr_density_field_backward_gather(int N, int K, int P, const float* x, const int64_t* nbr_idx, const float* centers,
                                       const float* inv_scaled_rot, const float* strengths, float density_factor,
                                       const float* dL_dopacities, const float* dL_ddensity, float* dL_dx, float* dL_dcenters,
-                                      float* dL_dinv_scaled_rot, float* dL_dstrengths, char* scratch, void* stream)
+                                      float* dL_dinv_scaled_rot, float* dL_dstrengths, char* scratch, const float* packed, void* stream)
 {
     if (P <= 0) return 0;
     if (N < 0 || K <= 0 || (N > 0 && (!x || !nbr_idx)) || !centers || !inv_scaled_rot || !strengths || !dL_dcenters ||
@@ -396,7 +428,7 @@ int sgr_density_field_backward_gather(int N, int K, int P, const float* x, const
     if (hipMemsetAsync(cnt, 0, ((size_t)P + 1) * 4, s) != hipSuccess) return SGR_E_HIP;
     if (N > 0) {
         hipLaunchKernelGGL(k_density_bwd_rank, dim3((N + 255) / 256), dim3(256), 0, s, N, K, x, nbr, centers, inv_scaled_rot,
-                           strengths, density_factor, dL_dopacities, dL_ddensity, dL_dx, cnt, rank);
+                           strengths, reinterpret_cast<const float4*>(packed), density_factor, dL_dopacities, dL_ddensity, dL_dx, cnt, rank);
     }
     hipLaunchKernelGGL(k_fscan_sums, dim3(n_blocks), dim3(256), 0, s, P, cnt, block_sums);
     hipLaunchKernelGGL(k_fscan_top, dim3(1), dim3(1024), 0, s, n_blocks, block_sums, start + P);
@@ -406,14 +438,14 @@ int sgr_density_field_backward_gather(int N, int K, int P, const float* x, const
                            pair_list);
     }
     hipLaunchKernelGGL(k_density_bwd_gather, dim3((P + 255) / 256), dim3(256), 0, s, P, K, x, centers, inv_scaled_rot, strengths,
-                       density_factor, dL_dopacities, dL_ddensity, start, pair_list, dL_dcenters, dL_dinv_scaled_rot, dL_dstrengths);
+                       reinterpret_cast<const float4*>(packed), density_factor, dL_dopacities, dL_ddensity, start, pair_list, dL_dcenters, dL_dinv_scaled_rot, dL_dstrengths);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 
 int sgr_level_set_points(int N, int K, const float* world_points, const int64_t* nbr_idx, const float* cam_center,
                          const float* centers, const float* inv_scaled_rot, const float* strengths,
                          const float* gaussian_std, int n_levels, const float* levels_host, int n_range, float range_size,
-                         float density_factor, uint8_t* valid, float* points, float* normals, void* stream)
+                         float density_factor, uint8_t* valid, float* points, float* normals, const float* packed, void* stream)
 {
     if (N <= 0) return 0;
     if (K <= 0 || n_levels <= 0 || n_levels > LS_MAX_LEVELS || n_range < 2 || n_range > LS_MAX_RANGE || !world_points ||
@@ -423,7 +455,7 @@ int sgr_level_set_points(int N, int K, const float* world_points, const int64_t*
     la.n = n_levels;
     for (int i = 0; i < LS_MAX_LEVELS; i++) la.v[i] = i < n_levels ? levels_host[i] : 0.f;
     hipLaunchKernelGGL(k_level_set, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, N, K, world_points,
-                       reinterpret_cast<const long long*>(nbr_idx), cam_center, centers, inv_scaled_rot, strengths, gaussian_std,
+                       reinterpret_cast<const long long*>(nbr_idx), cam_center, centers, inv_scaled_rot, strengths, reinterpret_cast<const float4*>(packed), gaussian_std,
                        la, n_range, range_size, density_factor, valid, points, normals);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }

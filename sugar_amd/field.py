@@ -23,6 +23,17 @@ def _stream(dev):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+def _pack(lib, ce, Bm, st):
+    """one 64-byte record per Gaussian for the kernels' neighbour gathers (sgr_pack_gaussians)"""
+    P, dev = ce.shape[0], ce.device
+    packed = torch.empty(P, 16, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.sgr_pack_gaussians(P, _p(ce), _p(Bm), _p(st), _p(packed), _stream(dev))
+    if rc < 0:
+        raise RuntimeError(f"sgr_pack_gaussians failed ({rc})")
+    return packed
+
+
 def _prep(x, nbr_idx, centers, B, strengths):
     if not x.is_cuda:
         raise RuntimeError("the HIP density field needs tensors on a ROCm device; there is no CPU fallback")
@@ -42,12 +53,13 @@ class _DensityField(torch.autograd.Function):
         dev = xs.device
         opac = torch.empty(N, K, device=dev)
         dens = torch.empty(N, device=dev)
+        packed = _pack(lib, ce, Bm, st)
         with torch.cuda.device(dev):
             rc = lib.sgr_density_field_forward(N, K, _p(xs), _p(nb), _p(ce), _p(Bm), _p(st), float(density_factor), _p(opac),
-                                               _p(dens), _stream(dev))
+                                               _p(dens), _p(packed), _stream(dev))
         if rc < 0:
             raise RuntimeError(f"sgr_density_field_forward failed ({rc})")
-        ctx.save_for_backward(xs, nb, ce, Bm, st)
+        ctx.save_for_backward(xs, nb, ce, Bm, st, packed)
         ctx.factor = float(density_factor)
         ctx.shapes = (inv_scaled_rot.shape, strengths.shape)
         return opac, dens
@@ -55,7 +67,7 @@ class _DensityField(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_opac, g_dens):
         lib = _lib.load()
-        xs, nb, ce, Bm, st = ctx.saved_tensors
+        xs, nb, ce, Bm, st, packed = ctx.saved_tensors
         N, K = nb.shape
         dev = xs.device
         P = ce.shape[0]
@@ -68,12 +80,12 @@ class _DensityField(torch.autograd.Function):
             scratch = torch.empty(lib.sgr_density_field_backward_scratch_bytes(N, K, P), dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
                 rc = lib.sgr_density_field_backward_gather(N, K, P, _p(xs), _p(nb), _p(ce), _p(Bm), _p(st), ctx.factor, _p(go), _p(gd),
-                                                           _p(dx), _p(dce), _p(dB), _p(dst), _p(scratch), _stream(dev))
+                                                           _p(dx), _p(dce), _p(dB), _p(dst), _p(scratch), _p(packed), _stream(dev))
         else:
             dce = torch.zeros(P, 3, device=dev); dB = torch.zeros(P, 9, device=dev); dst = torch.zeros(P, device=dev)
             with torch.cuda.device(dev):
                 rc = lib.sgr_density_field_backward(N, K, _p(xs), _p(nb), _p(ce), _p(Bm), _p(st), ctx.factor, _p(go), _p(gd), _p(dx),
-                                                    _p(dce), _p(dB), _p(dst), _stream(dev))
+                                                    _p(dce), _p(dB), _p(dst), _p(packed), _stream(dev))
         if rc < 0:
             raise RuntimeError(f"sgr_density_field_backward failed ({rc})")
         Bshape, sshape = ctx.shapes
@@ -102,10 +114,11 @@ def level_set_points(world_points, nbr_idx, cam_center, centers, inv_scaled_rot,
     pts = torch.empty(L, N, 3, device=dev)
     nrm = torch.empty(L, N, 3, device=dev) if return_normals else None
     lv = (C.c_float * L)(*[float(v) for v in surface_levels])
+    packed = _pack(lib, ce, Bm, st)
     with torch.cuda.device(dev):
         rc = lib.sgr_level_set_points(N, K, _p(wp), _p(nb), _p(cam), _p(ce), _p(Bm), _p(st), _p(gstd), L, lv,
                                       int(n_points_in_range), float(range_size), float(density_factor), _p(valid), _p(pts),
-                                      _p(nrm), _stream(dev))
+                                      _p(nrm), _p(packed), _stream(dev))
     if rc < 0:
         raise RuntimeError(f"sgr_level_set_points failed ({rc})")
     out = {}
