@@ -208,6 +208,14 @@ int sgr_adam_step(long long n, float* params, const float* grads, float* exp_avg
  *   (normalised where >= 1), per level (HOST array, <= 8) the first crossing with linear interpolation and the normal
  *   -normalize(grad density).  Outputs are level-major: valid[L,N] (0 = the reference's empty_pixels), points[L,N,3],
  *   normals[L,N,3] (may be NULL); rows with valid == 0 are zero. */
+/* SuGaR.get_covariance(return_sqrt=True, inverse_scales=...), sugar_scene/sugar_model.py:730-736:
+ * out[P,3,3] = quaternion_to_matrix(quaternions[P,4]) * s[:, None],  s = scaling[P,3] or 1 / clamp(scaling, 1e-8)
+ * (real part first; any non-zero quaternion: the matrix is scaled by 2 / |q|^2 as in pytorch3d).  16-byte aligned quaternions. */
+int sgr_scaled_rotation_forward(int P, const float* quaternions, const float* scaling, int inverse_scales, float* out,
+                                void* stream);
+int sgr_scaled_rotation_backward(int P, const float* quaternions, const float* scaling, int inverse_scales,
+                                 const float* dL_dout, float* dL_dquaternions, float* dL_dscaling, void* stream);
+
 /* Optional `packed` argument of the four functions below: [P][16] floats from sgr_pack_gaussians ({centre, strength,
  * inverse-scaled rotation, pad}: one 64-byte record per Gaussian, four 16-byte loads per neighbour instead of thirteen scalar
  * ones), or NULL to read the three arrays directly.  Must be 16-byte aligned. */

@@ -37,7 +37,7 @@ for name, do_bwd in (("config3", True), ("config5", False)):
 # backwards, the density-field regulariser on 1M samples x 16 neighbours, and the k-NN rebuild timed apart.
 def sugar_coarse_step():
     from sugar_amd.shcolor import sh_to_rgb
-    from sugar_amd.field import density_field
+    from sugar_amd.field import density_field, scaled_rotation
     from sugar_amd.knn import knn_points
     scene, cams, bg = syn.make_config("config3")
     cam = cams[0]
@@ -62,12 +62,7 @@ def sugar_coarse_step():
         st_d = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, max_depth.expand(3).contiguous(), 1.0, view, proj, 3, campos, False, False)
         dimg, _ = GaussianRasterizer(st_d)(m, torch.zeros_like(m, requires_grad=True), op, colors_precomp=depth.expand(-1, 3).contiguous(), scales=sc, rotations=ro)
         x = (m[gi] + sc[gi] * noise).detach()
-        R = torch.nn.functional.normalize(ro, dim=-1)
-        r_, i_, j_, k_ = R.unbind(-1)
-        Rm = torch.stack([1 - 2 * (j_ * j_ + k_ * k_), 2 * (i_ * j_ - k_ * r_), 2 * (i_ * k_ + j_ * r_),
-                          2 * (i_ * j_ + k_ * r_), 1 - 2 * (i_ * i_ + k_ * k_), 2 * (j_ * k_ - i_ * r_),
-                          2 * (i_ * k_ - j_ * r_), 2 * (j_ * k_ + i_ * r_), 1 - 2 * (i_ * i_ + j_ * j_)], -1).reshape(-1, 3, 3)
-        B = Rm * (1.0 / sc.clamp(min=1e-8))[:, None]
+        B = scaled_rotation(torch.nn.functional.normalize(ro, dim=-1), sc, inverse_scales=True)  # get_covariance(sqrt, inverse)
         _, dens = density_field(x, knn_idx[gi], m, B, op)
         loss = (rgb * g_img).mean() + dimg.mean() + dens.mean()
         loss.backward()

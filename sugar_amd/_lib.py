@@ -47,6 +47,8 @@ SIGNATURES = {
     "sgr_density_field_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgr_density_field_backward_scratch_bytes": (_sz, [_i, _i, _i]),
     "sgr_density_field_backward_gather": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sgr_scaled_rotation_forward": (_i, [_i, _vp, _vp, _i, _vp, _vp]),
+    "sgr_scaled_rotation_backward": (_i, [_i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "sgr_pack_gaussians": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "sgr_level_set_points": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "sgr_sh_to_rgb_forward": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

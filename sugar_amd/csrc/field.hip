@@ -271,6 +271,75 @@ __global__ void __launch_bounds__(256) k_density_bwd_gather(int P, int K, const 
     dstrengths[t] = ds;
 }
 
+// ---- SuGaR.get_covariance(return_sqrt=True[, inverse_scales=True]), sugar_scene/sugar_model.py:730-736 ---------------------
+// out[a][b] = R(q)[a][b] * s[b],  R = pytorch3d's quaternion_to_matrix (real part first, two_s = 2 / |q|^2: any non-zero q),
+// s = scaling or 1 / clamp(scaling, 1e-8).  The reference builds it with ~25 elementwise launches (plus autograd twins) every
+// time the regulariser or the level-set sampler runs.
+__device__ __forceinline__ void quat_M(float r, float i, float j, float k, float M[9])
+{
+    M[0] = -(j * j + k * k); M[1] = i * j - k * r;     M[2] = i * k + j * r;
+    M[3] = i * j + k * r;    M[4] = -(i * i + k * k);  M[5] = j * k - i * r;
+    M[6] = i * k - j * r;    M[7] = j * k + i * r;     M[8] = -(i * i + j * j);
+}
+
+__global__ void __launch_bounds__(256) k_scaled_rotation_fwd(int P, const float* __restrict__ quats, const float* __restrict__ scaling,
+                                                             int inverse, float* __restrict__ out)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= P) return;
+    const float4 q = reinterpret_cast<const float4*>(quats)[g];
+    float s[3] = {scaling[3 * (size_t)g], scaling[3 * (size_t)g + 1], scaling[3 * (size_t)g + 2]};
+    if (inverse) { for (int b = 0; b < 3; b++) s[b] = 1.0f / fmaxf(s[b], 1e-8f); }
+    const float t = 2.0f / (q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    float M[9];
+    quat_M(q.x, q.y, q.z, q.w, M);
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) out[9 * (size_t)g + 3 * a + b] = ((a == b ? 1.0f : 0.0f) + t * M[3 * a + b]) * s[b];
+}
+
+__global__ void __launch_bounds__(256) k_scaled_rotation_bwd(int P, const float* __restrict__ quats, const float* __restrict__ scaling,
+                                                             int inverse, const float* __restrict__ g_out,
+                                                             float* __restrict__ d_quats, float* __restrict__ d_scaling)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= P) return;
+    const float4 q = reinterpret_cast<const float4*>(quats)[g];
+    const float r = q.x, i = q.y, j = q.z, k = q.w;
+    float raw[3] = {scaling[3 * (size_t)g], scaling[3 * (size_t)g + 1], scaling[3 * (size_t)g + 2]};
+    float s[3];
+    for (int b = 0; b < 3; b++) s[b] = inverse ? 1.0f / fmaxf(raw[b], 1e-8f) : raw[b];
+    const float n = r * r + i * i + j * j + k * k;
+    const float t = 2.0f / n;
+    float M[9];
+    quat_M(r, i, j, k, M);
+    float G[9], ds[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            const float go = g_out[9 * (size_t)g + 3 * a + b];
+            ds[b] += go * ((a == b ? 1.0f : 0.0f) + t * M[3 * a + b]);
+            G[3 * a + b] = go * s[b];  // dL/dR
+        }
+    float GM = 0.f;
+#pragma unroll
+    for (int e = 0; e < 9; e++) GM += G[e] * M[e];
+    // dL/dq = t * sum G : dM/dq  +  (G : M) * dt/dq,   dt/dq = -t^2 q
+    const float dr = t * (-k * G[1] + j * G[2] + k * G[3] - i * G[5] - j * G[6] + i * G[7]) - GM * t * t * r;
+    const float di = t * (j * G[1] + k * G[2] + j * G[3] - 2.f * i * G[4] - r * G[5] + k * G[6] + r * G[7] - 2.f * i * G[8]) - GM * t * t * i;
+    const float dj = t * (-2.f * j * G[0] + i * G[1] + r * G[2] + i * G[3] + k * G[5] - r * G[6] + k * G[7] - 2.f * j * G[8]) - GM * t * t * j;
+    const float dk = t * (-2.f * k * G[0] - r * G[1] + i * G[2] + r * G[3] - 2.f * k * G[4] + j * G[5] + i * G[6] + j * G[7]) - GM * t * t * k;
+    reinterpret_cast<float4*>(d_quats)[g] = make_float4(dr, di, dj, dk);
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        float v = ds[b];
+        if (inverse) v = raw[b] > 1e-8f ? -v * s[b] * s[b] : 0.f;  // d (1 / clamp(x, 1e-8)) = -1/x^2 inside the clamp range
+        d_scaling[3 * (size_t)g + b] = v;
+    }
+}
+
 #define LS_MAX_RANGE 32
 #define LS_MAX_LEVELS 8
 struct LevelArgs { int n; float v[LS_MAX_LEVELS]; };
@@ -387,6 +456,27 @@ int sgr_density_field_backward(int N, int K, const float* x, const int64_t* nbr_
     hipLaunchKernelGGL(k_density_bwd, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, K, x,
                        reinterpret_cast<const long long*>(nbr_idx), centers, inv_scaled_rot, strengths, reinterpret_cast<const float4*>(packed),
                        density_factor, dL_dopacities, dL_ddensity, dL_dx, dL_dcenters, dL_dinv_scaled_rot, dL_dstrengths);
+    return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
+}
+
+int sgr_scaled_rotation_forward(int P, const float* quaternions, const float* scaling, int inverse_scales, float* out, void* stream)
+{
+    if (P <= 0) return 0;
+    if (!quaternions || !scaling || !out || ((uintptr_t)quaternions & 15)) return SGR_E_INVALID;
+    hipLaunchKernelGGL(k_scaled_rotation_fwd, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, quaternions, scaling,
+                       inverse_scales, out);
+    return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
+}
+
+int sgr_scaled_rotation_backward(int P, const float* quaternions, const float* scaling, int inverse_scales, const float* dL_dout,
+                                 float* dL_dquaternions, float* dL_dscaling, void* stream)
+{
+    if (P <= 0) return 0;
+    if (!quaternions || !scaling || !dL_dout || !dL_dquaternions || !dL_dscaling ||
+        (((uintptr_t)quaternions | (uintptr_t)dL_dquaternions) & 15))
+        return SGR_E_INVALID;
+    hipLaunchKernelGGL(k_scaled_rotation_bwd, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, quaternions, scaling,
+                       inverse_scales, dL_dout, dL_dquaternions, dL_dscaling);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 

@@ -92,6 +92,42 @@ class _DensityField(torch.autograd.Function):
         return dx, None, dce, dB.reshape(Bshape), dst.reshape(sshape), None
 
 
+class _ScaledRotation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, quaternions, scaling, inverse_scales):
+        lib = _lib.load()
+        if not quaternions.is_cuda:
+            raise RuntimeError("the HIP scaled-rotation op needs tensors on a ROCm device; there is no CPU fallback")
+        q, s = quaternions.contiguous().float(), scaling.contiguous().float()
+        P, dev = q.shape[0], q.device
+        out = torch.empty(P, 3, 3, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.sgr_scaled_rotation_forward(P, _p(q), _p(s), int(bool(inverse_scales)), _p(out), _stream(dev))
+        if rc < 0:
+            raise RuntimeError(f"sgr_scaled_rotation_forward failed ({rc})")
+        ctx.save_for_backward(q, s)
+        ctx.inverse = int(bool(inverse_scales))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        q, s = ctx.saved_tensors
+        P, dev = q.shape[0], q.device
+        dq, ds = torch.empty_like(q), torch.empty_like(s)
+        with torch.cuda.device(dev):
+            rc = lib.sgr_scaled_rotation_backward(P, _p(q), _p(s), ctx.inverse, _p(g.contiguous().float()), _p(dq), _p(ds), _stream(dev))
+        if rc < 0:
+            raise RuntimeError(f"sgr_scaled_rotation_backward failed ({rc})")
+        return dq, ds, None
+
+
+def scaled_rotation(quaternions, scaling, inverse_scales: bool = False):
+    """SuGaR.get_covariance(return_sqrt=True, inverse_scales=...) (sugar_scene/sugar_model.py:730-736):
+    quaternion_to_matrix(quaternions) * s[:, None] with s = scaling or 1 / scaling.clamp(min=1e-8); differentiable."""
+    return _ScaledRotation.apply(quaternions, scaling, inverse_scales)
+
+
 def density_field(x, nbr_idx, centers, inv_scaled_rot, strengths, density_factor: float = 1.0):
     """Returns (neighbor_opacities[N,K], densities[N]) exactly as sugar_model.py:1270-1276, differentiable w.r.t. x,
     centers, inv_scaled_rot and strengths."""

@@ -81,3 +81,33 @@ def test_level_set_sampler_matches_reference_restatement():
         scale = gstd[nb[:, 0]][both]
         assert float(((pr[both] - po[both]).norm(dim=1) / scale).quantile(0.999)) < 1e-3
         assert float((nr[both] * no[both]).sum(dim=1).quantile(0.001)) > 0.9999
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_scaled_rotation_matches_the_reference_expression(inverse):
+    """get_covariance(return_sqrt=True, inverse_scales=inverse), sugar_model.py:730-736, on pytorch3d's quaternion_to_matrix
+    (restated in sugar_amd/shims), values and autograd gradients, un-normalised quaternions included"""
+    from sugar_amd import shims
+    shims.install()
+    from pytorch3d.transforms import quaternion_to_matrix
+    from sugar_amd.field import scaled_rotation
+    g = torch.Generator().manual_seed(2)
+    P = 30001
+    q = torch.randn(P, 4, generator=g, dtype=torch.float64) * 1.7
+    s = torch.exp(torch.randn(P, 3, generator=g, dtype=torch.float64))
+    if inverse:
+        s[:5] = 1e-9  # inside the clamp: zero gradient
+    w = torch.randn(P, 3, 3, generator=g, dtype=torch.float64)
+    qr, sr = q.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    scaling = 1.0 / sr.clamp(min=1e-8) if inverse else sr
+    ref = quaternion_to_matrix(qr) * scaling[:, None]
+    (ref * w).sum().backward()
+    dev = torch.device("cuda:0")
+    qd, sd = q.float().to(dev).requires_grad_(True), s.float().to(dev).requires_grad_(True)
+    out = scaled_rotation(qd, sd, inverse)
+    (out * w.float().to(dev)).sum().backward()
+    rel = lambda a, b: float((a.detach().cpu().double() - b.detach()).norm() / b.detach().norm())
+    assert rel(out[5:], ref[5:]) < 1e-6
+    assert rel(qd.grad[5:], qr.grad[5:]) < 1e-5 and rel(sd.grad[5:], sr.grad[5:]) < 1e-5
+    if inverse:
+        assert float(sd.grad[:5].abs().max()) == 0.0
