@@ -379,14 +379,13 @@ Bin2Layout sgr_bin2_layout(int P, int gx, int gy)
 }
 
 // level 1 + the counting half of level 2: leaves tile_count[T] (consumed by sgr_launch_tile_scan) and the header
-void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scratch, const uint2* rects, uint32_t* tile_count,
-                           hipStream_t s)
+void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scratch, uint32_t* hdr, const uint2* rects,
+                           uint32_t* tile_count, hipStream_t s)
 {
     uint32_t* hist1 = reinterpret_cast<uint32_t*>(scratch + L.hist1);
     uint32_t* sup_count = reinterpret_cast<uint32_t*>(scratch + L.sup_count);
     uint32_t* sup_start = reinterpret_cast<uint32_t*>(scratch + L.sup_start);
     uint32_t* chunk_base = reinterpret_cast<uint32_t*>(scratch + L.chunk_base);
-    uint32_t* hdr = reinterpret_cast<uint32_t*>(scratch + L.hdr);
     uint32_t* L1 = reinterpret_cast<uint32_t*>(scratch + L.L1);
     uint32_t* cnt2 = reinterpret_cast<uint32_t*>(scratch + L.cnt2);
     uint32_t* chunk_sup = reinterpret_cast<uint32_t*>(scratch + L.chunk_sup);
@@ -408,13 +407,12 @@ void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scr
     hipLaunchKernelGGL(k_tile_scan2, dim3(L.T1), dim3(64), 0, s, gx, gy, L.sgx, chunk_base, hdr, cnt2, tile_count);
 }
 
-void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, uint32_t n_chunks, const uint2* rects,
+void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, const uint32_t* hdr, uint32_t n_chunks, const uint2* rects,
                            const uint32_t* order, const uint32_t* tile_start, uint32_t* point_list, hipStream_t s)
 {
     if (n_chunks == 0) return;
     const uint32_t* sup_start = reinterpret_cast<const uint32_t*>(scratch + L.sup_start);
     const uint32_t* chunk_base = reinterpret_cast<const uint32_t*>(scratch + L.chunk_base);
-    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(scratch + L.hdr);
     const uint32_t* L1 = reinterpret_cast<const uint32_t*>(scratch + L.L1);
     uint32_t* cnt2 = reinterpret_cast<uint32_t*>(scratch + L.cnt2);
     const uint32_t* chunk_sup = reinterpret_cast<const uint32_t*>(scratch + L.chunk_sup);

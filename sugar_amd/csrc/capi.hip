@@ -206,7 +206,7 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     {
         StageTimer t(s, SGR_STAGE_SCAN);
         if (two_level) {
-            sgr_launch_bin2_count(P, IL.gx, IL.gy, B2, bin2, rects, tile_cursor, s);
+            sgr_launch_bin2_count(P, IL.gx, IL.gy, B2, bin2, header + 4, rects, tile_cursor, s);
         } else {
             sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, blk_hist, s);
             sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
@@ -216,8 +216,8 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     STAGE_CHECK("bin_count");
 
     if (!g_pinned.p) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_pinned.p), 64, hipHostMallocDefault));
-    HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 16, hipMemcpyDeviceToHost, s));
-    if (two_level) HIP_TRY(hipMemcpyAsync(g_pinned.p + 4, bin2 + B2.hdr, 16, hipMemcpyDeviceToHost, s));
+    // words 0-3: the tile scan's header (R, ...); words 4-6: the two-level binning's (R1, chunks, overflow) -- one copy
+    HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));  // the one host round trip of the forward (rasterizer_impl.cu:280-281)
     if (two_level && g_pinned.p[4 + SGR_B2_HDR_OVERFLOW]) {
         // more (Gaussian, super-tile) pairs than the level-1 list holds (huge splats): the single-level path has no such limit
@@ -239,7 +239,8 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     if (R > 0) {
         StageTimer t(s, SGR_STAGE_SCATTER);
         if (two_level)
-            sgr_launch_bin2_write(IL.gx, IL.gy, B2, bin2, g_pinned.p[4 + SGR_B2_HDR_CHUNKS], rects, order, tile_start, point_list, s);
+            sgr_launch_bin2_write(IL.gx, IL.gy, B2, bin2, header + 4, g_pinned.p[4 + SGR_B2_HDR_CHUNKS], rects, order, tile_start,
+                                  point_list, s);
         else
             sgr_launch_bin_scatter(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, tile_start, blk_hist, point_list, s);
     }

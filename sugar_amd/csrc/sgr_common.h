@@ -71,9 +71,10 @@ struct Bin2Layout {
     uint32_t cap1, chunk_cap;
 };
 Bin2Layout sgr_bin2_layout(int P, int gx, int gy);
-void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scratch, const uint2* rects, uint32_t* tile_count,
-                           hipStream_t s);
-void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, uint32_t n_chunks, const uint2* rects,
+// hdr: three words (SGR_B2_HDR_*) next to the image header, so that one device-to-host copy brings both
+void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scratch, uint32_t* hdr, const uint2* rects,
+                           uint32_t* tile_count, hipStream_t s);
+void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, const uint32_t* hdr, uint32_t n_chunks, const uint2* rects,
                            const uint32_t* order, const uint32_t* tile_start, uint32_t* point_list, hipStream_t s);
 
 struct BinLayout { size_t point_list, total; };
