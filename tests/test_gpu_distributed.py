@@ -83,4 +83,5 @@ def test_two_ranks_match_sequential_accumulation(tmp_path):
     # a full update apart, the update as a whole must agree
     dev_frac = float((np.abs(flats[0] - ref) > 1e-2 * upd).mean())
     rel = float(np.linalg.norm(flats[0] - ref) / np.linalg.norm(ref - start))
-    assert dev_frac < 1e-4 and rel < 1e-2, (dev_frac, rel)
+    print("two-rank vs sequential: deviating fraction %.2e, relative update error %.2e" % (dev_frac, rel))
+    assert dev_frac < 1e-4 and rel < 1e-3, (dev_frac, rel)  # measured: 0 and 1.3e-5
