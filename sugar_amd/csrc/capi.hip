@@ -162,8 +162,10 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     if (!cov3D_precomp && (!scales || !rotations)) return fail(SGR_E_INVALID, "need scales+rotations or cov3D_precomp");
 
     const ImgLayout IL = sgr_img_layout(width, height);
-    if ((size_t)IL.T * 4 > 150 * 1024 || IL.gx > 65535 || IL.gy > 65535)
-        return fail(SGR_E_INVALID, "image too large: one counter per tile must fit in 150 KB of LDS (about 38 000 tiles)");
+    const bool legacy_ok = IL.n_blocks > 0;  // one LDS counter per tile fits (about 38 000 tiles)
+    if (IL.gx > 65535 || IL.gy > 65535) return fail(SGR_E_INVALID, "image too large: more than 65535 tiles per axis");
+    if (!legacy_ok && g_binning_mode == 1)
+        return fail(SGR_E_INVALID, "image too large for the single-level binning (one LDS counter per tile, about 38 000 tiles)");
     const Bin2Layout B2 = sgr_bin2_layout(P, IL.gx, IL.gy);
     char* geom = geom_alloc(geom_user, sgr_geom_bytes(P));
     char* img = img_alloc(img_user, IL.total + B2.total);  // [ image state | two-level binning scratch ]
@@ -180,7 +182,7 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
 
     uint32_t* blk_hist = reinterpret_cast<uint32_t*>(img + IL.blk_hist);
     char* sort_scratch = geom + sgr_geom_sort_offset(P);
-    const int per_block = (((P + IL.n_blocks - 1) / IL.n_blocks + 63) / 64) * 64;  // Gaussians per slice
+    const int per_block = legacy_ok ? (((P + IL.n_blocks - 1) / IL.n_blocks + 63) / 64) * 64 : 0;  // Gaussians per slice
     uint2* rects = reinterpret_cast<uint2*>(sort_scratch + sgr_sort_rects_offset(P));
 
     PreprocessArgs pa;
@@ -221,6 +223,8 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     HIP_TRY(hipStreamSynchronize(s));  // the one host round trip of the forward (rasterizer_impl.cu:280-281)
     if (two_level && g_pinned.p[4 + SGR_B2_HDR_OVERFLOW]) {
         // more (Gaussian, super-tile) pairs than the level-1 list holds (huge splats): the single-level path has no such limit
+        if (!legacy_ok)
+            return fail(SGR_E_INVALID, "level-1 binning list overflow on an image too large for the single-level fallback");
         two_level = false;
         sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, blk_hist, s);
         sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);

@@ -8,6 +8,7 @@
 #define SGR_TILE_Y 16  // BLOCK_Y, DGR/cuda_rasterizer/config.h:17
 #define SGR_TILE_PIX 256
 #define SGR_NUM_CUS 256              // MI355X
+#define SGR_LEGACY_LDS_BYTES (150 * 1024)
 #define SGR_BIN_SLICES 1024          // slices of the depth order in the ordered binning (one T-entry LDS histogram each)
 
 // ---- private scratch layouts -----------------------------------------------------------------
@@ -52,7 +53,8 @@ static inline ImgLayout sgr_img_layout(int W, int H)
     L.tile_maxc = off;   off = sgr_align(off + (size_t)L.T * 4);
     L.tile_walked = off; off = sgr_align(off + (size_t)L.T * 4);
     L.header = off;      off = sgr_align(off + 64);
-    L.n_blocks = SGR_BIN_SLICES;
+    // the single-level fallback keeps one LDS counter per tile: beyond ~38 000 tiles (8K images) only the two-level path exists
+    L.n_blocks = ((size_t)L.T * 4 <= SGR_LEGACY_LDS_BYTES) ? SGR_BIN_SLICES : 0;
     L.blk_hist = off;    off = sgr_align(off + (size_t)L.n_blocks * L.T * 4);
     L.total = off;
     return L;

@@ -217,6 +217,22 @@ def test_large_tile_grid_4k():
     _check(scene, syn.orbit_cameras(3840, 2160)[1], torch.zeros(3), grads=False)
 
 
+def test_8k_image_runs_on_the_two_level_binning_only():
+    """7680x4320 = 129 600 tiles: beyond the single-level path's one-LDS-counter-per-tile limit; the default path has none"""
+    from sugar_amd import _lib
+    scene = syn.make_scene(20000, 35, 0.002, 0.01)
+    cam = syn.orbit_cameras(7680, 4320)[2]
+    _check(scene, cam, torch.zeros(3), grads=False)
+    lib = _lib.load()
+    assert lib.sgr_last_binning_mode() == 0
+    old = lib.sgr_set_binning_mode(1)
+    try:
+        with pytest.raises(RuntimeError, match="too large for the single-level"):
+            pu.run_hip(scene, cam, torch.zeros(3))
+    finally:
+        lib.sgr_set_binning_mode(old)
+
+
 def test_tiny_image():
     scene = syn.make_scene(2000, 34, 0.02, 0.2)
     _check(scene, syn.orbit_cameras(100, 20)[0], torch.tensor([0.5, 0.1, 0.9]))
