@@ -109,12 +109,12 @@ struct StageFwd {
     float4 a[BATCH];      // x, y, -0.5*conic.x*log2e, -conic.y*log2e
     float4 b[BATCH];      // -0.5*conic.z*log2e, opacity, r, g
     float c[BATCH];       // b
-    uint8_t list[4][BATCH];  // per strip (wave): staged indices of the entries that can touch it, in list order
+    uint8_t list[4][BATCH];  // per wave (its 8x8 block): staged indices of the entries that can touch it, in list order
     uint32_t cnt[4][4];   // [staging wave][strip] hit counts
 };
 
 // Forward blend.  The workgroup stages 256 list entries at a time (one 48-B record gather per thread), computes each
-// entry's strip mask and compacts, per strip, the indices of the entries that can touch it.  Every wave then walks ONLY
+// entry's block mask and compacts, per wave, the indices of the entries that can touch it.  Every wave then walks ONLY
 // its own compacted list, in list order, with a branch-free body (the skip tests of forward.cu:336-351 become lane
 // predicates), and stops as soon as its own 64 pixels are done.  Conic terms are pre-scaled by log2(e) at staging so a
 // pair costs one v_exp_f32.

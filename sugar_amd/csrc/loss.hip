@@ -5,9 +5,10 @@
 // grouped 11x11 conv2d calls plus ~25 elementwise kernels and their autograd twins; on an MI355X that costs far more than
 // the rasterizer it scores.  Here the window is applied separably through LDS and the backward is analytic:
 //
-//   forward kernel : per 16x16 tile, stage x, y (+5 px halo, zero padded like conv2d(padding=5)) in LDS, horizontal then
+//   forward kernel : per 32x32 tile, stage x, y (+5 px halo, zero padded like conv2d(padding=5)) in LDS, horizontal then
 //                    vertical 11-tap pass for {x, y, x^2, y^2, xy}, SSIM map value S and the three partials
-//                    dS/dmu1, dS/dE[x^2], dS/dE[xy]; tile sums of S and |x-y| go to two double accumulators.
+//                    dS/dmu1, dS/dE[x^2], dS/dE[xy]; tile sums of S and |x-y| go to one partial per tile, added in double by
+//                    a finishing kernel.
 //   backward kernel: dL/dx = gL * [ (1-lambda)/N * sign(x-y) - lambda/N * ( G*(dS/dmu1) + 2x * G*(dS/dE[x^2]) + y * G*(dS/dE[xy]) ) ]
 //                    (G is symmetric, so the adjoint of the window is the same separable filter).
 // HBM traffic: x, y read twice, three partial maps written and read once: ~9 floats per pixel-channel in total.

@@ -6,12 +6,14 @@ Restates the vanilla 3DGS optimisation step that SuGaR builds on (SURVEY.md sect
     l1_loss / ssim          sugar_utils/loss_utils.py:17-63
     parameter activations   gaussian_splatting/scene/gaussian_model.py:33-52 (exp / sigmoid / normalize)
     Adam groups and lrs     gaussian_splatting/scene/gaussian_model.py:152-166, arguments/__init__.py:74-83
-Only the rasterizer underneath is this repository's HIP code; loss and Adam are stock PyTorch ops, exactly
-as in the reference.
+On a ROCm device every piece runs on this repository's HIP kernels (rasterizer, fused loss, fused activations, SH-Adam and
+flat Adam); on CPU tensors the same step runs on stock PyTorch ops over whatever rasterizer class is passed in (the tests
+pass the oracle-backed stand-in) -- that path is the parity reference, not a fallback of the product.
 
-Multi-GPU: the path shards by view.  Every rank holds a full replica of the Gaussians,
-renders its own camera, and the parameter gradients meet in ONE flat all-reduce (RCCL over xGMI when the
-process group backend is "nccl"; gloo on CPU for the rehearsal tests) before identical Adam steps.
+Multi-GPU: the path shards by view.  Every rank holds a full replica of the Gaussians and renders its
+own camera; the ranks exchange the clamp-masked colour gradients (all-gather, started from inside the rasterizer backward)
+and the 11 non-SH gradient floats per Gaussian (all-reduce) -- RCCL over xGMI when the process group backend is "nccl", gloo
+for the rehearsal tests -- and take identical Adam steps (see ViewShardedTrainer).
 """
 from __future__ import annotations
 
@@ -121,8 +123,8 @@ class _Activations(torch.autograd.Function):
 
 class GaussianParams:
     """Raw (pre-activation) 3DGS parameters, 59 floats per Gaussian at SH degree 3, stored as views of ONE flat buffer:
-    the data-parallel gradient exchange is a single all-reduce of one contiguous tensor and the optimiser a single
-    streaming kernel.  The SH coefficients are ONE [P,M,3] tensor (the layout the rasterizer consumes); the reference keeps
+    the gradient exchange works on contiguous slices of it (the 11 non-SH floats per Gaussian are one prefix) and the
+    optimiser is two streaming kernels.  The SH coefficients are ONE [P,M,3] tensor (the layout the rasterizer consumes); the reference keeps
     f_dc / f_rest apart and torch.cat()s them every step (gaussian_model.py:108-111: 192 MB of copies per step at 1M)."""
 
     NAMES = ("xyz", "opacity", "scaling", "rotation", "features")  # the SH tensor last: everything else is one prefix
