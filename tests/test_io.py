@@ -76,3 +76,37 @@ def test_gaussian_ply_round_trip_and_layout(tmp_path):
     # lower SH degree and reordered / extra properties are handled by name
     sio.save_gaussian_ply(str(tmp_path / "d1.ply"), t["xyz"], t["features"][:, :4], t["opacity"], t["scaling"], t["rotation"])
     assert sio.load_gaussian_ply(str(tmp_path / "d1.ply"))["features"].shape == (P, 4, 3)
+
+
+def test_ply_reader_accepts_reordered_properties_and_comments(tmp_path):
+    """properties are found by name (load_ply does the same through plyfile), header comments are skipped"""
+    g = torch.Generator().manual_seed(3)
+    P, M = 11, 4
+    feats = torch.randn(P, M, 3, generator=g)
+    t = dict(xyz=torch.randn(P, 3, generator=g), opacity=torch.randn(P, 1, generator=g), scaling=torch.randn(P, 3, generator=g),
+             rotation=torch.randn(P, 4, generator=g))
+    names = sio.gaussian_ply_attributes(M)
+    cols = {"x": t["xyz"][:, 0], "y": t["xyz"][:, 1], "z": t["xyz"][:, 2], "nx": torch.zeros(P), "ny": torch.zeros(P), "nz": torch.zeros(P),
+            "opacity": t["opacity"][:, 0]}
+    for c in range(3):
+        cols[f"f_dc_{c}"] = feats[:, 0, c]
+        for k in range(M - 1):
+            cols[f"f_rest_{c * (M - 1) + k}"] = feats[:, 1 + k, c]
+    for i in range(3):
+        cols[f"scale_{i}"] = t["scaling"][:, i]
+    for i in range(4):
+        cols[f"rot_{i}"] = t["rotation"][:, i]
+    order = list(reversed(names))  # any order
+    header = "ply\nformat binary_little_endian 1.0\ncomment written by a test\nelement vertex %d\n" % P
+    header += "".join(f"property float {n}\n" for n in order) + "end_header\n"
+    body = np.stack([cols[n].numpy().astype("<f4") for n in order], axis=1).tobytes()
+    path = tmp_path / "reordered.ply"
+    path.write_bytes(header.encode() + body)
+    back = sio.load_gaussian_ply(str(path))
+    assert torch.equal(back["features"], feats)
+    for k in t:
+        assert torch.equal(back[k], t[k]), k
+    import pytest
+    (tmp_path / "ascii.ply").write_text("ply\nformat ascii 1.0\nelement vertex 0\nend_header\n")
+    with pytest.raises(ValueError):
+        sio.load_gaussian_ply(str(tmp_path / "ascii.ply"))
