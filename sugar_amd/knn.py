@@ -29,6 +29,7 @@ def _check(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+SUPPORTED_K = (1, 2, 3, 4, 8, 16, 32)  # kernel instantiations; other K <= 32 take the next one and a prefix of its result
 GRID_THRESHOLD = 4096  # below this the exhaustive LDS-tiled kernel is as fast; both give identical results
 
 
@@ -62,6 +63,10 @@ def knn_points(p1: torch.Tensor, p2: torch.Tensor, lengths1=None, lengths2=None,
         raise RuntimeError("knn_points: expected p1[1,N,3], p2[1,M,3] (the shapes SuGaR uses)")
     q, r = _check(p1[0], "p1"), _check(p2[0], "p2")
     N, M = q.shape[0], r.shape[0]
+    K_req = int(K)
+    if K_req < 1 or K_req > SUPPORTED_K[-1]:
+        raise RuntimeError(f"knn_points: K must be in 1..{SUPPORTED_K[-1]}")
+    K = next(k for k in SUPPORTED_K if k >= K_req)  # the kernels are instantiated for these; a prefix of a longer list is exact
     d = torch.empty(N, K, dtype=torch.float32, device=q.device)
     i = torch.empty(N, K, dtype=torch.int64, device=q.device)
     with torch.cuda.device(q.device):
@@ -74,7 +79,9 @@ def knn_points(p1: torch.Tensor, p2: torch.Tensor, lengths1=None, lengths2=None,
             rc = lib.sgr_knn(N, C.c_void_p(q.data_ptr()), M, C.c_void_p(r.data_ptr()), int(K), C.c_void_p(d.data_ptr()),
                              C.c_void_p(i.data_ptr()), stream)
     if rc < 0:
-        raise RuntimeError(f"sgr_knn failed ({rc}); supported K: 1,2,3,4,8,16,32")
+        raise RuntimeError(f"sgr_knn failed ({rc})")
+    if K != K_req:
+        d, i = d[:, :K_req].contiguous(), i[:, :K_req].contiguous()
     return _KNN(d[None], i[None], r[i][None] if return_nn else None)
 
 
@@ -83,7 +90,7 @@ def knn_points_pytorch3d(original):
     (batched clouds, lengths, other dimensions, L1) to the original."""
     def knn_points_dispatch(p1, p2, lengths1=None, lengths2=None, norm=2, K=1, version=-1, return_nn=False, return_sorted=True):
         ok = (p1.is_cuda and p1.dim() == 3 and p2.dim() == 3 and p1.shape[0] == 1 and p2.shape[0] == 1 and p1.shape[2] == 3 and
-              p2.shape[2] == 3 and lengths1 is None and lengths2 is None and norm == 2 and K in (1, 2, 3, 4, 8, 16, 32) and
+              p2.shape[2] == 3 and lengths1 is None and lengths2 is None and norm == 2 and 1 <= K <= SUPPORTED_K[-1] and
               p1.dtype == torch.float32 and p2.dtype == torch.float32 and not (p1.requires_grad or p2.requires_grad))
         if ok:
             return knn_points(p1, p2, K=K, return_nn=return_nn)

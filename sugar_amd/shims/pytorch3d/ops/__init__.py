@@ -18,11 +18,9 @@ def estimate_pointcloud_normals(pointclouds, neighborhood_size: int = 50, disamb
     if N <= neighborhood_size:
         raise ValueError("The neighborhood_size argument has to be strictly smaller than the number of points in the cloud.")
     K = int(neighborhood_size)
-    supported = (1, 2, 3, 4, 8, 16, 32)
-    Kq = next((k for k in supported if k >= K), None)
-    if Kq is None:
-        raise ValueError(f"neighborhood_size up to {supported[-1]} is supported")
-    idx = knn_points(pts[None].contiguous(), pts[None].contiguous(), K=Kq).idx[0][:, :K]
+    if K > 32:
+        raise ValueError("neighborhood_size up to 32 is supported")
+    idx = knn_points(pts[None].contiguous(), pts[None].contiguous(), K=K).idx[0]
     nbrs = pts[idx]                                   # [N,K,3]
     central = nbrs - nbrs.mean(dim=1, keepdim=True)
     cov = (central.unsqueeze(3) * central.unsqueeze(2)).mean(dim=1)  # [N,3,3]

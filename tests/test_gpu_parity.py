@@ -233,6 +233,18 @@ def test_8k_image_runs_on_the_two_level_binning_only():
         lib.sgr_set_binning_mode(old)
 
 
+def test_knn_with_an_uninstantiated_k_is_a_prefix_of_the_next_one():
+    from sugar_amd.knn import knn_points
+    dev = torch.device("cuda:0")
+    pts = syn.make_scene(6000, 36, 0.01, 0.02).means3D.to(dev)
+    a = knn_points(pts[None], pts[None], K=5, return_nn=True)
+    b = knn_points(pts[None], pts[None], K=8)
+    assert a.dists.shape == (1, 6000, 5) and a.knn.shape == (1, 6000, 5, 3)
+    assert torch.equal(a.idx, b.idx[..., :5]) and torch.equal(a.dists, b.dists[..., :5])
+    with pytest.raises(RuntimeError):
+        knn_points(pts[None], pts[None], K=33)
+
+
 def test_tiny_image():
     scene = syn.make_scene(2000, 34, 0.02, 0.2)
     _check(scene, syn.orbit_cameras(100, 20)[0], torch.tensor([0.5, 0.1, 0.9]))
