@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--gaussians", type=int, default=None, help="override the Gaussian count (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="skip the per-stage HIP events (debug: measures their cost)")
+    ap.add_argument("--host-sync", action="store_true", help="forward with the host round trip for num_rendered (A/B of the sync-free forward)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,7 +91,8 @@ def main():
     gtor = torch.Generator().manual_seed(1234)
     gts = [torch.rand(3, H, W, generator=gtor).to(dev) for _ in range(len(cams))]
     params = GaussianParams(scene, dev)
-    trainer = ViewShardedTrainer(params, GaussianRasterizer, GaussianRasterizationSettings, bg_d)
+    trainer = ViewShardedTrainer(params, GaussianRasterizer, GaussianRasterizationSettings, bg_d,
+                                 sync_free=False if args.host_sync else None)
 
     def cam_index(step):
         return (step * world + rank) % len(cams)
@@ -137,7 +139,7 @@ def main():
         img = lf["img"]
         walked += img[off_walk: off_walk + 4 * T].view(torch.int32).sum()
         walked_b += img[off_maxc: off_maxc + 4 * T].view(torch.int32).sum()
-        rendered += lf["num_rendered"]
+        rendered += trainer.last_num_rendered
     torch.cuda.synchronize(dev)
     lib.sgr_profile_enable(0)
     lib.sgr_profile_read(ms, cnt, len(STAGES))

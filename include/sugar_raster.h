@@ -59,6 +59,26 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user,
                     float tan_fovx, float tan_fovy, int prefiltered,
                     float* out_color, int* radii, int debug, void* stream);
 
+/* sgr_forward without the host round trip (extension).  The reference copies num_rendered to the host in the middle of
+ * the forward to size the instance list (rasterizer_impl.cu:280-281): the GPU idles for the round trip.
+ * binning_capacity > 0 selects the SYNC-FREE forward: the list is allocated for `binning_capacity` instances, nothing is
+ * copied back and the call returns binning_capacity (pass it to sgr_backward as R).  The device-side header (8 uint32 at
+ * sgr_img_header_offset() of the image scratch: word 0 = the real num_rendered, word 6 != 0 = level-1 binning overflow)
+ * tells whether the forward is VALID: if word 0 > capacity or word 6 != 0 the blend kernel has returned without touching
+ * its outputs, and the caller must discard this forward and repeat it (binning_capacity = 0, or a larger one) BEFORE running
+ * the backward.  binning_capacity == 0, or the single-level binning selected: exactly sgr_forward. */
+int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user,
+                       sgr_alloc_fn binning_alloc, void* binning_user,
+                       sgr_alloc_fn img_alloc, void* img_user,
+                       int P, int D, int M,
+                       const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* opacities, const float* scales, float scale_modifier,
+                       const float* rotations, const float* cov3D_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                       float tan_fovx, float tan_fovy, int prefiltered,
+                       float* out_color, int* radii, int debug, void* stream, int64_t binning_capacity);
+
 /* Rasterizer::backward, DGR/cuda_rasterizer/rasterizer.h:57-84 / rasterizer_impl.cu:340-434.
  *   R = the value sgr_forward returned; geom/binning/img = the buffers its callbacks handed out.
  *   dL_dpix[3*H*W] in; gradient outputs (float32):
@@ -131,13 +151,14 @@ size_t sgr_binning_bytes(int64_t R);
 /* ---- introspection for parity tests (read-only views into the private scratch layout) ---------
  * Each returns a byte offset into the corresponding buffer.  The geometry record of Gaussian i is
  * 12 floats at geom + sgr_geom_rec_offset() + 48*i:
- *   {x, y, conic.x, conic.y, conic.z, opacity, r, g, b, depth, bitcast(radius), bitcast(clamped bits)} */
+ *   {x, y, conic.x, conic.y, conic.z, opacity, depth, bitcast(radius), r, g, b, bitcast(clamped bits)} */
 size_t sgr_geom_rec_offset(int P);
 size_t sgr_img_final_T_offset(int width, int height);   /* float[W*H] */
 size_t sgr_img_n_contrib_offset(int width, int height); /* uint32[W*H] */
 size_t sgr_img_tile_start_offset(int width, int height);/* uint32[T+1]: tile t owns [start[t], start[t+1]) */
 size_t sgr_img_tile_maxc_offset(int width, int height); /* uint32[T]: max n_contrib over the tile's pixels */
-size_t sgr_img_tile_walked_offset(int width, int height);/* uint32[T]: furthest list position any pixel examined */
+size_t sgr_img_tile_walked_offset(int width, int height); /* uint32[T]: furthest list position any pixel examined */
+size_t sgr_img_header_offset(int width, int height);      /* 8 x uint32: see sgr_forward_ex */
 size_t sgr_binning_point_list_offset(int64_t R);        /* uint32[R]: Gaussian ids, tile-major, depth order */
 
 /* ---- optional per-stage timing (HIP events recorded on the caller's stream, process-wide) --
@@ -148,6 +169,7 @@ size_t sgr_binning_point_list_offset(int64_t R);        /* uint32[R]: Gaussian i
 void sgr_profile_enable(int stage_mask); /* bit s set: record events around stage s (0 disables; each event pair costs
                                             several microseconds of GPU pipeline, so time only what is being measured) */
 int sgr_profile_read(double* ms_sum, int64_t* count, int n_stages);
+
 
 /* ---- k-NN helpers sharing the Gaussian position buffer ------------------------------------------
  * sgr_dist2: simple_knn._C.distCUDA2 (simple-knn/spatial.cu:15-26 -> SimpleKNN::knn, simple-knn/

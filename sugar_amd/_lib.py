@@ -20,6 +20,8 @@ SIGNATURES = {
     "sgr_last_error": (C.c_char_p, []),
     "sgr_forward": (_i64, [ALLOC_FN, _vp, ALLOC_FN, _vp, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp,
                            _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp]),
+    "sgr_forward_ex": (_i64, [ALLOC_FN, _vp, ALLOC_FN, _vp, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp,
+                              _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp, _i64]),
     "sgr_backward": (_i, [_i, _i, _i, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp,
                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sgr_backward_phase": (_i, [_i, _i, _i, _i, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp,
@@ -36,6 +38,7 @@ SIGNATURES = {
     "sgr_img_tile_start_offset": (_sz, [_i, _i]),
     "sgr_img_tile_maxc_offset": (_sz, [_i, _i]),
     "sgr_img_tile_walked_offset": (_sz, [_i, _i]),
+    "sgr_img_header_offset": (_sz, [_i, _i]),
     "sgr_binning_point_list_offset": (_sz, [_i64]),
     "sgr_profile_enable": (None, [_i]),
     "sgr_profile_read": (_i, [_vp, _vp, _i]),

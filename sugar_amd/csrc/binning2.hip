@@ -222,7 +222,8 @@ __global__ void __launch_bounds__(64) k_tile_pass(int gx, int gy, int sgx, int T
                                                   const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ L1,
                                                   const uint2* __restrict__ rects,
                                                   const uint32_t* __restrict__ order, uint32_t* __restrict__ cnt2,
-                                                  const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ point_list)
+                                                  const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ point_list,
+                                                  uint32_t list_cap)
 {
     __shared__ uint32_t s_row[WRITE ? SGR_B2_CHUNK : 1];
     if (hdr[SGR_B2_HDR_OVERFLOW]) return;
@@ -287,7 +288,8 @@ __global__ void __launch_bounds__(64) k_tile_pass(int gx, int gy, int sgx, int T
                         // the stores)
                         LDS_ORDER();
                         const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)base, t + 32 * half);
-                        for (uint32_t j = lane; j < cnt; j += 64) point_list[dst + j] = s_row[j];
+                        for (uint32_t j = lane; j < cnt; j += 64)
+                            if (dst + j < list_cap) point_list[dst + j] = s_row[j];  // (sync-free mode: the list has the caller's capacity)
                         LDS_ORDER();
                     }
                 }
@@ -403,12 +405,12 @@ void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scr
                        sup_start, hist1, hdr, L1);
     const uint32_t grid = L.chunk_cap < 8192u ? L.chunk_cap : 8192u;  // the chunk count lives on the device: grid-stride
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_pass<false>), dim3(grid), dim3(64), 0, s, gx, gy, L.sgx, L.T1, sup_start, chunk_base,
-                       chunk_sup, hdr, L1, rects, (const uint32_t*)nullptr, cnt2, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                       chunk_sup, hdr, L1, rects, (const uint32_t*)nullptr, cnt2, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
     hipLaunchKernelGGL(k_tile_scan2, dim3(L.T1), dim3(64), 0, s, gx, gy, L.sgx, chunk_base, hdr, cnt2, tile_count);
 }
 
 void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, const uint32_t* hdr, uint32_t n_chunks, const uint2* rects,
-                           const uint32_t* order, const uint32_t* tile_start, uint32_t* point_list, hipStream_t s)
+                           const uint32_t* order, const uint32_t* tile_start, uint32_t* point_list, uint32_t list_cap, hipStream_t s)
 {
     if (n_chunks == 0) return;
     const uint32_t* sup_start = reinterpret_cast<const uint32_t*>(scratch + L.sup_start);
@@ -417,5 +419,5 @@ void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, c
     uint32_t* cnt2 = reinterpret_cast<uint32_t*>(scratch + L.cnt2);
     const uint32_t* chunk_sup = reinterpret_cast<const uint32_t*>(scratch + L.chunk_sup);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_pass<true>), dim3(n_chunks), dim3(64), 0, s, gx, gy, L.sgx, L.T1, sup_start,
-                       chunk_base, chunk_sup, hdr, L1, rects, order, cnt2, tile_start, point_list);
+                       chunk_base, chunk_sup, hdr, L1, rects, order, cnt2, tile_start, point_list, list_cap);
 }

@@ -123,8 +123,13 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
                                                    const GeomRec* __restrict__ rec, const float* __restrict__ bg,
                                                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                    uint32_t* __restrict__ tile_maxc, uint32_t* __restrict__ tile_walked,
-                                                   float* __restrict__ out_color)
+                                                   float* __restrict__ out_color, const uint32_t* __restrict__ guard_hdr,
+                                                   uint32_t list_cap)
 {
+    // sync-free forward (sgr_forward_ex with a binning capacity): the host has not seen R.  If the lists did not fit the
+    // capacity, or the level-1 binning overflowed, the ranges are meaningless: touch nothing (the caller reads the header,
+    // discards this forward and repeats it)
+    if (guard_hdr && (guard_hdr[SGR_HDR_R] > list_cap || guard_hdr[4 + SGR_B2_HDR_OVERFLOW])) return;
     __shared__ StageFwd st;
     __shared__ int s_done[4];
     __shared__ uint32_t s_maxc[4];
@@ -162,8 +167,8 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
             const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
             hit = block_hit_mask(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)x0, (float)y0);
             st.a[tid] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
-            st.b[tid] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v1.z, v1.w);
-            st.c[tid] = v2.x;
+            st.b[tid] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v2.x, v2.y);
+            st.c[tid] = v2.z;
         }
         unsigned long long bal[4];
 #pragma unroll
@@ -338,8 +343,8 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
                 const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
                 // conic pre-scaled by log2(e) (and the -1/2 folded in): a pair costs one v_exp_f32 and no extra multiplies
                 sh.a[tid] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
-                sh.b[tid] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v1.z, v1.w);
-                sh.c[tid] = v2.x; sh.id[tid] = id;
+                sh.b[tid] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v2.x, v2.y);
+                sh.c[tid] = v2.z; sh.id[tid] = id;
                 hit = strip_hit_mask(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)x0, (float)y0);
             }
             sh.hit[tid] = hit;
@@ -438,10 +443,10 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
 
 void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
-                          uint32_t* tile_walked, float* out_color, hipStream_t s)
+                          uint32_t* tile_walked, float* out_color, const uint32_t* guard_hdr, uint32_t list_cap, hipStream_t s)
 {
     hipLaunchKernelGGL(k_blend_fwd, dim3(gx * gy), dim3(256), 0, s, W, H, gx, tile_start, point_list, rec, bg, final_T,
-                       n_contrib, tile_maxc, tile_walked, out_color);
+                       n_contrib, tile_maxc, tile_walked, out_color, guard_hdr, list_cap);
 }
 
 void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,

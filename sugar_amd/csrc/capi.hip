@@ -111,6 +111,7 @@ size_t sgr_img_n_contrib_offset(int w, int h) { return sgr_img_layout(w, h).n_co
 size_t sgr_img_tile_start_offset(int w, int h) { return sgr_img_layout(w, h).tile_start; }
 size_t sgr_img_tile_maxc_offset(int w, int h) { return sgr_img_layout(w, h).tile_maxc; }
 size_t sgr_img_tile_walked_offset(int w, int h) { return sgr_img_layout(w, h).tile_walked; }
+size_t sgr_img_header_offset(int w, int h) { return sgr_img_layout(w, h).header; }
 size_t sgr_binning_point_list_offset(int64_t R) { return sgr_bin_layout(R).point_list; }
 
 void sgr_profile_enable(int stage_mask) { g_prof.mask = (unsigned)stage_mask; }
@@ -142,13 +143,13 @@ int sgr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
     return 0;
 }
 
-int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binning_alloc, void* binning_user,
-                    sgr_alloc_fn img_alloc, void* img_user, int P, int D, int M, const float* background, int width,
-                    int height, const float* means3D, const float* shs, const float* colors_precomp,
-                    const float* opacities, const float* scales, float scale_modifier, const float* rotations,
-                    const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
-                    float tan_fovx, float tan_fovy, int prefiltered, float* out_color, int* radii, int debug,
-                    void* stream)
+int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binning_alloc, void* binning_user,
+                       sgr_alloc_fn img_alloc, void* img_user, int P, int D, int M, const float* background, int width,
+                       int height, const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                       const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                       float tan_fovx, float tan_fovy, int prefiltered, float* out_color, int* radii, int debug,
+                       void* stream, int64_t binning_capacity)
 {
     (void)prefiltered;  // the reference only uses it to trap on an inconsistent pre-filter (auxiliary.h:156-160)
     hipStream_t s = (hipStream_t)stream;
@@ -217,22 +218,35 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     }
     STAGE_CHECK("bin_count");
 
-    if (!g_pinned.p) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_pinned.p), 64, hipHostMallocDefault));
-    // words 0-3: the tile scan's header (R, ...); words 4-6: the two-level binning's (R1, chunks, overflow) -- one copy
-    HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 32, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));  // the one host round trip of the forward (rasterizer_impl.cu:280-281)
-    if (two_level && g_pinned.p[4 + SGR_B2_HDR_OVERFLOW]) {
-        // more (Gaussian, super-tile) pairs than the level-1 list holds (huge splats): the single-level path has no such limit
-        if (!legacy_ok)
-            return fail(SGR_E_INVALID, "level-1 binning list overflow on an image too large for the single-level fallback");
-        two_level = false;
-        sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, blk_hist, s);
-        sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
-        sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, s);
-        HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 16, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+    // Sync-free mode (binning_capacity > 0, two-level binning): no device-to-host copy of R and no host wait -- the
+    // instance list gets the caller's capacity, the write pass clamps to it and the blend kernel returns at once when the
+    // header says the forward is invalid (R > capacity, or level-1 overflow).  The caller reads the header later.
+    const bool nosync = binning_capacity > 0 && two_level;
+    if (binning_capacity > 0xFFFFFFFFll) binning_capacity = 0xFFFFFFFFll;
+    int64_t R = 0;
+    uint32_t n_chunks = 0;
+    if (nosync) {
+        R = binning_capacity;
+        n_chunks = B2.chunk_cap < 8192u ? B2.chunk_cap : 8192u;  // the chunk count lives on the device: grid-stride
+    } else {
+        if (!g_pinned.p) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_pinned.p), 64, hipHostMallocDefault));
+        // words 0-3: the tile scan's header (R, ...); words 4-6: the two-level binning's (R1, chunks, overflow) -- one copy
+        HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 32, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));  // the one host round trip of the forward (rasterizer_impl.cu:280-281)
+        if (two_level && g_pinned.p[4 + SGR_B2_HDR_OVERFLOW]) {
+            // more (Gaussian, super-tile) pairs than the level-1 list holds (huge splats): the single-level path has no such limit
+            if (!legacy_ok)
+                return fail(SGR_E_INVALID, "level-1 binning list overflow on an image too large for the single-level fallback");
+            two_level = false;
+            sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, blk_hist, s);
+            sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
+            sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, s);
+            HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 16, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+        R = (int64_t)g_pinned.p[SGR_HDR_R];
+        n_chunks = g_pinned.p[4 + SGR_B2_HDR_CHUNKS];
     }
-    const int64_t R = (int64_t)g_pinned.p[SGR_HDR_R];
     g_last_binning = two_level ? 0 : 1;
 
     const BinLayout BL = sgr_bin_layout(R);
@@ -243,8 +257,8 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     if (R > 0) {
         StageTimer t(s, SGR_STAGE_SCATTER);
         if (two_level)
-            sgr_launch_bin2_write(IL.gx, IL.gy, B2, bin2, header + 4, g_pinned.p[4 + SGR_B2_HDR_CHUNKS], rects, order, tile_start,
-                                  point_list, s);
+            sgr_launch_bin2_write(IL.gx, IL.gy, B2, bin2, header + 4, n_chunks, rects, order, tile_start, point_list,
+                                  nosync ? (uint32_t)R : 0xFFFFFFFFu, s);
         else
             sgr_launch_bin_scatter(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, tile_start, blk_hist, point_list, s);
     }
@@ -252,10 +266,23 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
     {
         StageTimer t(s, SGR_STAGE_BLEND_FWD);
         sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
-                             tile_maxc, tile_walked, out_color, s);
+                             tile_maxc, tile_walked, out_color, nosync ? header : nullptr, (uint32_t)(nosync ? R : 0), s);
     }
     STAGE_CHECK("blend_fwd");
     return R;
+}
+
+int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binning_alloc, void* binning_user,
+                    sgr_alloc_fn img_alloc, void* img_user, int P, int D, int M, const float* background, int width,
+                    int height, const float* means3D, const float* shs, const float* colors_precomp,
+                    const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                    const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                    float tan_fovx, float tan_fovy, int prefiltered, float* out_color, int* radii, int debug,
+                    void* stream)
+{
+    return sgr_forward_ex(geom_alloc, geom_user, binning_alloc, binning_user, img_alloc, img_user, P, D, M, background, width, height,
+                          means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                          projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug, stream, 0);
 }
 
 // phase 0: everything; 1: the blend half (accumulator reset, blend backward, and in compact mode the masked colour

@@ -20,9 +20,9 @@
 // binning: [ point_list u32[R] ]
 struct GeomRec {
     float x, y, cx, cy;          // pixel-space mean, conic.x, conic.y
-    float cz, opacity, r, g;     // conic.z, opacity, colour
-    float b, depth;              // colour, view-space depth
+    float cz, opacity, depth;    // conic.z, opacity, view-space depth
     int radius;                  // 0 = culled
+    float r, g, b;               // colour
     uint32_t clamped;            // bit c set <=> SH colour channel c was clamped at 0
 };
 static_assert(sizeof(GeomRec) == 48, "GeomRec must be 48 bytes");
@@ -77,7 +77,7 @@ Bin2Layout sgr_bin2_layout(int P, int gx, int gy);
 void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scratch, uint32_t* hdr, const uint2* rects,
                            uint32_t* tile_count, hipStream_t s);
 void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, const uint32_t* hdr, uint32_t n_chunks, const uint2* rects,
-                           const uint32_t* order, const uint32_t* tile_start, uint32_t* point_list, hipStream_t s);
+                           const uint32_t* order, const uint32_t* tile_start, uint32_t* point_list, uint32_t list_cap, hipStream_t s);
 
 struct BinLayout { size_t point_list, total; };
 static inline BinLayout sgr_bin_layout(int64_t R)
@@ -144,7 +144,7 @@ void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_star
 
 void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
-                          uint32_t* tile_walked, float* out_color, hipStream_t s);
+                          uint32_t* tile_walked, float* out_color, const uint32_t* guard_hdr, uint32_t list_cap, hipStream_t s);
 void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, const float* final_T, const uint32_t* n_contrib,
                           const uint32_t* tile_maxc, const float* dL_dpix, float* acc, hipStream_t s);

@@ -28,6 +28,8 @@ from .. import _lib
 # `grad_sink(compact_sh=True, out=holder)` selects the compact SH mode of sgr_backward: no SH gradient is produced (the
 # autograd gradient of `shs` is None) and holder["masked_colors"] receives the clamp-masked dL/dRGB [P,3] from which
 # sugar_amd.train_step rebuilds the SH gradient summed over all views (sgr_sh_grad_from_views).
+# `grad_sink(binning_capacity=n, header_out=pinned int32[8], header_event=torch.cuda.Event)` selects the sync-free forward
+# (sgr_forward_ex): no host round trip for num_rendered; the caller checks the header before running the backward.
 _GRAD_SINK: dict = {}
 
 
@@ -131,15 +133,26 @@ class _CModule:
         scratch = _Scratch(dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            rendered = lib.sgr_forward(
+            # sync-free forward: `binning_capacity=n` (instances); the 8-word device header is copied into the pinned
+            # tensor `header_out` behind the forward and `header_event` recorded: the CALLER must check it (word 0 = real
+            # num_rendered <= n and word 6 == 0) before running the backward, and repeat the forward otherwise
+            capacity = int(_GRAD_SINK.get("binning_capacity") or 0) if _GRAD_SINK else 0
+            rendered = lib.sgr_forward_ex(
                 scratch.cb("geom"), None, scratch.cb("binning"), None, scratch.cb("img"), None,
                 P, int(degree), int(M), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
                 _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
                 _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
-                _ptr(out_color), _ptr(radii), int(bool(debug)), C.c_void_p(stream))
+                _ptr(out_color), _ptr(radii), int(bool(debug)), C.c_void_p(stream), capacity)
         if rendered < 0:
             raise RuntimeError(f"sgr_forward failed ({rendered}): {_lib.last_error()}")
         t = scratch.tensors
+        if capacity > 0:
+            off = lib.sgr_img_header_offset(W, H)
+            hdr_out, hdr_ev = _GRAD_SINK.get("header_out"), _GRAD_SINK.get("header_event")
+            if hdr_out is None or hdr_ev is None:
+                raise RuntimeError("binning_capacity needs header_out (pinned int32[8]) and header_event (torch.cuda.Event)")
+            hdr_out.copy_(t["img"][off: off + 32].view(torch.int32), non_blocking=True)
+            hdr_ev.record(torch.cuda.current_stream(dev))
         # introspection only (bench.py's roofline accounting, parity tests): the most recent forward's scratch
         _CModule.last_forward = dict(num_rendered=int(rendered), W=W, H=H, P=P, geom=t["geom"], binning=t["binning"],
                                      img=t["img"])

@@ -226,38 +226,61 @@ class FlatAdam:
         the SH tensor is updated by sgr_sh_adam_from_views straight from the per-view colour gradients (its 48-float gradient
         is never materialised) and the flat kernel covers the other 11 floats per Gaussian only; `before_small` is called
         between the two launches."""
-        C, p = self._C, self.params
+        self.begin_step()
+        if sh_views is not None:
+            self.step_sh(sh_views, grad_scale)
+            if before_small is not None:
+                before_small()  # e.g. wait for the all-reduce of the small gradients, which ran next to the SH kernel
+            self.step_small(grad_scale)
+        else:
+            self._flat_step(self.params.flat.numel(), self._seg, self._n, grad_scale)
+
+    def begin_step(self):
         self.t += 1
+
+    def step_sh(self, sh_views, grad_scale: float = 1.0):
+        """The SH half of the step on the CURRENT stream (a trainer may run it on a second stream, next to step_small and the
+        geometry half of the next forward).  `means3D` must hold the positions the views were rendered with."""
+        C, p = self._C, self.params
+        dev = p.flat.device
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        means3D, campos_all, dcolor_all, sh_degree = sh_views
+        off = p.offsets["features"]
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            dcol, vstride = _view_rows(dcolor_all)
+            rc = self._lib.sgr_sh_adam_from_views(
+                p.P, int(dcolor_all.shape[0]), int(sh_degree), p.M, vp(means3D), vp(campos_all.contiguous()),
+                vp(dcol), int(vstride), C.c_void_p(p.flat.data_ptr() + 4 * off),
+                C.c_void_p(self.exp_avg.data_ptr() + 4 * off), C.c_void_p(self.exp_avg_sq.data_ptr() + 4 * off),
+                p.LRS["features"], p.REST_LR, self.betas[0], self.betas[1], self.eps, self.t, float(grad_scale), stream)
+        if rc < 0:
+            raise RuntimeError(f"sgr_sh_adam_from_views failed ({rc})")
+
+    def step_small(self, grad_scale: float = 1.0):
+        """Everything but the SH tensor: the 11 other floats per Gaussian (positions included)."""
+        self._flat_step(self.params.n_small, self._seg_small, self._n_small, grad_scale)
+
+    def _flat_step(self, n_flat, seg, n_seg, grad_scale):
+        C, p = self._C, self.params
         dev = p.flat.device
         vp = lambda t: C.c_void_p(t.data_ptr())
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            n_flat, seg, n_seg = p.flat.numel(), self._seg, self._n
-            if sh_views is not None:
-                means3D, campos_all, dcolor_all, sh_degree = sh_views
-                off = p.offsets["features"]
-                dcol, vstride = _view_rows(dcolor_all)
-                rc = self._lib.sgr_sh_adam_from_views(
-                    p.P, int(dcolor_all.shape[0]), int(sh_degree), p.M, vp(means3D), vp(campos_all.contiguous()),
-                    vp(dcol), int(vstride), C.c_void_p(p.flat.data_ptr() + 4 * off),
-                    C.c_void_p(self.exp_avg.data_ptr() + 4 * off), C.c_void_p(self.exp_avg_sq.data_ptr() + 4 * off),
-                    p.LRS["features"], p.REST_LR, self.betas[0], self.betas[1], self.eps, self.t, float(grad_scale), stream)
-                if rc < 0:
-                    raise RuntimeError(f"sgr_sh_adam_from_views failed ({rc})")
-                n_flat, seg, n_seg = p.n_small, self._seg_small, self._n_small  # positions are updated after they were read
-                if before_small is not None:
-                    before_small()  # e.g. wait for the all-reduce of the small gradients, which ran next to the SH kernel
             rc = self._lib.sgr_adam_step(n_flat, vp(p.flat), vp(p.flat_grad), vp(self.exp_avg), vp(self.exp_avg_sq), n_seg,
                                          *seg, self.betas[0], self.betas[1], self.eps, self.t, float(grad_scale), stream)
         if rc < 0:
             raise RuntimeError(f"sgr_adam_step failed ({rc})")
 
 
-def render(params: GaussianParams, cam, bg, rasterizer_cls, settings_cls, sh_degree=3, debug=False):
-    """gaussian_splatting/gaussian_renderer/__init__.py:18-100 with SH and scale/rotation handled in the rasterizer"""
+def render(params: GaussianParams, cam, bg, rasterizer_cls, settings_cls, sh_degree=3, debug=False, means2D=None,
+           visibility=True):
+    """gaussian_splatting/gaussian_renderer/__init__.py:18-100 with SH and scale/rotation handled in the rasterizer.
+    `means2D`: a caller-owned [P,3] zero tensor with requires_grad (the reference zero-fills a fresh one per call, :27-31; its
+    values are never read, it only carries dL/dmeans2D); `visibility=False` skips the `radii > 0` mask (:97)."""
     a = params.activated()
     dev = a["means3D"].device
-    screenspace_points = torch.zeros_like(a["means3D"], requires_grad=True)
+    screenspace_points = torch.zeros_like(a["means3D"], requires_grad=True) if means2D is None else means2D
     settings = settings_cls(image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=cam.tanfovx,
                             tanfovy=cam.tanfovy, bg=bg, scale_modifier=1.0, viewmatrix=cam.viewmatrix,
                             projmatrix=cam.projmatrix, sh_degree=sh_degree, campos=cam.campos, prefiltered=False,
@@ -265,7 +288,13 @@ def render(params: GaussianParams, cam, bg, rasterizer_cls, settings_cls, sh_deg
     rasterizer = rasterizer_cls(raster_settings=settings)
     image, radii = rasterizer(means3D=a["means3D"], means2D=screenspace_points, shs=a["shs"], colors_precomp=None,
                               opacities=a["opacities"], scales=a["scales"], rotations=a["rotations"], cov3D_precomp=None)
-    return dict(render=image, viewspace_points=screenspace_points, visibility_filter=radii > 0, radii=radii)
+    return dict(render=image, viewspace_points=screenspace_points, visibility_filter=(radii > 0) if visibility else None,
+                radii=radii)
+
+
+def _current_sink():
+    from . import diff_gaussian_rasterization as dgr
+    return dict(dgr._GRAD_SINK)
 
 
 def _view_rows(dcolor_all):
@@ -308,7 +337,8 @@ class ViewShardedTrainer:
     on the wire instead of 59."""
 
     def __init__(self, params: GaussianParams, rasterizer_cls, settings_cls, bg, sh_degree=3, lambda_dssim=0.2,
-                 fused_loss=True, compact_sh=None, sh_grad_fn=None, grad_sink_cm=None, fused_sh_adam=None):
+                 fused_loss=True, compact_sh=None, sh_grad_fn=None, grad_sink_cm=None, fused_sh_adam=None, sync_free=None,
+                 visibility=False):
         self.fused_loss = fused_loss
         self.params = params
         self.opt = params.make_optimizer()
@@ -325,6 +355,21 @@ class ViewShardedTrainer:
         self.grad_sink_cm = grad_sink_cm  # context manager factory honoured by the rasterizer's backward (None: plain autograd)
         self._send = self._recv = None    # all-gather buffers of the compact exchange
         self._work = None                 # the all-gather in flight
+        # Sync-free forward (sgr_forward_ex with a binning capacity): the rasterizer does not wait for num_rendered in the
+        # middle of the forward; the trainer reads the device header behind the loss and repeats an (extremely rare) forward
+        # whose instance list outgrew the capacity, before any backward or collective runs.
+        on_hip = params.flat.is_cuda and self.grad_sink_cm is not None
+        self.sync_free = on_hip if sync_free is None else bool(sync_free)
+        if self.sync_free and not on_hip:
+            raise ValueError("sync_free needs the HIP rasterizer")
+        self._bin_cap = 0                 # instances the binning buffer is sized for (0: next forward runs with the host round trip)
+        self._hdr = torch.zeros(8, dtype=torch.int32).pin_memory() if self.sync_free else None
+        self._ev_hdr = torch.cuda.Event() if self.sync_free else None
+        self.last_num_rendered = 0
+        self.redone = 0                   # forwards repeated because the capacity was too small
+        self.visibility = visibility      # the step itself has no use for the radii > 0 mask
+        self._means2D = (torch.zeros(params.P, 3, dtype=torch.float32, device=params.flat.device, requires_grad=True)
+                         if params.flat.is_cuda else None)
 
     def _start_gather(self, colors):
         """Called by the rasterizer backward between its two halves: the masked colour gradients (already in the send
@@ -333,6 +378,24 @@ class ViewShardedTrainer:
         if colors.data_ptr() != self._send.data_ptr():
             self._send[: colors.shape[0]].copy_(colors)
         self._work = dist.all_gather_into_tensor(self._recv, self._send, async_op=True)
+
+    def _forward(self, cam, gt_image, capacity):
+        from .diff_gaussian_rasterization import grad_sink
+        extra = dict(binning_capacity=capacity, header_out=self._hdr, header_event=self._ev_hdr) if capacity else {}
+        import contextlib
+        with (grad_sink(**{**_current_sink(), **extra}) if extra else contextlib.nullcontext()):
+            pkg = render(self.params, cam, self.bg, self.rasterizer_cls, self.settings_cls, self.sh_degree,
+                         means2D=self._means2D, visibility=self.visibility)
+            loss = train_loss(pkg["render"], gt_image, self.lambda_dssim, self.fused_loss)
+        return pkg, loss
+
+    @staticmethod
+    def _last_forward_R():
+        try:
+            from .diff_gaussian_rasterization import _C
+            return int(_C.last_forward.get("num_rendered", -1))
+        except Exception:
+            return -1
 
     def step(self, cam, gt_image):
         """gaussian_splatting/train.py:86-128 for one view per rank.  Gradients are taken with torch.autograd.grad and
@@ -360,11 +423,25 @@ class ViewShardedTrainer:
             ctxm = self.grad_sink_cm(**sinks)
         else:
             ctxm = contextlib.nullcontext()
+        cap = self._bin_cap if self.sync_free else 0
         with ctxm:
-            pkg = render(p, cam, self.bg, self.rasterizer_cls, self.settings_cls, self.sh_degree)
-            loss = train_loss(pkg["render"], gt_image, self.lambda_dssim, self.fused_loss)
+            pkg, loss = self._forward(cam, gt_image, cap)
+            if cap:
+                # the header was copied right behind the tile scan: long done by the time the loss is enqueued
+                self._ev_hdr.synchronize()
+                R = int(self._hdr[0]) & 0xFFFFFFFF
+                if R > cap or int(self._hdr[6]) != 0:
+                    self.redone += 1
+                    pkg, loss = self._forward(cam, gt_image, 0)  # with the host round trip: any size
+                    R = self._last_forward_R()
+            else:
+                R = self._last_forward_R()
+            if self.sync_free and R >= 0 and (cap == 0 or 5 * R > 4 * cap):
+                self._bin_cap = R + R // 2 + 65536
+            self.last_num_rendered = R
             grads = torch.autograd.grad(loss, leaves, allow_unused=True)
         sh_views = wait_small = None
+        scale = 1.0 / self.world
         with torch.no_grad():
             for name, leaf, g in zip(names, leaves, grads):
                 if g is None:
@@ -372,9 +449,9 @@ class ViewShardedTrainer:
                         leaf.grad.zero_()
                 elif g.data_ptr() != leaf.grad.data_ptr():
                     leaf.grad.copy_(g)
+            if self.compact_sh and "masked_colors" not in holder:
+                raise RuntimeError("compact_sh: the rasterizer backward did not deliver the masked colour gradients")
             if self.compact_sh:
-                if "masked_colors" not in holder:
-                    raise RuntimeError("compact_sh: the rasterizer backward did not deliver the masked colour gradients")
                 g_rgb = holder["masked_colors"].contiguous()
                 campos = cam.campos.reshape(1, 3).to(g_rgb.dtype).contiguous()
                 if self.world > 1:
@@ -407,7 +484,6 @@ class ViewShardedTrainer:
             elif self.world > 1:
                 # plain path: one flat all-reduce of all 59 floats per Gaussian
                 dist.all_reduce(p.flat_grad, op=dist.ReduceOp.SUM)
-        scale = 1.0 / self.world
         if isinstance(self.opt, FlatAdam):
             self.opt.step(grad_scale=scale, sh_views=sh_views, before_small=wait_small)  # (the mean over views is folded in)
         else:

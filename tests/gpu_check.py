@@ -22,9 +22,9 @@ def check(name, scene, cam, bg, **opts):
     rec = hp["rec"]
     print("  means2D bits equal:", np.array_equal(rec[vis, 0:2].view(np.uint32), st["means2D"][vis].view(np.uint32)),
           " conic bits:", np.array_equal(rec[vis][:, [2, 3, 4]].view(np.uint32), st["conic_opacity"][vis][:, :3].view(np.uint32)),
-          " depth bits:", np.array_equal(rec[vis, 9].view(np.uint32), st["depths"][vis].view(np.uint32)))
+          " depth bits:", np.array_equal(rec[vis, pu.REC_DEPTH].view(np.uint32), st["depths"][vis].view(np.uint32)))
     if "shs" in pu.scene_kwargs(scene, cam, bg, **opts):
-        print("  rgb:", pu.rel_stats(rec[vis, 6:9], st["rgb"][vis]))
+        print("  rgb:", pu.rel_stats(rec[vis, pu.REC_RGB], st["rgb"][vis]))
     lens_o = st["ranges"][:, 1] - st["ranges"][:, 0]
     lens_h = np.diff(hp["tile_start"])
     print("  tile lens equal:", np.array_equal(lens_o, lens_h), " point_list equal:", np.array_equal(st["point_list"], hp["point_list"]))

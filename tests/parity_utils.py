@@ -79,7 +79,7 @@ def run_hip(scene, cam, bg, *, use_sh=True, use_cov=False, sh_degree=3, scale_mo
     R = fn.num_rendered
     out["num_rendered"] = R
     rec = geom.cpu().numpy()[: P * 48].view(np.float32).reshape(P, 12)
-    out["rec"] = rec
+    out["rec"] = rec  # columns: REC_* below (GeomRec, sugar_amd/csrc/sgr_common.h)
     imgb = img.cpu().numpy()
     T = ((W + 15) // 16) * ((H + 15) // 16)
     o = lib.sgr_img_final_T_offset(W, H); out["final_T"] = imgb[o:o + W * H * 4].view(np.float32)
@@ -91,6 +91,10 @@ def run_hip(scene, cam, bg, *, use_sh=True, use_cov=False, sh_degree=3, scale_mo
         color.backward(torch.as_tensor(grad_out).to(dev))
         out["grads"] = {k: (v.grad.detach().cpu().numpy() if v.grad is not None else None) for k, v in leaves.items()}
     return out
+
+
+# float columns of the private 48-byte geometry record (GeomRec, sugar_amd/csrc/sgr_common.h)
+REC_XY, REC_CONIC, REC_OPACITY, REC_DEPTH, REC_RADIUS, REC_RGB, REC_CLAMPED = slice(0, 2), [2, 3, 4], 5, 6, 7, slice(8, 11), 11
 
 
 def rel_stats(a, b, floor_frac=1e-3):

@@ -35,13 +35,13 @@ def _check(scene, cam, bg, grads=True, **opts):
     rec = hp["rec"]
     assert np.array_equal(rec[vis, 0:2].view(np.uint32), st["means2D"][vis].view(np.uint32))
     assert np.array_equal(rec[vis][:, [2, 3, 4]].view(np.uint32), st["conic_opacity"][vis][:, :3].view(np.uint32))
-    assert np.array_equal(rec[vis, 9].view(np.uint32), st["depths"][vis].view(np.uint32))
-    assert np.array_equal(rec[:, 10].view(np.int32), st["radii"])
+    assert np.array_equal(rec[vis, pu.REC_DEPTH].view(np.uint32), st["depths"][vis].view(np.uint32))
+    assert np.array_equal(rec[:, pu.REC_RADIUS].view(np.int32), st["radii"])
     assert np.array_equal(np.diff(hp["tile_start"]), st["ranges"][:, 1] - st["ranges"][:, 0])
     assert np.array_equal(hp["point_list"], st["point_list"])
     if "shs" in pu.scene_kwargs(scene, cam, bg, **opts):
-        np.testing.assert_allclose(rec[vis, 6:9], st["rgb"][vis], rtol=1e-6, atol=1e-7)
-        cl = rec[:, 11].view(np.uint32)
+        np.testing.assert_allclose(rec[vis, pu.REC_RGB], st["rgb"][vis], rtol=1e-6, atol=1e-7)
+        cl = rec[:, pu.REC_CLAMPED].view(np.uint32)
         assert np.array_equal((cl[vis, None] >> np.arange(3)) & 1, st["clamped"][vis])
     # ---- tolerance part
     assert (hp["n_contrib"] != st["n_contrib"]).mean() <= 1e-4
@@ -166,7 +166,7 @@ def test_full_size_properties(config):
     rec, pl, ts = hp["rec"], hp["point_list"].astype(np.int64), hp["tile_start"].astype(np.int64)
     R = hp["num_rendered"]
     assert ts[-1] == R == len(pl)
-    depth_bits = rec[:, 9].view(np.uint32).astype(np.uint64)
+    depth_bits = rec[:, pu.REC_DEPTH].view(np.uint32).astype(np.uint64)
     key = (depth_bits[pl] << np.uint64(32)) | pl.astype(np.uint64)
     tile_of = np.repeat(np.arange(len(ts) - 1), np.diff(ts))
     same_tile = tile_of[1:] == tile_of[:-1]

@@ -121,7 +121,7 @@ def test_product_vs_reference_default_contraction():
     rd, rg = _ref_run(scene, cam, bg, "default", g)
     hp = pu.run_hip(scene, cam, bg, grad_out=g)
     assert (hp["radii"] != rd["radii"]).mean() <= 1e-4
-    assert (hp["rec"][:, 10].view(np.int32) > 0).sum() == (rd["radii"] > 0).sum()
+    assert (hp["rec"][:, pu.REC_RADIUS].view(np.int32) > 0).sum() == (rd["radii"] > 0).sum()
     assert abs(hp["num_rendered"] - rd["num_rendered"]) <= 1e-4 * rd["num_rendered"]
     assert (hp["n_contrib"] != rd["n_contrib"]).mean() <= 2e-3
     e = pu.rel_stats(hp["color"], rd["color"])

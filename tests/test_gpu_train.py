@@ -75,7 +75,7 @@ def test_trainer_compact_and_flat_paths_agree():
         assert float((flats[0] - other).abs().max()) < 2e-2 * float((flats[0] - start).abs().max())
         assert float((flats[0] - other).norm() / (flats[0] - start).norm()) < 1e-3
     tr = ViewShardedTrainer(GaussianParams(scene, dev), GaussianRasterizer, GaussianRasterizationSettings, torch.zeros(3, device=dev))
-    assert tr.compact_sh and tr.fused_sh_adam  # the defaults on a ROCm device
+    assert tr.compact_sh and tr.fused_sh_adam and tr.sync_free  # the defaults on a ROCm device
 
 
 def test_fused_activations_match_torch_ops():
@@ -154,3 +154,49 @@ def test_two_phase_backward_hands_over_final_colour_gradients():
     assert torch.equal(seen[0], send) and torch.equal(holder["masked_colors"], send)  # the second half did not touch them
     for a, b in zip([grads[0], grads[2], grads[3], grads[4]], [ref[0], ref[2], ref[3], ref[4]]):
         assert rel(a, b) < 1e-5
+
+
+def test_sync_free_forward_matches_and_recovers_from_a_small_capacity():
+    """sgr_forward_ex with a binning capacity: same image and lists as the forward with the host round trip; a capacity
+    that is too small is flagged in the header (and leaves the outputs alone) so the caller can repeat the forward"""
+    from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, grad_sink, _C
+    from sugar_amd import _lib
+    dev = torch.device(DEV)
+    scene = syn.make_scene(30000, 10, 0.01, 0.08)
+    cam = syn.orbit_cameras(320, 200)[5]
+    st = GaussianRasterizationSettings(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy, torch.zeros(3, device=dev),
+                                       1.0, cam.viewmatrix.to(dev), cam.projmatrix.to(dev), 3, cam.campos.to(dev), False, False)
+    args = dict(means3D=scene.means3D.to(dev), means2D=torch.zeros(30000, 3, device=dev), opacities=scene.opacities.to(dev),
+                shs=scene.shs.to(dev), scales=scene.scales.to(dev), rotations=scene.rotations.to(dev))
+    with torch.no_grad():
+        color0, _ = GaussianRasterizer(st)(**args)
+    R = _C.last_forward["num_rendered"]
+    list0 = _C.last_forward["binning"][: 4 * R].clone()
+    hdr, ev = torch.zeros(8, dtype=torch.int32).pin_memory(), torch.cuda.Event()
+    for cap, ok in ((R + 1000, True), (R, True), (R - 1, False), (R // 3, False)):
+        with torch.no_grad(), grad_sink(binning_capacity=cap, header_out=hdr, header_event=ev):
+            color, _ = GaussianRasterizer(st)(**args)
+        ev.synchronize()
+        assert int(hdr[0]) == R and int(hdr[6]) == 0
+        assert _C.last_forward["num_rendered"] == cap
+        if ok:
+            assert torch.equal(color, color0)
+            assert torch.equal(_C.last_forward["binning"][: 4 * R], list0)
+    # the trainer notices and repeats the forward
+    from sugar_amd.train_step import GaussianParams, ViewShardedTrainer
+    cams = [c._replace(viewmatrix=c.viewmatrix.to(dev), projmatrix=c.projmatrix.to(dev), campos=c.campos.to(dev))
+            for c in syn.orbit_cameras(320, 200)]
+    gt = torch.rand(3, 200, 320, generator=torch.Generator().manual_seed(3)).to(dev)
+    res = []
+    for shrink in (False, True):
+        p = GaussianParams(scene, dev)
+        tr = ViewShardedTrainer(p, GaussianRasterizer, GaussianRasterizationSettings, torch.zeros(3, device=dev))
+        assert tr.sync_free
+        for i in range(3):
+            if shrink and i == 2:
+                tr._bin_cap = 1000  # far too small: step 3 must detect it and run the forward again
+            tr.step(cams[i], gt)
+        assert tr.redone == (1 if shrink else 0) and tr.last_num_rendered > 1000
+        res.append(p.flat.clone())
+    start = GaussianParams(scene, dev).flat
+    assert float((res[0] - res[1]).norm() / (res[0] - start).norm()) < 1e-3
