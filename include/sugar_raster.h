@@ -269,6 +269,7 @@ int sgr_level_set_points(int N, int K, const float* world_points, const int64_t*
  * and ranges.  sgr_set_binning_mode returns the previous mode; sgr_last_binning_mode the path the last forward took. */
 int sgr_set_binning_mode(int mode);
 int sgr_last_binning_mode(void);
+int sgr_set_blend_variant(int variant); /* development switch between blend kernel variants; returns the old value */
 
 /* ---- SuGaR.get_points_rgb, sugar_scene/sugar_model.py:839-883 (with sugar_utils/spherical_harmonics.py:117-172) -----
  * colors[P,3] = clamp_min(eval_sh(D, sh, dir) + 0.5, 0),  dir = F.normalize(positions - camera_centers) when positions is

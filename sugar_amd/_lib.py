@@ -60,6 +60,7 @@ SIGNATURES = {
     "sgr_activations_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgr_set_binning_mode": (_i, [_i]),
     "sgr_last_binning_mode": (_i, []),
+    "sgr_set_blend_variant": (_i, [_i]),
     "sgr_dist2": (_i, [_i, _vp, _vp, _vp]),
     "sgr_knn": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "sgr_knn_grid_scratch_bytes": (_sz, [_i]),

@@ -16,6 +16,8 @@
 // recorded by the forward) instead of at the end of the tile's list.
 #include "sgr_common.h"
 
+int g_sgr_blend_variant = 0;  // development switch (sgr_set_blend_variant): bit 0 = wave-per-block forward
+
 #ifdef SGR_COUNT
 __device__ unsigned long long g_sgr_count[8];
 extern "C" void sgr_debug_counts(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sgr_count), sizeof(g_sgr_count)); unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_sgr_count), z, sizeof(z)); }
@@ -250,6 +252,225 @@ __global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const u
 }
 
 // ---------------------------------------------------------------------------------------------
+// Forward blend, one WAVE per 8 x 8 pixel block (variant 1).
+//
+// k_blend_fwd above runs four waves per tile in lock step: three workgroup barriers per 256-entry batch, and a wave whose
+// 64 pixels are saturated keeps staging for the others until the whole tile is done.  Here every 8 x 8 block is its own
+// 64-thread workgroup: the wave gathers 64 list entries (one 48-byte record per lane), culls them against ITS block with the
+// exact ellipse-vs-rectangle test, compacts the survivors into LDS (wave-private: LDS operations of a wave execute in
+// order, no barrier at all) and walks them; the gather of the next 64 entries is in flight during the walk.  The four blocks
+// of a tile re-read the same records (L2 hits: they are placed on the same XCD) and each computes one block test per entry
+// instead of four -- ~4 wave-instructions per entry in total, against ~30 per walked (entry, block) pair.
+__device__ __forceinline__ bool block_hit(float gxc, float gyc, float cx, float cy, float cz, float op, float bx0, float by0)
+{
+    if (op < 1.0f / 255.0f) return false;
+    const float det = cx * cz - cy * cy;
+    if (!(det > 0.f) || !(cx > 0.f) || !(cz > 0.f)) return true;
+    const float tau2 = 2.0f * __logf(255.0f * op) * 1.002f + 1e-3f;
+    const float icx = __builtin_amdgcn_rcpf(cx), icz = __builtin_amdgcn_rcpf(cz);
+    const float det_cz = det * icz, det_cx = det * icx;
+    const float kyx = -cy * icz, kxy = -cy * icx;
+    const float dxl = bx0 - gxc, dxr = dxl + 7.0f;
+    const float dyl = by0 - gyc, dyh = dyl + 7.0f;
+    const float sL = kyx * dxl, sR = kyx * dxr;
+    const float tL = fminf(fmaxf(sL, dyl), dyh) - sL, tR = fminf(fmaxf(sR, dyl), dyh) - sR;
+    float q = fminf(det_cz * dxl * dxl + cz * tL * tL, det_cz * dxr * dxr + cz * tR * tR);
+    const float sT = kxy * dyl, sB = kxy * dyh;
+    const float tT = fminf(fmaxf(sT, dxl), dxr) - sT, tB = fminf(fmaxf(sB, dxl), dxr) - sB;
+    q = fminf(q, fminf(det_cx * dyl * dyl + cx * tT * tT, det_cx * dyh * dyh + cx * tB * tB));
+    const bool inside = dxl <= 0.f && dxr >= 0.f && dyl <= 0.f && dyh >= 0.f;
+    return inside || q <= tau2;
+}
+
+// The walk over a compacted batch, hand-scheduled (the compiler's version of this loop carries ~30 VALU and ~23 SALU
+// instructions per entry; this one 22 and 9).  Lanes whose pixel is finished are simply removed from EXEC for the whole walk,
+// the reference's three skip tests (forward.cu:336-351) narrow EXEC further inside an iteration, and the state updates are
+// plain moves under that mask -- no v_cndmask, no per-lane bookkeeping.  The 10 dwords of entry k+1 are fetched from LDS
+// (uniform address: broadcast) while entry k is evaluated (two register sets, A = v[40:49], B = v[50:59]).
+//   in : exec-independent; live = lanes still accumulating, n = entries to walk (> 0), addr = LDS byte address of entry 0
+//   out: live updated, n = entries not yet started when every lane had finished (0: the batch was walked to its end)
+// gfx950 hazards observed by hand (the compiler does not look inside): one independent instruction between v_exp_f32 and the
+// use of its result; EXEC is only ever written by SALU instructions before VALU instructions depend on it.
+#define SGR_FWD_BODY(X, Y, A, B, CZ, OP, R, G, BL, POS)                                             \
+    "v_sub_f32 v60, " X ", %[px]\n"                                                                 \
+    "v_sub_f32 v61, " Y ", %[py]\n"                                                                 \
+    "v_mul_f32 v62, " B ", v61\n"                                                                   \
+    "v_fmac_f32 v62, " A ", v60\n"                                                                  \
+    "v_mul_f32 v63, " CZ ", v61\n"                                                                  \
+    "v_mul_f32 v63, v63, v61\n"                                                                     \
+    "v_fmac_f32 v63, v60, v62\n"        /* log2(e) * power */                                       \
+    "v_exp_f32 v62, v63\n"                                                                          \
+    "s_mov_b64 %[live], exec\n"                                                                     \
+    "v_cmp_nlt_f32 vcc, 0, v63\n"       /* !(power > 0) */                                          \
+    "v_mul_f32 v62, " OP ", v62\n"                                                                  \
+    "v_min_f32 v62, 0x3f7d70a4, v62\n"  /* alpha = min(0.99, opacity * G) */                        \
+    "s_and_b64 exec, exec, vcc\n"                                                                   \
+    "v_cmp_ngt_f32 vcc, 0x3b808081, v62\n" /* !(alpha < 1/255) */                                   \
+    "v_sub_f32 v60, 1.0, v62\n"                                                                     \
+    "v_mul_f32 v60, %[T], v60\n"        /* test_T */                                                \
+    "s_and_b64 exec, exec, vcc\n"                                                                   \
+    "v_cmp_gt_f32 vcc, 0x38d1b717, v60\n" /* test_T < 0.0001: this lane is finished */              \
+    "v_mul_f32 v61, v62, %[T]\n"                                                                    \
+    "s_andn2_b64 %[live], %[live], vcc\n"                                                           \
+    "s_andn2_b64 exec, exec, vcc\n"                                                                 \
+    "v_mov_b32 %[T], v60\n"                                                                         \
+    "v_fmac_f32 %[C0], " R ", v61\n"                                                                \
+    "v_fmac_f32 %[C1], " G ", v61\n"                                                                \
+    "v_fmac_f32 %[C2], " BL ", v61\n"                                                               \
+    "v_mov_b32 %[last], " POS "\n"                                                                  \
+    "s_mov_b64 exec, %[live]\n"
+
+#define SGR_FWD_ENTRY_BYTES 48
+
+// One 48-byte record per lane, issued without a wait (the compiler cannot see the loads: gather_wait must run before the
+// registers are read; its own s_waitcnt counts only become more conservative by the extra loads in flight).
+typedef float f4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gather_issue(const GeomRec* p, f4_t& a, f4_t& b, f4_t& c)
+{
+    asm volatile("global_load_dwordx4 %0, %3, off\n"
+                 "global_load_dwordx4 %1, %3, off offset:16\n"
+                 "global_load_dwordx4 %2, %3, off offset:32"
+                 : "=&v"(a), "=&v"(b), "=&v"(c)
+                 : "v"(p)
+                 : "memory");
+}
+__device__ __forceinline__ void id_issue(const uint32_t* p, uint32_t& id)
+{
+    asm volatile("global_load_dword %0, %1, off" : "=&v"(id) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void gather_wait(f4_t& a, f4_t& b, f4_t& c, uint32_t& id)
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(id)::"memory");
+}
+
+__device__ __forceinline__ void fwd_walk(uint32_t addr, int& n, unsigned long long& live, float pixfx, float pixfy, float& T,
+                                         float& C0, float& C1, float& C2, uint32_t& last)
+{
+    unsigned long long full;
+    asm volatile(
+        "s_mov_b64 %[full], exec\n"
+        "s_and_b64 exec, exec, %[live]\n"
+        "s_waitcnt lgkmcnt(0)\n"  /* scalar loads return out of order: none may be pending while LDS reads are counted */
+        "ds_read_b128 v[40:43], %[addr]\n"
+        "ds_read_b128 v[44:47], %[addr] offset:16\n"
+        "ds_read_b64 v[48:49], %[addr] offset:32\n"
+        "1:\n"
+        "ds_read_b128 v[50:53], %[addr] offset:48\n"
+        "ds_read_b128 v[54:57], %[addr] offset:64\n"
+        "ds_read_b64 v[58:59], %[addr] offset:80\n"
+        "s_waitcnt lgkmcnt(3)\n"
+        SGR_FWD_BODY("v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49")
+        "s_cbranch_execz 3f\n"
+        "s_add_i32 %[n], %[n], -1\n"
+        "s_cmp_eq_u32 %[n], 0\n"
+        "s_cbranch_scc1 3f\n"
+        "ds_read_b128 v[40:43], %[addr] offset:96\n"
+        "ds_read_b128 v[44:47], %[addr] offset:112\n"
+        "ds_read_b64 v[48:49], %[addr] offset:128\n"
+        "v_add_u32 %[addr], 96, %[addr]\n"
+        "s_waitcnt lgkmcnt(3)\n"
+        SGR_FWD_BODY("v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59")
+        "s_cbranch_execz 3f\n"
+        "s_add_i32 %[n], %[n], -1\n"
+        "s_cmp_eq_u32 %[n], 0\n"
+        "s_cbranch_scc0 1b\n"
+        "3:\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_mov_b64 exec, %[full]\n"
+        : [T] "+v"(T), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [last] "+v"(last), [addr] "+v"(addr), [n] "+s"(n),
+          [live] "+s"(live), [full] "=&s"(full)
+        : [px] "v"(pixfx), [py] "v"(pixfy)
+        : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56",
+          "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc", "memory");
+}
+
+__global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_start,
+                                                    const uint32_t* __restrict__ point_list, const GeomRec* __restrict__ rec,
+                                                    const float* __restrict__ bg, float* __restrict__ final_T,
+                                                    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_maxc,
+                                                    uint32_t* __restrict__ tile_walked, float* __restrict__ out_color,
+                                                    const uint32_t* __restrict__ guard_hdr, uint32_t list_cap)
+{
+    if (guard_hdr && (guard_hdr[SGR_HDR_R] > list_cap || guard_hdr[4 + SGR_B2_HDR_OVERFLOW])) return;
+    // entry k: {x, y, -0.5*conic.x*log2e, -conic.y*log2e | -0.5*conic.z*log2e, opacity, r, g | b, bitcast(1-based list position), -, -}
+    // (one spare entry: the walk's look-ahead reads one entry past the last)
+    __shared__ __attribute__((aligned(16))) float s_e[65 * (SGR_FWD_ENTRY_BYTES / 4)];
+    // workgroup b runs on XCD b % 8: the four blocks of a tile share an XCD (and its L2)
+    const int wg = blockIdx.x;
+    const int sub = (wg >> 3) & 3;
+    const int tile = ((wg >> 5) << 3) + (wg & 7);
+    if (tile >= T_tiles) return;
+    const int tx = tile % gx, ty = tile / gx;
+    const int lane = threadIdx.x;
+    const int bx0 = tx * SGR_TILE_X + 8 * (sub & 1), by0 = ty * SGR_TILE_Y + 8 * (sub >> 1);
+    const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pixfx = (float)px, pixfy = (float)py;
+    const uint32_t r0 = tile_start[tile];
+    const int total = (int)(tile_start[tile + 1] - r0);
+
+    float T = 1.0f;
+    uint32_t last_contributor = 0;
+    uint32_t walked = (uint32_t)total;
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    unsigned long long live = __ballot(inside);  // lanes still accumulating
+
+    // Two-deep gather pipeline: the records of batch b+1 (addressed by ids that arrived during batch b-1) and the ids of
+    // batch b+2 travel while batch b is walked.  The record loads are issued from inline asm so that nothing waits for them
+    // before the next iteration's gather_wait.
+    f4_t v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0;
+    uint32_t id_next = 0;
+    if (lane < total) gather_issue(rec + point_list[r0 + lane], v0, v1, v2);
+    if (64 + lane < total) id_issue(point_list + r0 + 64 + lane, id_next);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)s_e;  // LDS byte address of the staging area
+    for (int base = 0; base < total && live != 0ull; base += 64) {
+        gather_wait(v0, v1, v2, id_next);
+        const bool hit = (base + lane < total) && block_hit(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)bx0, (float)by0);
+        const unsigned long long m = __ballot(hit);
+        int n = __popcll(m);
+        if (hit) {
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            float4* e = reinterpret_cast<float4*>(s_e + pos * (SGR_FWD_ENTRY_BYTES / 4));
+            e[0] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
+            e[1] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v2.x, v2.y);
+            *reinterpret_cast<float2*>(e + 2) = make_float2(v2.z, __uint_as_float((uint32_t)(base + lane + 1)));
+        }
+        if (base + 64 + lane < total) gather_issue(rec + id_next, v0, v1, v2);
+        if (base + 128 + lane < total) id_issue(point_list + r0 + base + 128 + lane, id_next);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (n > 0) {
+            const int n0 = n;
+            fwd_walk(lds0, n, live, pixfx, pixfy, T, C0, C1, C2, last_contributor);
+            if (live == 0ull) {  // every pixel finished at compacted entry n0 - n: its list position is the furthest examined
+                walked = __float_as_uint(s_e[(n0 - n) * (SGR_FWD_ENTRY_BYTES / 4) + 9]);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // gathers may still be in flight (early exit): their destination registers must not be reused before they land
+    gather_wait(v0, v1, v2, id_next);
+    if (inside) {
+        const size_t pix_id = (size_t)W * py + px;
+        const size_t HW = (size_t)H * W;
+        final_T[pix_id] = T;
+        n_contrib[pix_id] = last_contributor;
+        out_color[pix_id] = C0 + T * bg[0];
+        out_color[HW + pix_id] = C1 + T * bg[1];
+        out_color[2 * HW + pix_id] = C2 + T * bg[2];
+    }
+    // deepest contributor / furthest examined position of the TILE (zeroed by the launcher): maximum over its four blocks
+    uint32_t mc = inside ? last_contributor : 0u;
+    for (int o = 32; o > 0; o >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, o));
+    if (lane == 0) {
+        atomicMax(&tile_maxc[tile], mc);
+        atomicMax(&tile_walked[tile], __ballot(inside) ? walked : 0u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward blend.
 //
 // The reference adds nine floats with global atomics for every contributing (pixel, Gaussian) pair
@@ -445,6 +666,14 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
                           uint32_t* tile_walked, float* out_color, const uint32_t* guard_hdr, uint32_t list_cap, hipStream_t s)
 {
+    if (g_sgr_blend_variant & 1) {
+        const int T = gx * gy;
+        // tile_maxc and tile_walked are adjacent (each padded to 256 bytes): one memset
+        (void)hipMemsetAsync(tile_maxc, 0, (size_t)((char*)tile_walked - (char*)tile_maxc) + (size_t)T * 4, s);
+        hipLaunchKernelGGL(k_blend_fwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg,
+                           final_T, n_contrib, tile_maxc, tile_walked, out_color, guard_hdr, list_cap);
+        return;
+    }
     hipLaunchKernelGGL(k_blend_fwd, dim3(gx * gy), dim3(256), 0, s, W, H, gx, tile_start, point_list, rec, bg, final_T,
                        n_contrib, tile_maxc, tile_walked, out_color, guard_hdr, list_cap);
 }

@@ -100,6 +100,14 @@ int sgr_set_binning_mode(int mode)
 }
 
 int sgr_last_binning_mode(void) { return g_last_binning; }
+
+extern int g_sgr_blend_variant;
+int sgr_set_blend_variant(int v)
+{
+    const int old = g_sgr_blend_variant;
+    g_sgr_blend_variant = v;
+    return old;
+}
 const char* sgr_last_error(void) { return g_err.c_str(); }
 
 size_t sgr_geom_bytes(int P) { return sgr_geom_total(P); }
