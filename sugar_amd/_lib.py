@@ -89,6 +89,8 @@ def load() -> C.CDLL:
         fn.argtypes = args
     if lib.sgr_abi_version() != 1:
         raise ImportError("sugar_raster ABI version mismatch")
+    if os.environ.get("SGR_BLEND_VARIANT"):  # development switch, see sgr_set_blend_variant
+        lib.sgr_set_blend_variant(int(os.environ["SGR_BLEND_VARIANT"]))
     _lib = lib
     return lib
 

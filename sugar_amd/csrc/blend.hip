@@ -322,26 +322,6 @@ __device__ __forceinline__ bool block_hit(float gxc, float gyc, float cx, float 
 
 #define SGR_FWD_ENTRY_BYTES 48
 
-// One 48-byte record per lane, issued without a wait (the compiler cannot see the loads: gather_wait must run before the
-// registers are read; its own s_waitcnt counts only become more conservative by the extra loads in flight).
-typedef float f4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void gather_issue(const GeomRec* p, f4_t& a, f4_t& b, f4_t& c)
-{
-    asm volatile("global_load_dwordx4 %0, %3, off\n"
-                 "global_load_dwordx4 %1, %3, off offset:16\n"
-                 "global_load_dwordx4 %2, %3, off offset:32"
-                 : "=&v"(a), "=&v"(b), "=&v"(c)
-                 : "v"(p)
-                 : "memory");
-}
-__device__ __forceinline__ void id_issue(const uint32_t* p, uint32_t& id)
-{
-    asm volatile("global_load_dword %0, %1, off" : "=&v"(id) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void gather_wait(f4_t& a, f4_t& b, f4_t& c, uint32_t& id)
-{
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(id)::"memory");
-}
 
 __device__ __forceinline__ void fwd_walk(uint32_t addr, int& n, unsigned long long& live, float pixfx, float pixfy, float& T,
                                          float& C0, float& C1, float& C2, uint32_t& last)
@@ -415,16 +395,19 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
     unsigned long long live = __ballot(inside);  // lanes still accumulating
 
-    // Two-deep gather pipeline: the records of batch b+1 (addressed by ids that arrived during batch b-1) and the ids of
-    // batch b+2 travel while batch b is walked.  The record loads are issued from inline asm so that nothing waits for them
-    // before the next iteration's gather_wait.
-    f4_t v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0;
-    uint32_t id_next = 0;
-    if (lane < total) gather_issue(rec + point_list[r0 + lane], v0, v1, v2);
-    if (64 + lane < total) id_issue(point_list + r0 + 64 + lane, id_next);
+    // The ids of the next batch are fetched while this one is walked; the records are gathered at the top of the iteration
+    // (compiler-scheduled loads: other resident waves cover the latency.  Loads issued from inline asm into registers that
+    // stay in flight across the loop edge are NOT safe: the compiler may copy or reuse the destination registers before
+    // the data lands.)
+    // (loads are unconditional with clamped indices: a load under a lane predicate makes the compiler's wait counts
+    // path-dependent and it then drains everything at the first use)
+    uint32_t id_next = 0u;
+    if (total > 0) id_next = point_list[r0 + (uint32_t)min(lane, total - 1)];  // (uniform branch)
     const uint32_t lds0 = (uint32_t)(uintptr_t)s_e;  // LDS byte address of the staging area
     for (int base = 0; base < total && live != 0ull; base += 64) {
-        gather_wait(v0, v1, v2, id_next);
+        const float4* rp = reinterpret_cast<const float4*>(rec + id_next);
+        const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
+        id_next = point_list[r0 + (uint32_t)min(base + 64 + lane, total - 1)];
         const bool hit = (base + lane < total) && block_hit(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)bx0, (float)by0);
         const unsigned long long m = __ballot(hit);
         int n = __popcll(m);
@@ -435,8 +418,6 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
             e[1] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v2.x, v2.y);
             *reinterpret_cast<float2*>(e + 2) = make_float2(v2.z, __uint_as_float((uint32_t)(base + lane + 1)));
         }
-        if (base + 64 + lane < total) gather_issue(rec + id_next, v0, v1, v2);
-        if (base + 128 + lane < total) id_issue(point_list + r0 + base + 128 + lane, id_next);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (n > 0) {
@@ -450,8 +431,6 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    // gathers may still be in flight (early exit): their destination registers must not be reused before they land
-    gather_wait(v0, v1, v2, id_next);
     if (inside) {
         const size_t pix_id = (size_t)W * py + px;
         const size_t HW = (size_t)H * W;
@@ -648,7 +627,7 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
             const int g = tid >> 2, cpart = tid & 3;
             if (g < nb && cpart < 3) {
                 float* src = &sh.part[g][cpart * 3];
-                float* dst = acc + (size_t)sh.id[g] * 12 + cpart * 3;
+                float* dst = acc + (size_t)sh.id[g] * SGR_ACC_STRIDE + cpart * 3;
 #pragma unroll
                 for (int v = 0; v < 3; v++) {
                     const float val = src[v];
@@ -657,6 +636,291 @@ __global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const u
             }
         }
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward blend, one WAVE per 8 x 8 pixel block (variant bit 1).
+//
+// Same two-phase scheme as k_blend_bwd (phase A lane = pixel, phase B lane = (Gaussian, two pixel rows)), restructured like
+// k_blend_fwd_w: no workgroup barriers, the gather of the next 64 list entries in flight, exact block culling with
+// compaction -- and the compacted entries go through a small LDS queue, so phase B always sees full groups of 16 Gaussians
+// (a batch of 64 list entries leaves ~19 survivors: without the queue every second phase B would run a quarter full).
+// A (block, Gaussian) pair is met exactly once, so its nine sums go straight to global memory (nine float atomics by the
+// sixteen q == 0 lanes); the moments are taken about the block origin and shifted to the Gaussian's centre once per pair.
+// Phase A is hand-scheduled like the forward walk: ~30 VALU per entry, the reference's tests as EXEC masks.
+#define BW_QCAP 80          // queue entries: at most 15 left over + 64 new
+#define BW_SUB 16
+#define BW_ZW_STRIDE 65     // float2 units: conflict-free for the phase-A writes and the phase-B reads
+#define BW_ENTRY_DW 12      // x, y, A, B | C, opacity, r, g | b, list position (1-based), id, -
+
+#define SGR_BWD_BODY(X, Y, A, B, CZ, OP, R, G_, BL, POS)                                          \
+    "v_sub_f32 v120, " X ", %[px]\n"                                                              \
+    "v_sub_f32 v121, " Y ", %[py]\n"                                                              \
+    "v_mul_f32 v122, " B ", v121\n"                                                               \
+    "v_fmac_f32 v122, " A ", v120\n"                                                              \
+    "v_mul_f32 v123, " CZ ", v121\n"                                                              \
+    "v_mul_f32 v123, v123, v121\n"                                                                \
+    "v_fmac_f32 v123, v120, v122\n"      /* log2(e) * power */                                    \
+    "v_exp_f32 v124, v123\n"             /* G */                                                  \
+    "v_mov_b32 v126, 0\n"                                                                         \
+    "v_mov_b32 v127, 0\n"                                                                         \
+    "v_cmp_nlt_f32 %[m0], 0, v123\n"     /* !(power > 0) */                                       \
+    "v_cmp_le_u32 %[m1], " POS ", %[lastc]\n" /* at or before this pixel's last contributor */    \
+    "v_mul_f32 v125, " OP ", v124\n"                                                              \
+    "v_min_f32 v125, 0x3f7d70a4, v125\n" /* alpha */                                              \
+    "s_and_b64 %[m0], %[m0], %[m1]\n"                                                             \
+    "v_cmp_ngt_f32 vcc, 0x3b808081, v125\n" /* !(alpha < 1/255) */                                \
+    "s_and_b64 %[m0], %[m0], %[inside]\n"                                                         \
+    "s_and_b64 exec, %[m0], vcc\n"                                                                \
+    "v_sub_f32 v120, 1.0, v125\n"                                                                 \
+    "v_rcp_f32 v120, v120\n"             /* 1 / (1 - alpha) */                                    \
+    "v_sub_f32 v121, %[lc], %[acc]\n"                                                             \
+    "v_fmac_f32 %[acc], %[la], v121\n"   /* accum_rec . g  (backward.cu:514-516) */               \
+    "v_mul_f32 %[T], %[T], v120\n"                                                                \
+    "v_mul_f32 %[lc], " R ", %[g0]\n"                                                             \
+    "v_fmac_f32 %[lc], " G_ ", %[g1]\n"                                                           \
+    "v_fmac_f32 %[lc], " BL ", %[g2]\n"  /* last_color . g */                                     \
+    "v_mul_f32 v127, v125, %[T]\n"       /* Wt = alpha * T */                                     \
+    "v_sub_f32 v122, %[lc], %[acc]\n"                                                             \
+    "v_mul_f32 v122, v122, %[T]\n"                                                                \
+    "v_fmac_f32 v122, %[ntb], v120\n"    /* dL_dalpha (backward.cu:523-529) */                    \
+    "v_mov_b32 %[la], v125\n"                                                                     \
+    "v_mul_f32 v126, v124, v122\n"       /* Z = G * dL_dalpha */                                  \
+    "s_mov_b64 exec, %[full]\n"                                                                   \
+    "ds_write_b64 %[waddr], v[126:127]\n"                                                         \
+    "v_add_u32 %[waddr], 520, %[waddr]\n"
+
+// rows (1..16) queue entries starting at LDS address e_addr -> panel rows 0..rows-1 at w_addr (+ 8 * lane already added)
+__device__ __forceinline__ void bwd_phase_a(uint32_t e_addr, uint32_t w_addr, int rows, unsigned long long inside_mask, float pixfx,
+                                            float pixfy, float g0, float g1, float g2, float ntb, uint32_t lastc, float& T,
+                                            float& acc_g, float& lc_g, float& last_alpha)
+{
+    unsigned long long full, m0, m1;
+    asm volatile(
+        "s_mov_b64 %[full], exec\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "ds_read_b128 v[100:103], %[eaddr]\n"
+        "ds_read_b128 v[104:107], %[eaddr] offset:16\n"
+        "ds_read_b64 v[108:109], %[eaddr] offset:32\n"
+        "1:\n"
+        "ds_read_b128 v[110:113], %[eaddr] offset:48\n"
+        "ds_read_b128 v[114:117], %[eaddr] offset:64\n"
+        "ds_read_b64 v[118:119], %[eaddr] offset:80\n"
+        "s_waitcnt lgkmcnt(3)\n"
+        SGR_BWD_BODY("v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109")
+        "s_add_i32 %[n], %[n], -1\n"
+        "s_cmp_eq_u32 %[n], 0\n"
+        "s_cbranch_scc1 3f\n"
+        "ds_read_b128 v[100:103], %[eaddr] offset:96\n"
+        "ds_read_b128 v[104:107], %[eaddr] offset:112\n"
+        "ds_read_b64 v[108:109], %[eaddr] offset:128\n"
+        "v_add_u32 %[eaddr], 96, %[eaddr]\n"
+        "s_waitcnt lgkmcnt(4)\n"  /* the panel write of the previous entry may still be counted */
+        SGR_BWD_BODY("v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119")
+        "s_add_i32 %[n], %[n], -1\n"
+        "s_cmp_eq_u32 %[n], 0\n"
+        "s_cbranch_scc0 1b\n"
+        "3:\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        : [T] "+v"(T), [acc] "+v"(acc_g), [lc] "+v"(lc_g), [la] "+v"(last_alpha), [eaddr] "+v"(e_addr), [waddr] "+v"(w_addr),
+          [n] "+s"(rows), [full] "=&s"(full), [m0] "=&s"(m0), [m1] "=&s"(m1)
+        : [px] "v"(pixfx), [py] "v"(pixfy), [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [ntb] "v"(ntb), [lastc] "v"(lastc),
+          [inside] "s"(inside_mask)
+        : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114",
+          "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "vcc", "scc",
+          "memory");
+}
+
+#ifdef SGR_BWD_REF_A
+// C++ restatement of bwd_phase_a (debug aid: -DSGR_BWD_REF_A)
+__device__ __forceinline__ void bwd_phase_a_ref(const float* q, float2* zw, int lane, int rows, bool inside, float pixfx, float pixfy,
+                                                float g0, float g1, float g2, float ntb, uint32_t lastc, float& T, float& acc_g,
+                                                float& lc_g, float& last_alpha)
+{
+    for (int r = 0; r < rows; r++) {
+        const float* e = q + r * BW_ENTRY_DW;
+        const float dx = e[0] - pixfx, dy = e[1] - pixfy;
+        const float power = dx * (e[2] * dx + e[3] * dy) + e[4] * dy * dy;
+        const float G = __builtin_amdgcn_exp2f(power);
+        const float alpha = fminf(0.99f, e[5] * G);
+        const bool active = inside && (__float_as_uint(e[9]) <= lastc) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+        float Z = 0.f, Wt = 0.f;
+        if (active) {
+            const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+            acc_g += last_alpha * (lc_g - acc_g);
+            T = T * inv;
+            lc_g = e[6] * g0 + e[7] * g1 + e[8] * g2;
+            Wt = alpha * T;
+            const float d = (lc_g - acc_g) * T + ntb * inv;
+            last_alpha = alpha;
+            Z = G * d;
+        }
+        zw[r * BW_ZW_STRIDE + lane] = make_float2(Z, Wt);
+    }
+}
+#endif
+
+__global__ void __launch_bounds__(64) k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_start,
+                                                    const uint32_t* __restrict__ point_list, const GeomRec* __restrict__ rec,
+                                                    const float* __restrict__ bg, const float* __restrict__ final_Ts,
+                                                    const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_maxc,
+                                                    const float* __restrict__ dL_dpix, float* __restrict__ acc)
+{
+    __shared__ __attribute__((aligned(16))) float s_q[(BW_QCAP + 1) * BW_ENTRY_DW];  // (+1: phase A's look-ahead)
+    __shared__ float2 s_zw[BW_SUB * BW_ZW_STRIDE];
+    const int wg = blockIdx.x;
+    const int sub = (wg >> 3) & 3;
+    const int tile = ((wg >> 5) << 3) + (wg & 7);
+    if (tile >= T_tiles) return;
+    const int total = (int)tile_maxc[tile];  // entries at list positions > tile_maxc contribute to no pixel of the tile
+    if (total == 0) return;
+    const int tx = tile % gx, ty = tile / gx;
+    const int lane = threadIdx.x;
+    const int bx0 = tx * SGR_TILE_X + 8 * (sub & 1), by0 = ty * SGR_TILE_Y + 8 * (sub >> 1);
+    const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const unsigned long long inside_mask = __ballot(inside);
+    if (inside_mask == 0ull) return;
+    const float pixfx = (float)px, pixfy = (float)py;
+    const uint32_t r0 = tile_start[tile];
+    const size_t pix_id = (size_t)W * py + px;
+    const size_t HW = (size_t)H * W;
+    const float T_final = inside ? final_Ts[pix_id] : 0.f;
+    float T = T_final;
+    const uint32_t last_contributor = inside ? n_contrib[pix_id] : 0u;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (inside) { g0 = dL_dpix[pix_id]; g1 = dL_dpix[HW + pix_id]; g2 = dL_dpix[2 * HW + pix_id]; }
+    const float ntb = -T_final * (bg[0] * g0 + bg[1] * g1 + bg[2] * g2);
+    float acc_g = 0.f, lc_g = 0.f, last_alpha = 0.f;
+
+    // phase-B role: panel row bg_ (Gaussian), pixels 16 bq .. 16 bq + 15 of the block (rows 2 bq and 2 bq + 1)
+    const int bg_ = lane & 15, bq = lane >> 4;
+    float rg0[16], rg1[16], rg2[16];
+    {
+        float* gp = reinterpret_cast<float*>(s_zw);
+        gp[lane] = g0; gp[64 + lane] = g1; gp[128 + lane] = g2;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 16; i++) { rg0[i] = gp[16 * bq + i]; rg1[i] = gp[64 + 16 * bq + i]; rg2[i] = gp[128 + 16 * bq + i]; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const uint32_t q_lds = (uint32_t)(uintptr_t)s_q;
+    const uint32_t zw_lds = (uint32_t)(uintptr_t)s_zw + 8u * (uint32_t)lane;
+
+    // back to front: lane l of batch `base` holds list entry total - 1 - base - l.  The ids of the next batch are fetched
+    // while this one is processed, the records are gathered at the top of the iteration (unconditional loads with
+    // clamped indices, see k_blend_fwd_w).
+    uint32_t id_next = point_list[r0 + (uint32_t)max(total - 1 - lane, 0)];
+    int qn = 0;  // entries waiting in the queue (they sit at its front)
+    for (int base = 0; base < total; base += 64) {
+        const uint32_t id_cur = id_next;
+        const float4* rp = reinterpret_cast<const float4*>(rec + id_cur);
+        const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
+        id_next = point_list[r0 + (uint32_t)max(total - 1 - base - 64 - lane, 0)];
+        const bool hit = (base + lane < total) && block_hit(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)bx0, (float)by0);
+        const unsigned long long m = __ballot(hit);
+        if (hit) {
+            const uint32_t pos = (uint32_t)qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            float4* e = reinterpret_cast<float4*>(s_q + pos * BW_ENTRY_DW);
+            e[0] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
+            e[1] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v2.x, v2.y);
+            e[2] = make_float4(v2.z, __uint_as_float((uint32_t)(total - base - lane)), __uint_as_float(id_cur), 0.f);
+        }
+        qn += __popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool last_batch = base + 64 >= total;
+        int qs = 0;
+        while (qn - qs >= BW_SUB || (last_batch && qn > qs)) {
+            const int rows = min(BW_SUB, qn - qs);
+#ifdef SGR_BWD_REF_A
+            bwd_phase_a_ref(s_q + qs * BW_ENTRY_DW, s_zw, lane, rows, inside, pixfx, pixfy, g0, g1, g2, ntb, last_contributor, T, acc_g,
+                            lc_g, last_alpha);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#else
+            bwd_phase_a(q_lds + (uint32_t)qs * (BW_ENTRY_DW * 4), zw_lds, rows, inside_mask, pixfx, pixfy, g0, g1, g2, ntb,
+                        last_contributor, T, acc_g, lc_g, last_alpha);
+#endif
+            // ---------------- phase B: lane = (panel row bg_, pixel rows 2 bq and 2 bq + 1)
+            if (bg_ < rows) {
+                const float* e = s_q + (qs + bg_) * BW_ENTRY_DW;
+                const float2* row = s_zw + bg_ * BW_ZW_STRIDE + 16 * bq;
+                float s0 = 0.f, sx = 0.f, sxx = 0.f, t0 = 0.f, tx1 = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const float2 v = row[i];
+                    const float xi = (float)(i & 7);
+                    s0 += v.x; sx += v.x * xi; sxx += v.x * (xi * xi);
+                    if (i >= 8) { t0 += v.x; tx1 += v.x * xi; }
+                    k0 += v.y * rg0[i]; k1 += v.y * rg1[i]; k2 += v.y * rg2[i];
+                }
+                // raw moments about the block origin: y = 2 bq + (i >> 3)
+                const float y0 = (float)(2 * bq);
+                float o[9] = {k0, k1, k2, s0, sx, y0 * s0 + t0, sxx, y0 * sx + tx1, y0 * y0 * s0 + (2.f * y0 + 1.f) * t0};
+#pragma unroll
+                for (int v = 0; v < 9; v++) o[v] = sum_over_rows(o[v]);
+                {
+                    // d = centre - pixel = (xb - x, yb - y): shift the raw moments to the Gaussian's centre (every lane: the
+                    // four lanes of a Gaussian hold the same sums after the reduction)
+                    const float xb = e[0] - (float)bx0, yb = e[1] - (float)by0;
+                    const float S0 = o[3], Sx = o[4], Sy = o[5], Sxx = o[6], Sxy = o[7], Syy = o[8];
+                    const float dxs = xb * S0 - Sx, dys = yb * S0 - Sy;
+                    const float dxx = xb * (xb * S0 - 2.f * Sx) + Sxx;
+                    const float dyy = yb * (yb * S0 - 2.f * Sy) + Syy;
+                    const float dxy = xb * dys - yb * Sx + Sxy;  // xb yb S0 - xb Sy - yb Sx + Sxy
+                    // the nine sums of a pair are handed to nine neighbouring lanes through LDS (the panel is free now), so
+                    // that one atomic instruction carries whole 36-byte records (four Gaussians at a time) and the memory
+                    // system sees ONE request per (block, Gaussian) pair instead of nine
+                    float* tb = reinterpret_cast<float*>(s_zw) + bg_ * 16;
+                    if (bq == 0) { tb[0] = o[0]; tb[1] = o[1]; tb[2] = o[2]; tb[3] = S0; }
+                    else if (bq == 1) { tb[4] = dxs; tb[5] = dys; tb[6] = dxx; tb[7] = dxy; }
+                    else if (bq == 2) { tb[8] = dyy; tb[9] = e[10]; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            {
+                const float* tbl = reinterpret_cast<const float*>(s_zw);
+                const int c = lane & 15;
+#pragma unroll
+                for (int pass = 0; pass < 4; pass++) {
+                    const int g = 4 * pass + (lane >> 4);
+                    if (g < rows && c < 9) {
+                        const float val = tbl[g * 16 + c];
+#ifndef SGR_BWD_NO_ATOMICS
+                        if (val != 0.f) atomicAdd(acc + (size_t)__float_as_uint(tbl[g * 16 + 9]) * SGR_ACC_STRIDE + c, val);
+#else
+                        if (val == 12345.f) atomicAdd(acc + (size_t)__float_as_uint(tbl[g * 16 + 9]) * SGR_ACC_STRIDE + c, val);
+#endif
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            qs += rows;
+        }
+        // the (fewer than 16) entries left over move to the front of the queue
+        const int rem = qn - qs;
+        if (qs > 0 && rem > 0) {
+            float4 t0v, t1v, t2v;
+            if (lane < rem) {
+                const float4* src = reinterpret_cast<const float4*>(s_q + (qs + lane) * BW_ENTRY_DW);
+                t0v = src[0]; t1v = src[1]; t2v = src[2];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rem) {
+                float4* dstq = reinterpret_cast<float4*>(s_q + lane * BW_ENTRY_DW);
+                dstq[0] = t0v; dstq[1] = t1v; dstq[2] = t2v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        qn = rem;
     }
 }
 
@@ -682,6 +946,12 @@ void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
                           const GeomRec* rec, const float* bg, const float* final_T, const uint32_t* n_contrib,
                           const uint32_t* tile_maxc, const float* dL_dpix, float* acc, hipStream_t s)
 {
+    if (g_sgr_blend_variant & 2) {
+        const int T = gx * gy;
+        hipLaunchKernelGGL(k_blend_bwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg,
+                           final_T, n_contrib, tile_maxc, dL_dpix, acc);
+        return;
+    }
     hipLaunchKernelGGL(k_blend_bwd, dim3(gx * gy), dim3(256), 0, s, W, H, gx, tile_start, point_list, rec, bg, final_T,
                        n_contrib, tile_maxc, dL_dpix, acc);
 }

@@ -328,7 +328,7 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
     // the blend backward accumulates nine sums per Gaussian with atomics into the private acc[P][12] table
     float* acc = reinterpret_cast<float*>(geom_buffer + sgr_geom_acc_offset(P));
     if (phase != 2) {
-        HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * 48, s));
+        HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * SGR_ACC_STRIDE * 4, s));
         if (R > 0) {
             StageTimer t(s, SGR_STAGE_BLEND_BWD);
             sgr_launch_blend_bwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,

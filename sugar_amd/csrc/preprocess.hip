@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
     float dcol[3], dm2x, dm2y;
     float g0, g1, g3;
     {
-        const float4* ap = reinterpret_cast<const float4*>(a.acc + 12 * (size_t)idx);
+        const float4* ap = reinterpret_cast<const float4*>(a.acc + SGR_ACC_STRIDE * (size_t)idx);
         const float4 s0 = ap[0], s1 = ap[1], s2 = ap[2];  // {k0,k1,k2,S0} {Sx,Sy,Sxx,Sxy} {Syy,-,-,-}
         const float op = rp->opacity, cx = rp->cx, cy = rp->cy, cz = rp->cz;
         dcol[0] = s0.x; dcol[1] = s0.y; dcol[2] = s0.z;
@@ -529,7 +529,7 @@ __global__ void __launch_bounds__(256) k_masked_colors(int P, const GeomRec* __r
     const size_t i3 = 3 * (size_t)idx;
     if (!(rp->radius > 0)) { out[i3] = 0.f; out[i3 + 1] = 0.f; out[i3 + 2] = 0.f; return; }
     const uint32_t clamped = rp->clamped;
-    const float4 s0 = *reinterpret_cast<const float4*>(acc + 12 * (size_t)idx);
+    const float4 s0 = *reinterpret_cast<const float4*>(acc + SGR_ACC_STRIDE * (size_t)idx);
     out[i3] = (clamped & 1u) ? 0.f : s0.x;
     out[i3 + 1] = (clamped & 2u) ? 0.f : s0.y;
     out[i3 + 2] = (clamped & 4u) ? 0.f : s0.z;

@@ -12,7 +12,7 @@
 #define SGR_BIN_SLICES 1024          // slices of the depth order in the ordered binning (one T-entry LDS histogram each)
 
 // ---- private scratch layouts -----------------------------------------------------------------
-// geom  : [ GeomRec rec[P] | acc f32[P][12] | sort scratch ]   48 B / Gaussian record (AoS: one gather = 1-2 lines),
+// geom  : [ GeomRec rec[P] | acc f32[P][16] | sort scratch ]   48 B / Gaussian record (AoS: one gather = 1-2 lines),
 //           the backward's per-Gaussian accumulator (zeroed by each backward), and the depth sort's ping-pong
 //           key/value arrays (the sorted Gaussian order stays there for the backward-free forward only)
 // img   : [ final_T f32[WH] | n_contrib u32[WH] | tile_start u32[T+1] | tile_count u32[T] |
@@ -30,7 +30,9 @@ static_assert(sizeof(GeomRec) == 48, "GeomRec must be 48 bytes");
 static inline size_t sgr_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline size_t sgr_geom_acc_offset(int P) { return sgr_align((size_t)(P > 0 ? P : 1) * 48); }
 size_t sgr_sort_scratch_bytes(int P);  // binning.hip
-static inline size_t sgr_geom_sort_offset(int P) { return sgr_geom_acc_offset(P) + sgr_align((size_t)(P > 0 ? P : 1) * 48); }
+#define SGR_ACC_STRIDE 16  // floats per Gaussian in the backward's accumulator table: 64-byte records, nine used
+                           // (one record = one half cache line: the nine atomics of a (block, Gaussian) pair coalesce)
+static inline size_t sgr_geom_sort_offset(int P) { return sgr_geom_acc_offset(P) + sgr_align((size_t)(P > 0 ? P : 1) * SGR_ACC_STRIDE * 4); }
 size_t sgr_sort_rects_offset(int P);    // binning.hip: offset of the packed rectangles inside the sort scratch
 static inline size_t sgr_geom_total(int P) { return sgr_geom_sort_offset(P) + sgr_sort_scratch_bytes(P); }
 
@@ -119,7 +121,7 @@ struct PreprocessBwdArgs {
     const float* cov3D_precomp; const float* viewmatrix; const float* projmatrix; const float* cam_pos;
     int W, H; float tan_fovx, tan_fovy, focal_x, focal_y;
     const GeomRec* rec;
-    const float* acc;  // [P][12] sums from the blend backward: {dcol r,g,b, S0, Sx, Sy, Sxx, Sxy, Syy, pad x3}
+    const float* acc;  // [P][SGR_ACC_STRIDE] sums from the blend backward: {dcol r,g,b, S0, Sx, Sy, Sxx, Sxy, Syy, pad x3}
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor;  // written here from acc
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
 };
