@@ -16,7 +16,7 @@
 // recorded by the forward) instead of at the end of the tile's list.
 #include "sgr_common.h"
 
-int g_sgr_blend_variant = 0;  // development switch (sgr_set_blend_variant): bit 0 = wave-per-block forward
+int g_sgr_blend_variant = 3;  // development switch (sgr_set_blend_variant): bit 0 = wave-per-block forward, bit 1 = wave-per-block backward
 
 #ifdef SGR_COUNT
 __device__ unsigned long long g_sgr_count[8];
@@ -810,29 +810,13 @@ __global__ void __launch_bounds__(64) k_blend_bwd_w(int W, int H, int gx, int T_
     const uint32_t q_lds = (uint32_t)(uintptr_t)s_q;
     const uint32_t zw_lds = (uint32_t)(uintptr_t)s_zw + 8u * (uint32_t)lane;
 
-    // back to front: lane l of batch `base` holds list entry total - 1 - base - l.  The ids of the next batch are fetched
-    // while this one is processed, the records are gathered at the top of the iteration (unconditional loads with
-    // clamped indices, see k_blend_fwd_w).
-    uint32_t id_next = point_list[r0 + (uint32_t)max(total - 1 - lane, 0)];
+    // back to front: lane l of batch `base` holds list entry total - 1 - base - l.  Software pipeline over the batches: the
+    // gather of batch b (and the ids of batch b + 1) is ISSUED, then the groups already waiting in the queue are processed
+    // while those loads travel, and only then are the loaded records culled and appended to the queue.  (The loads are
+    // plain compiler-scheduled ones, issued and consumed inside the same iteration, unconditional with clamped indices.)
     int qn = 0;  // entries waiting in the queue (they sit at its front)
-    for (int base = 0; base < total; base += 64) {
-        const uint32_t id_cur = id_next;
-        const float4* rp = reinterpret_cast<const float4*>(rec + id_cur);
-        const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
-        id_next = point_list[r0 + (uint32_t)max(total - 1 - base - 64 - lane, 0)];
-        const bool hit = (base + lane < total) && block_hit(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)bx0, (float)by0);
-        const unsigned long long m = __ballot(hit);
-        if (hit) {
-            const uint32_t pos = (uint32_t)qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            float4* e = reinterpret_cast<float4*>(s_q + pos * BW_ENTRY_DW);
-            e[0] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
-            e[1] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v2.x, v2.y);
-            e[2] = make_float4(v2.z, __uint_as_float((uint32_t)(total - base - lane)), __uint_as_float(id_cur), 0.f);
-        }
-        qn += __popcll(m);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const bool last_batch = base + 64 >= total;
+    // process the queued entries in groups of 16 (all of them if `last_batch`), then move the rest to the front
+    auto drain = [&](const bool last_batch) {
         int qs = 0;
         while (qn - qs >= BW_SUB || (last_batch && qn > qs)) {
             const int rows = min(BW_SUB, qn - qs);
@@ -852,6 +836,9 @@ __global__ void __launch_bounds__(64) k_blend_bwd_w(int W, int H, int gx, int T_
                 float s0 = 0.f, sx = 0.f, sxx = 0.f, t0 = 0.f, tx1 = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
+#ifdef SGR_BWD_HALF
+                    if (i == 8) __builtin_amdgcn_sched_barrier(0);  // two groups of eight loads: fewer registers in flight
+#endif
                     const float2 v = row[i];
                     const float xi = (float)(i & 7);
                     s0 += v.x; sx += v.x * xi; sxx += v.x * (xi * xi);
@@ -921,7 +908,28 @@ __global__ void __launch_bounds__(64) k_blend_bwd_w(int W, int H, int gx, int T_
             __builtin_amdgcn_wave_barrier();
         }
         qn = rem;
+    };
+    uint32_t id_next = point_list[r0 + (uint32_t)max(total - 1 - lane, 0)];
+    for (int base = 0; base < total; base += 64) {
+        const uint32_t id_cur = id_next;
+        const float4* rp = reinterpret_cast<const float4*>(rec + id_cur);
+        const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
+        id_next = point_list[r0 + (uint32_t)max(total - 1 - base - 64 - lane, 0)];
+        drain(false);
+        const bool hit = (base + lane < total) && block_hit(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)bx0, (float)by0);
+        const unsigned long long m = __ballot(hit);
+        if (hit) {
+            const uint32_t pos = (uint32_t)qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            float4* e = reinterpret_cast<float4*>(s_q + pos * BW_ENTRY_DW);
+            e[0] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
+            e[1] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v2.x, v2.y);
+            e[2] = make_float4(v2.z, __uint_as_float((uint32_t)(total - base - lane)), __uint_as_float(id_cur), 0.f);
+        }
+        qn += __popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
+    drain(true);
 }
 
 }  // namespace
