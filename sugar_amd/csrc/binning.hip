@@ -48,7 +48,7 @@ namespace {
         __builtin_amdgcn_wave_barrier();     \
     } while (0)
 
-#define RS_ITEMS 1024  // keys per workgroup chunk (one wave scatters a chunk: 16 keys per lane held in registers)
+#define RS_ITEMS 4096  // keys per workgroup chunk (256 threads x 16 keys)
 
 // per-chunk digit histogram, written digit-major: hist[digit * n_chunks + chunk]
 __global__ void __launch_bounds__(256) k_rs_hist(int n, const uint32_t* __restrict__ keys, int shift, int n_chunks,
@@ -91,72 +91,108 @@ __global__ void __launch_bounds__(256) k_rs_scan_rows(int n_chunks, uint32_t* __
     if (tid == 255) totals[blockIdx.x] = s_part[255];
 }
 
-// One wave per chunk walks its keys 64 at a time IN ORDER.  Within a group of 64 the rank among equal digits comes from
-// eight ballots (wave-wide match); across groups a per-digit running offset lives in LDS.  Stable by construction.
-__global__ void __launch_bounds__(64) k_rs_scatter(int n, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                   uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int shift,
-                                                   int n_chunks, const uint32_t* __restrict__ hist,
-                                                   const uint32_t* __restrict__ totals, const uint2* __restrict__ aux_by_val,
-                                                   uint2* __restrict__ aux_out)
+// One 256-thread workgroup per chunk of 4096 keys.  Wave w ranks keys [1024 w, 1024 w + 1024) of the chunk 64 at a time IN
+// ORDER (rank among equal digits of a group from eight ballots, running per-wave digit counters in LDS), the four waves'
+// counts are combined into the chunk's stable order, the pairs are permuted into that order through LDS, and consecutive
+// threads then store consecutive slots of every digit's run: the global stores are coalesced runs instead of one
+// transaction per key (the single-wave version spent most of its time in the store unit: ~4-key runs on the low mantissa
+// bits).  Stable by construction.
+__global__ void __launch_bounds__(256) k_rs_scatter(int n, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int shift,
+                                                    int n_chunks, const uint32_t* __restrict__ hist,
+                                                    const uint32_t* __restrict__ totals, const uint2* __restrict__ aux_by_val,
+                                                    uint2* __restrict__ aux_out)
 {
-    __shared__ uint32_t s_off[256];
-    const int lane = threadIdx.x;
-    {   // digit bases: exclusive scan of the 256 row totals (4 per lane + wave scan), plus this chunk's offset in the row
-        const uint32_t t0 = totals[4 * lane], t1 = totals[4 * lane + 1], t2 = totals[4 * lane + 2], t3 = totals[4 * lane + 3];
-        const uint32_t mine = t0 + t1 + t2 + t3;
-        uint32_t incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
-            if (lane >= o) incl += v;
-        }
-        const uint32_t base = incl - mine;
-        const size_t c = blockIdx.x;
-        s_off[4 * lane + 0] = base + hist[(size_t)(4 * lane + 0) * n_chunks + c];
-        s_off[4 * lane + 1] = base + t0 + hist[(size_t)(4 * lane + 1) * n_chunks + c];
-        s_off[4 * lane + 2] = base + t0 + t1 + hist[(size_t)(4 * lane + 2) * n_chunks + c];
-        s_off[4 * lane + 3] = base + t0 + t1 + t2 + hist[(size_t)(4 * lane + 3) * n_chunks + c];
-    }
-    WAVE_FENCE();
+    __shared__ uint32_t s_cnt[4][256];   // per-wave digit counts, then per-wave first slot (chunk-local)
+    __shared__ uint32_t s_loc[256];      // chunk-local first slot of every digit
+    __shared__ uint32_t s_base[256];     // global first slot of every digit's run for this chunk
+    __shared__ uint32_t s_scan[256];
+    __shared__ uint32_t s_k[RS_ITEMS], s_v[RS_ITEMS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int base = blockIdx.x * RS_ITEMS;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    // all loads of the chunk are issued before the ordered walk starts (the walk itself is a dependent chain)
-    uint32_t rk[RS_ITEMS / 64], rv[RS_ITEMS / 64];
+    constexpr int G = RS_ITEMS / 256;  // groups of 64 keys per wave
+    uint32_t rk[G], rv[G];
 #pragma unroll
-    for (int i = 0; i < RS_ITEMS / 64; i++) {
-        const int k = base + i * 64 + lane;
+    for (int i = 0; i < G; i++) {
+        const int k = base + wave * (RS_ITEMS / 4) + i * 64 + lane;
         rk[i] = (k < n) ? keys_in[k] : 0xFFFFFFFFu;
         rv[i] = (k < n) ? (vals_in ? vals_in[k] : (uint32_t)k) : 0u;
     }
+    s_cnt[0][tid] = 0; s_cnt[1][tid] = 0; s_cnt[2][tid] = 0; s_cnt[3][tid] = 0;
+    __syncthreads();
+    uint32_t lrank[G];  // rank of the key among the keys of ITS WAVE with the same digit
 #pragma unroll
-    for (int i = 0; i < RS_ITEMS / 64; i++) {
-        const int k = base + i * 64 + lane;
+    for (int i = 0; i < G; i++) {
+        const int k = base + wave * (RS_ITEMS / 4) + i * 64 + lane;
         const bool live = k < n;
-        const unsigned long long live_mask = __ballot(live);
-        if (live_mask == 0ull) break;
-        const uint32_t key = rk[i];
-        const uint32_t val = rv[i];
-        const uint32_t digit = (key >> shift) & 255u;
-        unsigned long long same = live_mask;
+        const uint32_t digit = (rk[i] >> shift) & 255u;
+        unsigned long long same = __ballot(live);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
             const bool bit = (digit >> b) & 1u;
             const unsigned long long bal = __ballot(bit);
             same &= bit ? bal : ~bal;
         }
-        const uint32_t rank = (uint32_t)__popcll(same & below);
-        const uint32_t cnt = (uint32_t)__popcll(same);
-        uint32_t off = 0;
-        if (live) off = s_off[digit];
+        const uint32_t prev = s_cnt[wave][digit];
+        lrank[i] = prev + (uint32_t)__popcll(same & below);
         WAVE_FENCE();
-        if (live) {
-            const uint32_t dst = off + rank;
+        if (live && (same & below) == 0ull) s_cnt[wave][digit] = prev + (uint32_t)__popcll(same);
+        WAVE_FENCE();
+    }
+    __syncthreads();
+    {   // thread d: digit d.  chunk-local starts (exclusive scan of the chunk's digit counts) and the global run starts
+        const uint32_t c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid], c3 = s_cnt[3][tid];
+        const uint32_t mine = c0 + c1 + c2 + c3;
+        const uint32_t tot = totals[tid];
+        // two exclusive scans over the 256 digits at once: chunk counts (low) and global totals (high) do not fit one word
+        // (totals up to 2^32): scan them separately
+        s_scan[tid] = mine;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const uint32_t v = (tid >= o) ? s_scan[tid - o] : 0u;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t loc = s_scan[tid] - mine;
+        __syncthreads();
+        s_scan[tid] = tot;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const uint32_t v = (tid >= o) ? s_scan[tid - o] : 0u;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t gbase = s_scan[tid] - tot;
+        s_loc[tid] = loc;
+        s_base[tid] = gbase + hist[(size_t)tid * n_chunks + blockIdx.x];
+        s_cnt[0][tid] = loc; s_cnt[1][tid] = loc + c0; s_cnt[2][tid] = loc + c0 + c1; s_cnt[3][tid] = loc + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < G; i++) {
+        const int k = base + wave * (RS_ITEMS / 4) + i * 64 + lane;
+        if (k < n) {
+            const uint32_t digit = (rk[i] >> shift) & 255u;
+            const uint32_t pos = s_cnt[wave][digit] + lrank[i];
+            s_k[pos] = rk[i]; s_v[pos] = rv[i];
+        }
+    }
+    __syncthreads();
+    const int live_n = min(RS_ITEMS, n - base);
+#pragma unroll
+    for (int i = 0; i < G; i++) {
+        const int j = i * 256 + tid;
+        if (j < live_n) {
+            const uint32_t key = s_k[j], val = s_v[j];
+            const uint32_t digit = (key >> shift) & 255u;
+            const uint32_t dst = s_base[digit] + ((uint32_t)j - s_loc[digit]);
             keys_out[dst] = key;
             vals_out[dst] = val;
             if (aux_out) aux_out[dst] = aux_by_val[val];  // last pass: the tile rectangles in sorted order
-            if (rank == 0) s_off[digit] = off + cnt;
         }
-        WAVE_FENCE();
     }
 }
 
@@ -372,7 +408,7 @@ void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_
         const int shift = 8 * pass;
         hipLaunchKernelGGL(k_rs_hist, dim3(chunks), dim3(256), 0, s, P, kin, shift, chunks, hist);
         hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(256), 0, s, chunks, hist, totals);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(chunks), dim3(64), 0, s, P, kin, vin, kout, vout, shift, chunks, hist, totals,
+        hipLaunchKernelGGL(k_rs_scatter, dim3(chunks), dim3(256), 0, s, P, kin, vin, kout, vout, shift, chunks, hist, totals,
                            rect_by_id, pass == 3 ? rects_sorted : (uint2*)nullptr);
         kin = kout; vin = vout;
     }
