@@ -187,7 +187,7 @@ def main():
             "ms_fwd_bwd": sum(stages.values()),
             "stages_ms": stages,
             "roofline": {
-                "kernel": "k_blend_fwd", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "kernel": "k_blend_fwd_w", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": blend_ms,
                 "pair_evals_per_s": (256.0 * R_f) / (blend_ms * 1e-3) if blend_ms > 0 else 0.0,

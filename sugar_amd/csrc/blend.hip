@@ -1,22 +1,25 @@
-// blend.hip -- per-tile front-to-back alpha compositing (forward) and its backward for gfx950.
+// blend.hip -- front-to-back alpha compositing (forward) and its backward for gfx950.
 //
 // Replaces renderCUDA forward  DGR/cuda_rasterizer/forward.cu:261-374
 //      and renderCUDA backward DGR/cuda_rasterizer/backward.cu:399-557.
 //
-// One 256-thread workgroup (4 wave64) per 16x16 tile.  Forward: wave w owns the 8x8 pixel block (w & 1, w >> 1), lane l its
-// pixel (l & 7, l >> 3); backward: wave w owns the 16x4 strip of rows 4w.., lane l pixel (l & 15, l >> 4) (its phase B walks
-// rows of 16 pixels).
-// The tile's depth-sorted Gaussian list is staged through LDS in batches: each thread gathers ONE 48-byte
-// GeomRec (three dwordx4 loads from one or two cache lines) and the whole workgroup then walks the batch
-// with uniform-address (broadcast, conflict-free) LDS reads.
+// The reference runs one 256-thread block per 16 x 16 tile in lock step.  Here every 8 x 8 pixel BLOCK of a tile is its own
+// 64-thread workgroup (one wave64, lane l = pixel (l & 7, l >> 3)): no workgroup barriers anywhere, a block stops when ITS
+// 64 pixels are done, and 4 x more (smaller) work items balance better over the 256 CUs.  The four blocks of a tile are
+// placed on the same XCD (workgroup b runs on XCD b % 8), so the tile's Gaussian records are fetched from HBM once.
 //
-// Backward: see the comment above k_blend_bwd -- per-pair terms are transposed through a wave-private LDS panel and
-// summed in registers, so a (tile, Gaussian) pair costs at most one 48-byte record of global atomics instead of the
-// reference's up to 256 x 9 (backward.cu:523-554).  The walk starts at the tile's deepest contributor (tile_maxc,
-// recorded by the forward) instead of at the end of the tile's list.
+// Forward (k_blend_fwd_w): the wave gathers 64 entries of the tile's depth-sorted list (one 48-byte GeomRec per lane),
+// culls them against its block with an EXACT ellipse-vs-rectangle test, compacts the survivors into LDS and walks them with
+// a hand-scheduled loop (the reference's skip tests as EXEC masks).  The survivors' (id, list position) pairs are also
+// appended to the block's own list in global memory: the backward starts from those and neither culls nor compacts again.
+//
+// Backward (k_blend_bwd_w): per-pair terms are transposed through a wave-private LDS panel and summed in registers
+// (phase A lane = pixel, phase B lane = (Gaussian, two pixel rows)), so a (block, Gaussian) pair costs ONE coalesced
+// 36-byte atomic request into a 64-byte accumulator record instead of the reference's up to 64 x 9 float atomics
+// (backward.cu:523-554).
 #include "sgr_common.h"
 
-int g_sgr_blend_variant = 3;  // development switch (sgr_set_blend_variant): bit 0 = wave-per-block forward, bit 1 = wave-per-block backward
+int g_sgr_blend_variant = 0;  // development switch between kernel variants under test (sgr_set_blend_variant); unused at present
 
 #ifdef SGR_COUNT
 __device__ unsigned long long g_sgr_count[8];
@@ -25,76 +28,7 @@ extern "C" void sgr_debug_counts(unsigned long long* out) { hipMemcpyFromSymbol(
 
 namespace {
 
-#define BATCH 256
 #define LOG2E 1.4426950408889634f
-
-// Which of the tile's four 16x4 pixel strips (one per wave) can a Gaussian contribute to?  A pair contributes only if
-// power <= 0 and opacity * exp(power) >= 1/255 (forward.cu:336-345), i.e. the pixel lies inside the ellipse
-//     q(d) = cx dx^2 + 2 cy dx dy + cz dy^2 <= tau^2 = 2 ln(255 opacity)        (d = pixel - centre).
-// The test is exact for the strip's rectangle: q is convex, so unless the centre lies in the rectangle its minimum over
-// the rectangle is attained on one of the four edges, where q is a 1-D parabola,
-//     q(dx, .) = (det/cz) dx^2 + cz (dy - dy*)^2,  dy* = -cy dx / cz      (and symmetrically for a horizontal edge),
-// minimised by clamping dy* to the edge.  tau^2 is inflated by 0.2 % + 1e-3 against rounding (at the threshold that is a
-// 1 % margin in alpha, the float evaluation of the pair differs from the exact one by ~1e-6).  Skipping an entry for a
-// strip is therefore exact: no pixel of that strip would have passed the reference's tests.  Elongated, diagonal
-// splats miss most of the strips of their bounding box.  Degenerate conics fall back to "all strips".
-__device__ __forceinline__ uint32_t strip_hit_mask(float gxc, float gyc, float cx, float cy, float cz, float op, float x0,
-                                                   float y0)
-{
-    if (op < 1.0f / 255.0f) return 0u;  // alpha <= opacity < 1/255 everywhere
-    const float det = cx * cz - cy * cy;
-    if (!(det > 0.f) || !(cx > 0.f) || !(cz > 0.f)) return 0xFu;
-    const float tau2 = 2.0f * __logf(255.0f * op) * 1.002f + 1e-3f;
-    const float icx = __builtin_amdgcn_rcpf(cx), icz = __builtin_amdgcn_rcpf(cz);
-    const float det_cz = det * icz, det_cx = det * icx;   // curvature left along an edge after minimising across it
-    const float kyx = -cy * icz, kxy = -cy * icx;         // dy* = kyx dx,  dx* = kxy dy
-    const float dxl = x0 - gxc, dxr = dxl + 15.0f;
-    const bool in_x = dxl <= 0.f && dxr >= 0.f;
-    const float sL = kyx * dxl, sR = kyx * dxr;           // optimal dy on the left / right edge
-    const float bL = det_cz * dxl * dxl, bR = det_cz * dxr * dxr;
-    uint32_t m = 0u;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const float dyl = y0 + 4.0f * w - gyc, dyh = dyl + 3.0f;
-        float tL = fminf(fmaxf(sL, dyl), dyh) - sL, tR = fminf(fmaxf(sR, dyl), dyh) - sR;
-        float q = fminf(bL + cz * tL * tL, bR + cz * tR * tR);
-        const float sT = kxy * dyl, sB = kxy * dyh;       // optimal dx on the top / bottom edge
-        const float tT = fminf(fmaxf(sT, dxl), dxr) - sT, tB = fminf(fmaxf(sB, dxl), dxr) - sB;
-        q = fminf(q, fminf(det_cx * dyl * dyl + cx * tT * tT, det_cx * dyh * dyh + cx * tB * tB));
-        const bool inside = in_x && dyl <= 0.f && dyh >= 0.f;
-        if (inside || q <= tau2) m |= 1u << w;
-    }
-    return m;
-}
-
-// The same test for the forward's wave shape: four 8 x 8 pixel blocks in a 2 x 2 arrangement (bit w: block (w & 1, w >> 1)).
-// A square block is touched by ~10 % fewer splats than a 16 x 4 strip of the same area.
-__device__ __forceinline__ uint32_t block_hit_mask(float gxc, float gyc, float cx, float cy, float cz, float op, float x0,
-                                                   float y0)
-{
-    if (op < 1.0f / 255.0f) return 0u;
-    const float det = cx * cz - cy * cy;
-    if (!(det > 0.f) || !(cx > 0.f) || !(cz > 0.f)) return 0xFu;
-    const float tau2 = 2.0f * __logf(255.0f * op) * 1.002f + 1e-3f;
-    const float icx = __builtin_amdgcn_rcpf(cx), icz = __builtin_amdgcn_rcpf(cz);
-    const float det_cz = det * icz, det_cx = det * icx;
-    const float kyx = -cy * icz, kxy = -cy * icx;
-    uint32_t m = 0u;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const float dxl = x0 + 8.0f * (w & 1) - gxc, dxr = dxl + 7.0f;
-        const float dyl = y0 + 8.0f * (w >> 1) - gyc, dyh = dyl + 7.0f;
-        const float sL = kyx * dxl, sR = kyx * dxr;
-        const float tL = fminf(fmaxf(sL, dyl), dyh) - sL, tR = fminf(fmaxf(sR, dyl), dyh) - sR;
-        float q = fminf(det_cz * dxl * dxl + cz * tL * tL, det_cz * dxr * dxr + cz * tR * tR);
-        const float sT = kxy * dyl, sB = kxy * dyh;
-        const float tT = fminf(fmaxf(sT, dxl), dxr) - sT, tB = fminf(fmaxf(sB, dxl), dxr) - sB;
-        q = fminf(q, fminf(det_cx * dyl * dyl + cx * tT * tT, det_cx * dyh * dyh + cx * tB * tB));
-        const bool inside = dxl <= 0.f && dxr >= 0.f && dyl <= 0.f && dyh >= 0.f;
-        if (inside || q <= tau2) m |= 1u << w;
-    }
-    return m;
-}
 
 // x summed over the four 16-lane rows of the wave (lanes l, l+16, l+32, l+48), result in every lane: two gfx950 lane-swap
 // VALU ops instead of two ds_bpermute round trips through the LDS pipeline.
@@ -107,160 +41,19 @@ __device__ __forceinline__ float sum_over_rows(float x)
     return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
-struct StageFwd {
-    float4 a[BATCH];      // x, y, -0.5*conic.x*log2e, -conic.y*log2e
-    float4 b[BATCH];      // -0.5*conic.z*log2e, opacity, r, g
-    float c[BATCH];       // b
-    uint8_t list[4][BATCH];  // per wave (its 8x8 block): staged indices of the entries that can touch it, in list order
-    uint32_t cnt[4][4];   // [staging wave][strip] hit counts
-};
-
-// Forward blend.  The workgroup stages 256 list entries at a time (one 48-B record gather per thread), computes each
-// entry's block mask and compacts, per wave, the indices of the entries that can touch it.  Every wave then walks ONLY
-// its own compacted list, in list order, with a branch-free body (the skip tests of forward.cu:336-351 become lane
-// predicates), and stops as soon as its own 64 pixels are done.  Conic terms are pre-scaled by log2(e) at staging so a
-// pair costs one v_exp_f32.
-__global__ void __launch_bounds__(256) k_blend_fwd(int W, int H, int gx, const uint32_t* __restrict__ tile_start,
-                                                   const uint32_t* __restrict__ point_list,
-                                                   const GeomRec* __restrict__ rec, const float* __restrict__ bg,
-                                                   float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                   uint32_t* __restrict__ tile_maxc, uint32_t* __restrict__ tile_walked,
-                                                   float* __restrict__ out_color, const uint32_t* __restrict__ guard_hdr,
-                                                   uint32_t list_cap)
-{
-    // sync-free forward (sgr_forward_ex with a binning capacity): the host has not seen R.  If the lists did not fit the
-    // capacity, or the level-1 binning overflowed, the ranges are meaningless: touch nothing (the caller reads the header,
-    // discards this forward and repeats it)
-    if (guard_hdr && (guard_hdr[SGR_HDR_R] > list_cap || guard_hdr[4 + SGR_B2_HDR_OVERFLOW])) return;
-    __shared__ StageFwd st;
-    __shared__ int s_done[4];
-    __shared__ uint32_t s_maxc[4];
-    __shared__ uint32_t s_walk[4];
-    const int tile = blockIdx.x;
-    const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int x0 = tx * SGR_TILE_X, y0 = ty * SGR_TILE_Y;
-    // wave w owns the 8 x 8 pixel block (w & 1, w >> 1) of the tile, lane l the pixel (l & 7, l >> 3) of it
-    const int px = x0 + 8 * (wave & 1) + (lane & 7), py = y0 + 8 * (wave >> 1) + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const float pixfx = (float)px, pixfy = (float)py;
-    const uint32_t r0 = tile_start[tile], r1 = tile_start[tile + 1];
-    const int total = (int)(r1 - r0);
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-
-    bool done = !inside;
-    float T = 1.0f;
-    uint32_t last_contributor = 0;
-    uint32_t wave_walked = (uint32_t)total;  // list position at which this wave's last pixel finished (whole list: never)
-    float C0 = 0.f, C1 = 0.f, C2 = 0.f;
-
-    for (int base = 0; base < total; base += BATCH) {
-        // workgroup vote: stop when every pixel is done (forward.cu:309-311)
-        const bool wave_done = __ballot(!done) == 0ull;
-        if (lane == 0) s_done[wave] = wave_done;
-        __syncthreads();
-        if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;
-        const int nb = min(BATCH, total - base);
-        uint32_t hit = 0u;
-        if (tid < nb) {
-            const uint32_t id = point_list[r0 + base + tid];
-            const float4* rp = reinterpret_cast<const float4*>(rec + id);
-            const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
-            hit = block_hit_mask(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)x0, (float)y0);
-            st.a[tid] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
-            st.b[tid] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v2.x, v2.y);
-            st.c[tid] = v2.z;
-        }
-        unsigned long long bal[4];
-#pragma unroll
-        for (int w = 0; w < 4; w++) bal[w] = __ballot((hit >> w) & 1u);
-        if (lane == 0) {
-#pragma unroll
-            for (int w = 0; w < 4; w++) st.cnt[wave][w] = (uint32_t)__popcll(bal[w]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            if ((hit >> w) & 1u) {
-                uint32_t pos = (uint32_t)__popcll(bal[w] & lt_mask);
-                for (int c = 0; c < wave; c++) pos += st.cnt[c][w];
-                st.list[w][pos] = (uint8_t)tid;
-            }
-        }
-        __syncthreads();
-        if (wave_done) continue;  // this wave's pixels are finished; it only helps staging
-        const int n_mine = __builtin_amdgcn_readfirstlane(
-            (int)(st.cnt[0][wave] + st.cnt[1][wave] + st.cnt[2][wave] + st.cnt[3][wave]));
-        for (int k = 0; k < n_mine; k++) {
-            const int j = __builtin_amdgcn_readfirstlane((int)st.list[wave][k]);  // wave-uniform: keep it scalar
-            const float4 a = st.a[j];
-            const float4 b = st.b[j];
-            const float cb = st.c[j];
-            const uint32_t pos = (uint32_t)(base + j + 1);
-            const float dx = a.x - pixfx, dy = a.y - pixfy;
-            const float power2 = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;  // log2(e) * power
-            const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power2));
-            const bool ok = !done && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
-            const float test_T = T * (1.0f - alpha);
-            const bool stop = ok && (test_T < 0.0001f);
-            const bool upd = ok && !stop;
-            const float w = upd ? alpha * T : 0.0f;
-            C0 += b.z * w; C1 += b.w * w; C2 += cb * w;
-            T = upd ? test_T : T;
-            last_contributor = upd ? pos : last_contributor;
-            done = done || stop;
-#ifdef SGR_COUNT
-            {   // lanes that pass the tests per wave iteration, and how many 8x2 row pairs / 4x4 sub-blocks hold one
-                const unsigned long long okm = __ballot(ok);
-                if (lane == 0) {
-                    atomicAdd(&g_sgr_count[0], 1ull);                               // (entry, wave) iterations
-                    atomicAdd(&g_sgr_count[1], (unsigned long long)__popcll(okm));  // passing lanes
-                    int rows = ((okm & 0xFFFFull) != 0) + ((okm & 0xFFFF0000ull) != 0) + ((okm & 0xFFFF00000000ull) != 0) + ((okm >> 48) != 0);
-                    atomicAdd(&g_sgr_count[2], (unsigned long long)rows);
-                    // lane = 8 * y + x: sub-block (x >> 2, y >> 2)
-                    const unsigned long long m00 = 0x0F0F0F0Full, m10 = 0xF0F0F0F0ull;
-                    const int blocks = ((okm & m00) != 0) + ((okm & m10) != 0) + ((okm & (m00 << 32)) != 0) + ((okm & (m10 << 32)) != 0);
-                    atomicAdd(&g_sgr_count[3], (unsigned long long)blocks);
-                }
-            }
-#endif
-            if (__ballot(!done) == 0ull) { wave_walked = pos; break; }
-        }
-    }
-    if (inside) {
-        const size_t pix_id = (size_t)W * py + px;
-        const size_t HW = (size_t)H * W;
-        final_T[pix_id] = T;
-        n_contrib[pix_id] = last_contributor;
-        out_color[pix_id] = C0 + T * bg[0];
-        out_color[HW + pix_id] = C1 + T * bg[1];
-        out_color[2 * HW + pix_id] = C2 + T * bg[2];
-    }
-    // deepest contributor of the tile, consumed by the backward
-    uint32_t mc = inside ? last_contributor : 0u;
-    for (int o = 32; o > 0; o >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, o));
-    // furthest list position any pixel examined (R_f of the roofline accounting): the entry that
-    // finished the wave's last pixel, or the whole list for a wave with a pixel that never saturated
-    uint32_t wk = __ballot(inside) ? wave_walked : 0u;
-    if (lane == 0) { s_maxc[wave] = mc; s_walk[wave] = wk; }
-    __syncthreads();
-    if (tid == 0) {
-        tile_maxc[tile] = max(max(s_maxc[0], s_maxc[1]), max(s_maxc[2], s_maxc[3]));
-        tile_walked[tile] = max(max(s_walk[0], s_walk[1]), max(s_walk[2], s_walk[3]));
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Forward blend, one WAVE per 8 x 8 pixel block (variant 1).
+// Forward blend.
 //
-// k_blend_fwd above runs four waves per tile in lock step: three workgroup barriers per 256-entry batch, and a wave whose
-// 64 pixels are saturated keeps staging for the others until the whole tile is done.  Here every 8 x 8 block is its own
-// 64-thread workgroup: the wave gathers 64 list entries (one 48-byte record per lane), culls them against ITS block with the
-// exact ellipse-vs-rectangle test, compacts the survivors into LDS (wave-private: LDS operations of a wave execute in
-// order, no barrier at all) and walks them; the gather of the next 64 entries is in flight during the walk.  The four blocks
-// of a tile re-read the same records (L2 hits: they are placed on the same XCD) and each computes one block test per entry
-// instead of four -- ~4 wave-instructions per entry in total, against ~30 per walked (entry, block) pair.
+// Which entries of the tile's list can touch this block?  A pair contributes only if power <= 0 and
+// opacity * exp(power) >= 1/255 (forward.cu:336-345), i.e. the pixel lies inside the ellipse
+//     q(d) = cx dx^2 + 2 cy dx dy + cz dy^2 <= tau^2 = 2 ln(255 opacity)        (d = pixel - centre).
+// The test is exact for the block's rectangle: q is convex, so unless the centre lies in the rectangle its minimum over
+// the rectangle is attained on one of the four edges, where q is a 1-D parabola,
+//     q(dx, .) = (det/cz) dx^2 + cz (dy - dy*)^2,  dy* = -cy dx / cz      (and symmetrically for a horizontal edge),
+// minimised by clamping dy* to the edge.  tau^2 is inflated by 0.2 % + 1e-3 against rounding (at the threshold that is a
+// 1 % margin in alpha, the float evaluation of the pair differs from the exact one by ~1e-6).  Skipping an entry for a
+// block is therefore exact: no pixel of the block would have passed the reference's tests.  Elongated, diagonal splats
+// miss most of the blocks of their bounding box (~70 % of the (entry, block) pairs go).  Degenerate conics: "hit".
 __device__ __forceinline__ bool block_hit(float gxc, float gyc, float cx, float cy, float cz, float op, float bx0, float by0)
 {
     if (op < 1.0f / 255.0f) return false;
@@ -369,6 +162,7 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
                                                     const float* __restrict__ bg, float* __restrict__ final_T,
                                                     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_maxc,
                                                     uint32_t* __restrict__ tile_walked, float* __restrict__ out_color,
+                                                    uint2* __restrict__ blk_list, uint32_t* __restrict__ blk_cnt,
                                                     const uint32_t* __restrict__ guard_hdr, uint32_t list_cap)
 {
     if (guard_hdr && (guard_hdr[SGR_HDR_R] > list_cap || guard_hdr[4 + SGR_B2_HDR_OVERFLOW])) return;
@@ -404,8 +198,13 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
     uint32_t id_next = 0u;
     if (total > 0) id_next = point_list[r0 + (uint32_t)min(lane, total - 1)];  // (uniform branch)
     const uint32_t lds0 = (uint32_t)(uintptr_t)s_e;  // LDS byte address of the staging area
+    // this block's own list for the backward: the (id, list position) pairs of the entries that survive the cull, in list
+    // order, in the block's segment [4 r0 + sub * total, + total) of blk_list
+    uint2* my_list = blk_list + 4 * (size_t)r0 + (size_t)sub * (size_t)total;
+    int n_list = 0;
     for (int base = 0; base < total && live != 0ull; base += 64) {
-        const float4* rp = reinterpret_cast<const float4*>(rec + id_next);
+        const uint32_t id_cur = id_next;
+        const float4* rp = reinterpret_cast<const float4*>(rec + id_cur);
         const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
         id_next = point_list[r0 + (uint32_t)min(base + 64 + lane, total - 1)];
         const bool hit = (base + lane < total) && block_hit(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)bx0, (float)by0);
@@ -417,7 +216,9 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
             e[0] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
             e[1] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v2.x, v2.y);
             *reinterpret_cast<float2*>(e + 2) = make_float2(v2.z, __uint_as_float((uint32_t)(base + lane + 1)));
+            my_list[n_list + (int)pos] = make_uint2(id_cur, (uint32_t)(base + lane + 1));
         }
+        n_list += n;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (n > 0) {
@@ -446,210 +247,30 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
     if (lane == 0) {
         atomicMax(&tile_maxc[tile], mc);
         atomicMax(&tile_walked[tile], __ballot(inside) ? walked : 0u);
+        blk_cnt[4 * tile + sub] = mc ? (uint32_t)n_list : 0u;  // (a block nothing contributed to has no backward)
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Backward blend.
 //
-// The reference adds nine floats with global atomics for every contributing (pixel, Gaussian) pair
-// (backward.cu:523-554).  Here a workgroup walks its tile's list back to front in batches of 64 Gaussians, and every
-// wave alternates two lane mappings over sub-batches of 16 Gaussians:
-//
-//   phase A  lane = pixel (16x4 strip of the wave).  The per-pixel recurrence of backward.cu:486-534 (T /= 1-alpha,
-//            accum_rec, dL_dalpha) runs sequentially over the 16 Gaussians; for each pair the lane stores just
-//            Z = G * dL_dalpha and Wt = alpha * T into a wave-private LDS panel zw[g][pixel].
-//   phase B  lane = (Gaussian g, pixel row q).  Each lane streams the 16 pixels of its row out of the panel and
-//            accumulates, in registers, the colour sums  sum Wt*dL_dpix  and the moments  sum Z, sum Z*dx, sum Z*dx^2
-//            (dy is constant along a row, so the y-moments factor out).  No cross-lane traffic at all in the loop;
-//            one 4-lane shuffle reduction per sub-batch, then LDS float atomics into a per-workgroup table.
-//
+// Two lane mappings alternate over groups of 16 Gaussians of the block's list (walked back to front):
+//   phase A  lane = pixel.  The per-pixel recurrence of backward.cu:486-534 (T /= 1-alpha, accum_rec, dL_dalpha) runs
+//            sequentially over the 16 Gaussians; for each pair the lane stores just Z = G * dL_dalpha and Wt = alpha * T into
+//            a wave-private LDS panel zw[g][pixel].  Hand-scheduled like the forward walk: ~30 VALU per entry, the
+//            reference's tests as EXEC masks.
+//   phase B  lane = (Gaussian g, pixel rows 2q and 2q+1).  Each lane streams its 16 pixels out of the panel and accumulates,
+//            in registers, the colour sums  sum Wt*dL_dpix  and the raw moments of Z about the block origin; one
+//            4-lane reduction with gfx950 lane swaps per group.
 // All gradient terms of a pair are linear in {Wt*g_c, Z, Z*dx, Z*dy, Z*dx^2, Z*dx*dy, Z*dy^2} with per-Gaussian
-// coefficients (backward.cu:538-554), so only those nine sums leave the workgroup: at most one 48-byte record of global
-// float atomics per (tile, Gaussian), into acc[P][12].  The coefficients are applied once per Gaussian by the fused
-// backward-preprocess kernel.  The panel's row stride (65 float2) makes both the phase-A writes and the phase-B reads
-// bank-conflict free.
-#define BWD_BATCH 64
-#define BWD_SUB 16
-#define ZW_STRIDE 65
-
-struct __attribute__((aligned(16))) BwdShared {
-    float4 a[BWD_BATCH];                  // x, y, conic.x, conic.y
-    float4 b[BWD_BATCH];                  // conic.z, opacity, r, g
-    float c[BWD_BATCH];                   // b
-    uint32_t id[BWD_BATCH];
-    uint32_t hit[BWD_BATCH];              // strip_hit_mask: which waves' strips the entry can touch
-    float part[BWD_BATCH][12];            // per-workgroup sums of the current batch
-    float2 zw[4][BWD_SUB * ZW_STRIDE];    // wave-private (Z, Wt) panels; before the walk starts the same memory carries
-                                          // dL_dpix of the tile once (gpix view below): 39 KB total -> 4 workgroups per CU
-};
-
-__global__ void __launch_bounds__(256) k_blend_bwd(int W, int H, int gx, const uint32_t* __restrict__ tile_start,
-                                                   const uint32_t* __restrict__ point_list,
-                                                   const GeomRec* __restrict__ rec, const float* __restrict__ bg,
-                                                   const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
-                                                   const uint32_t* __restrict__ tile_maxc, const float* __restrict__ dL_dpix,
-                                                   float* __restrict__ acc)
-{
-    __shared__ BwdShared sh;
-    const int tile = blockIdx.x;
-    const int total = (int)tile_maxc[tile];  // entries at list positions > tile_maxc contribute to no pixel
-    if (total == 0) return;
-    const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int x0 = tx * SGR_TILE_X, y0 = ty * SGR_TILE_Y;
-    const int px = x0 + (tid & 15), py = y0 + (tid >> 4);
-    const bool inside = px < W && py < H;
-    const float pixfx = (float)px, pixfy = (float)py;
-    const uint32_t r0 = tile_start[tile];
-
-    const size_t pix_id = (size_t)W * py + px;
-    const size_t HW = (size_t)H * W;
-    const float T_final = inside ? final_Ts[pix_id] : 0.f;
-    float T = T_final;
-    const int last_contributor = inside ? (int)n_contrib[pix_id] : 0;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    if (inside) { g0 = dL_dpix[pix_id]; g1 = dL_dpix[HW + pix_id]; g2 = dL_dpix[2 * HW + pix_id]; }
-    const float neg_Tfinal_bg = -T_final * (bg[0] * g0 + bg[1] * g1 + bg[2] * g2);
-    // accum_rec and last_color of backward.cu:514-516 only ever meet dL_dpixel in a dot product: the recurrence is carried
-    // for the scalars  accum_rec . dL_dpixel  and  last_color . dL_dpixel  (6 instead of 12 instructions per pair)
-    float acc_g = 0.f, lc_g = 0.f;
-    float last_alpha = 0.f;
-
-    // phase-B lane role and the dL_dpix of its 16-pixel row, kept in registers for the whole kernel
-    const int bg_g = lane & 15, bq = lane >> 4;
-    float* gpix = reinterpret_cast<float*>(&sh.zw[0][0]);  // [3][256], one-time exchange through the panel memory
-    gpix[tid] = g0; gpix[256 + tid] = g1; gpix[512 + tid] = g2;
-    for (int i = tid; i < BWD_BATCH * 12; i += 256) (&sh.part[0][0])[i] = 0.f;
-    __syncthreads();
-    float rg0[16], rg1[16], rg2[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int p = wave * 64 + bq * 16 + i;
-        rg0[i] = gpix[p]; rg1[i] = gpix[256 + p]; rg2[i] = gpix[512 + p];
-    }
-    __syncthreads();  // the panels are written from here on
-    const float rowy = (float)(y0 + wave * 4 + bq);
-    float2* zw = sh.zw[wave];
-
-    for (int base = 0; base < total; base += BWD_BATCH) {
-        const int nb = min(BWD_BATCH, total - base);
-        if (tid < BWD_BATCH) {
-            uint32_t hit = 0u;
-            if (tid < nb) {
-                const uint32_t id = point_list[r0 + (uint32_t)(total - 1 - base - tid)];
-                const float4* rp = reinterpret_cast<const float4*>(rec + id);
-                const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
-                // conic pre-scaled by log2(e) (and the -1/2 folded in): a pair costs one v_exp_f32 and no extra multiplies
-                sh.a[tid] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
-                sh.b[tid] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v2.x, v2.y);
-                sh.c[tid] = v2.z; sh.id[tid] = id;
-                hit = strip_hit_mask(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)x0, (float)y0);
-            }
-            sh.hit[tid] = hit;
-        }
-        __syncthreads();
-        // entries of this batch that can touch this wave's strip, walked in list order in groups of <= 16 panel rows
-        unsigned long long bits = __ballot((sh.hit[lane] >> wave) & 1u);
-        while (bits) {
-            // ---------------- phase A: lane = pixel
-            int rows = 0;   // wave-uniform: panel rows in use
-            int myj = 0;    // phase-B role: batch index of the Gaussian in panel row bg_g
-            while (bits && rows < BWD_SUB) {
-                const int j = __builtin_ctzll(bits);
-                bits &= bits - 1;
-                const int pos = total - base - j;  // 1-based list position of this entry
-                const float4 a = sh.a[j];
-                const float4 b = sh.b[j];
-                const float dx = a.x - pixfx, dy = a.y - pixfy;
-                const float power = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;  // log2(e) * power of backward.cu:489
-                const float G = __builtin_amdgcn_exp2f(power);
-                const float alpha = fminf(0.99f, b.y * G);
-                const bool active = (pos <= last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                if (__ballot(active) == 0ull) continue;  // wave-uniform
-                float Z = 0.f, Wt = 0.f;
-                if (active) {
-                    // 1/(1-alpha) with the hardware reciprocal (1 ulp): the reference's two IEEE divisions
-                    // (backward.cu:503,534) cost ~24 instructions per pair; 1-alpha >= 0.01, so no range issue
-                    const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                    T = T * inv_1ma;
-                    Wt = alpha * T;
-                    const float c0 = b.z, c1 = b.w, c2 = sh.c[j];
-                    // accum_rec = last_alpha * last_color + (1 - last_alpha) * accum_rec  (backward.cu:514-516)
-                    acc_g += last_alpha * (lc_g - acc_g);
-                    lc_g = c0 * g0 + c1 * g1 + c2 * g2;
-                    float dL_dalpha = lc_g - acc_g;
-                    last_alpha = alpha;
-                    dL_dalpha = dL_dalpha * T + neg_Tfinal_bg * inv_1ma;  // backward.cu:523-529
-                    Z = G * dL_dalpha;
-                }
-                zw[rows * ZW_STRIDE + lane] = make_float2(Z, Wt);
-                if (bg_g == rows) myj = j;
-                rows++;
-            }
-            if (rows == 0) continue;  // wave-uniform (bits is now 0)
-            // the panel is exchanged between lanes of ONE wave: LDS operations of a wave execute in order, so a
-            // wave-scope fence (compiler ordering) is all that is needed, no workgroup barrier
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // ---------------- phase B: lane = (panel row bg_g, pixel row bq)
-            if (bg_g < rows) {
-                const float4 a = sh.a[myj];
-                const float dyr = a.y - rowy;
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
-                const float2* row = zw + bg_g * ZW_STRIDE + bq * 16;
-                const float xb = a.x - (float)x0;
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const float2 v = row[i];
-                    s0 += v.x; s1 += v.x * (float)i; s2 += v.x * (float)(i * i);  // moments about the tile's left edge
-                    k0 += v.y * rg0[i]; k1 += v.y * rg1[i]; k2 += v.y * rg2[i];
-                }
-                // sum Z (xb - i) and sum Z (xb - i)^2 from the raw moments
-                const float sx = xb * s0 - s1;
-                const float sxx = xb * (xb * s0 - 2.f * s1) + s2;
-                float o[9] = {k0, k1, k2, s0, sx, dyr * s0, sxx, dyr * sx, dyr * dyr * s0};
-#pragma unroll
-                for (int v = 0; v < 9; v++) o[v] = sum_over_rows(o[v]);
-                if (bq == 0) {
-                    float* dst = sh.part[myj];
-#pragma unroll
-                    for (int v = 0; v < 9; v++) atomicAdd(&dst[v], o[v]);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        __syncthreads();
-        // flush this batch: 4 lanes per Gaussian, 3 values each; untouched Gaussians cost nothing
-        {
-            const int g = tid >> 2, cpart = tid & 3;
-            if (g < nb && cpart < 3) {
-                float* src = &sh.part[g][cpart * 3];
-                float* dst = acc + (size_t)sh.id[g] * SGR_ACC_STRIDE + cpart * 3;
-#pragma unroll
-                for (int v = 0; v < 3; v++) {
-                    const float val = src[v];
-                    if (val != 0.f) { atomicAdd(&dst[v], val); src[v] = 0.f; }
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Backward blend, one WAVE per 8 x 8 pixel block (variant bit 1).
-//
-// Same two-phase scheme as k_blend_bwd (phase A lane = pixel, phase B lane = (Gaussian, two pixel rows)), restructured like
-// k_blend_fwd_w: no workgroup barriers, the gather of the next 64 list entries in flight, exact block culling with
-// compaction -- and the compacted entries go through a small LDS queue, so phase B always sees full groups of 16 Gaussians
-// (a batch of 64 list entries leaves ~19 survivors: without the queue every second phase B would run a quarter full).
-// A (block, Gaussian) pair is met exactly once, so its nine sums go straight to global memory (nine float atomics by the
-// sixteen q == 0 lanes); the moments are taken about the block origin and shifted to the Gaussian's centre once per pair.
-// Phase A is hand-scheduled like the forward walk: ~30 VALU per entry, the reference's tests as EXEC masks.
-#define BW_QCAP 80          // queue entries: at most 15 left over + 64 new
+// coefficients (backward.cu:538-554), so only those nine sums leave the block; the coefficients are applied once per
+// Gaussian by the fused backward-preprocess kernel.  A (block, Gaussian) pair is met exactly once, so the nine sums go
+// straight to global memory: they are handed to nine neighbouring lanes through LDS, and one atomic instruction then
+// carries whole 36-byte records -- ONE request per pair into acc[P][16] (64-byte records).  (Nine separate 16-lane atomic
+// instructions per group cost 5x the whole rest of the kernel.)
+// The list entries come from the block list the forward wrote (no second cull, every lane of a gather is useful); the
+// gather of batch b + 1 is issued before the groups of batch b are processed (plain compiler-scheduled loads).
+#define BW_QCAP 64          // staged entries: one batch
 #define BW_SUB 16
 #define BW_ZW_STRIDE 65     // float2 units: conflict-free for the phase-A writes and the phase-B reads
 #define BW_ENTRY_DW 12      // x, y, A, B | C, opacity, r, g | b, list position (1-based), id, -
@@ -761,10 +382,10 @@ __device__ __forceinline__ void bwd_phase_a_ref(const float* q, float2* zw, int 
 }
 #endif
 
-__global__ void __launch_bounds__(64) k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_start,
-                                                    const uint32_t* __restrict__ point_list, const GeomRec* __restrict__ rec,
-                                                    const float* __restrict__ bg, const float* __restrict__ final_Ts,
-                                                    const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_maxc,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_start,
+                                                    const uint2* __restrict__ blk_list, const uint32_t* __restrict__ blk_cnt,
+                                                    const GeomRec* __restrict__ rec, const float* __restrict__ bg,
+                                                    const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                                                     const float* __restrict__ dL_dpix, float* __restrict__ acc)
 {
     __shared__ __attribute__((aligned(16))) float s_q[(BW_QCAP + 1) * BW_ENTRY_DW];  // (+1: phase A's look-ahead)
@@ -773,7 +394,7 @@ __global__ void __launch_bounds__(64) k_blend_bwd_w(int W, int H, int gx, int T_
     const int sub = (wg >> 3) & 3;
     const int tile = ((wg >> 5) << 3) + (wg & 7);
     if (tile >= T_tiles) return;
-    const int total = (int)tile_maxc[tile];  // entries at list positions > tile_maxc contribute to no pixel of the tile
+    const int total = (int)blk_cnt[4 * tile + sub];  // entries of this block's list (0: nothing contributed to the block)
     if (total == 0) return;
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
@@ -781,9 +402,9 @@ __global__ void __launch_bounds__(64) k_blend_bwd_w(int W, int H, int gx, int T_
     const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
     const bool inside = px < W && py < H;
     const unsigned long long inside_mask = __ballot(inside);
-    if (inside_mask == 0ull) return;
     const float pixfx = (float)px, pixfy = (float)py;
     const uint32_t r0 = tile_start[tile];
+    const uint2* my_list = blk_list + 4 * (size_t)r0 + (size_t)sub * (size_t)(tile_start[tile + 1] - r0);
     const size_t pix_id = (size_t)W * py + px;
     const size_t HW = (size_t)H * W;
     const float T_final = inside ? final_Ts[pix_id] : 0.f;
@@ -810,15 +431,11 @@ __global__ void __launch_bounds__(64) k_blend_bwd_w(int W, int H, int gx, int T_
     const uint32_t q_lds = (uint32_t)(uintptr_t)s_q;
     const uint32_t zw_lds = (uint32_t)(uintptr_t)s_zw + 8u * (uint32_t)lane;
 
-    // back to front: lane l of batch `base` holds list entry total - 1 - base - l.  Software pipeline over the batches: the
-    // gather of batch b (and the ids of batch b + 1) is ISSUED, then the groups already waiting in the queue are processed
-    // while those loads travel, and only then are the loaded records culled and appended to the queue.  (The loads are
-    // plain compiler-scheduled ones, issued and consumed inside the same iteration, unconditional with clamped indices.)
-    int qn = 0;  // entries waiting in the queue (they sit at its front)
-    // process the queued entries in groups of 16 (all of them if `last_batch`), then move the rest to the front
-    auto drain = [&](const bool last_batch) {
+    int qn = 0;  // staged entries
+    // the staged entries in groups of 16 (the last group of the list may be smaller)
+    auto drain = [&]() {
         int qs = 0;
-        while (qn - qs >= BW_SUB || (last_batch && qn > qs)) {
+        while (qs < qn) {
             const int rows = min(BW_SUB, qn - qs);
 #ifdef SGR_BWD_REF_A
             bwd_phase_a_ref(s_q + qs * BW_ENTRY_DW, s_zw, lane, rows, inside, pixfx, pixfy, g0, g1, g2, ntb, last_contributor, T, acc_g,
@@ -890,76 +507,51 @@ __global__ void __launch_bounds__(64) k_blend_bwd_w(int W, int H, int gx, int T_
             __builtin_amdgcn_wave_barrier();
             qs += rows;
         }
-        // the (fewer than 16) entries left over move to the front of the queue
-        const int rem = qn - qs;
-        if (qs > 0 && rem > 0) {
-            float4 t0v, t1v, t2v;
-            if (lane < rem) {
-                const float4* src = reinterpret_cast<const float4*>(s_q + (qs + lane) * BW_ENTRY_DW);
-                t0v = src[0]; t1v = src[1]; t2v = src[2];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (lane < rem) {
-                float4* dstq = reinterpret_cast<float4*>(s_q + lane * BW_ENTRY_DW);
-                dstq[0] = t0v; dstq[1] = t1v; dstq[2] = t2v;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        qn = rem;
+        qn = 0;
     };
-    uint32_t id_next = point_list[r0 + (uint32_t)max(total - 1 - lane, 0)];
+    // back to front: lane l of batch `base` holds entry total - 1 - base - l of the block's list.  Software pipeline: the
+    // gather of batch b (and the list entries of batch b + 1) is ISSUED, the groups staged from batch b - 1 are processed
+    // while those loads travel, and only then are the loaded records staged.  (Plain compiler-scheduled loads, issued and
+    // consumed inside one iteration, unconditional with clamped indices: see k_blend_fwd_w.)
+    uint2 ip_next = my_list[max(total - 1 - lane, 0)];
     for (int base = 0; base < total; base += 64) {
-        const uint32_t id_cur = id_next;
-        const float4* rp = reinterpret_cast<const float4*>(rec + id_cur);
+        const uint2 ip = ip_next;
+        const float4* rp = reinterpret_cast<const float4*>(rec + ip.x);
         const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
-        id_next = point_list[r0 + (uint32_t)max(total - 1 - base - 64 - lane, 0)];
-        drain(false);
-        const bool hit = (base + lane < total) && block_hit(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)bx0, (float)by0);
-        const unsigned long long m = __ballot(hit);
-        if (hit) {
-            const uint32_t pos = (uint32_t)qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            float4* e = reinterpret_cast<float4*>(s_q + pos * BW_ENTRY_DW);
+        ip_next = my_list[max(total - 1 - base - 64 - lane, 0)];
+        drain();
+        if (base + lane < total) {
+            float4* e = reinterpret_cast<float4*>(s_q + lane * BW_ENTRY_DW);
             e[0] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
             e[1] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v2.x, v2.y);
-            e[2] = make_float4(v2.z, __uint_as_float((uint32_t)(total - base - lane)), __uint_as_float(id_cur), 0.f);
+            e[2] = make_float4(v2.z, __uint_as_float(ip.y), __uint_as_float(ip.x), 0.f);
         }
-        qn += __popcll(m);
+        qn = min(64, total - base);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    drain(true);
+    drain();
 }
 
 }  // namespace
 
 void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
-                          uint32_t* tile_walked, float* out_color, const uint32_t* guard_hdr, uint32_t list_cap, hipStream_t s)
+                          uint32_t* tile_walked, float* out_color, uint2* blk_list, uint32_t* blk_cnt, const uint32_t* guard_hdr,
+                          uint32_t list_cap, hipStream_t s)
 {
-    if (g_sgr_blend_variant & 1) {
-        const int T = gx * gy;
-        // tile_maxc and tile_walked are adjacent (each padded to 256 bytes): one memset
-        (void)hipMemsetAsync(tile_maxc, 0, (size_t)((char*)tile_walked - (char*)tile_maxc) + (size_t)T * 4, s);
-        hipLaunchKernelGGL(k_blend_fwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg,
-                           final_T, n_contrib, tile_maxc, tile_walked, out_color, guard_hdr, list_cap);
-        return;
-    }
-    hipLaunchKernelGGL(k_blend_fwd, dim3(gx * gy), dim3(256), 0, s, W, H, gx, tile_start, point_list, rec, bg, final_T,
-                       n_contrib, tile_maxc, tile_walked, out_color, guard_hdr, list_cap);
+    const int T = gx * gy;
+    // tile_maxc and tile_walked are adjacent (each padded to 256 bytes): one memset (the blocks of a tile combine with atomicMax)
+    (void)hipMemsetAsync(tile_maxc, 0, (size_t)((char*)tile_walked - (char*)tile_maxc) + (size_t)T * 4, s);
+    hipLaunchKernelGGL(k_blend_fwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg, final_T,
+                       n_contrib, tile_maxc, tile_walked, out_color, blk_list, blk_cnt, guard_hdr, list_cap);
 }
 
-void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
-                          const GeomRec* rec, const float* bg, const float* final_T, const uint32_t* n_contrib,
-                          const uint32_t* tile_maxc, const float* dL_dpix, float* acc, hipStream_t s)
+void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint2* blk_list, const uint32_t* blk_cnt,
+                          const GeomRec* rec, const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
+                          float* acc, hipStream_t s)
 {
-    if (g_sgr_blend_variant & 2) {
-        const int T = gx * gy;
-        hipLaunchKernelGGL(k_blend_bwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg,
-                           final_T, n_contrib, tile_maxc, dL_dpix, acc);
-        return;
-    }
-    hipLaunchKernelGGL(k_blend_bwd, dim3(gx * gy), dim3(256), 0, s, W, H, gx, tile_start, point_list, rec, bg, final_T,
-                       n_contrib, tile_maxc, dL_dpix, acc);
+    const int T = gx * gy;
+    hipLaunchKernelGGL(k_blend_bwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, blk_list, blk_cnt, rec, bg,
+                       final_T, n_contrib, dL_dpix, acc);
 }

@@ -187,6 +187,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     uint32_t* tile_cursor = reinterpret_cast<uint32_t*>(img + IL.tile_cursor);
     uint32_t* tile_maxc = reinterpret_cast<uint32_t*>(img + IL.tile_maxc);
     uint32_t* tile_walked = reinterpret_cast<uint32_t*>(img + IL.tile_walked);
+    uint32_t* blk_cnt = reinterpret_cast<uint32_t*>(img + IL.blk_cnt);
     uint32_t* header = reinterpret_cast<uint32_t*>(img + IL.header);
 
     uint32_t* blk_hist = reinterpret_cast<uint32_t*>(img + IL.blk_hist);
@@ -261,6 +262,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     char* binning = binning_alloc(binning_user, BL.total);
     if (!binning) return fail(SGR_E_ALLOC, "binning scratch allocation failed");
     uint32_t* point_list = reinterpret_cast<uint32_t*>(binning + BL.point_list);
+    uint2* blk_list = reinterpret_cast<uint2*>(binning + BL.blk_list);
 
     if (R > 0) {
         StageTimer t(s, SGR_STAGE_SCATTER);
@@ -274,7 +276,8 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     {
         StageTimer t(s, SGR_STAGE_BLEND_FWD);
         sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
-                             tile_maxc, tile_walked, out_color, nosync ? header : nullptr, (uint32_t)(nosync ? R : 0), s);
+                             tile_maxc, tile_walked, out_color, blk_list, blk_cnt, nosync ? header : nullptr,
+                             (uint32_t)(nosync ? R : 0), s);
     }
     STAGE_CHECK("blend_fwd");
     return R;
@@ -322,8 +325,8 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
     const float* final_T = reinterpret_cast<const float*>(img_buffer + IL.final_T);
     const uint32_t* n_contrib = reinterpret_cast<const uint32_t*>(img_buffer + IL.n_contrib);
     const uint32_t* tile_start = reinterpret_cast<const uint32_t*>(img_buffer + IL.tile_start);
-    const uint32_t* tile_maxc = reinterpret_cast<const uint32_t*>(img_buffer + IL.tile_maxc);
-    const uint32_t* point_list = reinterpret_cast<const uint32_t*>(binning_buffer + BL.point_list);
+    const uint32_t* blk_cnt = reinterpret_cast<const uint32_t*>(img_buffer + IL.blk_cnt);
+    const uint2* blk_list = reinterpret_cast<const uint2*>(binning_buffer + BL.blk_list);
 
     // the blend backward accumulates nine sums per Gaussian with atomics into the private acc[P][12] table
     float* acc = reinterpret_cast<float*>(geom_buffer + sgr_geom_acc_offset(P));
@@ -331,8 +334,8 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
         HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * SGR_ACC_STRIDE * 4, s));
         if (R > 0) {
             StageTimer t(s, SGR_STAGE_BLEND_BWD);
-            sgr_launch_blend_bwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
-                                 tile_maxc, dL_dpix, acc, s);
+            sgr_launch_blend_bwd(width, height, IL.gx, IL.gy, tile_start, blk_list, blk_cnt, rec, background, final_T, n_contrib,
+                                 dL_dpix, acc, s);
         }
         STAGE_CHECK("blend_bwd");
         if (phase == 1) {
