@@ -370,6 +370,7 @@ class ViewShardedTrainer:
         self.visibility = visibility      # the step itself has no use for the radii > 0 mask
         self._means2D = (torch.zeros(params.P, 3, dtype=torch.float32, device=params.flat.device, requires_grad=True)
                          if params.flat.is_cuda else None)
+        self._one = torch.ones((), dtype=torch.float32, device=params.flat.device)  # d loss / d loss, not re-filled every step
 
     def _start_gather(self, colors):
         """Called by the rasterizer backward between its two halves: the masked colour gradients (already in the send
@@ -439,7 +440,7 @@ class ViewShardedTrainer:
             if self.sync_free and R >= 0 and (cap == 0 or 5 * R > 4 * cap):
                 self._bin_cap = R + R // 2 + 65536
             self.last_num_rendered = R
-            grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+            grads = torch.autograd.grad(loss, leaves, grad_outputs=self._one, allow_unused=True)
         sh_views = wait_small = None
         scale = 1.0 / self.world
         with torch.no_grad():
