@@ -146,7 +146,7 @@ int sgr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  * appended after the image state -- the offsets below stay valid. */
 size_t sgr_geom_bytes(int P);
 size_t sgr_img_bytes(int width, int height);
-size_t sgr_binning_bytes(int64_t R);
+size_t sgr_binning_bytes(int64_t R, int width, int height); /* instance list + per-block survivor masks for the backward */
 
 /* ---- introspection for parity tests (read-only views into the private scratch layout) ---------
  * Each returns a byte offset into the corresponding buffer.  The geometry record of Gaussian i is

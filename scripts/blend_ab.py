@@ -16,8 +16,8 @@ STAGES = ["preprocess", "bin_count_scan", "bin_scatter", "depth_sort", "blend_fw
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    variants = [int(a) for a in args] or [0, 1]
+    args = [a for a in sys.argv[1:] if a.lstrip("-").isdigit()]
+    variants = [int(a) for a in args] or [0]
     bwd = "--bwd" in sys.argv
     workload = "metric"
     if "--workload" in sys.argv:

@@ -31,7 +31,7 @@ SIGNATURES = {
     "sgr_sh_adam_from_views": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "sgr_geom_bytes": (_sz, [_i]),
     "sgr_img_bytes": (_sz, [_i, _i]),
-    "sgr_binning_bytes": (_sz, [_i64]),
+    "sgr_binning_bytes": (_sz, [_i64, _i, _i]),
     "sgr_geom_rec_offset": (_sz, [_i]),
     "sgr_img_final_T_offset": (_sz, [_i, _i]),
     "sgr_img_n_contrib_offset": (_sz, [_i, _i]),

@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
                                                     const float* __restrict__ bg, float* __restrict__ final_T,
                                                     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_maxc,
                                                     uint32_t* __restrict__ tile_walked, float* __restrict__ out_color,
-                                                    uint2* __restrict__ blk_list, uint32_t* __restrict__ blk_cnt,
+                                                    unsigned long long* __restrict__ blk_mask, uint32_t* __restrict__ blk_nb,
                                                     const uint32_t* __restrict__ guard_hdr, uint32_t list_cap)
 {
     if (guard_hdr && (guard_hdr[SGR_HDR_R] > list_cap || guard_hdr[4 + SGR_B2_HDR_OVERFLOW])) return;
@@ -198,13 +198,12 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
     uint32_t id_next = 0u;
     if (total > 0) id_next = point_list[r0 + (uint32_t)min(lane, total - 1)];  // (uniform branch)
     const uint32_t lds0 = (uint32_t)(uintptr_t)s_e;  // LDS byte address of the staging area
-    // this block's own list for the backward: the (id, list position) pairs of the entries that survive the cull, in list
-    // order, in the block's segment [4 r0 + sub * total, + total) of blk_list
-    uint2* my_list = blk_list + 4 * (size_t)r0 + (size_t)sub * (size_t)total;
-    int n_list = 0;
+    // for the backward: which lanes of every 64-entry batch survived this block's cull (one 64-bit mask per batch and block;
+    // batch b of the tile sits in slot (r0 >> 6) + tile + b: slots of different tiles never overlap)
+    unsigned long long* my_mask = blk_mask + 4 * ((size_t)(r0 >> 6) + (size_t)tile) + sub;
+    int n_batches = 0;
     for (int base = 0; base < total && live != 0ull; base += 64) {
-        const uint32_t id_cur = id_next;
-        const float4* rp = reinterpret_cast<const float4*>(rec + id_cur);
+        const float4* rp = reinterpret_cast<const float4*>(rec + id_next);
         const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
         id_next = point_list[r0 + (uint32_t)min(base + 64 + lane, total - 1)];
         const bool hit = (base + lane < total) && block_hit(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)bx0, (float)by0);
@@ -216,9 +215,9 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
             e[0] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
             e[1] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v2.x, v2.y);
             *reinterpret_cast<float2*>(e + 2) = make_float2(v2.z, __uint_as_float((uint32_t)(base + lane + 1)));
-            my_list[n_list + (int)pos] = make_uint2(id_cur, (uint32_t)(base + lane + 1));
         }
-        n_list += n;
+        if (lane == 0) my_mask[4 * (size_t)n_batches] = m;
+        n_batches++;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (n > 0) {
@@ -247,7 +246,7 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
     if (lane == 0) {
         atomicMax(&tile_maxc[tile], mc);
         atomicMax(&tile_walked[tile], __ballot(inside) ? walked : 0u);
-        blk_cnt[4 * tile + sub] = mc ? (uint32_t)n_list : 0u;  // (a block nothing contributed to has no backward)
+        blk_nb[4 * tile + sub] = mc ? (uint32_t)n_batches : 0u;  // batches with a mask (0: nothing contributed to the block)
     }
 }
 
@@ -268,48 +267,52 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
 // straight to global memory: they are handed to nine neighbouring lanes through LDS, and one atomic instruction then
 // carries whole 36-byte records -- ONE request per pair into acc[P][16] (64-byte records).  (Nine separate 16-lane atomic
 // instructions per group cost 5x the whole rest of the kernel.)
-// The list entries come from the block list the forward wrote (no second cull, every lane of a gather is useful); the
-// gather of batch b + 1 is issued before the groups of batch b are processed (plain compiler-scheduled loads).
-#define BW_QCAP 64          // staged entries: one batch
+// Which list entries to take comes from the forward: it leaves one 64-bit mask per (64-entry batch, block) -- the lanes that
+// survived the block's exact cull -- so the backward neither culls again nor gathers records it will not use; the
+// survivors of several batches are collected in a small LDS queue so that phase B always sees full groups of 16.
+#define BW_QCAP 80          // queue entries: at most 15 left over + 64 new
 #define BW_SUB 16
 #define BW_ZW_STRIDE 65     // float2 units: conflict-free for the phase-A writes and the phase-B reads
 #define BW_ENTRY_DW 12      // x, y, A, B | C, opacity, r, g | b, list position (1-based), id, -
 
-#define SGR_BWD_BODY(X, Y, A, B, CZ, OP, R, G_, BL, POS)                                          \
-    "v_sub_f32 v120, " X ", %[px]\n"                                                              \
-    "v_sub_f32 v121, " Y ", %[py]\n"                                                              \
-    "v_mul_f32 v122, " B ", v121\n"                                                               \
-    "v_fmac_f32 v122, " A ", v120\n"                                                              \
-    "v_mul_f32 v123, " CZ ", v121\n"                                                              \
-    "v_mul_f32 v123, v123, v121\n"                                                                \
-    "v_fmac_f32 v123, v120, v122\n"      /* log2(e) * power */                                    \
-    "v_exp_f32 v124, v123\n"             /* G */                                                  \
-    "v_mov_b32 v126, 0\n"                                                                         \
-    "v_mov_b32 v127, 0\n"                                                                         \
-    "v_cmp_nlt_f32 %[m0], 0, v123\n"     /* !(power > 0) */                                       \
+// The ten registers of an entry are reused in place as it is evaluated (no further temporaries):
+//   X -> dx -> Z        Y -> dy -> Wt       A -> G         B -> t -> 1/(1-alpha)       CZ -> power -> dL_dalpha     OP -> alpha
+// (X, Y must be an even-aligned register pair: they leave as the (Z, Wt) panel entry.)
+#define SGR_BWD_BODY(X, Y, A, B, CZ, OP, R, G_, BL, POS, XY)                                      \
+    "v_sub_f32 " X ", " X ", %[px]\n"                                                             \
+    "v_sub_f32 " Y ", " Y ", %[py]\n"                                                             \
+    "v_mul_f32 " B ", " B ", " Y "\n"                                                             \
+    "v_fmac_f32 " B ", " A ", " X "\n"                                                            \
+    "v_mul_f32 " CZ ", " CZ ", " Y "\n"                                                           \
+    "v_mul_f32 " CZ ", " CZ ", " Y "\n"                                                           \
+    "v_fmac_f32 " CZ ", " X ", " B "\n"  /* log2(e) * power */                                    \
+    "v_exp_f32 " A ", " CZ "\n"          /* G */                                                  \
+    "v_mov_b32 " X ", 0\n"                                                                        \
+    "v_mov_b32 " Y ", 0\n"                                                                        \
+    "v_cmp_nlt_f32 %[m0], 0, " CZ "\n"   /* !(power > 0) */                                       \
     "v_cmp_le_u32 %[m1], " POS ", %[lastc]\n" /* at or before this pixel's last contributor */    \
-    "v_mul_f32 v125, " OP ", v124\n"                                                              \
-    "v_min_f32 v125, 0x3f7d70a4, v125\n" /* alpha */                                              \
+    "v_mul_f32 " OP ", " OP ", " A "\n"                                                           \
+    "v_min_f32 " OP ", 0x3f7d70a4, " OP "\n" /* alpha */                                          \
     "s_and_b64 %[m0], %[m0], %[m1]\n"                                                             \
-    "v_cmp_ngt_f32 vcc, 0x3b808081, v125\n" /* !(alpha < 1/255) */                                \
+    "v_cmp_ngt_f32 vcc, 0x3b808081, " OP "\n" /* !(alpha < 1/255) */                              \
     "s_and_b64 %[m0], %[m0], %[inside]\n"                                                         \
     "s_and_b64 exec, %[m0], vcc\n"                                                                \
-    "v_sub_f32 v120, 1.0, v125\n"                                                                 \
-    "v_rcp_f32 v120, v120\n"             /* 1 / (1 - alpha) */                                    \
-    "v_sub_f32 v121, %[lc], %[acc]\n"                                                             \
-    "v_fmac_f32 %[acc], %[la], v121\n"   /* accum_rec . g  (backward.cu:514-516) */               \
-    "v_mul_f32 %[T], %[T], v120\n"                                                                \
+    "v_sub_f32 " B ", 1.0, " OP "\n"                                                              \
+    "v_rcp_f32 " B ", " B "\n"           /* 1 / (1 - alpha) */                                    \
+    "v_sub_f32 " CZ ", %[lc], %[acc]\n"                                                           \
+    "v_fmac_f32 %[acc], %[la], " CZ "\n" /* accum_rec . g  (backward.cu:514-516) */               \
+    "v_mul_f32 %[T], %[T], " B "\n"                                                               \
     "v_mul_f32 %[lc], " R ", %[g0]\n"                                                             \
     "v_fmac_f32 %[lc], " G_ ", %[g1]\n"                                                           \
     "v_fmac_f32 %[lc], " BL ", %[g2]\n"  /* last_color . g */                                     \
-    "v_mul_f32 v127, v125, %[T]\n"       /* Wt = alpha * T */                                     \
-    "v_sub_f32 v122, %[lc], %[acc]\n"                                                             \
-    "v_mul_f32 v122, v122, %[T]\n"                                                                \
-    "v_fmac_f32 v122, %[ntb], v120\n"    /* dL_dalpha (backward.cu:523-529) */                    \
-    "v_mov_b32 %[la], v125\n"                                                                     \
-    "v_mul_f32 v126, v124, v122\n"       /* Z = G * dL_dalpha */                                  \
+    "v_mul_f32 " Y ", " OP ", %[T]\n"    /* Wt = alpha * T */                                     \
+    "v_sub_f32 " CZ ", %[lc], %[acc]\n"                                                           \
+    "v_mul_f32 " CZ ", " CZ ", %[T]\n"                                                            \
+    "v_fmac_f32 " CZ ", %[ntb], " B "\n" /* dL_dalpha (backward.cu:523-529) */                    \
+    "v_mov_b32 %[la], " OP "\n"                                                                   \
+    "v_mul_f32 " X ", " A ", " CZ "\n"   /* Z = G * dL_dalpha */                                  \
     "s_mov_b64 exec, %[full]\n"                                                                   \
-    "ds_write_b64 %[waddr], v[126:127]\n"                                                         \
+    "ds_write_b64 %[waddr], " XY "\n"                                                             \
     "v_add_u32 %[waddr], 520, %[waddr]\n"
 
 // rows (1..16) queue entries starting at LDS address e_addr -> panel rows 0..rows-1 at w_addr (+ 8 * lane already added)
@@ -329,7 +332,7 @@ __device__ __forceinline__ void bwd_phase_a(uint32_t e_addr, uint32_t w_addr, in
         "ds_read_b128 v[114:117], %[eaddr] offset:64\n"
         "ds_read_b64 v[118:119], %[eaddr] offset:80\n"
         "s_waitcnt lgkmcnt(3)\n"
-        SGR_BWD_BODY("v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109")
+        SGR_BWD_BODY("v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v[100:101]")
         "s_add_i32 %[n], %[n], -1\n"
         "s_cmp_eq_u32 %[n], 0\n"
         "s_cbranch_scc1 3f\n"
@@ -338,7 +341,7 @@ __device__ __forceinline__ void bwd_phase_a(uint32_t e_addr, uint32_t w_addr, in
         "ds_read_b64 v[108:109], %[eaddr] offset:128\n"
         "v_add_u32 %[eaddr], 96, %[eaddr]\n"
         "s_waitcnt lgkmcnt(4)\n"  /* the panel write of the previous entry may still be counted */
-        SGR_BWD_BODY("v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119")
+        SGR_BWD_BODY("v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v[110:111]")
         "s_add_i32 %[n], %[n], -1\n"
         "s_cmp_eq_u32 %[n], 0\n"
         "s_cbranch_scc0 1b\n"
@@ -349,8 +352,7 @@ __device__ __forceinline__ void bwd_phase_a(uint32_t e_addr, uint32_t w_addr, in
         : [px] "v"(pixfx), [py] "v"(pixfy), [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [ntb] "v"(ntb), [lastc] "v"(lastc),
           [inside] "s"(inside_mask)
         : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114",
-          "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "vcc", "scc",
-          "memory");
+          "v115", "v116", "v117", "v118", "v119", "vcc", "scc", "memory");
 }
 
 #ifdef SGR_BWD_REF_A
@@ -382,11 +384,11 @@ __device__ __forceinline__ void bwd_phase_a_ref(const float* q, float2* zw, int 
 }
 #endif
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_start,
-                                                    const uint2* __restrict__ blk_list, const uint32_t* __restrict__ blk_cnt,
-                                                    const GeomRec* __restrict__ rec, const float* __restrict__ bg,
-                                                    const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
-                                                    const float* __restrict__ dL_dpix, float* __restrict__ acc)
+__global__ void __launch_bounds__(64)
+k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ point_list,
+              const unsigned long long* __restrict__ blk_mask, const uint32_t* __restrict__ blk_nb, const GeomRec* __restrict__ rec,
+              const float* __restrict__ bg, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
+              const float* __restrict__ dL_dpix, float* __restrict__ acc)
 {
     __shared__ __attribute__((aligned(16))) float s_q[(BW_QCAP + 1) * BW_ENTRY_DW];  // (+1: phase A's look-ahead)
     __shared__ float2 s_zw[BW_SUB * BW_ZW_STRIDE];
@@ -394,8 +396,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const int sub = (wg >> 3) & 3;
     const int tile = ((wg >> 5) << 3) + (wg & 7);
     if (tile >= T_tiles) return;
-    const int total = (int)blk_cnt[4 * tile + sub];  // entries of this block's list (0: nothing contributed to the block)
-    if (total == 0) return;
+    const int nb = (int)blk_nb[4 * tile + sub];  // batches the forward walked for this block (0: nothing contributed)
+    if (nb == 0) return;
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
     const int bx0 = tx * SGR_TILE_X + 8 * (sub & 1), by0 = ty * SGR_TILE_Y + 8 * (sub >> 1);
@@ -404,12 +406,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const unsigned long long inside_mask = __ballot(inside);
     const float pixfx = (float)px, pixfy = (float)py;
     const uint32_t r0 = tile_start[tile];
-    const uint2* my_list = blk_list + 4 * (size_t)r0 + (size_t)sub * (size_t)(tile_start[tile + 1] - r0);
+    const int total = (int)(tile_start[tile + 1] - r0);
+    const unsigned long long* my_mask = blk_mask + 4 * ((size_t)(r0 >> 6) + (size_t)tile) + sub;
     const size_t pix_id = (size_t)W * py + px;
     const size_t HW = (size_t)H * W;
     const float T_final = inside ? final_Ts[pix_id] : 0.f;
     float T = T_final;
     const uint32_t last_contributor = inside ? n_contrib[pix_id] : 0u;
+    // entries behind the block's deepest contributor are inactive for every pixel: they are dropped at staging
+    uint32_t blk_lc = last_contributor;
+    for (int o = 32; o > 0; o >>= 1) blk_lc = max(blk_lc, (uint32_t)__shfl_xor((int)blk_lc, o));
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (inside) { g0 = dL_dpix[pix_id]; g1 = dL_dpix[HW + pix_id]; g2 = dL_dpix[2 * HW + pix_id]; }
     const float ntb = -T_final * (bg[0] * g0 + bg[1] * g1 + bg[2] * g2);
@@ -431,11 +437,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const uint32_t q_lds = (uint32_t)(uintptr_t)s_q;
     const uint32_t zw_lds = (uint32_t)(uintptr_t)s_zw + 8u * (uint32_t)lane;
 
-    int qn = 0;  // staged entries
-    // the staged entries in groups of 16 (the last group of the list may be smaller)
-    auto drain = [&]() {
+    int qn = 0;  // entries waiting in the queue (they sit at its front)
+    // the queued entries in groups of 16 (all of them at the end, full groups only before), the rest moves to the front
+    auto drain = [&](const bool last_batch) {
         int qs = 0;
-        while (qs < qn) {
+        while (qn - qs >= BW_SUB || (last_batch && qn > qs)) {
             const int rows = min(BW_SUB, qn - qs);
 #ifdef SGR_BWD_REF_A
             bwd_phase_a_ref(s_q + qs * BW_ENTRY_DW, s_zw, lane, rows, inside, pixfx, pixfy, g0, g1, g2, ntb, last_contributor, T, acc_g,
@@ -507,51 +513,76 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             __builtin_amdgcn_wave_barrier();
             qs += rows;
         }
-        qn = 0;
+        const int rem = qn - qs;
+        if (qs > 0 && rem > 0) {
+            float4 t0v, t1v, t2v;
+            if (lane < rem) {
+                const float4* src = reinterpret_cast<const float4*>(s_q + (qs + lane) * BW_ENTRY_DW);
+                t0v = src[0]; t1v = src[1]; t2v = src[2];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rem) {
+                float4* dstq = reinterpret_cast<float4*>(s_q + lane * BW_ENTRY_DW);
+                dstq[0] = t0v; dstq[1] = t1v; dstq[2] = t2v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        qn = rem;
     };
-    // back to front: lane l of batch `base` holds entry total - 1 - base - l of the block's list.  Software pipeline: the
-    // gather of batch b (and the list entries of batch b + 1) is ISSUED, the groups staged from batch b - 1 are processed
-    // while those loads travel, and only then are the loaded records staged.  (Plain compiler-scheduled loads, issued and
-    // consumed inside one iteration, unconditional with clamped indices: see k_blend_fwd_w.)
-    uint2 ip_next = my_list[max(total - 1 - lane, 0)];
-    for (int base = 0; base < total; base += 64) {
-        const uint2 ip = ip_next;
-        const float4* rp = reinterpret_cast<const float4*>(rec + ip.x);
+    // The forward's batches back to front: batch b holds list entries 64 b .. 64 b + 63, of which the lanes in the forward's
+    // mask survived the block's cull; inside a batch the walk goes from lane 63 down.  Software pipeline: the ids of batch
+    // b - 1 and the records of batch b are ISSUED, the groups already queued are processed while those loads travel, and only
+    // then are the records staged.  (Plain compiler-scheduled loads, issued and consumed inside one iteration, unconditional
+    // with clamped addresses: see k_blend_fwd_w.  Lanes outside the mask re-read record 0 of the list: one cached line.)
+    unsigned long long m_next = my_mask[4 * (size_t)(nb - 1)];
+    uint32_t id_next = point_list[r0 + (uint32_t)min(64 * (nb - 1) + lane, total - 1)];
+    for (int b = nb - 1; b >= 0; b--) {
+        const unsigned long long m_all = m_next;
+        const uint32_t pos = (uint32_t)(64 * b + lane + 1);  // 1-based list position of this lane's entry
+        const bool take = ((m_all >> lane) & 1ull) && pos <= blk_lc;
+        const uint32_t id_cur = take ? id_next : point_list[r0];
+        const float4* rp = reinterpret_cast<const float4*>(rec + id_cur);
         const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
-        ip_next = my_list[max(total - 1 - base - 64 - lane, 0)];
-        drain();
-        if (base + lane < total) {
-            float4* e = reinterpret_cast<float4*>(s_q + lane * BW_ENTRY_DW);
+        m_next = my_mask[4 * (size_t)max(b - 1, 0)];
+        id_next = point_list[r0 + (uint32_t)min(64 * max(b - 1, 0) + lane, total - 1)];
+        drain(false);
+        const unsigned long long m = __ballot(take);
+        if (take) {
+            // back to front: rank = taken lanes ABOVE this one
+            const uint32_t slot = (uint32_t)qn + (uint32_t)__popcll(lane == 63 ? 0ull : (m >> (lane + 1)));
+            float4* e = reinterpret_cast<float4*>(s_q + slot * BW_ENTRY_DW);
             e[0] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
             e[1] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v2.x, v2.y);
-            e[2] = make_float4(v2.z, __uint_as_float(ip.y), __uint_as_float(ip.x), 0.f);
+            e[2] = make_float4(v2.z, __uint_as_float(pos), __uint_as_float(id_cur), 0.f);
         }
-        qn = min(64, total - base);
+        qn += __popcll(m);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    drain();
+    drain(true);
 }
 
 }  // namespace
 
 void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
-                          uint32_t* tile_walked, float* out_color, uint2* blk_list, uint32_t* blk_cnt, const uint32_t* guard_hdr,
-                          uint32_t list_cap, hipStream_t s)
+                          uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
+                          const uint32_t* guard_hdr, uint32_t list_cap, hipStream_t s)
 {
     const int T = gx * gy;
     // tile_maxc and tile_walked are adjacent (each padded to 256 bytes): one memset (the blocks of a tile combine with atomicMax)
     (void)hipMemsetAsync(tile_maxc, 0, (size_t)((char*)tile_walked - (char*)tile_maxc) + (size_t)T * 4, s);
     hipLaunchKernelGGL(k_blend_fwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg, final_T,
-                       n_contrib, tile_maxc, tile_walked, out_color, blk_list, blk_cnt, guard_hdr, list_cap);
+                       n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, guard_hdr, list_cap);
 }
 
-void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint2* blk_list, const uint32_t* blk_cnt,
-                          const GeomRec* rec, const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
-                          float* acc, hipStream_t s)
+void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
+                          const unsigned long long* blk_mask, const uint32_t* blk_nb, const GeomRec* rec, const float* bg,
+                          const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* acc, hipStream_t s)
 {
     const int T = gx * gy;
-    hipLaunchKernelGGL(k_blend_bwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, blk_list, blk_cnt, rec, bg,
-                       final_T, n_contrib, dL_dpix, acc);
+    hipLaunchKernelGGL(k_blend_bwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, blk_mask, blk_nb, rec,
+                       bg, final_T, n_contrib, dL_dpix, acc);
 }

@@ -112,7 +112,7 @@ const char* sgr_last_error(void) { return g_err.c_str(); }
 
 size_t sgr_geom_bytes(int P) { return sgr_geom_total(P); }
 size_t sgr_img_bytes(int width, int height) { return sgr_img_layout(width, height).total; }
-size_t sgr_binning_bytes(int64_t R) { return sgr_bin_layout(R).total; }
+size_t sgr_binning_bytes(int64_t R, int width, int height) { return sgr_bin_layout(R, sgr_img_layout(width, height).T).total; }
 size_t sgr_geom_rec_offset(int) { return 0; }
 size_t sgr_img_final_T_offset(int w, int h) { return sgr_img_layout(w, h).final_T; }
 size_t sgr_img_n_contrib_offset(int w, int h) { return sgr_img_layout(w, h).n_contrib; }
@@ -120,7 +120,7 @@ size_t sgr_img_tile_start_offset(int w, int h) { return sgr_img_layout(w, h).til
 size_t sgr_img_tile_maxc_offset(int w, int h) { return sgr_img_layout(w, h).tile_maxc; }
 size_t sgr_img_tile_walked_offset(int w, int h) { return sgr_img_layout(w, h).tile_walked; }
 size_t sgr_img_header_offset(int w, int h) { return sgr_img_layout(w, h).header; }
-size_t sgr_binning_point_list_offset(int64_t R) { return sgr_bin_layout(R).point_list; }
+size_t sgr_binning_point_list_offset(int64_t R) { return sgr_bin_layout(R, 0).point_list; }
 
 void sgr_profile_enable(int stage_mask) { g_prof.mask = (unsigned)stage_mask; }
 
@@ -187,7 +187,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     uint32_t* tile_cursor = reinterpret_cast<uint32_t*>(img + IL.tile_cursor);
     uint32_t* tile_maxc = reinterpret_cast<uint32_t*>(img + IL.tile_maxc);
     uint32_t* tile_walked = reinterpret_cast<uint32_t*>(img + IL.tile_walked);
-    uint32_t* blk_cnt = reinterpret_cast<uint32_t*>(img + IL.blk_cnt);
+    uint32_t* blk_nb = reinterpret_cast<uint32_t*>(img + IL.blk_nb);
     uint32_t* header = reinterpret_cast<uint32_t*>(img + IL.header);
 
     uint32_t* blk_hist = reinterpret_cast<uint32_t*>(img + IL.blk_hist);
@@ -258,11 +258,11 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     }
     g_last_binning = two_level ? 0 : 1;
 
-    const BinLayout BL = sgr_bin_layout(R);
+    const BinLayout BL = sgr_bin_layout(R, IL.T);
     char* binning = binning_alloc(binning_user, BL.total);
     if (!binning) return fail(SGR_E_ALLOC, "binning scratch allocation failed");
     uint32_t* point_list = reinterpret_cast<uint32_t*>(binning + BL.point_list);
-    uint2* blk_list = reinterpret_cast<uint2*>(binning + BL.blk_list);
+    unsigned long long* blk_mask = reinterpret_cast<unsigned long long*>(binning + BL.blk_mask);
 
     if (R > 0) {
         StageTimer t(s, SGR_STAGE_SCATTER);
@@ -276,7 +276,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     {
         StageTimer t(s, SGR_STAGE_BLEND_FWD);
         sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
-                             tile_maxc, tile_walked, out_color, blk_list, blk_cnt, nosync ? header : nullptr,
+                             tile_maxc, tile_walked, out_color, blk_mask, blk_nb, nosync ? header : nullptr,
                              (uint32_t)(nosync ? R : 0), s);
     }
     STAGE_CHECK("blend_fwd");
@@ -320,13 +320,14 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
     if (phase != 0 && !compact) return fail(SGR_E_INVALID, "the two-phase backward is for the compact SH mode");
 
     const ImgLayout IL = sgr_img_layout(width, height);
-    const BinLayout BL = sgr_bin_layout(R);
+    const BinLayout BL = sgr_bin_layout(R, IL.T);
     const GeomRec* rec = reinterpret_cast<const GeomRec*>(geom_buffer);
     const float* final_T = reinterpret_cast<const float*>(img_buffer + IL.final_T);
     const uint32_t* n_contrib = reinterpret_cast<const uint32_t*>(img_buffer + IL.n_contrib);
     const uint32_t* tile_start = reinterpret_cast<const uint32_t*>(img_buffer + IL.tile_start);
-    const uint32_t* blk_cnt = reinterpret_cast<const uint32_t*>(img_buffer + IL.blk_cnt);
-    const uint2* blk_list = reinterpret_cast<const uint2*>(binning_buffer + BL.blk_list);
+    const uint32_t* blk_nb = reinterpret_cast<const uint32_t*>(img_buffer + IL.blk_nb);
+    const uint32_t* point_list = reinterpret_cast<const uint32_t*>(binning_buffer + BL.point_list);
+    const unsigned long long* blk_mask = reinterpret_cast<const unsigned long long*>(binning_buffer + BL.blk_mask);
 
     // the blend backward accumulates nine sums per Gaussian with atomics into the private acc[P][12] table
     float* acc = reinterpret_cast<float*>(geom_buffer + sgr_geom_acc_offset(P));
@@ -334,8 +335,8 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
         HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * SGR_ACC_STRIDE * 4, s));
         if (R > 0) {
             StageTimer t(s, SGR_STAGE_BLEND_BWD);
-            sgr_launch_blend_bwd(width, height, IL.gx, IL.gy, tile_start, blk_list, blk_cnt, rec, background, final_T, n_contrib,
-                                 dL_dpix, acc, s);
+            sgr_launch_blend_bwd(width, height, IL.gx, IL.gy, tile_start, point_list, blk_mask, blk_nb, rec, background, final_T,
+                                 n_contrib, dL_dpix, acc, s);
         }
         STAGE_CHECK("blend_bwd");
         if (phase == 1) {

@@ -16,7 +16,7 @@
 //           the backward's per-Gaussian accumulator (zeroed by each backward), and the depth sort's ping-pong
 //           key/value arrays (the sorted Gaussian order stays there for the backward-free forward only)
 // img   : [ final_T f32[WH] | n_contrib u32[WH] | tile_start u32[T+1] | tile_count u32[T] |
-//           tile_maxc u32[T] | tile_walked u32[T] | blk_cnt u32[4T] | header u32[8] | blk_hist u32[n_blocks][T] ]
+//           tile_maxc u32[T] | tile_walked u32[T] | blk_nb u32[4T] | header u32[8] | blk_hist u32[n_blocks][T] ]
 // binning: [ point_list u32[R] ]
 struct GeomRec {
     float x, y, cx, cy;          // pixel-space mean, conic.x, conic.y
@@ -37,7 +37,7 @@ size_t sgr_sort_rects_offset(int P);    // binning.hip: offset of the packed rec
 static inline size_t sgr_geom_total(int P) { return sgr_geom_sort_offset(P) + sgr_sort_scratch_bytes(P); }
 
 struct ImgLayout {
-    size_t final_T, n_contrib, tile_start, tile_cursor, tile_maxc, tile_walked, blk_cnt, header, blk_hist, total;
+    size_t final_T, n_contrib, tile_start, tile_cursor, tile_maxc, tile_walked, blk_nb, header, blk_hist, total;
     int n_blocks;      // slices of the depth order in the ordered binning
     int gx, gy, T;
 };
@@ -54,7 +54,7 @@ static inline ImgLayout sgr_img_layout(int W, int H)
     L.tile_cursor = off; off = sgr_align(off + (size_t)L.T * 4);
     L.tile_maxc = off;   off = sgr_align(off + (size_t)L.T * 4);
     L.tile_walked = off; off = sgr_align(off + (size_t)L.T * 4);
-    L.blk_cnt = off;     off = sgr_align(off + (size_t)L.T * 16);  // entries of every block's list
+    L.blk_nb = off;      off = sgr_align(off + (size_t)L.T * 16);  // batches the forward walked, per block
     L.header = off;      off = sgr_align(off + 64);
     // the single-level fallback keeps one LDS counter per tile: beyond ~38 000 tiles (8K images) only the two-level path exists
     L.n_blocks = ((size_t)L.T * 4 <= SGR_LEGACY_LDS_BYTES) ? SGR_BIN_SLICES : 0;
@@ -82,16 +82,16 @@ void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scr
 void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, const uint32_t* hdr, uint32_t n_chunks, const uint2* rects,
                            const uint32_t* order, const uint32_t* tile_start, uint32_t* point_list, uint32_t list_cap, hipStream_t s);
 
-// binning: [ point_list u32[R] | blk_list uint2[4R] ]   blk_list: per 8x8 block of every tile, the (id, list position) pairs of
-//           the list entries that survive the block's exact cull (written by the forward blend for the backward); the
-//           segment of block `sub` of a tile with list [r0, r0 + n) is [4 r0 + sub n, + n)
-struct BinLayout { size_t point_list, blk_list, total; };
-static inline BinLayout sgr_bin_layout(int64_t R)
+// binning: [ point_list u32[R] | blk_mask u64[(R/64 + T + 1) * 4] ]   blk_mask: per 64-entry batch of every tile's list and per
+//           8x8 block of the tile, the lanes (entries) that survive the block's exact cull -- written by the forward blend
+//           for the backward; batch b of tile t (list start r0) sits in slot (r0 >> 6) + t + b
+struct BinLayout { size_t point_list, blk_mask, total; };
+static inline BinLayout sgr_bin_layout(int64_t R, int T)
 {
     BinLayout L;
     size_t off = 0;
     L.point_list = off; off = sgr_align(off + (size_t)R * 4);
-    L.blk_list = off;   off = sgr_align(off + (size_t)R * 32);
+    L.blk_mask = off;   off = sgr_align(off + ((size_t)(R >> 6) + (size_t)T + 2) * 32);
     L.total = off < 256 ? 256 : off;
     return L;
 }
@@ -151,8 +151,8 @@ void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_star
 
 void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
-                          uint32_t* tile_walked, float* out_color, uint2* blk_list, uint32_t* blk_cnt, const uint32_t* guard_hdr,
-                          uint32_t list_cap, hipStream_t s);
-void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint2* blk_list, const uint32_t* blk_cnt,
-                          const GeomRec* rec, const float* bg, const float* final_T, const uint32_t* n_contrib, const float* dL_dpix,
-                          float* acc, hipStream_t s);
+                          uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
+                          const uint32_t* guard_hdr, uint32_t list_cap, hipStream_t s);
+void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
+                          const unsigned long long* blk_mask, const uint32_t* blk_nb, const GeomRec* rec, const float* bg,
+                          const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* acc, hipStream_t s);

@@ -41,8 +41,8 @@ def test_scratch_layout_queries(hip_lib):
             L.sgr_img_tile_maxc_offset(W, H), L.sgr_img_tile_walked_offset(W, H)]
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
     assert offs[1] - offs[0] >= 4 * W * H and L.sgr_img_bytes(W, H) >= offs[-1] + 4 * T
-    assert L.sgr_binning_point_list_offset(1000) % 256 == 0 and L.sgr_binning_bytes(1000) >= 4000
-    assert L.sgr_binning_bytes(0) > 0
+    assert L.sgr_binning_point_list_offset(1000) % 256 == 0 and L.sgr_binning_bytes(1000, 64, 64) >= 4000
+    assert L.sgr_binning_bytes(0, 64, 64) > 0
     assert L.sgr_geom_bytes(1000) >= 96 * 1000 + 16 * 1000  # records + backward accumulators + depth-sort scratch
 
 
