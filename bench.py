@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--gaussians", type=int, default=None, help="override the Gaussian count (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="skip the per-stage HIP events (debug: measures their cost)")
+    ap.add_argument("--no-fuse-activations", action="store_true", help="stand-alone activation kernels (A/B of the raw-parameter mode)")
     ap.add_argument("--host-sync", action="store_true", help="forward with the host round trip for num_rendered (A/B of the sync-free forward)")
     args = ap.parse_args()
 
@@ -92,7 +93,8 @@ def main():
     gts = [torch.rand(3, H, W, generator=gtor).to(dev) for _ in range(len(cams))]
     params = GaussianParams(scene, dev)
     trainer = ViewShardedTrainer(params, GaussianRasterizer, GaussianRasterizationSettings, bg_d,
-                                 sync_free=False if args.host_sync else None)
+                                 sync_free=False if args.host_sync else None,
+                                 fuse_activations=False if args.no_fuse_activations else None)
 
     def cam_index(step):
         return (step * world + rank) % len(cams)

@@ -77,7 +77,15 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user,
                        const float* rotations, const float* cov3D_precomp,
                        const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                        float tan_fovx, float tan_fovy, int prefiltered,
-                       float* out_color, int* radii, int debug, void* stream, int64_t binning_capacity);
+                       float* out_color, int* radii, int debug, void* stream, int64_t binning_capacity, int flags);
+
+/* flags of sgr_forward_ex.  SGR_FLAG_RAW_PARAMS: `scales`, `rotations` and `opacities` are the RAW parameters of the 3DGS model
+ * (log scale, unnormalised quaternion, opacity logit) and the activations of gaussian_model.py:92-117 (exp, F.normalize,
+ * sigmoid) are applied inside the preprocess kernel -- same arithmetic as sgr_activations_forward, without its round trip
+ * through memory.  The matching backward is sgr_backward_phase with SGR_MODE_RAW_PARAMS: dL_dscale, dL_drot and dL_dopacity
+ * are then the gradients w.r.t. the raw parameters (sgr_activations_backward folded in).  Ignored with cov3D_precomp. */
+#define SGR_FLAG_RAW_PARAMS 1
+#define SGR_MODE_RAW_PARAMS 4 /* or-ed into the `phase` argument of sgr_backward_phase (phases 0, 1, 2 as before) */
 
 /* Rasterizer::backward, DGR/cuda_rasterizer/rasterizer.h:57-84 / rasterizer_impl.cu:340-434.
  *   R = the value sgr_forward returned; geom/binning/img = the buffers its callbacks handed out.

@@ -157,7 +157,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
                        const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                        float tan_fovx, float tan_fovy, int prefiltered, float* out_color, int* radii, int debug,
-                       void* stream, int64_t binning_capacity)
+                       void* stream, int64_t binning_capacity, int flags)
 {
     (void)prefiltered;  // the reference only uses it to trap on an inconsistent pre-filter (auxiliary.h:156-160)
     hipStream_t s = (hipStream_t)stream;
@@ -204,6 +204,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     pa.focal_y = height / (2.0f * tan_fovy);  // rasterizer_impl.cu:222-223
     pa.focal_x = width / (2.0f * tan_fovx);
     pa.gx = IL.gx; pa.gy = IL.gy;
+    pa.raw_params = (flags & SGR_FLAG_RAW_PARAMS) && !cov3D_precomp;
     pa.radii = radii; pa.rec = rec; pa.sort_keys = reinterpret_cast<uint32_t*>(sort_scratch);
     pa.rect_by_id = reinterpret_cast<uint2*>(sort_scratch + sgr_sort_rect_by_id_offset(P));
     { StageTimer t(s, SGR_STAGE_PREPROCESS); sgr_launch_preprocess_fwd(pa, s); }
@@ -293,7 +294,7 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
 {
     return sgr_forward_ex(geom_alloc, geom_user, binning_alloc, binning_user, img_alloc, img_user, P, D, M, background, width, height,
                           means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
-                          projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug, stream, 0);
+                          projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug, stream, 0, 0);
 }
 
 // phase 0: everything; 1: the blend half (accumulator reset, blend backward, and in compact mode the masked colour
@@ -307,6 +308,8 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
                          float* dL_dscale, float* dL_drot, int debug, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
+    const int raw_params = (phase & SGR_MODE_RAW_PARAMS) ? 1 : 0;
+    phase &= 3;
     if (phase < 0 || phase > 2) return fail(SGR_E_INVALID, "phase must be 0, 1 or 2");
     if (P <= 0 || width <= 0 || height <= 0) return fail(SGR_E_INVALID, "P, width and height must be positive");
     if (!geom_buffer || !binning_buffer || !img_buffer || !dL_dpix) return fail(SGR_E_INVALID, "null scratch / dL_dpix");
@@ -355,6 +358,7 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
     pb.focal_y = height / (2.0f * tan_fovy);
     pb.focal_x = width / (2.0f * tan_fovx);
     pb.rec = rec;
+    pb.raw_params = raw_params && !cov3D_precomp;
     pb.acc = acc;
     pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dopacity = dL_dopacity;
     pb.dL_dcolor = phase == 2 ? nullptr : dL_dcolor;  // phase 2: already written (and possibly being sent) by phase 1

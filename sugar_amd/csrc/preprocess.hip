@@ -222,6 +222,15 @@ __global__ void __launch_bounds__(256) k_mark_visible(int P, const float* __rest
     present[idx] = (pv.z <= 0.2f) ? 0 : 1;
 }
 
+// The parameter activations of gaussian_model.py:92-117 (exp / F.normalize / sigmoid), applied on the fly in the raw-parameter
+// mode.  Same arithmetic, operation for operation, as the stand-alone kernels of activations.hip (which is compiled with FMA
+// contraction: the fused multiply-adds are spelled out here).
+__device__ __forceinline__ float quat_norm_contracted(const float4 q)
+{
+    return sqrtf(__builtin_fmaf(q.w, q.w, __builtin_fmaf(q.z, q.z, __builtin_fmaf(q.y, q.y, q.x * q.x))));
+}
+__device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
 // One Gaussian: writes its GeomRec and radius, returns its tile rectangle (empty when culled).
 __device__ __forceinline__ void preprocess_one(const PreprocessArgs& a, const int idx, int& minx, int& miny, int& maxx, int& maxy)
 {
@@ -252,7 +261,12 @@ __device__ __forceinline__ void preprocess_one(const PreprocessArgs& a, const in
             for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * (size_t)idx + k];
         } else {
             float sc[3] = {a.scales[i3], a.scales[i3 + 1], a.scales[i3 + 2]};
-            const float4 q4 = *reinterpret_cast<const float4*>(a.rotations + 4 * (size_t)idx);
+            float4 q4 = *reinterpret_cast<const float4*>(a.rotations + 4 * (size_t)idx);
+            if (a.raw_params) {
+                sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
+                const float inv = 1.0f / fmaxf(quat_norm_contracted(q4), 1e-12f);
+                q4 = make_float4(q4.x * inv, q4.y * inv, q4.z * inv, q4.w * inv);
+            }
             float q[4] = {q4.x, q4.y, q4.z, q4.w};
             cov3d_from_scale_rot(sc, a.scale_modifier, q, c6);
         }
@@ -290,7 +304,7 @@ __device__ __forceinline__ void preprocess_one(const PreprocessArgs& a, const in
                     rec.r = fmax_(c0, 0.0f); rec.g = fmax_(c1, 0.0f); rec.b = fmax_(c2, 0.0f);
                 }
                 rec.x = pix_x; rec.y = pix_y; rec.cx = conx; rec.cy = cony; rec.cz = conz;
-                rec.opacity = a.opacities[idx];
+                rec.opacity = a.raw_params ? sigmoid_(a.opacities[idx]) : a.opacities[idx];
                 rec.depth = p_view.z;
                 rec.radius = r_int;
                 out_radius = r_int;
@@ -347,13 +361,20 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
     V3 mean = {a.means3D[i3], a.means3D[i3 + 1], a.means3D[i3 + 2]};
     const float* v = a.viewmatrix;
     float sc[3] = {0, 0, 0}, q[4] = {0, 0, 0, 0};
+    float4 q_raw = make_float4(0.f, 0.f, 0.f, 0.f);
     float c6[6];
     if (a.cov3D_precomp) {
 #pragma unroll
         for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * (size_t)idx + k];
     } else {
         sc[0] = a.scales[i3]; sc[1] = a.scales[i3 + 1]; sc[2] = a.scales[i3 + 2];
-        const float4 q4 = *reinterpret_cast<const float4*>(a.rotations + 4 * (size_t)idx);
+        float4 q4 = *reinterpret_cast<const float4*>(a.rotations + 4 * (size_t)idx);
+        q_raw = q4;
+        if (a.raw_params) {
+            sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
+            const float inv = 1.0f / fmaxf(quat_norm_contracted(q4), 1e-12f);
+            q4 = make_float4(q4.x * inv, q4.y * inv, q4.z * inv, q4.w * inv);
+        }
         q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
         cov3d_from_scale_rot(sc, a.scale_modifier, q, c6);
     }
@@ -372,7 +393,8 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
         a.dL_dmean2D[i3] = dm2x; a.dL_dmean2D[i3 + 1] = dm2y; a.dL_dmean2D[i3 + 2] = 0;
         float4 gc = {g0, g1, 0.f, g3};
         *reinterpret_cast<float4*>(a.dL_dconic + 4 * (size_t)idx) = gc;
-        a.dL_dopacity[idx] = s0.w;
+        // raw mode: d sigmoid = s (1 - s), the activated opacity is in the record (sgr_activations_backward's arithmetic)
+        a.dL_dopacity[idx] = a.raw_params ? s0.w * op * (1.0f - op) : s0.w;
         if (a.dL_dcolor) { a.dL_dcolor[i3] = dcol[0]; a.dL_dcolor[i3 + 1] = dcol[1]; a.dL_dcolor[i3 + 2] = dcol[2]; }
     }
     // ---- K9, backward.cu:144-274
@@ -497,8 +519,10 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
 #pragma unroll
             for (int rr = 0; rr < 3; rr++) dMt[c][rr] = dM[rr][c];
 #pragma unroll
-        for (int k = 0; k < 3; k++)
-            a.dL_dscale[i3 + k] = R[0][k] * dMt[k][0] + R[1][k] * dMt[k][1] + R[2][k] * dMt[k][2];
+        for (int k = 0; k < 3; k++) {
+            const float ds = R[0][k] * dMt[k][0] + R[1][k] * dMt[k][1] + R[2][k] * dMt[k][2];
+            a.dL_dscale[i3 + k] = a.raw_params ? ds * sc[k] : ds;  // raw mode: d exp = exp
+        }
 #pragma unroll
         for (int k = 0; k < 3; k++)
 #pragma unroll
@@ -508,6 +532,19 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
         dq.y = 2 * y * (dMt[1][0] + dMt[0][1]) + 2 * z * (dMt[2][0] + dMt[0][2]) + 2 * r * (dMt[1][2] - dMt[2][1]) - 4 * x * (dMt[2][2] + dMt[1][1]);
         dq.z = 2 * x * (dMt[1][0] + dMt[0][1]) + 2 * r * (dMt[2][0] - dMt[0][2]) + 2 * z * (dMt[1][2] + dMt[2][1]) - 4 * y * (dMt[2][2] + dMt[0][0]);
         dq.w = 2 * r * (dMt[0][1] - dMt[1][0]) + 2 * x * (dMt[2][0] + dMt[0][2]) + 2 * y * (dMt[1][2] + dMt[2][1]) - 4 * z * (dMt[1][1] + dMt[0][0]);
+        if (a.raw_params) {
+            // d (v / |v|) = (I - n n^T) / |v|   (sgr_activations_backward's arithmetic, its FMA contraction spelled out)
+            const float n = quat_norm_contracted(q_raw);
+            if (n > 1e-12f) {
+                const float inv = 1.0f / n;
+                const float nx = q_raw.x * inv, ny = q_raw.y * inv, nz = q_raw.z * inv, nw = q_raw.w * inv;
+                const float dot = __builtin_fmaf(nw, dq.w, __builtin_fmaf(nz, dq.z, __builtin_fmaf(ny, dq.y, nx * dq.x)));
+                dq = make_float4(__builtin_fmaf(-nx, dot, dq.x) * inv, __builtin_fmaf(-ny, dot, dq.y) * inv,
+                                 __builtin_fmaf(-nz, dot, dq.z) * inv, __builtin_fmaf(-nw, dot, dq.w) * inv);
+            } else {
+                dq = make_float4(dq.x * 1e12f, dq.y * 1e12f, dq.z * 1e12f, dq.w * 1e12f);
+            }
+        }
         *reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = dq;
     }
     a.dL_dmean3D[i3] = dmean[0]; a.dL_dmean3D[i3 + 1] = dmean[1]; a.dL_dmean3D[i3 + 2] = dmean[2];

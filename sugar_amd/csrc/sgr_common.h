@@ -114,6 +114,7 @@ struct PreprocessArgs {
     int W, H; float tan_fovx, tan_fovy, focal_x, focal_y;
     int gx, gy;
     int* radii; GeomRec* rec;
+    int raw_params;       // scales / rotations / opacities are the RAW parameters (log scale, unnormalised quaternion, logit)
     uint32_t* sort_keys;  // [P] depth bits of visible Gaussians, 0xFFFFFFFF for culled ones (input of the depth sort)
     uint2* rect_by_id;    // [P] packed tile rectangle of every Gaussian (w == 0: culled)
 };
@@ -126,6 +127,7 @@ struct PreprocessBwdArgs {
     const float* cov3D_precomp; const float* viewmatrix; const float* projmatrix; const float* cam_pos;
     int W, H; float tan_fovx, tan_fovy, focal_x, focal_y;
     const GeomRec* rec;
+    int raw_params;    // as in PreprocessArgs: dL_dscale / dL_drot / dL_dopacity are then gradients w.r.t. the raw parameters
     const float* acc;  // [P][SGR_ACC_STRIDE] sums from the blend backward: {dcol r,g,b, S0, Sx, Sy, Sxx, Sxy, Syy, pad x3}
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor;  // written here from acc
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;

@@ -137,12 +137,14 @@ class _CModule:
             # tensor `header_out` behind the forward and `header_event` recorded: the CALLER must check it (word 0 = real
             # num_rendered <= n and word 6 == 0) before running the backward, and repeat the forward otherwise
             capacity = int(_GRAD_SINK.get("binning_capacity") or 0) if _GRAD_SINK else 0
+            # `raw_params=True`: scales / rotations / opacities are the raw 3DGS parameters, activated inside the kernels
+            flags = 1 if (_GRAD_SINK and _GRAD_SINK.get("raw_params")) else 0
             rendered = lib.sgr_forward_ex(
                 scratch.cb("geom"), None, scratch.cb("binning"), None, scratch.cb("img"), None,
                 P, int(degree), int(M), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
                 _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
                 _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
-                _ptr(out_color), _ptr(radii), int(bool(debug)), C.c_void_p(stream), capacity)
+                _ptr(out_color), _ptr(radii), int(bool(debug)), C.c_void_p(stream), capacity, flags)
         if rendered < 0:
             raise RuntimeError(f"sgr_forward failed ({rendered}): {_lib.last_error()}")
         t = scratch.tensors
@@ -175,12 +177,13 @@ class _CModule:
         dL_dmeans2D = torch.empty(P, 3, **f)
         dL_dcolors = _sink_or_empty(grad_out, "colors", (P, 3), **f)
         dL_dconic = torch.empty(P, 2, 2, **f)
-        dL_dopacity = torch.empty(P, 1, **f)
+        dL_dopacity = _sink_or_empty(grad_out, "opacities", (P, 1), **f)
         dL_dcov3D = torch.empty(P, 6, **f)
         compact_sh = bool(grad_out and grad_out.get("compact_sh")) and M > 0
         dL_dsh = None if compact_sh else _sink_or_empty(grad_out, "shs", (P, M, 3), **f)
-        dL_dscales = torch.zeros(P, 3, **f) if use_cov else torch.empty(P, 3, **f)
-        dL_drotations = torch.zeros(P, 4, **f) if use_cov else torch.empty(P, 4, **f)
+        dL_dscales = torch.zeros(P, 3, **f) if use_cov else _sink_or_empty(grad_out, "scales", (P, 3), **f)
+        dL_drotations = torch.zeros(P, 4, **f) if use_cov else _sink_or_empty(grad_out, "rotations", (P, 4), **f)
+        raw_mode = 4 if (grad_out and grad_out.get("raw_params")) else 0  # SGR_MODE_RAW_PARAMS
         if P != 0:
             means3D = _dev_f32(means3D, dev, "means3D")
             dL = _dev_f32(dL_dout_color, dev, "dL_dout_color")
@@ -200,10 +203,12 @@ class _CModule:
                 if on_colors is not None:
                     # two halves: the masked colour gradients are final after the blend half, so the caller can start
                     # exchanging them while the preprocess half runs
-                    rc = lib.sgr_backward_phase(1, *args)
+                    rc = lib.sgr_backward_phase(1 | raw_mode, *args)
                     if rc >= 0:
                         on_colors(dL_dcolors)
-                        rc = lib.sgr_backward_phase(2, *args)
+                        rc = lib.sgr_backward_phase(2 | raw_mode, *args)
+                elif raw_mode:
+                    rc = lib.sgr_backward_phase(raw_mode, *args)
                 else:
                     rc = lib.sgr_backward(*args)
             if rc < 0:

@@ -161,10 +161,13 @@ class GaussianParams:
             self.params["scaling"].copy_(torch.log(scene.scales))
             self.params["rotation"].copy_(scene.rotations)
 
-    def activated(self, fused=None):
+    def activated(self, fused=None, raw=False):
         """gaussian_model.py:92-117: exp / normalize / sigmoid -- one HIP kernel each way on a ROCm device (the gradients
-        land directly in the flat gradient buffer), stock torch ops otherwise."""
+        land directly in the flat gradient buffer), stock torch ops otherwise.  `raw=True`: the raw tensors themselves, for a
+        rasterizer call in raw-parameter mode (the activations then happen inside its preprocess kernels)."""
         p = self.params
+        if raw:
+            return dict(means3D=p["xyz"], scales=p["scaling"], rotations=p["rotation"], opacities=p["opacity"], shs=p["features"])
         if self.flat.is_cuda if fused is None else fused:
             scales, rotations, opacities = _Activations.apply(p["scaling"], p["rotation"], p["opacity"],
                                                              (p["scaling"].grad, p["rotation"].grad, p["opacity"].grad))
@@ -274,11 +277,11 @@ class FlatAdam:
 
 
 def render(params: GaussianParams, cam, bg, rasterizer_cls, settings_cls, sh_degree=3, debug=False, means2D=None,
-           visibility=True):
+           visibility=True, raw_params=False):
     """gaussian_splatting/gaussian_renderer/__init__.py:18-100 with SH and scale/rotation handled in the rasterizer.
     `means2D`: a caller-owned [P,3] zero tensor with requires_grad (the reference zero-fills a fresh one per call, :27-31; its
     values are never read, it only carries dL/dmeans2D); `visibility=False` skips the `radii > 0` mask (:97)."""
-    a = params.activated()
+    a = params.activated(raw=raw_params)  # raw_params: the caller has put the rasterizer into raw-parameter mode (grad_sink)
     dev = a["means3D"].device
     screenspace_points = torch.zeros_like(a["means3D"], requires_grad=True) if means2D is None else means2D
     settings = settings_cls(image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=cam.tanfovx,
@@ -338,7 +341,7 @@ class ViewShardedTrainer:
 
     def __init__(self, params: GaussianParams, rasterizer_cls, settings_cls, bg, sh_degree=3, lambda_dssim=0.2,
                  fused_loss=True, compact_sh=None, sh_grad_fn=None, grad_sink_cm=None, fused_sh_adam=None, sync_free=None,
-                 visibility=False):
+                 visibility=False, fuse_activations=None):
         self.fused_loss = fused_loss
         self.params = params
         self.opt = params.make_optimizer()
@@ -362,6 +365,11 @@ class ViewShardedTrainer:
         self.sync_free = on_hip if sync_free is None else bool(sync_free)
         if self.sync_free and not on_hip:
             raise ValueError("sync_free needs the HIP rasterizer")
+        # exp / normalize / sigmoid of the raw parameters inside the rasterizer's preprocess kernels (raw-parameter mode) instead
+        # of two stand-alone kernels and a round trip of the activated values and their gradients through memory
+        self.fuse_activations = on_hip if fuse_activations is None else bool(fuse_activations)
+        if self.fuse_activations and not on_hip:
+            raise ValueError("fuse_activations needs the HIP rasterizer")
         self._bin_cap = 0                 # instances the binning buffer is sized for (0: next forward runs with the host round trip)
         self._hdr = torch.zeros(8, dtype=torch.int32).pin_memory() if self.sync_free else None
         self._ev_hdr = torch.cuda.Event() if self.sync_free else None
@@ -386,7 +394,7 @@ class ViewShardedTrainer:
         import contextlib
         with (grad_sink(**{**_current_sink(), **extra}) if extra else contextlib.nullcontext()):
             pkg = render(self.params, cam, self.bg, self.rasterizer_cls, self.settings_cls, self.sh_degree,
-                         means2D=self._means2D, visibility=self.visibility)
+                         means2D=self._means2D, visibility=self.visibility, raw_params=self.fuse_activations)
             loss = train_loss(pkg["render"], gt_image, self.lambda_dssim, self.fused_loss)
         return pkg, loss
 
@@ -409,6 +417,9 @@ class ViewShardedTrainer:
         holder = {}
         if self.grad_sink_cm is not None:
             sinks = dict(means3D=p.params["xyz"].grad)
+            if self.fuse_activations:
+                sinks.update(raw_params=True, scales=p.params["scaling"].grad, rotations=p.params["rotation"].grad,
+                             opacities=p.params["opacity"].grad)
             if self.compact_sh:
                 sinks.update(compact_sh=True, out=holder)
                 if self.world > 1:

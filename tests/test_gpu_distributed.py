@@ -63,7 +63,7 @@ def test_two_ranks_match_sequential_accumulation(tmp_path):
     dev = torch.device("cuda:0")
     scene, cams, gts = _setup(dev)
     params = GaussianParams(scene, dev)
-    params.activated = lambda: GaussianParams.activated(params, fused=False)  # stock torch ops: gradients are fresh tensors
+    params.activated = lambda raw=False: GaussianParams.activated(params, fused=False)  # stock torch ops: gradients are fresh tensors
     start = params.flat.detach().cpu().numpy().copy()
     opt = params.make_optimizer()
     for s in range(STEPS):

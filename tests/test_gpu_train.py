@@ -200,3 +200,33 @@ def test_sync_free_forward_matches_and_recovers_from_a_small_capacity():
         res.append(p.flat.clone())
     start = GaussianParams(scene, dev).flat
     assert float((res[0] - res[1]).norm() / (res[0] - start).norm()) < 1e-3
+
+
+def test_raw_parameter_mode_equals_separate_activations():
+    """sgr_forward_ex / sgr_backward_phase in raw-parameter mode == activations kernels + rasterizer"""
+    from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from sugar_amd.train_step import GaussianParams, ViewShardedTrainer
+    dev = torch.device(DEV)
+    scene = syn.make_scene(30000, 6, 0.01, 0.06)
+    cams = [c._replace(viewmatrix=c.viewmatrix.to(dev), projmatrix=c.projmatrix.to(dev), campos=c.campos.to(dev))
+            for c in syn.orbit_cameras(400, 240)]
+    gts = [torch.rand(3, 240, 400, generator=torch.Generator().manual_seed(i)).to(dev) for i in range(3)]
+    flats, grads, images = [], [], []
+    for fuse in (False, True):
+        p = GaussianParams(scene, dev)
+        with torch.no_grad():
+            p.params["rotation"].mul_(2.5)  # un-normalised quaternions, as they are mid-training
+        tr = ViewShardedTrainer(p, GaussianRasterizer, GaussianRasterizationSettings, torch.zeros(3, device=dev), fuse_activations=fuse)
+        assert tr.fuse_activations == fuse
+        _, pkg = tr.step(cams[0], gts[0])
+        images.append(pkg["render"].detach().clone()); grads.append(p.flat_grad[: p.n_small].clone())
+        for i in (1, 2):
+            tr.step(cams[i], gts[i])
+        flats.append(p.flat.clone())
+    # (expf inlines differently into the two translation units -- one is built without FMA contraction --, so the activated
+    # values can differ in the last bit)
+    assert float((images[0] - images[1]).norm() / images[0].norm()) < 1e-5
+    # the backward sums with atomics in a run-dependent order: compare norm-wise
+    assert float((grads[0] - grads[1]).norm() / grads[0].norm()) < 1e-5
+    start = GaussianParams(scene, dev).flat
+    assert float((flats[0] - flats[1]).norm() / (flats[0] - start).norm()) < 1e-3
