@@ -10,8 +10,10 @@
 //
 // (This file holds the depth sort and the SINGLE-LEVEL binning, which is the fallback path; the default two-level binning
 //  lives in binning2.hip.)
-//   gsort      : stable LSD radix sort (4 x 8-bit passes) of (depth_bits, gaussian_id) over the P Gaussians.  Culled
-//                Gaussians carry key 0xFFFFFFFF and sink to the end.  Ties keep ascending id.
+//   gsort      : stable LSD radix sort (8-bit passes) of (depth_bits, gaussian_id) over the P Gaussians.  Culled
+//                Gaussians carry key 0xFFFFFFFF and sink to the end.  Ties keep ascending id.  The digits are taken from
+//                key - min(key) (culled: max + 1 - min), and when that range fits 24 bits -- depths within two or three
+//                binades, the rule -- the fourth pass is an identity and its kernels return at once.
 //                The last pass also carries each Gaussian's packed tile rectangle (8 bytes, written by the preprocess
 //                kernel) into sorted order: the walks below stream it.
 //   bin_count  : workgroup b owns a contiguous slice of the sorted order and a private histogram over all T tiles in LDS;
@@ -30,6 +32,7 @@
 // HBM traffic: ~100 B per Gaussian for the sort, 4 B per instance for point_list, 16 B per (workgroup, tile) of histogram
 // traffic -- versus ~144 B per INSTANCE for the reference's 6-pass radix sort of 12-byte pairs.  No global atomics.
 #include "sgr_device.h"
+#include <cstdlib>
 
 namespace {
 
@@ -50,18 +53,53 @@ namespace {
 
 #define RS_ITEMS 4096  // keys per workgroup chunk (256 threads x 16 keys)
 
-// per-chunk digit histogram, written digit-major: hist[digit * n_chunks + chunk]
+// sort parameters, reduced from the preprocess kernel's per-workgroup key ranges by the first histogram kernel
+struct RsParams { uint32_t kmin, kmax1 /* max + 1: the stand-in of a culled key */, skip3 /* (kmax1 - kmin) < 2^24 */, pad; };
+
+__device__ __forceinline__ uint32_t rs_digit(uint32_t key, uint32_t kmin, uint32_t kmax1, int shift)
+{
+    return (((key == 0xFFFFFFFFu ? kmax1 : key) - kmin) >> shift) & 255u;
+}
+
+// per-chunk digit histogram, written digit-major: hist[digit * n_chunks + chunk].  Pass 0 (minmax != NULL) first reduces the
+// preprocess kernel's per-workgroup key ranges (every workgroup redundantly: 8 bytes per 256 Gaussians) and workgroup 0
+// publishes the sort parameters for the kernels that follow.
 __global__ void __launch_bounds__(256) k_rs_hist(int n, const uint32_t* __restrict__ keys, int shift, int n_chunks,
-                                                 uint32_t* __restrict__ hist)
+                                                 uint32_t* __restrict__ hist, const uint2* __restrict__ minmax, int n_minmax,
+                                                 RsParams* __restrict__ params, int pass, int allow_skip)
 {
     __shared__ uint32_t s_h[256];
+    __shared__ uint32_t s_mm[2][4];
+    uint32_t kmin, kmax1;
+    if (minmax) {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        for (int i = threadIdx.x; i < n_minmax; i += 256) { const uint2 v = minmax[i]; lo = min(lo, v.x); hi = max(hi, v.y); }
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
+            hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
+        }
+        if ((threadIdx.x & 63) == 0) { s_mm[0][threadIdx.x >> 6] = lo; s_mm[1][threadIdx.x >> 6] = hi; }
+        __syncthreads();
+        lo = min(min(s_mm[0][0], s_mm[0][1]), min(s_mm[0][2], s_mm[0][3]));
+        hi = max(max(s_mm[1][0], s_mm[1][1]), max(s_mm[1][2], s_mm[1][3]));
+        if (lo > hi) { lo = 0u; hi = 0u; }  // nothing visible
+        kmin = lo; kmax1 = hi + 1u;         // (hi < 0x7F800000: a positive float)
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            RsParams pr; pr.kmin = kmin; pr.kmax1 = kmax1; pr.skip3 = (allow_skip && ((kmax1 - kmin) >> 24) == 0u) ? 1u : 0u; pr.pad = 0u;
+            *params = pr;
+        }
+    } else {
+        const RsParams pr = *params;
+        if (pass == 3 && pr.skip3) return;
+        kmin = pr.kmin; kmax1 = pr.kmax1;
+    }
     s_h[threadIdx.x] = 0;
     __syncthreads();
     const int base = blockIdx.x * RS_ITEMS;
 #pragma unroll
     for (int i = 0; i < RS_ITEMS / 256; i++) {
         const int k = base + i * 256 + threadIdx.x;
-        if (k < n) atomicAdd(&s_h[(keys[k] >> shift) & 255u], 1u);
+        if (k < n) atomicAdd(&s_h[rs_digit(keys[k], kmin, kmax1, shift)], 1u);
     }
     __syncthreads();
     hist[(size_t)threadIdx.x * n_chunks + blockIdx.x] = s_h[threadIdx.x];
@@ -69,9 +107,11 @@ __global__ void __launch_bounds__(256) k_rs_hist(int n, const uint32_t* __restri
 
 // Row scan: workgroup d turns hist[d][0..n_chunks) into its exclusive prefix over the chunks and writes the row total.
 // (The prefix ACROSS digits is taken from the 256 totals inside the scatter kernel.)
-__global__ void __launch_bounds__(256) k_rs_scan_rows(int n_chunks, uint32_t* __restrict__ hist, uint32_t* __restrict__ totals)
+__global__ void __launch_bounds__(256) k_rs_scan_rows(int n_chunks, uint32_t* __restrict__ hist, uint32_t* __restrict__ totals,
+                                                      const RsParams* __restrict__ params, int pass)
 {
     __shared__ uint32_t s_part[256];
+    if (pass == 3 && params->skip3) return;
     uint32_t* row = hist + (size_t)blockIdx.x * n_chunks;
     const int tid = threadIdx.x;
     const int per = (n_chunks + 255) / 256;
@@ -101,8 +141,18 @@ __global__ void __launch_bounds__(256) k_rs_scatter(int n, const uint32_t* __res
                                                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int shift,
                                                     int n_chunks, const uint32_t* __restrict__ hist,
                                                     const uint32_t* __restrict__ totals, const uint2* __restrict__ aux_by_val,
-                                                    uint2* __restrict__ aux_out)
+                                                    uint2* __restrict__ aux_out, const RsParams* __restrict__ params, int pass,
+                                                    uint32_t* __restrict__ keys_out_skip, uint32_t* __restrict__ vals_out_skip)
 {
+    // pass 2 is the last one when the key range fits 24 bits: it then writes where pass 3 would have (and carries the tile
+    // rectangles); pass 3 returns at once
+    const RsParams pr = *params;
+    if (pass == 3 && pr.skip3) return;
+    if (pass == 2) {
+        if (pr.skip3) { keys_out = keys_out_skip; vals_out = vals_out_skip; }
+        else aux_out = nullptr;
+    }
+    const uint32_t kmin = pr.kmin, kmax1 = pr.kmax1;
     __shared__ uint32_t s_cnt[4][256];   // per-wave digit counts, then per-wave first slot (chunk-local)
     __shared__ uint32_t s_loc[256];      // chunk-local first slot of every digit
     __shared__ uint32_t s_base[256];     // global first slot of every digit's run for this chunk
@@ -126,7 +176,7 @@ __global__ void __launch_bounds__(256) k_rs_scatter(int n, const uint32_t* __res
     for (int i = 0; i < G; i++) {
         const int k = base + wave * (RS_ITEMS / 4) + i * 64 + lane;
         const bool live = k < n;
-        const uint32_t digit = (rk[i] >> shift) & 255u;
+        const uint32_t digit = rs_digit(rk[i], kmin, kmax1, shift);
         unsigned long long same = __ballot(live);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
@@ -175,7 +225,7 @@ __global__ void __launch_bounds__(256) k_rs_scatter(int n, const uint32_t* __res
     for (int i = 0; i < G; i++) {
         const int k = base + wave * (RS_ITEMS / 4) + i * 64 + lane;
         if (k < n) {
-            const uint32_t digit = (rk[i] >> shift) & 255u;
+            const uint32_t digit = rs_digit(rk[i], kmin, kmax1, shift);
             const uint32_t pos = s_cnt[wave][digit] + lrank[i];
             s_k[pos] = rk[i]; s_v[pos] = rv[i];
         }
@@ -187,7 +237,7 @@ __global__ void __launch_bounds__(256) k_rs_scatter(int n, const uint32_t* __res
         const int j = i * 256 + tid;
         if (j < live_n) {
             const uint32_t key = s_k[j], val = s_v[j];
-            const uint32_t digit = (key >> shift) & 255u;
+            const uint32_t digit = rs_digit(key, kmin, kmax1, shift);
             const uint32_t dst = s_base[digit] + ((uint32_t)j - s_loc[digit]);
             keys_out[dst] = key;
             vals_out[dst] = val;
@@ -333,8 +383,10 @@ __global__ void __launch_bounds__(64) k_hist_scan(int T, int n_blocks, uint32_t*
 }
 
 // ---- tile scan: one 1024-thread workgroup, T <= a few 10^5 -----------------------------------
+// (also zeroes the two per-tile maxima the forward blend's blocks combine with atomicMax)
 __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __restrict__ tile_count,
-                                                    uint32_t* __restrict__ tile_start, uint32_t* __restrict__ header)
+                                                    uint32_t* __restrict__ tile_start, uint32_t* __restrict__ header,
+                                                    uint32_t* __restrict__ tile_maxc, uint32_t* __restrict__ tile_walked)
 {
     __shared__ uint32_t s_part[1024];
     __shared__ uint32_t s_max[16];
@@ -354,7 +406,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __res
         __syncthreads();
     }
     uint32_t run = s_part[tid] - sum;  // exclusive prefix of this thread's chunk
-    for (int i = b; i < e; i++) { tile_start[i] = run; run += tile_count[i]; }
+    for (int i = b; i < e; i++) { tile_start[i] = run; run += tile_count[i]; tile_maxc[i] = 0u; tile_walked[i] = 0u; }
     if (tid == 1023) {
         tile_start[T] = s_part[1023];
         header[SGR_HDR_R] = s_part[1023];
@@ -367,11 +419,25 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __res
 
 }  // namespace
 
-size_t sgr_sort_scratch_bytes(int P)
+// sort scratch: [ keys_a | keys_b | vals_a | vals_b | hist | totals | rects (sorted) | rects (by id) | keys_c | vals_c |
+//                 key ranges per preprocess workgroup | parameters ]
+static size_t sort_base_bytes(int P)
 {
     const size_t n = (size_t)(P > 0 ? P : 1);
     const size_t chunks = (n + RS_ITEMS - 1) / RS_ITEMS;
-    return sgr_align(n * 4) * 4 + sgr_align(chunks * 256 * 4) + 1024 + 2 * sgr_align(n * 8);  // + packed rectangles (sorted, by id)
+    return sgr_align(n * 4) * 4 + sgr_align(chunks * 256 * 4) + 1024 + 2 * sgr_align(n * 8);  // ... + packed rectangles (sorted, by id)
+}
+
+size_t sgr_sort_minmax_offset(int P)
+{
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    return sort_base_bytes(P) + 2 * sgr_align(n * 4);
+}
+
+size_t sgr_sort_scratch_bytes(int P)
+{
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    return sgr_sort_minmax_offset(P) + sgr_align((n + 255) / 256 * 8) + 256;
 }
 
 size_t sgr_sort_rect_by_id_offset(int P)
@@ -387,8 +453,9 @@ size_t sgr_sort_rects_offset(int P)
     return sgr_align(n * 4) * 4 + sgr_align(chunks * 256 * 4) + 1024;
 }
 
-// keys_a (the first array of sort_scratch) must hold the keys, written by the preprocess kernel; on return *order_out
-// points at the sorted Gaussian ids (inside sort_scratch).
+// keys_a (the first array of sort_scratch) must hold the keys and the key ranges theirs, both written by the preprocess
+// kernel; on return *order_out points at the sorted Gaussian ids (inside sort_scratch).
+// Buffers: pass 0 a -> b, pass 1 b -> c, pass 2 c -> b (or -> a when it is the last one), pass 3 b -> a.
 void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_out, const uint2* rect_by_id, uint2* rects_sorted,
                               hipStream_t s)
 {
@@ -401,18 +468,25 @@ void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_
     uint32_t* hist = reinterpret_cast<uint32_t*>(sort_scratch + 4 * arr);
     const int chunks = (P + RS_ITEMS - 1) / RS_ITEMS;
     uint32_t* totals = reinterpret_cast<uint32_t*>(sort_scratch + 4 * arr + sgr_align((size_t)chunks * 256 * 4));
-    const uint32_t* kin = keys_a; const uint32_t* vin = nullptr;
+    uint32_t* keys_c = reinterpret_cast<uint32_t*>(sort_scratch + sort_base_bytes(P));
+    uint32_t* vals_c = reinterpret_cast<uint32_t*>(sort_scratch + sort_base_bytes(P) + arr);
+    const uint2* minmax = reinterpret_cast<const uint2*>(sort_scratch + sgr_sort_minmax_offset(P));
+    const int n_minmax = (P + 255) / 256;
+    RsParams* params = reinterpret_cast<RsParams*>(sort_scratch + sgr_sort_minmax_offset(P) + sgr_align((size_t)n_minmax * 8));
+    const uint32_t* kin[4] = {keys_a, keys_b, keys_c, keys_b};
+    const uint32_t* vin[4] = {nullptr, vals_b, vals_c, vals_b};
+    uint32_t* kout[4] = {keys_b, keys_c, keys_b, keys_a};
+    uint32_t* vout[4] = {vals_b, vals_c, vals_b, vals_a};
+    static const int allow_skip = getenv("SGR_SORT_FOUR_PASSES") ? 0 : 1;  // (development: always run the fourth pass)
     for (int pass = 0; pass < 4; pass++) {
-        uint32_t* kout = (pass & 1) ? keys_a : keys_b;
-        uint32_t* vout = (pass & 1) ? vals_a : vals_b;
         const int shift = 8 * pass;
-        hipLaunchKernelGGL(k_rs_hist, dim3(chunks), dim3(256), 0, s, P, kin, shift, chunks, hist);
-        hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(256), 0, s, chunks, hist, totals);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(chunks), dim3(256), 0, s, P, kin, vin, kout, vout, shift, chunks, hist, totals,
-                           rect_by_id, pass == 3 ? rects_sorted : (uint2*)nullptr);
-        kin = kout; vin = vout;
+        hipLaunchKernelGGL(k_rs_hist, dim3(chunks), dim3(256), 0, s, P, kin[pass], shift, chunks, hist,
+                           pass == 0 ? minmax : (const uint2*)nullptr, n_minmax, params, pass, allow_skip);
+        hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(256), 0, s, chunks, hist, totals, params, pass);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(chunks), dim3(256), 0, s, P, kin[pass], vin[pass], kout[pass], vout[pass], shift, chunks,
+                           hist, totals, rect_by_id, pass >= 2 ? rects_sorted : (uint2*)nullptr, params, pass, keys_a, vals_a);
     }
-    *order_out = vals_a;  // pass 0 -> b, 1 -> a, 2 -> b, 3 -> a
+    *order_out = vals_a;
 }
 
 static void set_lds_limit(const void* fn, size_t bytes, size_t& configured)
@@ -448,7 +522,8 @@ void sgr_launch_hist_scan(int T, int n_blocks, uint32_t* blk_hist, uint32_t* til
     hipLaunchKernelGGL(k_hist_scan, dim3((T + 63) / 64), dim3(64), 0, s, T, n_blocks, blk_hist, tile_count);
 }
 
-void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* header, hipStream_t s)
+void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* header, uint32_t* tile_maxc,
+                          uint32_t* tile_walked, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, tile_count, tile_start, header);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, tile_count, tile_start, header, tile_maxc, tile_walked);
 }

@@ -571,9 +571,7 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
                           uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
                           const uint32_t* guard_hdr, uint32_t list_cap, hipStream_t s)
 {
-    const int T = gx * gy;
-    // tile_maxc and tile_walked are adjacent (each padded to 256 bytes): one memset (the blocks of a tile combine with atomicMax)
-    (void)hipMemsetAsync(tile_maxc, 0, (size_t)((char*)tile_walked - (char*)tile_maxc) + (size_t)T * 4, s);
+    const int T = gx * gy;  // (tile_maxc and tile_walked were zeroed by the tile scan: the blocks of a tile combine with atomicMax)
     hipLaunchKernelGGL(k_blend_fwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg, final_T,
                        n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, guard_hdr, list_cap);
 }

@@ -207,6 +207,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     pa.raw_params = (flags & SGR_FLAG_RAW_PARAMS) && !cov3D_precomp;
     pa.radii = radii; pa.rec = rec; pa.sort_keys = reinterpret_cast<uint32_t*>(sort_scratch);
     pa.rect_by_id = reinterpret_cast<uint2*>(sort_scratch + sgr_sort_rect_by_id_offset(P));
+    pa.key_minmax = reinterpret_cast<uint2*>(sort_scratch + sgr_sort_minmax_offset(P));
     { StageTimer t(s, SGR_STAGE_PREPROCESS); sgr_launch_preprocess_fwd(pa, s); }
     STAGE_CHECK("preprocess");
 
@@ -224,7 +225,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
             sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, blk_hist, s);
             sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
         }
-        sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, s);
+        sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, tile_maxc, tile_walked, s);
     }
     STAGE_CHECK("bin_count");
 
@@ -250,7 +251,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
             two_level = false;
             sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, blk_hist, s);
             sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
-            sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, s);
+            sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, tile_maxc, tile_walked, s);
             HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 16, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
         }

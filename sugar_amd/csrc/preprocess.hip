@@ -232,7 +232,7 @@ __device__ __forceinline__ float quat_norm_contracted(const float4 q)
 __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // One Gaussian: writes its GeomRec and radius, returns its tile rectangle (empty when culled).
-__device__ __forceinline__ void preprocess_one(const PreprocessArgs& a, const int idx, int& minx, int& miny, int& maxx, int& maxy)
+__device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, const int idx, int& minx, int& miny, int& maxx, int& maxy)
 {
     minx = miny = maxx = maxy = 0;
     GeomRec rec;
@@ -316,22 +316,39 @@ __device__ __forceinline__ void preprocess_one(const PreprocessArgs& a, const in
     dst[0] = srcv[0]; dst[1] = srcv[1]; dst[2] = srcv[2];
     if (a.radii) a.radii[idx] = out_radius;
     // key of the global depth sort (binning.hip): depth > 0.2, so the float bit pattern orders like the value
-    a.sort_keys[idx] = out_radius > 0 ? __float_as_uint(rec.depth) : 0xFFFFFFFFu;
+    const uint32_t key = out_radius > 0 ? __float_as_uint(rec.depth) : 0xFFFFFFFFu;
+    a.sort_keys[idx] = key;
+    return key;
 }
 
 __global__ void __launch_bounds__(256) k_preprocess_fwd(PreprocessArgs a)
 {
+    __shared__ uint32_t s_mm[2][4];
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
-    int minx, miny, maxx, maxy;
-    preprocess_one(a, idx, minx, miny, maxx, maxy);
-    // tile rectangle {minx | miny << 16, w | h << 16} (w == 0: culled); the last depth-sort pass carries it along
-    uint2 r = make_uint2(0u, 0u);
-    if (maxx > minx && maxy > miny) {
-        r.x = (uint32_t)minx | ((uint32_t)miny << 16);
-        r.y = (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16);
+    uint32_t key = 0xFFFFFFFFu;
+    if (idx < a.P) {
+        int minx, miny, maxx, maxy;
+        key = preprocess_one(a, idx, minx, miny, maxx, maxy);
+        // tile rectangle {minx | miny << 16, w | h << 16} (w == 0: culled); the last depth-sort pass carries it along
+        uint2 r = make_uint2(0u, 0u);
+        if (maxx > minx && maxy > miny) {
+            r.x = (uint32_t)minx | ((uint32_t)miny << 16);
+            r.y = (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16);
+        }
+        a.rect_by_id[idx] = r;
     }
-    a.rect_by_id[idx] = r;
+    // smallest and largest depth key of the workgroup's visible Gaussians: the depth sort works on key - min and drops its
+    // fourth pass when the range fits 24 bits (binning.hip)
+    uint32_t kmin = key, kmax = key == 0xFFFFFFFFu ? 0u : key;
+    for (int o = 32; o > 0; o >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o));
+    }
+    if ((threadIdx.x & 63) == 0) { s_mm[0][threadIdx.x >> 6] = kmin; s_mm[1][threadIdx.x >> 6] = kmax; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        a.key_minmax[blockIdx.x] = make_uint2(min(min(s_mm[0][0], s_mm[0][1]), min(s_mm[0][2], s_mm[0][3])),
+                                              max(max(s_mm[1][0], s_mm[1][1]), max(s_mm[1][2], s_mm[1][3])));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -117,6 +117,7 @@ struct PreprocessArgs {
     int raw_params;       // scales / rotations / opacities are the RAW parameters (log scale, unnormalised quaternion, logit)
     uint32_t* sort_keys;  // [P] depth bits of visible Gaussians, 0xFFFFFFFF for culled ones (input of the depth sort)
     uint2* rect_by_id;    // [P] packed tile rectangle of every Gaussian (w == 0: culled)
+    uint2* key_minmax;    // [ceil(P / 256)] smallest / largest depth key of every workgroup's visible Gaussians
 };
 void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 void sgr_launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
@@ -144,12 +145,14 @@ void sgr_launch_sh_adam_from_views(int P, int V, int D, int M, size_t vstride, c
 void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_out, const uint2* rect_by_id, uint2* rects_sorted,
                               hipStream_t s);
 size_t sgr_sort_rect_by_id_offset(int P);  // binning.hip: the by-id rectangles written by the preprocess kernel
+size_t sgr_sort_minmax_offset(int P);      // binning.hip: the per-workgroup key ranges written by the preprocess kernel
 void sgr_launch_bin_count(int P, int gx, int gy, int n_slices, int per_slice, const uint32_t* order, const uint2* rects,
                           uint32_t* blk_hist, hipStream_t s);
 void sgr_launch_bin_scatter(int P, int gx, int gy, int n_slices, int per_slice, const uint32_t* order, const uint2* rects,
                             const uint32_t* tile_start, uint32_t* blk_hist, uint32_t* point_list, hipStream_t s);
 void sgr_launch_hist_scan(int T, int n_blocks, uint32_t* blk_hist, uint32_t* tile_count, hipStream_t s);
-void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* header, hipStream_t s);
+void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* header, uint32_t* tile_maxc,
+                          uint32_t* tile_walked, hipStream_t s);
 
 void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
