@@ -97,7 +97,9 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user,
  *   caller does NOT need to pre-zero them; pre-zeroed buffers (rasterize_points.cu:151-159) work too.
  *   Compact SH mode: with shs given and dL_dsh == NULL no SH gradient is written and dL_dcolor receives the colour
  *   gradients masked by the forward's clamp flags (the dL_dRGB of backward.cu:31-34); sgr_sh_grad_from_views rebuilds
- *   the SH gradient, summed over any number of views, from those 3 floats per Gaussian and view. */
+ *   the SH gradient, summed over any number of views, from those 3 floats per Gaussian and view.
+ *   dL_dmean2D, dL_dconic and (without cov3D_precomp) dL_dcov3D may be NULL: they are then not written (a training step
+ *   that only wants the gradients of its parameters saves 52 bytes of writes per Gaussian). */
 int sgr_backward(int P, int D, int M, int64_t R,
                  const float* background, int width, int height,
                  const float* means3D, const float* shs, const float* colors_precomp,

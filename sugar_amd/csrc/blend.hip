@@ -369,6 +369,16 @@ __device__ __forceinline__ void bwd_phase_a_ref(const float* q, float2* zw, int 
         const float alpha = fminf(0.99f, e[5] * G);
         const bool active = inside && (__float_as_uint(e[9]) <= lastc) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
         float Z = 0.f, Wt = 0.f;
+#ifdef SGR_COUNT
+        {   // (entry, block) pairs walked by the backward, pairs with a contributing pixel, contributing lanes
+            const unsigned long long am = __ballot(active);
+            if (lane == 0) {
+                atomicAdd(&g_sgr_count[4], 1ull);
+                atomicAdd(&g_sgr_count[5], am ? 1ull : 0ull);
+                atomicAdd(&g_sgr_count[6], (unsigned long long)__popcll(am));
+            }
+        }
+#endif
         if (active) {
             const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
             acc_g += last_alpha * (lc_g - acc_g);

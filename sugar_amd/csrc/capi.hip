@@ -314,8 +314,9 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
     if (phase < 0 || phase > 2) return fail(SGR_E_INVALID, "phase must be 0, 1 or 2");
     if (P <= 0 || width <= 0 || height <= 0) return fail(SGR_E_INVALID, "P, width and height must be positive");
     if (!geom_buffer || !binning_buffer || !img_buffer || !dL_dpix) return fail(SGR_E_INVALID, "null scratch / dL_dpix");
-    if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
-        return fail(SGR_E_INVALID, "null gradient output");
+    // dL_dmean2D, dL_dconic and dL_dcov3D may be NULL: intermediate results a training step has no use for are then not written
+    if (!dL_dopacity || !dL_dcolor || !dL_dmean3D) return fail(SGR_E_INVALID, "null gradient output");
+    if (cov3D_precomp && !dL_dcov3D) return fail(SGR_E_INVALID, "dL_dcov3D required with cov3D_precomp");
     const bool use_sh = shs && !colors_precomp;
     // use_sh with dL_dsh == NULL selects the compact mode: dL_dcolor receives the clamp-masked colour gradients and no
     // SH gradient is materialised (see sgr_sh_grad_from_views)

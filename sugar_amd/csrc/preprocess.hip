@@ -364,12 +364,12 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
     float dmean[3] = {0, 0, 0}, dcov[6] = {0, 0, 0, 0, 0, 0};
     const int n_sh = a.M * 3;
     if (!(radius > 0)) {
-        a.dL_dmean2D[i3] = 0; a.dL_dmean2D[i3 + 1] = 0; a.dL_dmean2D[i3 + 2] = 0;
-        { float4 z4 = {0, 0, 0, 0}; *reinterpret_cast<float4*>(a.dL_dconic + 4 * (size_t)idx) = z4; }
+        if (a.dL_dmean2D) { a.dL_dmean2D[i3] = 0; a.dL_dmean2D[i3 + 1] = 0; a.dL_dmean2D[i3 + 2] = 0; }
+        if (a.dL_dconic) { float4 z4 = {0, 0, 0, 0}; *reinterpret_cast<float4*>(a.dL_dconic + 4 * (size_t)idx) = z4; }
         a.dL_dopacity[idx] = 0;
         if (a.dL_dcolor) { a.dL_dcolor[i3] = 0; a.dL_dcolor[i3 + 1] = 0; a.dL_dcolor[i3 + 2] = 0; }
         a.dL_dmean3D[i3] = 0; a.dL_dmean3D[i3 + 1] = 0; a.dL_dmean3D[i3 + 2] = 0;
-        for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = 0;
+        if (a.dL_dcov3D) for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = 0;
         if (a.dL_dsh) for (int k = 0; k < n_sh; k++) a.dL_dsh[(size_t)idx * n_sh + k] = 0;
         if (a.dL_dscale) { a.dL_dscale[i3] = 0; a.dL_dscale[i3 + 1] = 0; a.dL_dscale[i3 + 2] = 0; }
         if (a.dL_drot) { float4 z = {0, 0, 0, 0}; *reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = z; }
@@ -407,9 +407,9 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
         dm2x = -(op * ddelx_dx) * (cx * s1.x + cy * s1.y);
         dm2y = -(op * ddely_dy) * (cz * s1.y + cy * s1.x);
         g0 = -0.5f * op * s1.z; g1 = -0.5f * op * s1.w; g3 = -0.5f * op * s2.x;
-        a.dL_dmean2D[i3] = dm2x; a.dL_dmean2D[i3 + 1] = dm2y; a.dL_dmean2D[i3 + 2] = 0;
+        if (a.dL_dmean2D) { a.dL_dmean2D[i3] = dm2x; a.dL_dmean2D[i3 + 1] = dm2y; a.dL_dmean2D[i3 + 2] = 0; }
         float4 gc = {g0, g1, 0.f, g3};
-        *reinterpret_cast<float4*>(a.dL_dconic + 4 * (size_t)idx) = gc;
+        if (a.dL_dconic) *reinterpret_cast<float4*>(a.dL_dconic + 4 * (size_t)idx) = gc;
         // raw mode: d sigmoid = s (1 - s), the activated opacity is in the record (sgr_activations_backward's arithmetic)
         a.dL_dopacity[idx] = a.raw_params ? s0.w * op * (1.0f - op) : s0.w;
         if (a.dL_dcolor) { a.dL_dcolor[i3] = dcol[0]; a.dL_dcolor[i3 + 1] = dcol[1]; a.dL_dcolor[i3 + 2] = dcol[2]; }
@@ -565,8 +565,10 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
         *reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = dq;
     }
     a.dL_dmean3D[i3] = dmean[0]; a.dL_dmean3D[i3 + 1] = dmean[1]; a.dL_dmean3D[i3 + 2] = dmean[2];
+    if (a.dL_dcov3D) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+        for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+    }
 }
 
 // dL/dsh[k][c] = sum over views v of  basis_k(dir_v) * g_v[c]   with dir_v = normalize(mean - campos_v) and g_v the

@@ -171,14 +171,17 @@ class _CModule:
         M = sh.size(1) if sh.dim() == 3 else 0  # (the reference takes 0 for an empty tensor and then fails in autograd when P == 0)
         f = dict(dtype=torch.float32, device=dev)
         use_cov = cov3D_precomp.numel() != 0
+        _p = lambda t: None if t is None else _ptr(t)
         # Every row of these is written by sgr_backward, so no 300 MB of zero-fill per call
         # (the reference allocates nine torch::zeros, rasterize_points.cu:151-159).
         dL_dmeans3D = _sink_or_empty(grad_out, "means3D", (P, 3), **f)
-        dL_dmeans2D = torch.empty(P, 3, **f)
+        # `grad_sink(params_only=True)`: dL/dmeans2D, dL/dconic and dL/dcov3D are not produced (None gradients)
+        lean = bool(grad_out and grad_out.get("params_only")) and not use_cov
+        dL_dmeans2D = None if lean else torch.empty(P, 3, **f)
         dL_dcolors = _sink_or_empty(grad_out, "colors", (P, 3), **f)
-        dL_dconic = torch.empty(P, 2, 2, **f)
+        dL_dconic = None if lean else torch.empty(P, 2, 2, **f)
         dL_dopacity = _sink_or_empty(grad_out, "opacities", (P, 1), **f)
-        dL_dcov3D = torch.empty(P, 6, **f)
+        dL_dcov3D = None if lean else torch.empty(P, 6, **f)
         compact_sh = bool(grad_out and grad_out.get("compact_sh")) and M > 0
         dL_dsh = None if compact_sh else _sink_or_empty(grad_out, "shs", (P, M, 3), **f)
         dL_dscales = torch.zeros(P, 3, **f) if use_cov else _sink_or_empty(grad_out, "scales", (P, 3), **f)
@@ -196,8 +199,8 @@ class _CModule:
                         _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix.contiguous()),
                         _ptr(projmatrix.contiguous()), _ptr(campos.contiguous()), float(tan_fovx), float(tan_fovy), _ptr(radii),
                         _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL),
-                        _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D),
-                        _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations), int(bool(debug)),
+                        _p(dL_dmeans2D), _p(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D),
+                        _p(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations), int(bool(debug)),
                         C.c_void_p(stream))
                 on_colors = grad_out.get("on_colors") if (compact_sh and grad_out) else None
                 if on_colors is not None:

@@ -416,7 +416,7 @@ class ViewShardedTrainer:
         leaves = [p.params[k] for k in names]
         holder = {}
         if self.grad_sink_cm is not None:
-            sinks = dict(means3D=p.params["xyz"].grad)
+            sinks = dict(means3D=p.params["xyz"].grad, params_only=True)
             if self.fuse_activations:
                 sinks.update(raw_params=True, scales=p.params["scaling"].grad, rotations=p.params["rotation"].grad,
                              opacities=p.params["opacity"].grad)

@@ -1,4 +1,5 @@
-"""debug: lane utilisation of the forward blend (needs SGR_BLEND_DEFS=-DSGR_COUNT)"""
+"""debug: lane utilisation of the blend kernels (needs SGR_BLEND_DEFS="-DSGR_COUNT -DSGR_BWD_REF_A")"""
+import numpy as np
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sugar_amd import build, synthetic as syn
@@ -9,8 +10,10 @@ for name in ("metric", "config2"):
     scene, cams, bg = syn.make_config(name)
     buf = (C.c_ulonglong * 8)()
     lib.sgr_debug_counts(buf)
-    pu.run_hip(scene, cams[0], bg)
+    cam = cams[0]
+    g = np.random.default_rng(0).standard_normal((3, cam.image_height, cam.image_width)).astype(np.float32)
+    pu.run_hip(scene, cam, bg, grad_out=g)
     torch.cuda.synchronize()
     lib.sgr_debug_counts(buf)
-    it, ok, rows, blocks = buf[0], buf[1], buf[2], buf[3]
-    print(name, "wave-iterations", it, "ok lanes/iter", ok / it, "8x2 row pairs/iter", rows / it, "4x4 blocks/iter", blocks / it, flush=True)
+    print(name, "backward: (entry, block) pairs", buf[4], "with a contributing pixel", buf[5], f"({buf[5] / max(buf[4], 1):.3f})",
+          "contributing lanes per pair", buf[6] / max(buf[4], 1), flush=True)
