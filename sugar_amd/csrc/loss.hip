@@ -27,9 +27,12 @@ namespace {
 
 struct Win { float w[11]; };
 
-__device__ __forceinline__ float ld_pad(const float* __restrict__ img, int W, int H, int x, int y)
+// conv2d(padding=5) reads zeros outside the image: loads go to the clamped pixel (always a valid address, so they can
+// be issued unconditionally and in a batch) and the value is replaced by zero afterwards
+__device__ __forceinline__ bool in_image(int W, int H, int x, int y) { return x >= 0 && x < W && y >= 0 && y < H; }
+__device__ __forceinline__ unsigned ld_clamped(int W, int H, int x, int y)  // offset inside one plane (< 2^32 pixels)
 {
-    return (x >= 0 && x < W && y >= 0 && y < H) ? img[(size_t)y * W + x] : 0.0f;
+    return (unsigned)(min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1));
 }
 
 // Register-blocked separable window: in the horizontal pass a thread produces 4 adjacent outputs of one staged row from
@@ -49,10 +52,23 @@ __global__ void __launch_bounds__(256, 4) k_l1_ssim_fwd(int W, int H, const floa
     const float* y = Y + plane;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LTY;
     const int tid = threadIdx.x;
-    for (int i = tid; i < LRY * LR; i += 256) {
-        const int r = i / LR, cc = i - r * LR;
-        sx[r][cc] = ld_pad(x, W, H, x0 + cc - LH, y0 + r - LH);
-        sy[r][cc] = ld_pad(y, W, H, x0 + cc - LH, y0 + r - LH);
+    {
+        // all of a thread's staged values are requested before the first is used: written as a plain loop the compiler
+        // waits for each load in turn (14 serial HBM round trips per workgroup, two thirds of the kernel's time)
+        constexpr int NL = (LRY * LR + 255) / 256;
+        float vx[NL], vy[NL];
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const int i = tid + 256 * j, r = i / LR, cc = i - r * LR;
+            const unsigned o = ld_clamped(W, H, x0 + cc - LH, y0 + r - LH);
+            vx[j] = x[o]; vy[j] = y[o];
+        }
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const int i = tid + 256 * j, r = i / LR, cc = i - r * LR;
+            const bool in = in_image(W, H, x0 + cc - LH, y0 + r - LH);
+            if (i < LRY * LR) { sx[r][cc] = in ? vx[j] : 0.f; sy[r][cc] = in ? vy[j] : 0.f; }
+        }
     }
     __syncthreads();
     // horizontal pass: LRY rows x LT columns, five quantities; item = (row, group of 4 columns)
@@ -93,17 +109,14 @@ __global__ void __launch_bounds__(256, 4) k_l1_ssim_fwd(int W, int H, const floa
 #pragma unroll
             for (int q = 0; q < 5; q++) v[o][q] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 14; k++) {
-            float h[5];
+        for (int q = 0; q < 5; q++) {  // one quantity at a time: 14 staged values live instead of 70
 #pragma unroll
-            for (int q = 0; q < 5; q++) h[q] = hq[q][4 * lg + k][lx];
+            for (int k = 0; k < 14; k++) {
+                const float h = hq[q][4 * lg + k][lx];
 #pragma unroll
-            for (int o = 0; o < 4; o++) {
-                const int t = k - o;
-                if (t >= 0 && t < 11) {
-                    const float w = win.w[t];
-#pragma unroll
-                    for (int q = 0; q < 5; q++) v[o][q] += w * h[q];
+                for (int o = 0; o < 4; o++) {
+                    const int t = k - o;
+                    if (t >= 0 && t < 11) v[o][q] += win.w[t] * h;
                 }
             }
         }
@@ -118,10 +131,10 @@ __global__ void __launch_bounds__(256, 4) k_l1_ssim_fwd(int W, int H, const floa
                 const float A = 2.f * mu12 + C1, B = 2.f * sig12 + C2, Cc = mu1_sq + mu2_sq + C1, D = sig1 + sig2 + C2;
                 const float inv_cd = 1.0f / (Cc * D);
                 const float S = A * B * inv_cd;
-                const size_t oo = plane + (size_t)py * W + px;
-                dm1[oo] = 2.f * mu2 * (B - A) * inv_cd - 2.f * mu1 * S * (D - Cc) * inv_cd;
-                ds1[oo] = -S / D;
-                ds12[oo] = 2.f * A * inv_cd;
+                const unsigned oo = (unsigned)(py * W + px);
+                (dm1 + plane)[oo] = 2.f * mu2 * (B - A) * inv_cd - 2.f * mu1 * S * (D - Cc) * inv_cd;
+                (ds1 + plane)[oo] = -S / D;
+                (ds12 + plane)[oo] = 2.f * A * inv_cd;
                 s_val += S;
                 l1_val += fabsf(sx[ly + LH][lx + LH] - sy[ly + LH][lx + LH]);
             }
@@ -168,12 +181,29 @@ __global__ void __launch_bounds__(256) k_l1_ssim_bwd(int W, int H, const float* 
     const size_t plane = (size_t)c * W * H;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
     const int tid = threadIdx.x;
-    for (int i = tid; i < LR * LR; i += 256) {
-        const int r = i / LR, cc = i - r * LR;
-        const int gx = x0 + cc - LH, gy = y0 + r - LH;
-        sm[0][r][cc] = ld_pad(dm1 + plane, W, H, gx, gy);
-        sm[1][r][cc] = ld_pad(ds1 + plane, W, H, gx, gy);
-        sm[2][r][cc] = ld_pad(ds12 + plane, W, H, gx, gy);
+    const int lx = tid & 31, lg = tid >> 5;
+    const int px = x0 + lx;
+    float xv[4], yv[4];
+    {
+        constexpr int NL = (LR * LR + 255) / 256;
+        float v0[NL], v1[NL], v2[NL];
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const int i = tid + 256 * j, r = i / LR, cc = i - r * LR;
+            const unsigned o = ld_clamped(W, H, x0 + cc - LH, y0 + r - LH);
+            v0[j] = (dm1 + plane)[o]; v1[j] = (ds1 + plane)[o]; v2[j] = (ds12 + plane)[o];
+        }
+#pragma unroll
+        for (int o = 0; o < 4; o++) {  // the epilogue's operands, requested with the rest
+            const unsigned oo = ld_clamped(W, H, px, y0 + 4 * lg + o);
+            xv[o] = (X + plane)[oo]; yv[o] = (Y + plane)[oo];
+        }
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const int i = tid + 256 * j, r = i / LR, cc = i - r * LR;
+            const bool in = in_image(W, H, x0 + cc - LH, y0 + r - LH);
+            if (i < LR * LR) { sm[0][r][cc] = in ? v0[j] : 0.f; sm[1][r][cc] = in ? v1[j] : 0.f; sm[2][r][cc] = in ? v2[j] : 0.f; }
+        }
     }
     __syncthreads();
     for (int i = tid; i < LR * (LT / 4); i += 256) {
@@ -194,8 +224,6 @@ __global__ void __launch_bounds__(256) k_l1_ssim_bwd(int W, int H, const float* 
         for (int o = 0; o < 4; o++) { hq[0][r][c0 + o] = a[o][0]; hq[1][r][c0 + o] = a[o][1]; hq[2][r][c0 + o] = a[o][2]; }
     }
     __syncthreads();
-    const int lx = tid & 31, lg = tid >> 5;
-    const int px = x0 + lx;
     float g[4][3];
 #pragma unroll
     for (int o = 0; o < 4; o++) { g[o][0] = 0.f; g[o][1] = 0.f; g[o][2] = 0.f; }
@@ -213,12 +241,11 @@ __global__ void __launch_bounds__(256) k_l1_ssim_bwd(int W, int H, const float* 
     for (int o = 0; o < 4; o++) {
         const int py = y0 + 4 * lg + o;
         if (px < W && py < H) {
-            const size_t oo = plane + (size_t)py * W + px;
-            const float xv = X[oo], yv = Y[oo];
-            const float d = xv - yv;
+            const unsigned oo = (unsigned)(py * W + px);
+            const float d = xv[o] - yv[o];
             const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-            const float dssim = g[o][0] + 2.f * xv * g[o][1] + yv * g[o][2];
-            dX[oo] = gl * ((1.f - lambda) * sgn - lambda * dssim);
+            const float dssim = g[o][0] + 2.f * xv[o] * g[o][1] + yv[o] * g[o][2];
+            (dX + plane)[oo] = gl * ((1.f - lambda) * sgn - lambda * dssim);
         }
     }
 }
