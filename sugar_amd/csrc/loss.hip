@@ -5,8 +5,8 @@
 // grouped 11x11 conv2d calls plus ~25 elementwise kernels and their autograd twins; on an MI355X that costs far more than
 // the rasterizer it scores.  Here the window is applied separably through LDS and the backward is analytic:
 //
-//   forward kernel : per 32x32 tile, stage x, y (+5 px halo, zero padded like conv2d(padding=5)) in LDS, horizontal then
-//                    vertical 11-tap pass for {x, y, x^2, y^2, xy}, SSIM map value S and the three partials
+//   forward kernel : per 32x28 tile, stage x, y (+5 px halo, zero padded like conv2d(padding=5)) in LDS, horizontal then
+//                    vertical 11-tap pass for {x, y, x^2 + y^2, xy}, SSIM map value S and the three partials
 //                    dS/dmu1, dS/dE[x^2], dS/dE[xy]; tile sums of S and |x-y| go to one partial per tile, added in double by
 //                    a finishing kernel.
 //   backward kernel: dL/dx = gL * [ (1-lambda)/N * sign(x-y) - lambda/N * ( G*(dS/dmu1) + 2x * G*(dS/dE[x^2]) + y * G*(dS/dE[xy]) ) ]
@@ -17,7 +17,7 @@
 
 namespace {
 
-#define LT 32             // output tile: 32 columns x 28 rows (38.2 KB of LDS: four workgroups per CU; 32 x 32 allowed three)
+#define LT 32             // output tile: 32 columns x 28 rows (33 KB of LDS in the forward: four workgroups per CU)
 #define LTY 28
 #define LH 5              // window half width (window_size 11)
 #define LR (LT + 2 * LH)  // 42 staged columns
@@ -36,66 +36,75 @@ __device__ __forceinline__ unsigned ld_clamped(int W, int H, int x, int y)  // o
 }
 
 // Register-blocked separable window: in the horizontal pass a thread produces 4 adjacent outputs of one staged row from
-// 14 staged values (products x^2, y^2, xy formed once per value); in the vertical pass a thread produces 4 vertically
-// adjacent pixels of one column from 14 rows.  A 32x32 tile re-reads 1.7x its pixels as halo (a 16x16 tile: 2.6x).
-__global__ void __launch_bounds__(256, 4) k_l1_ssim_fwd(int W, int H, const float* __restrict__ X, const float* __restrict__ Y,
-                                                     Win win, float* __restrict__ dm1, float* __restrict__ ds1,
-                                                     float* __restrict__ ds12, float2* __restrict__ partial)
+// 14 staged values; in the vertical pass a thread produces 4 vertically adjacent pixels of one column from 14 rows.
+// A 32x32 tile re-reads 1.7x its pixels as halo (a 16x16 tile: 2.6x).
+//
+// The forward needs FOUR windowed quantities, not five: E[x^2] and E[y^2] only ever enter S through their sum (D below).
+// They are carried as two float2 pairs, {x, y} and {x^2 + y^2, xy}: every multiply-add of the two passes is one
+// v_pk_fma_f32 on a pair (twice the FP32 rate of v_fma_f32 on gfx950) and every LDS access moves a pair (ds_*_b64), which
+// halves the instruction count of a kernel that is bound by how fast its few resident waves issue.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__global__ void __launch_bounds__(256, 4) k_l1_ssim_fwd(int W, int H, const float* __restrict__ X,
+                                                             const float* __restrict__ Y, Win win, float* __restrict__ dm1,
+                                                             float* __restrict__ ds1, float* __restrict__ ds12,
+                                                             float2* __restrict__ partial)
 {
-    __shared__ float sx[LRY][LRP];
-    __shared__ float sy[LRY][LRP];
-    __shared__ float hq[5][LRY][LTP];
+    // row strides in 8-byte units are odd and a wave's lanes walk down rows (horizontal pass) or along a row (vertical
+    // pass), so the 16 lanes an LDS cycle serves fall into 16 different bank pairs
+    __shared__ f2 sxy[LRY][LRP];      // {x, y}, zero padded
+    __shared__ f2 hm[LRY][LTP];       // rows filtered: {mu1, mu2}
+    __shared__ f2 hs[LRY][LTP];       //                {E[x^2 + y^2], E[xy]}
     __shared__ float red[2][4];
     const int c = blockIdx.z;
     const size_t plane = (size_t)c * W * H;
-    const float* x = X + plane;
-    const float* y = Y + plane;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LTY;
     const int tid = threadIdx.x;
     {
-        // all of a thread's staged values are requested before the first is used: written as a plain loop the compiler
-        // waits for each load in turn (14 serial HBM round trips per workgroup, two thirds of the kernel's time)
-        constexpr int NL = (LRY * LR + 255) / 256;
-        float vx[NL], vy[NL];
+        // Staging: wave w takes the staged rows w, w + 4, ..., lane = staged column.  The row part of every address and of
+        // the zero-padding test is then wave-uniform (scalar registers, scalar ALU), the column part is computed once, and a
+        // load is one instruction with a scalar base and a 32-bit lane offset.  (Indexing the 38 x 42 region linearly cost
+        // ~35 vector instructions per element in divisions, clamps and 64-bit adds: more than the filter itself.)
+        // All values are requested before the first is used.
+        const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int gx = x0 + lane - LH;
+        const bool inx = lane < LR && gx >= 0 && gx < W;
+        const unsigned bx = (unsigned)min(max(gx, 0), W - 1) * 4u;
+        constexpr int NR = (LRY + 3) / 4;
+        float vx[NR], vy[NR];
 #pragma unroll
-        for (int j = 0; j < NL; j++) {
-            const int i = tid + 256 * j, r = i / LR, cc = i - r * LR;
-            const unsigned o = ld_clamped(W, H, x0 + cc - LH, y0 + r - LH);
-            vx[j] = x[o]; vy[j] = y[o];
+        for (int j = 0; j < NR; j++) {
+            const int gy = min(max(y0 + w + 4 * j - LH, 0), H - 1);
+            const size_t row = (plane + (size_t)gy * W) * 4;
+            vx[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(X) + row + bx);
+            vy[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Y) + row + bx);
         }
 #pragma unroll
-        for (int j = 0; j < NL; j++) {
-            const int i = tid + 256 * j, r = i / LR, cc = i - r * LR;
-            const bool in = in_image(W, H, x0 + cc - LH, y0 + r - LH);
-            if (i < LRY * LR) { sx[r][cc] = in ? vx[j] : 0.f; sy[r][cc] = in ? vy[j] : 0.f; }
+        for (int j = 0; j < NR; j++) {
+            const int r = w + 4 * j, gy = y0 + r - LH;
+            const bool in = inx && gy >= 0 && gy < H;
+            if (r < LRY && lane < LR) { f2 v = {in ? vx[j] : 0.f, in ? vy[j] : 0.f}; sxy[r][lane] = v; }
         }
     }
     __syncthreads();
-    // horizontal pass: LRY rows x LT columns, five quantities; item = (row, group of 4 columns)
+    // horizontal pass: LRY rows x LT columns; item = (group of 4 columns, row), consecutive lanes on consecutive rows
     for (int i = tid; i < LRY * (LT / 4); i += 256) {
-        const int r = i >> 3, c0 = (i & 7) * 4;
-        float a[4][5];
+        const int g = i / LRY, r = i - g * LRY, c0 = g * 4;
+        f2 am[4], as[4];
 #pragma unroll
-        for (int o = 0; o < 4; o++)
-#pragma unroll
-            for (int q = 0; q < 5; q++) a[o][q] = 0.f;
+        for (int o = 0; o < 4; o++) { am[o] = (f2){0.f, 0.f}; as[o] = (f2){0.f, 0.f}; }
 #pragma unroll
         for (int k = 0; k < 14; k++) {
-            const float vx = sx[r][c0 + k], vy = sy[r][c0 + k];
-            const float xx = vx * vx, yy = vy * vy, xy = vx * vy;
+            const f2 v = sxy[r][c0 + k];
+            const f2 p = {v.x * v.x + v.y * v.y, v.x * v.y};
 #pragma unroll
             for (int o = 0; o < 4; o++) {
                 const int t = k - o;  // tap index of output o for staged value k
-                if (t >= 0 && t < 11) {
-                    const float w = win.w[t];
-                    a[o][0] += w * vx; a[o][1] += w * vy; a[o][2] += w * xx; a[o][3] += w * yy; a[o][4] += w * xy;
-                }
+                if (t >= 0 && t < 11) { am[o] += win.w[t] * v; as[o] += win.w[t] * p; }
             }
         }
 #pragma unroll
-        for (int o = 0; o < 4; o++)
-#pragma unroll
-            for (int q = 0; q < 5; q++) hq[q][r][c0 + o] = a[o][q];
+        for (int o = 0; o < 4; o++) { hm[r][c0 + o] = am[o]; hs[r][c0 + o] = as[o]; }
     }
     __syncthreads();
     // vertical pass: thread = (column lx, rows 4*lg .. 4*lg+3)
@@ -103,40 +112,39 @@ __global__ void __launch_bounds__(256, 4) k_l1_ssim_fwd(int W, int H, const floa
     const int px = x0 + lx;
     float s_val = 0.f, l1_val = 0.f;
     if (4 * lg < LTY) {
-        float v[4][5];
+        f2 vm[4], vs[4];
 #pragma unroll
-        for (int o = 0; o < 4; o++)
+        for (int o = 0; o < 4; o++) { vm[o] = (f2){0.f, 0.f}; vs[o] = (f2){0.f, 0.f}; }
 #pragma unroll
-            for (int q = 0; q < 5; q++) v[o][q] = 0.f;
+        for (int k = 0; k < 14; k++) {
+            const f2 m = hm[4 * lg + k][lx], q = hs[4 * lg + k][lx];
 #pragma unroll
-        for (int q = 0; q < 5; q++) {  // one quantity at a time: 14 staged values live instead of 70
-#pragma unroll
-            for (int k = 0; k < 14; k++) {
-                const float h = hq[q][4 * lg + k][lx];
-#pragma unroll
-                for (int o = 0; o < 4; o++) {
-                    const int t = k - o;
-                    if (t >= 0 && t < 11) v[o][q] += win.w[t] * h;
-                }
+            for (int o = 0; o < 4; o++) {
+                const int t = k - o;
+                if (t >= 0 && t < 11) { vm[o] += win.w[t] * m; vs[o] += win.w[t] * q; }
             }
         }
 #pragma unroll
         for (int o = 0; o < 4; o++) {
             const int ly = 4 * lg + o, py = y0 + ly;
             if (px < W && py < H) {
-                const float mu1 = v[o][0], mu2 = v[o][1], ex2 = v[o][2], ey2 = v[o][3], exy = v[o][4];
+                const float mu1 = vm[o].x, mu2 = vm[o].y, e2 = vs[o].x, exy = vs[o].y;
                 const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
                 const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-                const float sig1 = ex2 - mu1_sq, sig2 = ey2 - mu2_sq, sig12 = exy - mu12;
-                const float A = 2.f * mu12 + C1, B = 2.f * sig12 + C2, Cc = mu1_sq + mu2_sq + C1, D = sig1 + sig2 + C2;
-                const float inv_cd = 1.0f / (Cc * D);
+                const float sig12 = exy - mu12;
+                const float A = 2.f * mu12 + C1, B = 2.f * sig12 + C2, Cc = mu1_sq + mu2_sq + C1;
+                const float D = (e2 - mu1_sq - mu2_sq) + C2;  // sigma1^2 + sigma2^2 + C2
+                // v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division: the maps feed an 11 x 11 average
+                const float inv_d = __builtin_amdgcn_rcpf(D);
+                const float inv_cd = __builtin_amdgcn_rcpf(Cc) * inv_d;
                 const float S = A * B * inv_cd;
-                const unsigned oo = (unsigned)(py * W + px);
-                (dm1 + plane)[oo] = 2.f * mu2 * (B - A) * inv_cd - 2.f * mu1 * S * (D - Cc) * inv_cd;
-                (ds1 + plane)[oo] = -S / D;
-                (ds12 + plane)[oo] = 2.f * A * inv_cd;
+                const unsigned ob = (unsigned)(py * W + px) * 4u;  // byte offset inside the plane: scalar base + 32-bit lane offset
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(dm1 + plane) + ob) = 2.f * mu2 * (B - A) * inv_cd - 2.f * mu1 * S * (D - Cc) * inv_cd;
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(ds1 + plane) + ob) = -S * inv_d;
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(ds12 + plane) + ob) = 2.f * A * inv_cd;
                 s_val += S;
-                l1_val += fabsf(sx[ly + LH][lx + LH] - sy[ly + LH][lx + LH]);
+                const f2 v = sxy[ly + LH][lx + LH];
+                l1_val += fabsf(v.x - v.y);
             }
         }
     }
@@ -169,14 +177,17 @@ __global__ void __launch_bounds__(1024) k_l1_ssim_finish(const float2* __restric
     }
 }
 
-// (the backward keeps 32 x 32 tiles: with 28 rows it was 11 % slower)
+// (the backward keeps 32 x 32 tiles: with 28 rows it was 11 % slower)  Three maps are windowed: {dS/dmu1, dS/dE[x^2]} travel
+// as a float2 pair (packed multiply-adds, 8-byte LDS accesses), dS/dE[xy] on its own.
 __global__ void __launch_bounds__(256) k_l1_ssim_bwd(int W, int H, const float* __restrict__ X, const float* __restrict__ Y,
                                                      Win win, const float* __restrict__ dm1, const float* __restrict__ ds1,
                                                      const float* __restrict__ ds12, const float* __restrict__ grad_loss,
                                                      float lambda, float inv_n, float* __restrict__ dX)
 {
-    __shared__ float sm[3][LR][LRP];
-    __shared__ float hq[3][LR][LTP];
+    __shared__ f2 sp[LR][LRP];
+    __shared__ float sq[LR][LRP];
+    __shared__ f2 hp[LR][LTP];
+    __shared__ float hq[LR][LTP];
     const int c = blockIdx.z;
     const size_t plane = (size_t)c * W * H;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
@@ -185,6 +196,8 @@ __global__ void __launch_bounds__(256) k_l1_ssim_bwd(int W, int H, const float* 
     const int px = x0 + lx;
     float xv[4], yv[4];
     {
+        // (the forward's row-per-wave staging needs 33 load instructions here instead of 21 and measured 4 % slower: this
+        // kernel is not bound by its vector ALU work)
         constexpr int NL = (LR * LR + 255) / 256;
         float v0[NL], v1[NL], v2[NL];
 #pragma unroll
@@ -202,38 +215,42 @@ __global__ void __launch_bounds__(256) k_l1_ssim_bwd(int W, int H, const float* 
         for (int j = 0; j < NL; j++) {
             const int i = tid + 256 * j, r = i / LR, cc = i - r * LR;
             const bool in = in_image(W, H, x0 + cc - LH, y0 + r - LH);
-            if (i < LR * LR) { sm[0][r][cc] = in ? v0[j] : 0.f; sm[1][r][cc] = in ? v1[j] : 0.f; sm[2][r][cc] = in ? v2[j] : 0.f; }
+            if (i < LR * LR) { f2 v = {in ? v0[j] : 0.f, in ? v1[j] : 0.f}; sp[r][cc] = v; sq[r][cc] = in ? v2[j] : 0.f; }
         }
     }
     __syncthreads();
     for (int i = tid; i < LR * (LT / 4); i += 256) {
-        const int r = i >> 3, c0 = (i & 7) * 4;
-        float a[4][3];
+        const int g = i / LR, r = i - g * LR, c0 = g * 4;  // consecutive lanes on consecutive rows (odd strides: no bank conflicts)
+        f2 ap[4];
+        float aq[4];
 #pragma unroll
-        for (int o = 0; o < 4; o++) { a[o][0] = 0.f; a[o][1] = 0.f; a[o][2] = 0.f; }
+        for (int o = 0; o < 4; o++) { ap[o] = (f2){0.f, 0.f}; aq[o] = 0.f; }
 #pragma unroll
         for (int k = 0; k < 14; k++) {
-            const float v0 = sm[0][r][c0 + k], v1 = sm[1][r][c0 + k], v2 = sm[2][r][c0 + k];
+            const f2 vp = sp[r][c0 + k];
+            const float vq = sq[r][c0 + k];
 #pragma unroll
             for (int o = 0; o < 4; o++) {
                 const int t = k - o;
-                if (t >= 0 && t < 11) { const float w = win.w[t]; a[o][0] += w * v0; a[o][1] += w * v1; a[o][2] += w * v2; }
+                if (t >= 0 && t < 11) { ap[o] += win.w[t] * vp; aq[o] += win.w[t] * vq; }
             }
         }
 #pragma unroll
-        for (int o = 0; o < 4; o++) { hq[0][r][c0 + o] = a[o][0]; hq[1][r][c0 + o] = a[o][1]; hq[2][r][c0 + o] = a[o][2]; }
+        for (int o = 0; o < 4; o++) { hp[r][c0 + o] = ap[o]; hq[r][c0 + o] = aq[o]; }
     }
     __syncthreads();
-    float g[4][3];
+    f2 gp[4];
+    float gq[4];
 #pragma unroll
-    for (int o = 0; o < 4; o++) { g[o][0] = 0.f; g[o][1] = 0.f; g[o][2] = 0.f; }
+    for (int o = 0; o < 4; o++) { gp[o] = (f2){0.f, 0.f}; gq[o] = 0.f; }
 #pragma unroll
     for (int k = 0; k < 14; k++) {
-        const float h0 = hq[0][4 * lg + k][lx], h1 = hq[1][4 * lg + k][lx], h2 = hq[2][4 * lg + k][lx];
+        const f2 h = hp[4 * lg + k][lx];
+        const float h2 = hq[4 * lg + k][lx];
 #pragma unroll
         for (int o = 0; o < 4; o++) {
             const int t = k - o;
-            if (t >= 0 && t < 11) { const float w = win.w[t]; g[o][0] += w * h0; g[o][1] += w * h1; g[o][2] += w * h2; }
+            if (t >= 0 && t < 11) { gp[o] += win.w[t] * h; gq[o] += win.w[t] * h2; }
         }
     }
     const float gl = grad_loss[0] * inv_n;
@@ -244,7 +261,7 @@ __global__ void __launch_bounds__(256) k_l1_ssim_bwd(int W, int H, const float* 
             const unsigned oo = (unsigned)(py * W + px);
             const float d = xv[o] - yv[o];
             const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-            const float dssim = g[o][0] + 2.f * xv[o] * g[o][1] + yv[o] * g[o][2];
+            const float dssim = gp[o].x + 2.f * xv[o] * gp[o].y + yv[o] * gq[o];
             (dX + plane)[oo] = gl * ((1.f - lambda) * sgn - lambda * dssim);
         }
     }

@@ -146,13 +146,22 @@ __device__ __forceinline__ float sh_channel(int deg, const float* sh, int c, flo
 }
 
 // Load this Gaussian's SH block into registers.  The [P,M,3] layout gives each lane 12*M contiguous
-// bytes; with M == 16 and a 16-B aligned base that is twelve dwordx4 loads per lane.
-template <int MAXC>
+// bytes; with M == 16 and a 16-B aligned base (FAST: decided by the launcher, so the kernel holds ONE load path and the
+// loaded values need not meet another path's at a join, which would make the compiler wait for them on the spot) that is
+// twelve dwordx4 loads per lane.
+template <int MAXC, bool FAST = false>
 __device__ __forceinline__ void load_sh(const float* shs, size_t idx, int M, float* sh)
 {
     const float* src = shs + idx * (size_t)M * 3;
     const int n = M * 3;
-    if (MAXC == 48 && n == 48 && ((uintptr_t)src & 15) == 0) {
+    if (FAST) {
+        const float4* s4 = reinterpret_cast<const float4*>(shs) + idx * 12;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            float4 v = s4[i];
+            sh[4 * i] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
+        }
+    } else if (MAXC == 48 && n == 48 && ((uintptr_t)src & 15) == 0) {
         const float4* s4 = reinterpret_cast<const float4*>(src);
 #pragma unroll
         for (int i = 0; i < 12; i++) {
@@ -164,6 +173,7 @@ __device__ __forceinline__ void load_sh(const float* shs, size_t idx, int M, flo
         for (int i = 0; i < MAXC; i++) sh[i] = (i < n) ? src[i] : 0.0f;
     }
 }
+__host__ __device__ __forceinline__ bool sh_fast_layout(const float* shs, int M) { return shs && M == 16 && ((uintptr_t)shs & 15) == 0; }
 
 // computeColorFromSH backward for one Gaussian (backward.cu:47-137): dsh[k][c] = basis_k(dir) * masked dL/dRGB[c] and the
 // gradient w.r.t. the (normalised) view direction.  `clamped` bit c set = channel c was clamped to 0 by the forward.
@@ -231,37 +241,85 @@ __device__ __forceinline__ float quat_norm_contracted(const float4 q)
 }
 __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// One Gaussian: writes its GeomRec and radius, returns its tile rectangle (empty when culled).
-__device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, const int idx, int& minx, int& miny, int& maxx, int& maxy)
+// The camera's 16 + 16 + 3 floats as wave-uniform values: ONE vector load (lane k fetches element k) and a v_readlane per
+// element.  Read through the pointers at every use they are per-lane loads (the pointers arrive in a by-value struct, so
+// the compiler has no aliasing information to make them scalar loads), each one another round trip in a kernel whose cost
+// is round trips.  Call with all 64 lanes active; `wait` the value returned by cam_request.
+struct Cam { float vm[16], pm[16], cp[3]; };
+__device__ __forceinline__ float cam_request(const float* vmat, const float* pmat, const float* campos)
 {
-    minx = miny = maxx = maxy = 0;
+    const int lane = threadIdx.x & 63;
+    const float* src = lane < 16 ? vmat + lane : (lane < 32 ? pmat + (lane - 16) : (campos ? campos + min(lane - 32, 2) : vmat));
+    return *src;
+}
+__device__ __forceinline__ void cam_unpack(const float v, Cam& c)
+{
+    const int iv = __float_as_int(v);
+#pragma unroll
+    for (int k = 0; k < 16; k++) c.vm[k] = __int_as_float(__builtin_amdgcn_readlane(iv, k));
+#pragma unroll
+    for (int k = 0; k < 16; k++) c.pm[k] = __int_as_float(__builtin_amdgcn_readlane(iv, 16 + k));
+#pragma unroll
+    for (int k = 0; k < 3; k++) c.cp[k] = __int_as_float(__builtin_amdgcn_readlane(iv, 32 + k));
+}
+
+// Forward preprocess, one lane per Gaussian: GeomRec, radius, tile rectangle and depth-sort key.
+// The kernel is a chain of dependent HBM round trips (a few hundred bytes per Gaussian, a few hundred flops), so the
+// loads are issued as early as their addresses are known: the mean, scale, rotation, opacity and the camera in one batch
+// at the top (lanes past the end re-read the last Gaussian, so nothing is predicated), the 192-byte SH block as soon as the
+// Gaussian is known to be in front of the camera, overlapping the covariance arithmetic.
+// COLOR: 0 = SH in the fast layout, 1 = SH in any layout, 2 = precomputed colours.  A compile-time mode keeps the SH
+// loads free of joins with other paths (at a join the compiler copies the loaded registers, i.e. waits for the loads).
+template <int COLOR>
+__global__ void __launch_bounds__(256) k_preprocess_fwd(PreprocessArgs a)
+{
+    __shared__ uint32_t s_mm[2][4];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = idx < a.P;
+    const int li = valid ? idx : a.P - 1;
+    const size_t i3 = 3 * (size_t)li;
+
+    const float cam_raw = cam_request(a.viewmatrix, a.projmatrix, a.cam_pos);
+    const V3 p_orig = {a.means3D[i3], a.means3D[i3 + 1], a.means3D[i3 + 2]};
+    float c6[6], sc[3] = {0.f, 0.f, 0.f};
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * (size_t)li + k];
+    } else {
+        sc[0] = a.scales[i3]; sc[1] = a.scales[i3 + 1]; sc[2] = a.scales[i3 + 2];
+        q4 = *reinterpret_cast<const float4*>(a.rotations + 4 * (size_t)li);
+    }
+    const float op_in = a.opacities[li];
+    float pre[3] = {0.f, 0.f, 0.f};
+    if (COLOR == 2) { pre[0] = a.colors_precomp[i3]; pre[1] = a.colors_precomp[i3 + 1]; pre[2] = a.colors_precomp[i3 + 2]; }
+    Cam cam;
+    cam_unpack(cam_raw, cam);
+
     GeomRec rec;
     rec.radius = 0;
     rec.clamped = 0;
     rec.x = rec.y = rec.cx = rec.cy = rec.cz = rec.opacity = rec.r = rec.g = rec.b = rec.depth = 0.0f;
     int out_radius = 0;
+    uint2 rect = make_uint2(0u, 0u);  // {minx | miny << 16, w | h << 16} (w == 0: culled); the last depth-sort pass carries it along
 
-    const size_t i3 = 3 * (size_t)idx;
-    V3 p_orig = {a.means3D[i3], a.means3D[i3 + 1], a.means3D[i3 + 2]};
-    const float* vm = a.viewmatrix;
-    const float* pm = a.projmatrix;
+    const float* vm = cam.vm;
+    const float* pm = cam.pm;
     V3 p_view = xform4x3(p_orig, vm);
-    bool alive = !(p_view.z <= 0.2f);  // in_frustum, auxiliary.h:152-163
+    const bool alive = valid && !(p_view.z <= 0.2f);  // in_frustum, auxiliary.h:152-163
 
     if (alive) {
+        float sh[48];
+        constexpr bool use_sh = COLOR != 2;
+        if (use_sh) load_sh<48, COLOR == 0>(a.shs, li, a.M, sh);
+
         float hx = pm[0] * p_orig.x + pm[4] * p_orig.y + pm[8] * p_orig.z + pm[12];
         float hy = pm[1] * p_orig.x + pm[5] * p_orig.y + pm[9] * p_orig.z + pm[13];
         float hw = pm[3] * p_orig.x + pm[7] * p_orig.y + pm[11] * p_orig.z + pm[15];
         float p_w = 1.0f / (hw + 0.0000001f);
         float proj_x = hx * p_w, proj_y = hy * p_w;
 
-        float c6[6];
-        if (a.cov3D_precomp) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * (size_t)idx + k];
-        } else {
-            float sc[3] = {a.scales[i3], a.scales[i3 + 1], a.scales[i3 + 2]};
-            float4 q4 = *reinterpret_cast<const float4*>(a.rotations + 4 * (size_t)idx);
+        if (!a.cov3D_precomp) {
             if (a.raw_params) {
                 sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
                 const float inv = 1.0f / fmaxf(quat_norm_contracted(q4), 1e-12f);
@@ -288,15 +346,16 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
             int rx0, ry0, rx1, ry1;
             sgr_get_rect(pix_x, pix_y, r_int, a.gx, a.gy, rx0, ry0, rx1, ry1);
             if ((rx1 - rx0) * (ry1 - ry0) != 0) {
-                minx = rx0; miny = ry0; maxx = rx1; maxy = ry1;
-                if (a.colors_precomp) {
-                    rec.r = a.colors_precomp[i3]; rec.g = a.colors_precomp[i3 + 1]; rec.b = a.colors_precomp[i3 + 2];
+                if (rx1 > rx0 && ry1 > ry0) {
+                    rect.x = (uint32_t)rx0 | ((uint32_t)ry0 << 16);
+                    rect.y = (uint32_t)(rx1 - rx0) | ((uint32_t)(ry1 - ry0) << 16);
+                }
+                if (!use_sh) {
+                    rec.r = pre[0]; rec.g = pre[1]; rec.b = pre[2];
                 } else {
-                    float dx = p_orig.x - a.cam_pos[0], dy = p_orig.y - a.cam_pos[1], dz = p_orig.z - a.cam_pos[2];
+                    float dx = p_orig.x - cam.cp[0], dy = p_orig.y - cam.cp[1], dz = p_orig.z - cam.cp[2];
                     float len = sqrtf(dx * dx + dy * dy + dz * dz);
                     dx = dx / len; dy = dy / len; dz = dz / len;
-                    float sh[48];
-                    load_sh<48>(a.shs, idx, a.M, sh);
                     float c0 = sh_channel(a.D, sh, 0, dx, dy, dz);
                     float c1 = sh_channel(a.D, sh, 1, dx, dy, dz);
                     float c2 = sh_channel(a.D, sh, 2, dx, dy, dz);
@@ -304,38 +363,22 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
                     rec.r = fmax_(c0, 0.0f); rec.g = fmax_(c1, 0.0f); rec.b = fmax_(c2, 0.0f);
                 }
                 rec.x = pix_x; rec.y = pix_y; rec.cx = conx; rec.cy = cony; rec.cz = conz;
-                rec.opacity = a.raw_params ? sigmoid_(a.opacities[idx]) : a.opacities[idx];
+                rec.opacity = a.raw_params ? sigmoid_(op_in) : op_in;
                 rec.depth = p_view.z;
                 rec.radius = r_int;
                 out_radius = r_int;
             }
         }
     }
-    float4* dst = reinterpret_cast<float4*>(a.rec + idx);
-    const float4* srcv = reinterpret_cast<const float4*>(&rec);
-    dst[0] = srcv[0]; dst[1] = srcv[1]; dst[2] = srcv[2];
-    if (a.radii) a.radii[idx] = out_radius;
     // key of the global depth sort (binning.hip): depth > 0.2, so the float bit pattern orders like the value
     const uint32_t key = out_radius > 0 ? __float_as_uint(rec.depth) : 0xFFFFFFFFu;
-    a.sort_keys[idx] = key;
-    return key;
-}
-
-__global__ void __launch_bounds__(256) k_preprocess_fwd(PreprocessArgs a)
-{
-    __shared__ uint32_t s_mm[2][4];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    uint32_t key = 0xFFFFFFFFu;
-    if (idx < a.P) {
-        int minx, miny, maxx, maxy;
-        key = preprocess_one(a, idx, minx, miny, maxx, maxy);
-        // tile rectangle {minx | miny << 16, w | h << 16} (w == 0: culled); the last depth-sort pass carries it along
-        uint2 r = make_uint2(0u, 0u);
-        if (maxx > minx && maxy > miny) {
-            r.x = (uint32_t)minx | ((uint32_t)miny << 16);
-            r.y = (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16);
-        }
-        a.rect_by_id[idx] = r;
+    if (valid) {
+        float4* dst = reinterpret_cast<float4*>(a.rec + idx);
+        const float4* srcv = reinterpret_cast<const float4*>(&rec);
+        dst[0] = srcv[0]; dst[1] = srcv[1]; dst[2] = srcv[2];
+        if (a.radii) a.radii[idx] = out_radius;
+        a.sort_keys[idx] = key;
+        a.rect_by_id[idx] = rect;
     }
     // smallest and largest depth key of the workgroup's visible Gaussians: the depth sort works on key - min and drops its
     // fourth pass when the range fits 24 bits (binning.hip)
@@ -354,13 +397,41 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreprocessArgs a)
 // ---------------------------------------------------------------------------------------------
 // Fused backward preprocess: K9 (conic grad -> cov2D -> cov3D + mean) and K10 (mean2D -> mean3D, SH backward,
 // cov3D -> scale/rotation).  Writes every output row (zeros for culled Gaussians).
+// Like the forward, a chain of round trips: everything whose address is known at entry (the record, the nine sums of the
+// blend backward, mean, scale, rotation, the camera) is requested in one batch, the SH block as soon as the radius says the
+// Gaussian was rendered.  STORE_SH = false is the compact mode (dL_dsh == NULL): the 48 basis products are not formed at all.
+// SH: 0 = fast layout, 1 = any layout, 2 = no SH (precomputed colours), compile-time for the reason given at the forward.
+template <bool STORE_SH, int SH>
 __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
+    const int idx0 = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = idx0 < a.P;
+    const int idx = valid ? idx0 : a.P - 1;  // lanes past the end re-read the last Gaussian and store nothing
     const size_t i3 = 3 * (size_t)idx;
-    const GeomRec* rp = a.rec + idx;
-    const int radius = rp->radius;
+    const float cam_raw = cam_request(a.viewmatrix, a.projmatrix, a.cam_pos);
+    const float4* rp4 = reinterpret_cast<const float4*>(a.rec + idx);
+    const float4 rec0 = rp4[0], rec1 = rp4[1], rec2 = rp4[2];  // {x,y,cx,cy} {cz,opacity,depth,radius} {r,g,b,clamped}
+    const float4* ap = reinterpret_cast<const float4*>(a.acc + SGR_ACC_STRIDE * (size_t)idx);
+    const float4 s0 = ap[0], s1 = ap[1];  // {k0,k1,k2,S0} {Sx,Sy,Sxx,Sxy} {Syy,-,-,-}
+    const float s2x = a.acc[SGR_ACC_STRIDE * (size_t)idx + 8];
+    const V3 mean = {a.means3D[i3], a.means3D[i3 + 1], a.means3D[i3 + 2]};
+    float sc[3] = {0, 0, 0}, q[4] = {0, 0, 0, 0};
+    float4 q_raw = make_float4(0.f, 0.f, 0.f, 0.f);
+    float c6[6];
+    if (a.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+    } else {
+        sc[0] = a.scales[i3]; sc[1] = a.scales[i3 + 1]; sc[2] = a.scales[i3 + 2];
+        q_raw = *reinterpret_cast<const float4*>(a.rotations + 4 * (size_t)idx);
+    }
+    const int radius = __float_as_int(rec1.w);
+    const uint32_t clamped = __float_as_uint(rec2.w);
+    Cam cam;
+    cam_unpack(cam_raw, cam);
+    if (!valid) return;
+    const float* v = cam.vm;
+
     float dmean[3] = {0, 0, 0}, dcov[6] = {0, 0, 0, 0, 0, 0};
     const int n_sh = a.M * 3;
     if (!(radius > 0)) {
@@ -370,23 +441,15 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
         if (a.dL_dcolor) { a.dL_dcolor[i3] = 0; a.dL_dcolor[i3 + 1] = 0; a.dL_dcolor[i3 + 2] = 0; }
         a.dL_dmean3D[i3] = 0; a.dL_dmean3D[i3 + 1] = 0; a.dL_dmean3D[i3 + 2] = 0;
         if (a.dL_dcov3D) for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = 0;
-        if (a.dL_dsh) for (int k = 0; k < n_sh; k++) a.dL_dsh[(size_t)idx * n_sh + k] = 0;
+        if (STORE_SH) for (int k = 0; k < n_sh; k++) a.dL_dsh[(size_t)idx * n_sh + k] = 0;
         if (a.dL_dscale) { a.dL_dscale[i3] = 0; a.dL_dscale[i3 + 1] = 0; a.dL_dscale[i3 + 2] = 0; }
         if (a.dL_drot) { float4 z = {0, 0, 0, 0}; *reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = z; }
         return;
     }
-    V3 mean = {a.means3D[i3], a.means3D[i3 + 1], a.means3D[i3 + 2]};
-    const float* v = a.viewmatrix;
-    float sc[3] = {0, 0, 0}, q[4] = {0, 0, 0, 0};
-    float4 q_raw = make_float4(0.f, 0.f, 0.f, 0.f);
-    float c6[6];
-    if (a.cov3D_precomp) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * (size_t)idx + k];
-    } else {
-        sc[0] = a.scales[i3]; sc[1] = a.scales[i3 + 1]; sc[2] = a.scales[i3 + 2];
-        float4 q4 = *reinterpret_cast<const float4*>(a.rotations + 4 * (size_t)idx);
-        q_raw = q4;
+    float sh[48];
+    if (SH != 2) load_sh<48, SH == 0>(a.shs, idx, a.M, sh);
+    if (!a.cov3D_precomp) {
+        float4 q4 = q_raw;
         if (a.raw_params) {
             sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
             const float inv = 1.0f / fmaxf(quat_norm_contracted(q4), 1e-12f);
@@ -399,14 +462,12 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
     float dcol[3], dm2x, dm2y;
     float g0, g1, g3;
     {
-        const float4* ap = reinterpret_cast<const float4*>(a.acc + SGR_ACC_STRIDE * (size_t)idx);
-        const float4 s0 = ap[0], s1 = ap[1], s2 = ap[2];  // {k0,k1,k2,S0} {Sx,Sy,Sxx,Sxy} {Syy,-,-,-}
-        const float op = rp->opacity, cx = rp->cx, cy = rp->cy, cz = rp->cz;
+        const float op = rec1.y, cx = rec0.z, cy = rec0.w, cz = rec1.x;
         dcol[0] = s0.x; dcol[1] = s0.y; dcol[2] = s0.z;
         const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
         dm2x = -(op * ddelx_dx) * (cx * s1.x + cy * s1.y);
         dm2y = -(op * ddely_dy) * (cz * s1.y + cy * s1.x);
-        g0 = -0.5f * op * s1.z; g1 = -0.5f * op * s1.w; g3 = -0.5f * op * s2.x;
+        g0 = -0.5f * op * s1.z; g1 = -0.5f * op * s1.w; g3 = -0.5f * op * s2x;
         if (a.dL_dmean2D) { a.dL_dmean2D[i3] = dm2x; a.dL_dmean2D[i3 + 1] = dm2y; a.dL_dmean2D[i3 + 2] = 0; }
         float4 gc = {g0, g1, 0.f, g3};
         if (a.dL_dconic) *reinterpret_cast<float4*>(a.dL_dconic + 4 * (size_t)idx) = gc;
@@ -460,7 +521,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
     }
     // ---- K10, backward.cu:346-396
     {
-        const float* proj = a.projmatrix;
+        const float* proj = cam.pm;
         float hw = proj[3] * mean.x + proj[7] * mean.y + proj[11] * mean.z + proj[15];
         float m_w = 1.0f / (hw + 0.0000001f);
         float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
@@ -471,15 +532,13 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
         float ddz = (proj[8] * m_w - proj[11] * mul1) * gx + (proj[9] * m_w - proj[11] * mul2) * gy;
         dmean[0] += ddx; dmean[1] += ddy; dmean[2] += ddz;
     }
-    if (a.shs) {  // computeColorFromSH backward, backward.cu:20-139
-        V3 dir_orig = {mean.x - a.cam_pos[0], mean.y - a.cam_pos[1], mean.z - a.cam_pos[2]};
+    if (SH != 2) {  // computeColorFromSH backward, backward.cu:20-139
+        V3 dir_orig = {mean.x - cam.cp[0], mean.y - cam.cp[1], mean.z - cam.cp[2]};
         float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
         float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
-        float sh[48], dsh[48];
-        load_sh<48>(a.shs, idx, a.M, sh);
+        float dsh[48];
 #pragma unroll
         for (int k = 0; k < 48; k++) dsh[k] = 0.0f;
-        const uint32_t clamped = rp->clamped;
         const int deg = a.D;
         float dL_ddir[3] = {0, 0, 0};
         sh_backward(deg, sh, dcol, clamped, x, y, z, dsh, dL_ddir);
@@ -493,14 +552,14 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
             float oz = (-vv.x * vv.z * dL_ddir[0] - vv.y * vv.z * dL_ddir[1] + (sum2 - vv.z * vv.z) * dL_ddir[2]) * invsum32;
             dmean[0] += ox; dmean[1] += oy; dmean[2] += oz;
         }
-        if (!a.dL_dsh && a.dL_dcolor) {
+        if (!STORE_SH && a.dL_dcolor) {
             // compact mode (view-sharded training): the SH gradient is the outer product basis(dir) x (masked dL/dRGB), so
             // only the 3 masked colour gradients leave this kernel; sgr_sh_grad_from_views rebuilds sum over views later
             a.dL_dcolor[i3] = ((clamped >> 0) & 1u) ? 0.f : dcol[0];
             a.dL_dcolor[i3 + 1] = ((clamped >> 1) & 1u) ? 0.f : dcol[1];
             a.dL_dcolor[i3 + 2] = ((clamped >> 2) & 1u) ? 0.f : dcol[2];
         }
-        float* dst = a.dL_dsh ? a.dL_dsh + (size_t)idx * n_sh : nullptr;
+        float* dst = STORE_SH ? a.dL_dsh + (size_t)idx * n_sh : nullptr;
         if (!dst) {
         } else if (n_sh == 48 && ((uintptr_t)dst & 15) == 0) {
             float4* d4 = reinterpret_cast<float4*>(dst);
@@ -840,13 +899,26 @@ void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatri
 void sgr_launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s)
 {
     if (a.P <= 0) return;
-    hipLaunchKernelGGL(k_preprocess_fwd, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+    const dim3 grid((a.P + 255) / 256);
+    if (a.colors_precomp) hipLaunchKernelGGL(k_preprocess_fwd<2>, grid, dim3(256), 0, s, a);
+    else if (sh_fast_layout(a.shs, a.M)) hipLaunchKernelGGL(k_preprocess_fwd<0>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_preprocess_fwd<1>, grid, dim3(256), 0, s, a);
 }
 
 void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
 {
     if (a.P <= 0) return;
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+    const dim3 grid((a.P + 255) / 256);
+    const int mode = !a.shs ? 2 : (sh_fast_layout(a.shs, a.M) ? 0 : 1);
+    if (a.dL_dsh) {
+        if (mode == 0) hipLaunchKernelGGL((k_preprocess_bwd<true, 0>), grid, dim3(256), 0, s, a);
+        else if (mode == 1) hipLaunchKernelGGL((k_preprocess_bwd<true, 1>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_preprocess_bwd<true, 2>), grid, dim3(256), 0, s, a);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((k_preprocess_bwd<false, 0>), grid, dim3(256), 0, s, a);
+        else if (mode == 1) hipLaunchKernelGGL((k_preprocess_bwd<false, 1>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_preprocess_bwd<false, 2>), grid, dim3(256), 0, s, a);
+    }
 }
 
 void sgr_launch_masked_colors(int P, const GeomRec* rec, const float* acc, float* out, hipStream_t s)
