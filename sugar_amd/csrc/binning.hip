@@ -61,88 +61,83 @@ __device__ __forceinline__ uint32_t rs_digit(uint32_t key, uint32_t kmin, uint32
     return (((key == 0xFFFFFFFFu ? kmax1 : key) - kmin) >> shift) & 255u;
 }
 
-// per-chunk digit histogram, written digit-major: hist[digit * n_chunks + chunk].  Pass 0 (minmax != NULL) first reduces the
-// preprocess kernel's per-workgroup key ranges (every workgroup redundantly: 8 bytes per 256 Gaussians) and workgroup 0
-// publishes the sort parameters for the kernels that follow.
-__global__ void __launch_bounds__(256) k_rs_hist(int n, const uint32_t* __restrict__ keys, int shift, int n_chunks,
-                                                 uint32_t* __restrict__ hist, const uint2* __restrict__ minmax, int n_minmax,
-                                                 RsParams* __restrict__ params, int pass, int allow_skip)
+// Chained scan ("decoupled look-back") state of a pass: one word per (chunk, digit), zero = nothing published yet,
+// otherwise the count in the low 30 bits and one of two flags: A = this chunk's own count, P = the inclusive sum over this
+// chunk and all chunks before it.  Value and flag share a word, so relaxed agent-scope loads and stores are enough.
+#define RS_FLAG_A 0x40000000u
+#define RS_FLAG_P 0x80000000u
+#define RS_VALUE 0x3FFFFFFFu
+#define RS_COUNTER_WORDS (4 * 256 + 4)  // global digit histograms of the four passes + one chunk ticket per pass
+
+__device__ __forceinline__ uint32_t rs_peek(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rs_post(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Before the passes: reduce the preprocess kernel's per-workgroup key ranges (every workgroup redundantly: 8 bytes per 256
+// Gaussians; workgroup 0 publishes the sort parameters), histogram all four digits of every key into the global counters
+// (they do not depend on the order of the keys, so one read of the keys serves every pass) and clear the look-back state.
+// `counters` is zeroed by the preprocess kernel.
+__global__ void __launch_bounds__(256) k_rs_prepare(int n, const uint32_t* __restrict__ keys, int n_chunks, uint32_t* __restrict__ status,
+                                                    const uint2* __restrict__ minmax, int n_minmax, RsParams* __restrict__ params,
+                                                    uint32_t* __restrict__ counters, int allow_skip)
 {
-    __shared__ uint32_t s_h[256];
+    __shared__ uint32_t s_h[4][256];
     __shared__ uint32_t s_mm[2][4];
-    uint32_t kmin, kmax1;
-    if (minmax) {
-        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-        for (int i = threadIdx.x; i < n_minmax; i += 256) { const uint2 v = minmax[i]; lo = min(lo, v.x); hi = max(hi, v.y); }
-        for (int o = 32; o > 0; o >>= 1) {
-            lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
-            hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
-        }
-        if ((threadIdx.x & 63) == 0) { s_mm[0][threadIdx.x >> 6] = lo; s_mm[1][threadIdx.x >> 6] = hi; }
-        __syncthreads();
-        lo = min(min(s_mm[0][0], s_mm[0][1]), min(s_mm[0][2], s_mm[0][3]));
-        hi = max(max(s_mm[1][0], s_mm[1][1]), max(s_mm[1][2], s_mm[1][3]));
-        if (lo > hi) { lo = 0u; hi = 0u; }  // nothing visible
-        kmin = lo; kmax1 = hi + 1u;         // (hi < 0x7F800000: a positive float)
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            RsParams pr; pr.kmin = kmin; pr.kmax1 = kmax1; pr.skip3 = (allow_skip && ((kmax1 - kmin) >> 24) == 0u) ? 1u : 0u; pr.pad = 0u;
-            *params = pr;
-        }
-    } else {
-        const RsParams pr = *params;
-        if (pass == 3 && pr.skip3) return;
-        kmin = pr.kmin; kmax1 = pr.kmax1;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (int i = threadIdx.x; i < n_minmax; i += 256) { const uint2 v = minmax[i]; lo = min(lo, v.x); hi = max(hi, v.y); }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
     }
-    s_h[threadIdx.x] = 0;
+    if ((threadIdx.x & 63) == 0) { s_mm[0][threadIdx.x >> 6] = lo; s_mm[1][threadIdx.x >> 6] = hi; }
+    s_h[0][threadIdx.x] = 0; s_h[1][threadIdx.x] = 0; s_h[2][threadIdx.x] = 0; s_h[3][threadIdx.x] = 0;
     __syncthreads();
+    lo = min(min(s_mm[0][0], s_mm[0][1]), min(s_mm[0][2], s_mm[0][3]));
+    hi = max(max(s_mm[1][0], s_mm[1][1]), max(s_mm[1][2], s_mm[1][3]));
+    if (lo > hi) { lo = 0u; hi = 0u; }  // nothing visible
+    const uint32_t kmin = lo, kmax1 = hi + 1u;  // (hi < 0x7F800000: a positive float)
+    const bool skip3 = allow_skip && ((kmax1 - kmin) >> 24) == 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        RsParams pr; pr.kmin = kmin; pr.kmax1 = kmax1; pr.skip3 = skip3 ? 1u : 0u; pr.pad = 0u;
+        *params = pr;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; p++) status[((size_t)p * n_chunks + blockIdx.x) * 256 + threadIdx.x] = 0u;
     const int base = blockIdx.x * RS_ITEMS;
 #pragma unroll
     for (int i = 0; i < RS_ITEMS / 256; i++) {
         const int k = base + i * 256 + threadIdx.x;
-        if (k < n) atomicAdd(&s_h[rs_digit(keys[k], kmin, kmax1, shift)], 1u);
+        if (k < n) {
+            const uint32_t key = keys[k];
+            const uint32_t nk = (key == 0xFFFFFFFFu ? kmax1 : key) - kmin;
+            atomicAdd(&s_h[0][nk & 255u], 1u);
+            atomicAdd(&s_h[1][(nk >> 8) & 255u], 1u);
+            atomicAdd(&s_h[2][(nk >> 16) & 255u], 1u);
+            if (!skip3) atomicAdd(&s_h[3][nk >> 24], 1u);
+        }
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * n_chunks + blockIdx.x] = s_h[threadIdx.x];
-}
-
-// Row scan: workgroup d turns hist[d][0..n_chunks) into its exclusive prefix over the chunks and writes the row total.
-// (The prefix ACROSS digits is taken from the 256 totals inside the scatter kernel.)
-__global__ void __launch_bounds__(256) k_rs_scan_rows(int n_chunks, uint32_t* __restrict__ hist, uint32_t* __restrict__ totals,
-                                                      const RsParams* __restrict__ params, int pass)
-{
-    __shared__ uint32_t s_part[256];
-    if (pass == 3 && params->skip3) return;
-    uint32_t* row = hist + (size_t)blockIdx.x * n_chunks;
-    const int tid = threadIdx.x;
-    const int per = (n_chunks + 255) / 256;
-    const int b = tid * per, e = min(n_chunks, b + per);
-    uint32_t sum = 0;
-    for (int i = b; i < e; i++) sum += row[i];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        uint32_t v = (tid >= o) ? s_part[tid - o] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const uint32_t c = s_h[p][threadIdx.x];
+        if (c) atomicAdd(&counters[p * 256 + threadIdx.x], c);
     }
-    uint32_t run = s_part[tid] - sum;
-    for (int i = b; i < e; i++) { const uint32_t v = row[i]; row[i] = run; run += v; }
-    if (tid == 255) totals[blockIdx.x] = s_part[255];
 }
 
-// One 256-thread workgroup per chunk of 4096 keys.  Wave w ranks keys [1024 w, 1024 w + 1024) of the chunk 64 at a time IN
-// ORDER (rank among equal digits of a group from eight ballots, running per-wave digit counters in LDS), the four waves'
-// counts are combined into the chunk's stable order, the pairs are permuted into that order through LDS, and consecutive
-// threads then store consecutive slots of every digit's run: the global stores are coalesced runs instead of one
-// transaction per key (the single-wave version spent most of its time in the store unit: ~4-key runs on the low mantissa
-// bits).  Stable by construction.
-__global__ void __launch_bounds__(256) k_rs_scatter(int n, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int shift,
-                                                    int n_chunks, const uint32_t* __restrict__ hist,
-                                                    const uint32_t* __restrict__ totals, const uint2* __restrict__ aux_by_val,
-                                                    uint2* __restrict__ aux_out, const RsParams* __restrict__ params, int pass,
-                                                    uint32_t* __restrict__ keys_out_skip, uint32_t* __restrict__ vals_out_skip)
+// One pass = ONE kernel, one 256-thread workgroup per chunk of 4096 keys (chunk = a ticket, so a workgroup only ever waits
+// for workgroups that started before it).  Wave w ranks keys [1024 w, 1024 w + 1024) of the chunk 64 at a time IN ORDER
+// (rank among equal digits of a group from eight ballots, running per-wave digit counters in LDS) and the four waves'
+// counts are combined into the chunk's stable order.  Thread d then owns digit d: it publishes the chunk's count, takes the
+// digit's global start from the pass histogram, adds the counts of the earlier chunks by looking back through their
+// published words, eight at a time, until it meets an inclusive sum (separate histogram and scan kernels cost two more
+// launches and two more trips through HBM per pass: 12 dependent launches for a 1M-key sort that moves 50 MB), and publishes
+// its own inclusive sum.  The pairs are permuted into the chunk's order through LDS, and consecutive threads store
+// consecutive slots of every digit's run: coalesced runs instead of one transaction per key.  Stable by construction.
+__global__ void __launch_bounds__(256) k_rs_pass(int n, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int shift,
+                                                 int n_chunks, uint32_t* __restrict__ status, uint32_t* __restrict__ counters,
+                                                 const uint2* __restrict__ aux_by_val, uint2* __restrict__ aux_out,
+                                                 const RsParams* __restrict__ params, int pass,
+                                                 uint32_t* __restrict__ keys_out_skip, uint32_t* __restrict__ vals_out_skip)
 {
     // pass 2 is the last one when the key range fits 24 bits: it then writes where pass 3 would have (and carries the tile
     // rectangles); pass 3 returns at once
@@ -158,8 +153,13 @@ __global__ void __launch_bounds__(256) k_rs_scatter(int n, const uint32_t* __res
     __shared__ uint32_t s_base[256];     // global first slot of every digit's run for this chunk
     __shared__ uint32_t s_scan[256];
     __shared__ uint32_t s_k[RS_ITEMS], s_v[RS_ITEMS];
+    __shared__ int s_chunk;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int base = blockIdx.x * RS_ITEMS;
+    if (tid == 0) s_chunk = (int)atomicAdd(&counters[4 * 256 + pass], 1u);
+    s_cnt[0][tid] = 0; s_cnt[1][tid] = 0; s_cnt[2][tid] = 0; s_cnt[3][tid] = 0;
+    __syncthreads();
+    const int chunk = s_chunk;
+    const int base = chunk * RS_ITEMS;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     constexpr int G = RS_ITEMS / 256;  // groups of 64 keys per wave
     uint32_t rk[G], rv[G];
@@ -169,8 +169,6 @@ __global__ void __launch_bounds__(256) k_rs_scatter(int n, const uint32_t* __res
         rk[i] = (k < n) ? keys_in[k] : 0xFFFFFFFFu;
         rv[i] = (k < n) ? (vals_in ? vals_in[k] : (uint32_t)k) : 0u;
     }
-    s_cnt[0][tid] = 0; s_cnt[1][tid] = 0; s_cnt[2][tid] = 0; s_cnt[3][tid] = 0;
-    __syncthreads();
     uint32_t lrank[G];  // rank of the key among the keys of ITS WAVE with the same digit
 #pragma unroll
     for (int i = 0; i < G; i++) {
@@ -191,12 +189,13 @@ __global__ void __launch_bounds__(256) k_rs_scatter(int n, const uint32_t* __res
         WAVE_FENCE();
     }
     __syncthreads();
-    {   // thread d: digit d.  chunk-local starts (exclusive scan of the chunk's digit counts) and the global run starts
+    {   // thread d: digit d
         const uint32_t c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid], c3 = s_cnt[3][tid];
         const uint32_t mine = c0 + c1 + c2 + c3;
-        const uint32_t tot = totals[tid];
-        // two exclusive scans over the 256 digits at once: chunk counts (low) and global totals (high) do not fit one word
-        // (totals up to 2^32): scan them separately
+        uint32_t* st = status + (size_t)pass * n_chunks * 256 + tid;  // this pass, digit d: word of chunk k at st[k * 256]
+        rs_post(st + (size_t)chunk * 256, mine | (chunk == 0 ? RS_FLAG_P : RS_FLAG_A));
+        const uint32_t tot = counters[pass * 256 + tid];
+        // two exclusive scans over the 256 digits: the chunk's counts (chunk-local starts) and the global totals (run starts)
         s_scan[tid] = mine;
         __syncthreads();
         for (int o = 1; o < 256; o <<= 1) {
@@ -216,8 +215,28 @@ __global__ void __launch_bounds__(256) k_rs_scatter(int n, const uint32_t* __res
             __syncthreads();
         }
         const uint32_t gbase = s_scan[tid] - tot;
+        // look back: keys of this digit in the chunks before this one
+        uint32_t prefix = 0;
+        int k = chunk - 1;
+        bool done = k < 0;
+        while (!done) {
+            uint32_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = (k - j >= 0) ? rs_peek(st + (size_t)(k - j) * 256) : RS_FLAG_P;
+            bool stalled = false;
+            int adv = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (!done && !stalled) {
+                    if (v[j] == 0u) stalled = true;  // not published yet: ask again from here
+                    else { prefix += v[j] & RS_VALUE; adv++; done = (v[j] & RS_FLAG_P) != 0u; }
+                }
+            }
+            k -= adv;
+        }
+        if (chunk != 0) rs_post(st + (size_t)chunk * 256, (prefix + mine) | RS_FLAG_P);
         s_loc[tid] = loc;
-        s_base[tid] = gbase + hist[(size_t)tid * n_chunks + blockIdx.x];
+        s_base[tid] = gbase + prefix;
         s_cnt[0][tid] = loc; s_cnt[1][tid] = loc + c0; s_cnt[2][tid] = loc + c0 + c1; s_cnt[3][tid] = loc + c0 + c1 + c2;
     }
     __syncthreads();
@@ -419,13 +438,19 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __res
 
 }  // namespace
 
-// sort scratch: [ keys_a | keys_b | vals_a | vals_b | hist | totals | rects (sorted) | rects (by id) | keys_c | vals_c |
-//                 key ranges per preprocess workgroup | parameters ]
-static size_t sort_base_bytes(int P)
+// sort scratch: [ keys_a | keys_b | vals_a | vals_b | look-back state | counters | rects (sorted) | rects (by id) | keys_c |
+//                 vals_c | key ranges per preprocess workgroup | parameters ]
+static size_t sort_state_bytes(int P)
 {
     const size_t n = (size_t)(P > 0 ? P : 1);
     const size_t chunks = (n + RS_ITEMS - 1) / RS_ITEMS;
-    return sgr_align(n * 4) * 4 + sgr_align(chunks * 256 * 4) + 1024 + 2 * sgr_align(n * 8);  // ... + packed rectangles (sorted, by id)
+    return sgr_align(chunks * 256 * 4 * 4) + sgr_align(RS_COUNTER_WORDS * 4);
+}
+
+static size_t sort_base_bytes(int P)
+{
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    return sgr_align(n * 4) * 4 + sort_state_bytes(P) + 2 * sgr_align(n * 8);  // ... + packed rectangles (sorted, by id)
 }
 
 size_t sgr_sort_minmax_offset(int P)
@@ -449,12 +474,20 @@ size_t sgr_sort_rect_by_id_offset(int P)
 size_t sgr_sort_rects_offset(int P)
 {
     const size_t n = (size_t)(P > 0 ? P : 1);
-    const size_t chunks = (n + RS_ITEMS - 1) / RS_ITEMS;
-    return sgr_align(n * 4) * 4 + sgr_align(chunks * 256 * 4) + 1024;
+    return sgr_align(n * 4) * 4 + sort_state_bytes(P);
 }
 
+// the RS_COUNTER_WORDS words the preprocess kernel zeroes for the sort that follows it
+size_t sgr_sort_counters_offset(int P)
+{
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    const size_t chunks = (n + RS_ITEMS - 1) / RS_ITEMS;
+    return sgr_align(n * 4) * 4 + sgr_align(chunks * 256 * 4 * 4);
+}
+int sgr_sort_counter_words() { return RS_COUNTER_WORDS; }
+
 // keys_a (the first array of sort_scratch) must hold the keys and the key ranges theirs, both written by the preprocess
-// kernel; on return *order_out points at the sorted Gaussian ids (inside sort_scratch).
+// kernel, which also zeroes the counters; on return *order_out points at the sorted Gaussian ids (inside sort_scratch).
 // Buffers: pass 0 a -> b, pass 1 b -> c, pass 2 c -> b (or -> a when it is the last one), pass 3 b -> a.
 void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_out, const uint2* rect_by_id, uint2* rects_sorted,
                               hipStream_t s)
@@ -465,9 +498,9 @@ void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_
     uint32_t* keys_b = reinterpret_cast<uint32_t*>(sort_scratch + arr);
     uint32_t* vals_a = reinterpret_cast<uint32_t*>(sort_scratch + 2 * arr);
     uint32_t* vals_b = reinterpret_cast<uint32_t*>(sort_scratch + 3 * arr);
-    uint32_t* hist = reinterpret_cast<uint32_t*>(sort_scratch + 4 * arr);
+    uint32_t* status = reinterpret_cast<uint32_t*>(sort_scratch + 4 * arr);
     const int chunks = (P + RS_ITEMS - 1) / RS_ITEMS;
-    uint32_t* totals = reinterpret_cast<uint32_t*>(sort_scratch + 4 * arr + sgr_align((size_t)chunks * 256 * 4));
+    uint32_t* counters = reinterpret_cast<uint32_t*>(sort_scratch + sgr_sort_counters_offset(P));
     uint32_t* keys_c = reinterpret_cast<uint32_t*>(sort_scratch + sort_base_bytes(P));
     uint32_t* vals_c = reinterpret_cast<uint32_t*>(sort_scratch + sort_base_bytes(P) + arr);
     const uint2* minmax = reinterpret_cast<const uint2*>(sort_scratch + sgr_sort_minmax_offset(P));
@@ -478,14 +511,10 @@ void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_
     uint32_t* kout[4] = {keys_b, keys_c, keys_b, keys_a};
     uint32_t* vout[4] = {vals_b, vals_c, vals_b, vals_a};
     static const int allow_skip = getenv("SGR_SORT_FOUR_PASSES") ? 0 : 1;  // (development: always run the fourth pass)
-    for (int pass = 0; pass < 4; pass++) {
-        const int shift = 8 * pass;
-        hipLaunchKernelGGL(k_rs_hist, dim3(chunks), dim3(256), 0, s, P, kin[pass], shift, chunks, hist,
-                           pass == 0 ? minmax : (const uint2*)nullptr, n_minmax, params, pass, allow_skip);
-        hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(256), 0, s, chunks, hist, totals, params, pass);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(chunks), dim3(256), 0, s, P, kin[pass], vin[pass], kout[pass], vout[pass], shift, chunks,
-                           hist, totals, rect_by_id, pass >= 2 ? rects_sorted : (uint2*)nullptr, params, pass, keys_a, vals_a);
-    }
+    hipLaunchKernelGGL(k_rs_prepare, dim3(chunks), dim3(256), 0, s, P, keys_a, chunks, status, minmax, n_minmax, params, counters, allow_skip);
+    for (int pass = 0; pass < 4; pass++)
+        hipLaunchKernelGGL(k_rs_pass, dim3(chunks), dim3(256), 0, s, P, kin[pass], vin[pass], kout[pass], vout[pass], 8 * pass, chunks,
+                           status, counters, rect_by_id, pass >= 2 ? rects_sorted : (uint2*)nullptr, params, pass, keys_a, vals_a);
     *order_out = vals_a;
 }
 

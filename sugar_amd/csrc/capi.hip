@@ -208,6 +208,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     pa.radii = radii; pa.rec = rec; pa.sort_keys = reinterpret_cast<uint32_t*>(sort_scratch);
     pa.rect_by_id = reinterpret_cast<uint2*>(sort_scratch + sgr_sort_rect_by_id_offset(P));
     pa.key_minmax = reinterpret_cast<uint2*>(sort_scratch + sgr_sort_minmax_offset(P));
+    pa.sort_counters = reinterpret_cast<uint32_t*>(sort_scratch + sgr_sort_counters_offset(P)); pa.n_sort_counters = sgr_sort_counter_words();
     { StageTimer t(s, SGR_STAGE_PREPROCESS); sgr_launch_preprocess_fwd(pa, s); }
     STAGE_CHECK("preprocess");
 

@@ -118,6 +118,7 @@ struct PreprocessArgs {
     uint32_t* sort_keys;  // [P] depth bits of visible Gaussians, 0xFFFFFFFF for culled ones (input of the depth sort)
     uint2* rect_by_id;    // [P] packed tile rectangle of every Gaussian (w == 0: culled)
     uint2* key_minmax;    // [ceil(P / 256)] smallest / largest depth key of every workgroup's visible Gaussians
+    uint32_t* sort_counters; int n_sort_counters;  // zeroed by workgroup 0 (histograms and tickets of the depth sort)
 };
 void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 void sgr_launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
@@ -146,6 +147,8 @@ void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_
                               hipStream_t s);
 size_t sgr_sort_rect_by_id_offset(int P);  // binning.hip: the by-id rectangles written by the preprocess kernel
 size_t sgr_sort_minmax_offset(int P);      // binning.hip: the per-workgroup key ranges written by the preprocess kernel
+size_t sgr_sort_counters_offset(int P);    // binning.hip: the counters the preprocess kernel zeroes for the sort
+int sgr_sort_counter_words();
 void sgr_launch_bin_count(int P, int gx, int gy, int n_slices, int per_slice, const uint32_t* order, const uint2* rects,
                           uint32_t* blk_hist, hipStream_t s);
 void sgr_launch_bin_scatter(int P, int gx, int gy, int n_slices, int per_slice, const uint32_t* order, const uint2* rects,
