@@ -434,8 +434,11 @@ void orc_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* po
     }
 }
 
-/* K8 renderCUDA backward, DGR/cuda_rasterizer/backward.cu:399-557.  The reference accumulates with
- * float atomicAdd in a nondeterministic order; here the adds are float too (omp atomic when threaded).
+/* K8 renderCUDA backward, DGR/cuda_rasterizer/backward.cu:399-557.  Every per-(pixel, Gaussian) term is formed in float
+ * exactly as the reference forms it.  The reference then adds the terms with float atomicAdd in a nondeterministic order,
+ * so its result is one draw from a cloud of roundings (relative spread ~1e-4 for Gaussians hundreds of pixels wide, whose
+ * terms cancel); the oracle's expected value is the centre of that cloud: the same float terms summed in double (order
+ * no longer matters at the 1e-16 level, so the oracle is deterministic when threaded) and rounded to float once.
  * Outputs must be zero-initialised by the caller (DGR/rasterize_points.cu:151-159):
  * dL_dmean2D[P*3], dL_dconic2D[P*4], dL_dopacity[P], dL_dcolors[P*3]. */
 void orc_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* bg_color,
@@ -446,6 +449,12 @@ void orc_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* p
     const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
     const float ddelx_dx = (float)(0.5 * W); /* backward.cu:460-461 */
     const float ddely_dy = (float)(0.5 * H);
+    /* double accumulators, 9 per Gaussian: {mean2D x, y, conic xx, xy, yy, opacity, colour r, g, b} */
+    const uint32_t R = ranges[2 * (gx * gy - 1) + 1];
+    uint32_t max_id = 0;
+    for (uint32_t i = 0; i < R; i++) if (point_list[i] > max_id) max_id = point_list[i];
+    double* acc = (double*)calloc((size_t)(max_id + 1) * 9, sizeof(double));
+    if (!acc) return;
 #pragma omp parallel for schedule(dynamic, 4)
     for (int tile = 0; tile < gx * gy; tile++) {
         const int tx = tile % gx, ty = tile / gx;
@@ -484,7 +493,7 @@ void orc_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* p
                         const float dL_dchannel = dL_dpixel[ch];
                         dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
 #pragma omp atomic
-                        dL_dcolors[id * NCH + ch] += dchannel_dcolor * dL_dchannel;
+                        acc[9 * (size_t)id + 6 + ch] += (double)(dchannel_dcolor * dL_dchannel);
                     }
                     dL_dalpha *= T;
                     last_alpha = alpha;
@@ -495,21 +504,33 @@ void orc_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* p
                     const float gdx = G * dx, gdy = G * dy;
                     const float dG_ddelx = -gdx * con_o[0] - gdy * con_o[1];
                     const float dG_ddely = -gdy * con_o[2] - gdx * con_o[1];
+                    double* a = acc + 9 * (size_t)id;
 #pragma omp atomic
-                    dL_dmean2D[3 * id + 0] += dL_dG * dG_ddelx * ddelx_dx;
+                    a[0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
 #pragma omp atomic
-                    dL_dmean2D[3 * id + 1] += dL_dG * dG_ddely * ddely_dy;
+                    a[1] += (double)(dL_dG * dG_ddely * ddely_dy);
 #pragma omp atomic
-                    dL_dconic2D[4 * id + 0] += -0.5f * gdx * dx * dL_dG;
+                    a[2] += (double)(-0.5f * gdx * dx * dL_dG);
 #pragma omp atomic
-                    dL_dconic2D[4 * id + 1] += -0.5f * gdx * dy * dL_dG;
+                    a[3] += (double)(-0.5f * gdx * dy * dL_dG);
 #pragma omp atomic
-                    dL_dconic2D[4 * id + 3] += -0.5f * gdy * dy * dL_dG;
+                    a[4] += (double)(-0.5f * gdy * dy * dL_dG);
 #pragma omp atomic
-                    dL_dopacity[id] += G * dL_dalpha;
+                    a[5] += (double)(G * dL_dalpha);
                 }
             }
     }
+    for (size_t id = 0; id <= max_id; id++) {
+        const double* a = acc + 9 * id;
+        dL_dmean2D[3 * id + 0] += (float)a[0];
+        dL_dmean2D[3 * id + 1] += (float)a[1];
+        dL_dconic2D[4 * id + 0] += (float)a[2];
+        dL_dconic2D[4 * id + 1] += (float)a[3];
+        dL_dconic2D[4 * id + 3] += (float)a[4];
+        dL_dopacity[id] += (float)a[5];
+        for (int ch = 0; ch < NCH; ch++) dL_dcolors[id * NCH + ch] += (float)a[6 + ch];
+    }
+    free(acc);
 }
 
 /* Backward of SH -> RGB, DGR/cuda_rasterizer/backward.cu:20-139 */

@@ -83,7 +83,13 @@ __global__ void __launch_bounds__(256) k_rs_prepare(int n, const uint32_t* __res
     __shared__ uint32_t s_h[4][256];
     __shared__ uint32_t s_mm[2][4];
     uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-    for (int i = threadIdx.x; i < n_minmax; i += 256) { const uint2 v = minmax[i]; lo = min(lo, v.x); hi = max(hi, v.y); }
+    for (int base = 0; base < n_minmax; base += 256 * 16) {  // 16 loads in flight per thread (a plain loop waits for each)
+        uint2 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = minmax[min(base + j * 256 + (int)threadIdx.x, n_minmax - 1)];
+#pragma unroll
+        for (int j = 0; j < 16; j++) { lo = min(lo, v[j].x); hi = max(hi, v[j].y); }
+    }
     for (int o = 32; o > 0; o >>= 1) {
         lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
         hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
@@ -402,36 +408,69 @@ __global__ void __launch_bounds__(64) k_hist_scan(int T, int n_blocks, uint32_t*
 }
 
 // ---- tile scan: one 1024-thread workgroup, T <= a few 10^5 -----------------------------------
-// (also zeroes the two per-tile maxima the forward blend's blocks combine with atomicMax)
+// inclusive scan over the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)v, d);
+        if (lane >= d) v += y;
+    }
+    return v;
+}
+
+// One workgroup: tile ranges (exclusive scan of the tile counts), R, the largest count; also clears the two per-tile maxima
+// the blend kernels combine into.  Everything a lane touches in HBM is next to what its neighbours touch: the tiles are
+// taken 8192 at a time as 8 rows of 1024 (thread t: tiles t, t + 1024, ...), each 64-tile segment is scanned inside its wave
+// with shuffles, the 128 segment totals by wave 0, and the loads of a round go out as one batch.  (With thread t owning 8
+// CONSECUTIVE tiles the one CU this runs on spent 17 us mostly on 32-byte-strided stores.)
 __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __restrict__ tile_count,
                                                     uint32_t* __restrict__ tile_start, uint32_t* __restrict__ header,
                                                     uint32_t* __restrict__ tile_maxc, uint32_t* __restrict__ tile_walked)
 {
-    __shared__ uint32_t s_part[1024];
+    __shared__ uint32_t s_seg[128];
     __shared__ uint32_t s_max[16];
-    const int tid = threadIdx.x;
-    const int per = (T + 1023) / 1024;
-    const int b = tid * per, e = min(T, b + per);
-    uint32_t sum = 0, mx = 0;
-    for (int i = b; i < e; i++) { uint32_t c = tile_count[i]; sum += c; mx = max(mx, c); }
-    s_part[tid] = sum;
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
-    if ((tid & 63) == 0) s_max[tid >> 6] = mx;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        uint32_t v = (tid >= o) ? s_part[tid - o] : 0;
+    __shared__ uint32_t s_total;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uint32_t carry = 0, mx = 0;
+    for (int base = 0; base < T; base += 8192) {
+        uint32_t c[8], incl[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) c[j] = tile_count[min(base + j * 1024 + tid, T - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (base + j * 1024 + tid >= T) c[j] = 0u;
+            mx = max(mx, c[j]);
+            incl[j] = wave_incl_scan(c[j]);
+            if (lane == 63) s_seg[j * 16 + wave] = incl[j];
+        }
         __syncthreads();
-        s_part[tid] += v;
+        if (wave == 0) {  // exclusive scan of the 128 segment totals, two per lane
+            const uint32_t a0 = s_seg[2 * lane], a1 = s_seg[2 * lane + 1];
+            const uint32_t p = wave_incl_scan(a0 + a1);
+            s_seg[2 * lane] = p - a0 - a1;
+            s_seg[2 * lane + 1] = p - a1;
+            if (lane == 63) s_total = p;
+        }
         __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int i = base + j * 1024 + tid;
+            if (i < T) { tile_start[i] = carry + s_seg[j * 16 + wave] + incl[j] - c[j]; tile_maxc[i] = 0u; tile_walked[i] = 0u; }
+        }
+        carry += s_total;
+        __syncthreads();  // s_seg / s_total are rewritten by the next round
     }
-    uint32_t run = s_part[tid] - sum;  // exclusive prefix of this thread's chunk
-    for (int i = b; i < e; i++) { tile_start[i] = run; run += tile_count[i]; tile_maxc[i] = 0u; tile_walked[i] = 0u; }
-    if (tid == 1023) {
-        tile_start[T] = s_part[1023];
-        header[SGR_HDR_R] = s_part[1023];
-        header[SGR_HDR_R_HI] = 0;
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    if (lane == 0) s_max[wave] = mx;
+    __syncthreads();
+    if (tid == 0) {
         uint32_t m = 0;
         for (int w = 0; w < 16; w++) m = max(m, s_max[w]);
+        tile_start[T] = carry;
+        header[SGR_HDR_R] = carry;
+        header[SGR_HDR_R_HI] = 0;
         header[SGR_HDR_MAXCOUNT] = m;
     }
 }

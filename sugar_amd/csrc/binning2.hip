@@ -323,27 +323,34 @@ __global__ void __launch_bounds__(64) k_tile_scan2(int gx, int gy, int sgx, cons
 }
 
 // exclusive scan over the slices of hist1[slice][t] for one bin t per workgroup (the bins are few, the slices many:
-// binning.hip's lane-per-bin column walk would leave the chip idle)
-__global__ void __launch_bounds__(256) k_sup_hist_scan(int T1, int n_slices, uint32_t* __restrict__ hist1,
-                                                       uint32_t* __restrict__ sup_count)
+// binning.hip's lane-per-bin column walk would leave the chip idle).  Thread i owns SGR_B2_SLICES / 256 consecutive slices;
+// their loads go out as one batch and the scan is a shuffle scan per wave plus the four wave totals.
+__global__ void __launch_bounds__(256) k_sup_hist_scan(int T1, uint32_t* __restrict__ hist1, uint32_t* __restrict__ sup_count)
 {
-    __shared__ uint32_t s_part[256];
-    const int t = blockIdx.x, tid = threadIdx.x;
-    const int per = (n_slices + 255) / 256;
-    const int b = tid * per, e = min(n_slices, b + per);
+    constexpr int PER = SGR_B2_SLICES / 256;
+    __shared__ uint32_t s_w[4];
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    uint32_t v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) v[j] = hist1[(size_t)(tid * PER + j) * T1 + t];
     uint32_t sum = 0;
-    for (int i = b; i < e; i++) sum += hist1[(size_t)i * T1 + t];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        const uint32_t v = (tid >= o) ? s_part[tid - o] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; j++) sum += v[j];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += y;
     }
-    uint32_t run = s_part[tid] - sum;
-    for (int i = b; i < e; i++) { const uint32_t v = hist1[(size_t)i * T1 + t]; hist1[(size_t)i * T1 + t] = run; run += v; }
-    if (tid == 255) sup_count[t] = s_part[255];
+    if (lane == 63) s_w[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const uint32_t x = s_w[w]; if (w < (tid >> 6)) before += x; total += x; }
+    uint32_t run = before + incl - sum;
+#pragma unroll
+    for (int j = 0; j < PER; j++) { hist1[(size_t)(tid * PER + j) * T1 + t] = run; run += v[j]; }
+    if (tid == 0) sup_count[t] = total;
 }
 
 void set_lds_limit(const void* fn, size_t bytes, size_t& configured)
@@ -398,7 +405,7 @@ void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scr
     set_lds_limit(reinterpret_cast<const void*>(&k_sup_count), lds, conf_a);
     set_lds_limit(reinterpret_cast<const void*>(&k_sup_scatter), lds_sc, conf_b);
     hipLaunchKernelGGL(k_sup_count, dim3(SGR_B2_SLICES), dim3(256), lds, s, P, L.sgx, L.T1, L.per_slice, rects, hist1);
-    hipLaunchKernelGGL(k_sup_hist_scan, dim3(L.T1), dim3(256), 0, s, L.T1, SGR_B2_SLICES, hist1, sup_count);
+    hipLaunchKernelGGL(k_sup_hist_scan, dim3(L.T1), dim3(256), 0, s, L.T1, hist1, sup_count);
     hipLaunchKernelGGL(k_sup_scan, dim3(1), dim3(1024), 0, s, L.T1, L.cap1, L.chunk_cap, sup_count, sup_start, chunk_base,
                        chunk_sup, hdr);
     hipLaunchKernelGGL(k_sup_scatter, dim3(SGR_B2_SLICES), dim3(64), lds_sc, s, P, L.sgx, L.T1, key_bits, L.per_slice, rects,
