@@ -152,17 +152,9 @@ def test_non_default_stream():
     assert np.array_equal(ref["color"], out["color"])
 
 
-@pytest.mark.parametrize("config", ["config2", "metric"])
-def test_full_size_properties(config):
-    """BASELINE config 2 (300k Gaussians, 800x800) and the metric case (1M Gaussians, 1920x1080) at full size:
-    size-independent properties instead of the oracle: every tile list is sorted by (depth, index), lists hold exactly the
-    Gaussians whose rectangle covers the tile, R = sum of rectangle areas, T in [0,1], colour bounded, backward finite and
-    zero for culled Gaussians."""
-    scene, cams, bg = syn.make_config(config)
-    cam = cams[0]
-    H, W = cam.image_height, cam.image_width
-    g = np.random.default_rng(0).standard_normal((3, H, W)).astype(np.float32)
-    hp = pu.run_hip(scene, cam, bg, grad_out=g)
+def _check_list_properties(hp, W, H):
+    """Size-independent properties of the binning: every tile list sorted by (depth bits, index), lists hold exactly the
+    Gaussians whose rectangle (getRect, auxiliary.h:46-56, recomputed on the host) covers the tile, R = sum of areas."""
     rec, pl, ts = hp["rec"], hp["point_list"].astype(np.int64), hp["tile_start"].astype(np.int64)
     R = hp["num_rendered"]
     assert ts[-1] == R == len(pl)
@@ -182,12 +174,39 @@ def test_full_size_properties(config):
     assert np.array_equal(np.bincount(pl, minlength=len(radii)), area)
     txs, tys = tile_of % gx, tile_of // gx
     assert np.all((txs >= minx[pl]) & (txs < maxx[pl]) & (tys >= miny[pl]) & (tys < maxy[pl]))
+
+
+@pytest.mark.parametrize("config", ["config2", "metric"])
+def test_full_size_properties(config):
+    """BASELINE config 2 (300k Gaussians, 800x800) and the metric case (1M Gaussians, 1920x1080) at full size:
+    size-independent properties instead of the oracle: every tile list is sorted by (depth, index), lists hold exactly the
+    Gaussians whose rectangle covers the tile, R = sum of rectangle areas, T in [0,1], colour bounded, backward finite and
+    zero for culled Gaussians."""
+    scene, cams, bg = syn.make_config(config)
+    cam = cams[0]
+    H, W = cam.image_height, cam.image_width
+    g = np.random.default_rng(0).standard_normal((3, H, W)).astype(np.float32)
+    hp = pu.run_hip(scene, cam, bg, grad_out=g)
+    _check_list_properties(hp, W, H)
+    radii = hp["radii"]
     assert np.all((hp["final_T"] >= 0) & (hp["final_T"] <= 1)) and np.isfinite(hp["color"]).all()
     assert hp["color"].min() >= 0 and hp["color"].max() <= 3.0
     for k, v in hp["grads"].items():
         assert np.isfinite(v).all(), k
         if k != "means2D":
             assert np.all(v.reshape(len(radii), -1)[hp["radii"] == 0] == 0), k
+
+
+def test_depth_sort_with_more_chunks_than_resident_workgroups():
+    """4.6M Gaussians = 1124 sort chunks, more than the ~1000 workgroups the chip holds at once: the look-back of the
+    one-kernel radix passes (binning.hip) then waits on chunks of earlier dispatch waves.  Forward only, tiny splats on a
+    small image; the tile lists must come out sorted by (depth bits, index) and complete."""
+    P = 4_600_000
+    scene = syn.make_scene(P, 21, 0.0004, 0.0015)
+    cam = syn.orbit_cameras(160, 128)[1]
+    hp = pu.run_hip(scene, cam, torch.zeros(3), use_sh=False)
+    assert (hp["radii"] > 0).sum() > P // 4
+    _check_list_properties(hp, 160, 128)
 
 
 def test_knn_and_dist2_match_oracle():
