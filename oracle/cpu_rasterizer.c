@@ -450,7 +450,8 @@ void orc_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* p
     const float ddelx_dx = (float)(0.5 * W); /* backward.cu:460-461 */
     const float ddely_dy = (float)(0.5 * H);
     /* double accumulators, 9 per Gaussian: {mean2D x, y, conic xx, xy, yy, opacity, colour r, g, b} */
-    const uint32_t R = ranges[2 * (gx * gy - 1) + 1];
+    uint32_t R = 0; /* (an empty tile's range is {0, 0}: rasterizer_impl.cu:116-138 writes only where a tile starts or ends) */
+    for (int t = 0; t < gx * gy; t++) if (ranges[2 * t + 1] > R) R = ranges[2 * t + 1];
     uint32_t max_id = 0;
     for (uint32_t i = 0; i < R; i++) if (point_list[i] > max_id) max_id = point_list[i];
     double* acc = (double*)calloc((size_t)(max_id + 1) * 9, sizeof(double));

@@ -61,6 +61,18 @@ __device__ __forceinline__ uint32_t rs_digit(uint32_t key, uint32_t kmin, uint32
     return (((key == 0xFFFFFFFFu ? kmax1 : key) - kmin) >> shift) & 255u;
 }
 
+// inclusive scan over the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)v, d);
+        if (lane >= d) v += y;
+    }
+    return v;
+}
+
 // Chained scan ("decoupled look-back") state of a pass: one word per (chunk, digit), zero = nothing published yet,
 // otherwise the count in the low 30 bits and one of two flags: A = this chunk's own count, P = the inclusive sum over this
 // chunk and all chunks before it.  Value and flag share a word, so relaxed agent-scope loads and stores are enough.
@@ -201,26 +213,15 @@ __global__ void __launch_bounds__(256) k_rs_pass(int n, const uint32_t* __restri
         uint32_t* st = status + (size_t)pass * n_chunks * 256 + tid;  // this pass, digit d: word of chunk k at st[k * 256]
         rs_post(st + (size_t)chunk * 256, mine | (chunk == 0 ? RS_FLAG_P : RS_FLAG_A));
         const uint32_t tot = counters[pass * 256 + tid];
-        // two exclusive scans over the 256 digits: the chunk's counts (chunk-local starts) and the global totals (run starts)
-        s_scan[tid] = mine;
+        // two exclusive scans over the 256 digits: the chunk's counts (chunk-local starts) and the global totals (run
+        // starts): shuffle scans inside the four waves, then the earlier waves' totals (one barrier instead of 32)
+        const uint32_t i_mine = wave_incl_scan(mine), i_tot = wave_incl_scan(tot);
+        if (lane == 63) { s_scan[wave] = i_mine; s_scan[4 + wave] = i_tot; }
         __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
-            const uint32_t v = (tid >= o) ? s_scan[tid - o] : 0u;
-            __syncthreads();
-            s_scan[tid] += v;
-            __syncthreads();
-        }
-        const uint32_t loc = s_scan[tid] - mine;
-        __syncthreads();
-        s_scan[tid] = tot;
-        __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
-            const uint32_t v = (tid >= o) ? s_scan[tid - o] : 0u;
-            __syncthreads();
-            s_scan[tid] += v;
-            __syncthreads();
-        }
-        const uint32_t gbase = s_scan[tid] - tot;
+        uint32_t loc = i_mine - mine, gbase = i_tot - tot;
+#pragma unroll
+        for (int w = 0; w < 3; w++)
+            if (w < wave) { loc += s_scan[w]; gbase += s_scan[4 + w]; }
         // look back: keys of this digit in the chunks before this one
         uint32_t prefix = 0;
         int k = chunk - 1;
@@ -408,18 +409,6 @@ __global__ void __launch_bounds__(64) k_hist_scan(int T, int n_blocks, uint32_t*
 }
 
 // ---- tile scan: one 1024-thread workgroup, T <= a few 10^5 -----------------------------------
-// inclusive scan over the 64 lanes of a wave
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
-{
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = (uint32_t)__shfl_up((int)v, d);
-        if (lane >= d) v += y;
-    }
-    return v;
-}
-
 // One workgroup: tile ranges (exclusive scan of the tile counts), R, the largest count; also clears the two per-tile maxima
 // the blend kernels combine into.  Everything a lane touches in HBM is next to what its neighbours touch: the tiles are
 // taken 8192 at a time as 8 rows of 1024 (thread t: tiles t, t + 1024, ...), each 64-tile segment is scanned inside its wave
