@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsugar_raster.so")
+LIB_PATH = os.environ.get("SGR_LIB_PATH") or os.path.join(_HERE, "libsugar_raster.so")  # (SGR_LIB_PATH: A/B of a variant build)
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 

@@ -51,7 +51,9 @@ namespace {
         __builtin_amdgcn_wave_barrier();     \
     } while (0)
 
+#ifndef RS_ITEMS
 #define RS_ITEMS 4096  // keys per workgroup chunk (256 threads x 16 keys)
+#endif
 
 // sort parameters, reduced from the preprocess kernel's per-workgroup key ranges by the first histogram kernel
 struct RsParams { uint32_t kmin, kmax1 /* max + 1: the stand-in of a culled key */, skip3 /* (kmax1 - kmin) < 2^24 */, pad; };
