@@ -65,7 +65,9 @@ static inline ImgLayout sgr_img_layout(int W, int H)
 // two-level binning (binning2.hip): scratch appended to the img allocation
 #define SGR_SUP 8                // tiles per super-tile edge
 #define SGR_SUP_SHIFT 3
+#ifndef SGR_B2_SLICES
 #define SGR_B2_SLICES 2048       // slices of the depth order in the level-1 ordered scatter
+#endif
 #define SGR_B2_CHUNK 512         // level-1 list entries per level-2 wave
 #define SGR_B2_HDR_R1 0          // level-1 entries (Gaussian x super-tile)
 #define SGR_B2_HDR_CHUNKS 1      // level-2 chunks
