@@ -18,6 +18,7 @@
 // 36-byte atomic request into a 64-byte accumulator record instead of the reference's up to 64 x 9 float atomics
 // (backward.cu:523-554).
 #include "sgr_common.h"
+#include <cstdlib>
 
 int g_sgr_blend_variant = 0;  // development switch between kernel variants under test (sgr_set_blend_variant); unused at present
 
@@ -398,14 +399,15 @@ __global__ void __launch_bounds__(64)
 k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ point_list,
               const unsigned long long* __restrict__ blk_mask, const uint32_t* __restrict__ blk_nb, const GeomRec* __restrict__ rec,
               const float* __restrict__ bg, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
-              const float* __restrict__ dL_dpix, float* __restrict__ acc)
+              const float* __restrict__ dL_dpix, float* __restrict__ acc, const uint32_t* __restrict__ tile_order)
 {
     __shared__ __attribute__((aligned(16))) float s_q[(BW_QCAP + 1) * BW_ENTRY_DW];  // (+1: phase A's look-ahead)
     __shared__ float2 s_zw[BW_SUB * BW_ZW_STRIDE];
     const int wg = blockIdx.x;
     const int sub = (wg >> 3) & 3;
-    const int tile = ((wg >> 5) << 3) + (wg & 7);
-    if (tile >= T_tiles) return;
+    const int slot = ((wg >> 5) << 3) + (wg & 7);
+    if (slot >= T_tiles) return;
+    const int tile = tile_order ? (int)tile_order[slot] : slot;  // deepest tiles first (k_tile_order)
     const int nb = (int)blk_nb[4 * tile + sub];  // batches the forward walked for this block (0: nothing contributed)
     if (nb == 0) return;
     const int tx = tile % gx, ty = tile / gx;
@@ -574,6 +576,38 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
     drain(true);
 }
 
+// Launch order of the backward: tiles by how deep the forward walked them (tile_maxc), deepest first, so that the waves still
+// running when the grid drains are the short ones.  (Workgroups start in index order; with ~2.5 dispatch rounds of waves whose
+// lifetimes spread over an order of magnitude, raster order leaves a quarter of the chip idle at the end.)  One workgroup:
+// a counting sort over 1024 depth classes; ties land in arbitrary order.
+__global__ void __launch_bounds__(1024) k_tile_order(int T, const uint32_t* __restrict__ tile_maxc, const uint32_t* __restrict__ header,
+                                                     uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t s_cls[1024];
+    __shared__ uint32_t s_w[16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t mc = header[SGR_HDR_MAXCOUNT];
+    const int shift = mc >= 1024u ? (32 - __builtin_clz(mc)) - 10 : 0;  // class = 1023 - (depth >> shift): class 0 = deepest
+    s_cls[tid] = 0u;
+    __syncthreads();
+    for (int i = tid; i < T; i += 1024) atomicAdd(&s_cls[1023u - min(tile_maxc[i] >> shift, 1023u)], 1u);
+    __syncthreads();
+    const uint32_t mine = s_cls[tid];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += y;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wave; w++) before += s_w[w];
+    s_cls[tid] = before + incl - mine;  // first slot of the class
+    __syncthreads();
+    for (int i = tid; i < T; i += 1024) order[atomicAdd(&s_cls[1023u - min(tile_maxc[i] >> shift, 1023u)], 1u)] = (uint32_t)i;
+}
+
 }  // namespace
 
 void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
@@ -588,9 +622,13 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
 
 void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const unsigned long long* blk_mask, const uint32_t* blk_nb, const GeomRec* rec, const float* bg,
-                          const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* acc, hipStream_t s)
+                          const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* acc,
+                          const uint32_t* tile_maxc, const uint32_t* header, uint32_t* tile_order, hipStream_t s)
 {
     const int T = gx * gy;
+    static const bool raster = getenv("SGR_BWD_RASTER_ORDER") != nullptr;  // (development: A/B of the launch order)
+    if (raster || 4 * T < 8192) tile_order = nullptr;  // (fewer waves than the chip holds at once: nothing to order)
+    else hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, T, tile_maxc, header, tile_order);
     hipLaunchKernelGGL(k_blend_bwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, blk_mask, blk_nb, rec,
-                       bg, final_T, n_contrib, dL_dpix, acc);
+                       bg, final_T, n_contrib, dL_dpix, acc, tile_order);
 }

@@ -341,8 +341,11 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
         HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * SGR_ACC_STRIDE * 4, s));
         if (R > 0) {
             StageTimer t(s, SGR_STAGE_BLEND_BWD);
+            // (the forward's per-tile counters are dead by now: their array holds the backward's launch order)
             sgr_launch_blend_bwd(width, height, IL.gx, IL.gy, tile_start, point_list, blk_mask, blk_nb, rec, background, final_T,
-                                 n_contrib, dL_dpix, acc, s);
+                                 n_contrib, dL_dpix, acc, reinterpret_cast<const uint32_t*>(img_buffer + IL.tile_maxc),
+                                 reinterpret_cast<const uint32_t*>(img_buffer + IL.header),
+                                 reinterpret_cast<uint32_t*>(img_buffer + IL.tile_cursor), s);
         }
         STAGE_CHECK("blend_bwd");
         if (phase == 1) {

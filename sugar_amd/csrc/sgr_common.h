@@ -165,4 +165,5 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
                           const uint32_t* guard_hdr, uint32_t list_cap, hipStream_t s);
 void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const unsigned long long* blk_mask, const uint32_t* blk_nb, const GeomRec* rec, const float* bg,
-                          const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* acc, hipStream_t s);
+                          const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* acc,
+                          const uint32_t* tile_maxc, const uint32_t* header, uint32_t* tile_order, hipStream_t s);
