@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="skip the per-stage HIP events (debug: measures their cost)")
     ap.add_argument("--no-fuse-activations", action="store_true", help="stand-alone activation kernels (A/B of the raw-parameter mode)")
+    ap.add_argument("--sh-dir-in-adam", action="store_true", help="form dRGB/d(view direction) -> dL/dxyz in the SH-Adam kernel instead of the backward preprocess kernel (A/B)")
     ap.add_argument("--host-sync", action="store_true", help="forward with the host round trip for num_rendered (A/B of the sync-free forward)")
     args = ap.parse_args()
 
@@ -94,7 +95,8 @@ def main():
     params = GaussianParams(scene, dev)
     trainer = ViewShardedTrainer(params, GaussianRasterizer, GaussianRasterizationSettings, bg_d,
                                  sync_free=False if args.host_sync else None,
-                                 fuse_activations=False if args.no_fuse_activations else None)
+                                 fuse_activations=False if args.no_fuse_activations else None,
+                                 sh_dir_in_adam=args.sh_dir_in_adam)
 
     def cam_index(step):
         return (step * world + rank) % len(cams)

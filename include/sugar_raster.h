@@ -86,6 +86,9 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user,
  * are then the gradients w.r.t. the raw parameters (sgr_activations_backward folded in).  Ignored with cov3D_precomp. */
 #define SGR_FLAG_RAW_PARAMS 1
 #define SGR_MODE_RAW_PARAMS 4 /* or-ed into the `phase` argument of sgr_backward_phase (phases 0, 1, 2 as before) */
+/* Compact SH mode only (dL_dsh == NULL): the backward skips the SH block altogether -- no read of shs, and dL_dmean3D
+ * comes out WITHOUT the term through the view direction; sgr_sh_adam_from_views_ex forms that term. */
+#define SGR_MODE_SH_DIR_ELSEWHERE 8
 
 /* Rasterizer::backward, DGR/cuda_rasterizer/rasterizer.h:57-84 / rasterizer_impl.cu:340-434.
  *   R = the value sgr_forward returned; geom/binning/img = the buffers its callbacks handed out.
@@ -145,6 +148,16 @@ int sgr_sh_adam_from_views(int P, int n_views, int D, int M, const float* means3
                            const float* dcolor_all, int64_t view_stride, float* sh_params, float* exp_avg, float* exp_avg_sq,
                            float lr_dc,
                            float lr_rest, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+
+/* As above, and the SH coefficients' other reader moves in with them: with dmean_extra != NULL the kernel also forms the
+ * view-direction part of dL/dmean3D (computeColorFromSH backward, backward.cu:99-139, + dnormvdv), summed over the views,
+ * and writes it to dmean_extra[P*3] (every row).  The backward that produced dcolor_all must then have been run with
+ * SGR_MODE_SH_DIR_ELSEWHERE (its dL_dmean3D lacks exactly that term and it does not read the SH tensor at all), and the
+ * position gradient is completed by sgr_adam_step_ex.  Saves one pass over the SH tensor per step (192 B per Gaussian). */
+int sgr_sh_adam_from_views_ex(int P, int n_views, int D, int M, const float* means3D, const float* campos_all,
+                              const float* dcolor_all, int64_t view_stride, float* sh_params, float* exp_avg, float* exp_avg_sq,
+                              float lr_dc, float lr_rest, float beta1, float beta2, float eps, int step, float grad_scale,
+                              float* dmean_extra, void* stream);
 
 /* Rasterizer::markVisible, DGR/cuda_rasterizer/rasterizer.h:24-29 / rasterizer_impl.cu:141-153.
  * present[P] is one byte per Gaussian (bool). */
@@ -224,6 +237,12 @@ int sgr_adam_step(long long n, float* params, const float* grads, float* exp_avg
                   const long long* seg_begin, const long long* seg_end, const float* seg_lr_a, const float* seg_lr_b,
                   const int* seg_period, const int* seg_split, float beta1, float beta2, float eps, int step,
                   float grad_scale, void* stream);
+/* The same step with a second gradient term: the gradient of element i < extra_n is grads[i] + extra[i] (both scaled by
+ * grad_scale).  Used for the position gradient of sgr_sh_adam_from_views_ex (positions first in the flat buffer). */
+int sgr_adam_step_ex(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n_seg,
+                     const long long* seg_begin, const long long* seg_end, const float* seg_lr_a, const float* seg_lr_b,
+                     const int* seg_period, const int* seg_split, float beta1, float beta2, float eps, int step,
+                     float grad_scale, const float* extra, long long extra_n, void* stream);
 
 /* ---- SuGaR density field and level-set surface sampler (share the Gaussian buffers) --------------
  * B_g = R_g diag(1 / max(s_g, 1e-8)) is SuGaR's get_covariance(return_full_matrix=True, return_sqrt=True,

@@ -29,6 +29,7 @@ SIGNATURES = {
     "sgr_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "sgr_sh_grad_from_views": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp]),
     "sgr_sh_adam_from_views": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    "sgr_sh_adam_from_views_ex": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
     "sgr_geom_bytes": (_sz, [_i]),
     "sgr_img_bytes": (_sz, [_i, _i]),
     "sgr_binning_bytes": (_sz, [_i64, _i, _i]),
@@ -46,6 +47,7 @@ SIGNATURES = {
     "sgr_l1_ssim_forward": (_i, [_i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "sgr_l1_ssim_backward": (_i, [_i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "sgr_adam_step": (_i, [C.c_longlong, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _i, _f, _vp]),
+    "sgr_adam_step_ex": (_i, [C.c_longlong, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _i, _f, _vp, C.c_longlong, _vp]),
     "sgr_density_field_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "sgr_density_field_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgr_density_field_backward_scratch_bytes": (_sz, [_i, _i, _i]),

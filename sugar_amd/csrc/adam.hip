@@ -66,11 +66,18 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256) k_adam(long long n4, f4* __restrict__ p, const f4* __restrict__ g,
                                               f4* __restrict__ m, f4* __restrict__ v, AdamSegs sg, float b1, float b2,
-                                              float eps, float bc1, float bc2_sqrt, float grad_scale)
+                                              float eps, float bc1, float bc2_sqrt, float grad_scale,
+                                              const float* __restrict__ extra, long long extra_n)
 {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         // g, m and v are touched once per step: stream them past the caches (p is read again by the next forward)
         f4 gg = __builtin_nontemporal_load(&g[i]);
+        if (4 * i < extra_n) {  // a second gradient term for the first extra_n elements (sgr_adam_step_ex)
+            float* gx = reinterpret_cast<float*>(&gg);
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (4 * i + c < extra_n) gx[c] += extra[4 * i + c];
+        }
         gg *= grad_scale;
         f4 pp = p[i], mm = __builtin_nontemporal_load(&m[i]), vv = __builtin_nontemporal_load(&v[i]);
         float* pf = reinterpret_cast<float*>(&pp);
@@ -94,12 +101,13 @@ __global__ void __launch_bounds__(256) k_adam(long long n4, f4* __restrict__ p, 
 
 }  // namespace
 
-extern "C" int sgr_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n_seg,
-                             const long long* seg_begin, const long long* seg_end, const float* seg_lr_a,
-                             const float* seg_lr_b, const int* seg_period, const int* seg_split, float beta1, float beta2,
-                             float eps, int step, float grad_scale, void* stream)
+extern "C" int sgr_adam_step_ex(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n_seg,
+                                const long long* seg_begin, const long long* seg_end, const float* seg_lr_a,
+                                const float* seg_lr_b, const int* seg_period, const int* seg_split, float beta1, float beta2,
+                                float eps, int step, float grad_scale, const float* extra, long long extra_n, void* stream)
 {
     if (n <= 0) return 0;
+    if (extra_n < 0 || extra_n > n || (extra_n > 0 && !extra)) return SGR_E_INVALID;
     if (!params || !grads || !exp_avg || !exp_avg_sq || n_seg < 0 || n_seg > ADAM_MAX_SEG || step < 1 || (n & 3)) return SGR_E_INVALID;
     AdamSegs sg;
     sg.n = n_seg;
@@ -115,6 +123,15 @@ extern "C" int sgr_adam_step(long long n, float* params, const float* grads, flo
     const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n4, reinterpret_cast<f4*>(params),
                        reinterpret_cast<const f4*>(grads), reinterpret_cast<f4*>(exp_avg),
-                       reinterpret_cast<f4*>(exp_avg_sq), sg, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale);
+                       reinterpret_cast<f4*>(exp_avg_sq), sg, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale, extra, extra_n);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
+}
+
+extern "C" int sgr_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n_seg,
+                             const long long* seg_begin, const long long* seg_end, const float* seg_lr_a,
+                             const float* seg_lr_b, const int* seg_period, const int* seg_split, float beta1, float beta2,
+                             float eps, int step, float grad_scale, void* stream)
+{
+    return sgr_adam_step_ex(n, params, grads, exp_avg, exp_avg_sq, n_seg, seg_begin, seg_end, seg_lr_a, seg_lr_b, seg_period, seg_split,
+                            beta1, beta2, eps, step, grad_scale, nullptr, 0, stream);
 }

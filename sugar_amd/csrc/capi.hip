@@ -311,6 +311,7 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
 {
     hipStream_t s = (hipStream_t)stream;
     const int raw_params = (phase & SGR_MODE_RAW_PARAMS) ? 1 : 0;
+    const int sh_dir_elsewhere = (phase & SGR_MODE_SH_DIR_ELSEWHERE) ? 1 : 0;
     phase &= 3;
     if (phase < 0 || phase > 2) return fail(SGR_E_INVALID, "phase must be 0, 1 or 2");
     if (P <= 0 || width <= 0 || height <= 0) return fail(SGR_E_INVALID, "P, width and height must be positive");
@@ -365,6 +366,7 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
     pb.focal_x = width / (2.0f * tan_fovx);
     pb.rec = rec;
     pb.raw_params = raw_params && !cov3D_precomp;
+    pb.sh_dir_elsewhere = sh_dir_elsewhere && use_sh && !dL_dsh;  // (compact SH mode only: see sgr_sh_adam_from_views_ex)
     pb.acc = acc;
     pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dopacity = dL_dopacity;
     pb.dL_dcolor = phase == 2 ? nullptr : dL_dcolor;  // phase 2: already written (and possibly being sent) by phase 1
@@ -419,9 +421,10 @@ int sgr_sh_grad_from_views(int P, int n_views, int D, int M, const float* means3
     return 0;
 }
 
-int sgr_sh_adam_from_views(int P, int n_views, int D, int M, const float* means3D, const float* campos_all,
-                           const float* dcolor_all, int64_t view_stride, float* sh_params, float* exp_avg, float* exp_avg_sq, float lr_dc,
-                           float lr_rest, float beta1, float beta2, float eps, int step, float grad_scale, void* stream)
+int sgr_sh_adam_from_views_ex(int P, int n_views, int D, int M, const float* means3D, const float* campos_all,
+                              const float* dcolor_all, int64_t view_stride, float* sh_params, float* exp_avg, float* exp_avg_sq, float lr_dc,
+                              float lr_rest, float beta1, float beta2, float eps, int step, float grad_scale, float* dmean_extra,
+                              void* stream)
 {
     if (P <= 0) return 0;
     if (n_views <= 0 || D < 0 || D > 3 || M < (D + 1) * (D + 1) || M > 16 || step < 1 || !means3D || !campos_all || !dcolor_all ||
@@ -430,11 +433,21 @@ int sgr_sh_adam_from_views(int P, int n_views, int D, int M, const float* means3
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     if (view_stride != 0 && view_stride < P) return fail(SGR_E_INVALID, "sgr_sh_adam_from_views: view_stride < P");
+    if (dmean_extra && (M != 16 || ((uintptr_t)sh_params & 15)))
+        return fail(SGR_E_INVALID, "sgr_sh_adam_from_views_ex: dmean_extra needs M == 16 and 16-byte aligned sh_params");
     sgr_launch_sh_adam_from_views(P, n_views, D, M, (size_t)(view_stride ? view_stride : P), means3D, campos_all, dcolor_all, sh_params, exp_avg, exp_avg_sq, lr_dc, lr_rest,
-                                  beta1, beta2, eps, bc1, bc2_sqrt, grad_scale, (hipStream_t)stream);
+                                  beta1, beta2, eps, bc1, bc2_sqrt, grad_scale, dmean_extra, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SGR_E_HIP, std::string("sh_adam_from_views: ") + hipGetErrorString(e));
     return 0;
+}
+
+int sgr_sh_adam_from_views(int P, int n_views, int D, int M, const float* means3D, const float* campos_all,
+                           const float* dcolor_all, int64_t view_stride, float* sh_params, float* exp_avg, float* exp_avg_sq, float lr_dc,
+                           float lr_rest, float beta1, float beta2, float eps, int step, float grad_scale, void* stream)
+{
+    return sgr_sh_adam_from_views_ex(P, n_views, D, M, means3D, campos_all, dcolor_all, view_stride, sh_params, exp_avg, exp_avg_sq, lr_dc,
+                                     lr_rest, beta1, beta2, eps, step, grad_scale, nullptr, stream);
 }
 
 }  // extern "C"

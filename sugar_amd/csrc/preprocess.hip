@@ -175,6 +175,34 @@ __device__ __forceinline__ void load_sh(const float* shs, size_t idx, int M, flo
 }
 __host__ __device__ __forceinline__ bool sh_fast_layout(const float* shs, int M) { return shs && M == 16 && ((uintptr_t)shs & 15) == 0; }
 
+// d RGB_c / d(view direction) for one colour channel from its 16 coefficients h[k] (backward.cu:99-131): the derivative half
+// of computeColorFromSH's backward, shared by the backward preprocess kernel and the SH-Adam kernel.
+__device__ __forceinline__ void sh_dir_channel(const int deg, const float* h, const float x, const float y, const float z,
+                                               float& dRGBdx, float& dRGBdy, float& dRGBdz)
+{
+    dRGBdx = 0; dRGBdy = 0; dRGBdz = 0;
+    if (deg > 0) {
+        dRGBdx = -SH_C1 * h[3]; dRGBdy = -SH_C1 * h[1]; dRGBdz = SH_C1 * h[2];
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            dRGBdx += SH_C2[0] * y * h[4] + SH_C2[2] * 2.f * -x * h[6] + SH_C2[3] * z * h[7] + SH_C2[4] * 2.f * x * h[8];
+            dRGBdy += SH_C2[0] * x * h[4] + SH_C2[1] * z * h[5] + SH_C2[2] * 2.f * -y * h[6] + SH_C2[4] * 2.f * -y * h[8];
+            dRGBdz += SH_C2[1] * y * h[5] + SH_C2[2] * 2.f * 2.f * z * h[6] + SH_C2[3] * x * h[7];
+            if (deg > 2) {
+                dRGBdx += (SH_C3[0] * h[9] * 3.f * 2.f * xy + SH_C3[1] * h[10] * yz + SH_C3[2] * h[11] * -2.f * xy +
+                           SH_C3[3] * h[12] * -3.f * 2.f * xz + SH_C3[4] * h[13] * (-3.f * xx + 4.f * zz - yy) +
+                           SH_C3[5] * h[14] * 2.f * xz + SH_C3[6] * h[15] * 3.f * (xx - yy));
+                dRGBdy += (SH_C3[0] * h[9] * 3.f * (xx - yy) + SH_C3[1] * h[10] * xz +
+                           SH_C3[2] * h[11] * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * h[12] * -3.f * 2.f * yz +
+                           SH_C3[4] * h[13] * -2.f * xy + SH_C3[5] * h[14] * -2.f * yz + SH_C3[6] * h[15] * -3.f * 2.f * xy);
+                dRGBdz += (SH_C3[1] * h[10] * xy + SH_C3[2] * h[11] * 4.f * 2.f * yz +
+                           SH_C3[3] * h[12] * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * h[13] * 4.f * 2.f * xz +
+                           SH_C3[5] * h[14] * (xx - yy));
+            }
+        }
+    }
+}
+
 // computeColorFromSH backward for one Gaussian (backward.cu:47-137): dsh[k][c] = basis_k(dir) * masked dL/dRGB[c] and the
 // gradient w.r.t. the (normalised) view direction.  `clamped` bit c set = channel c was clamped to 0 by the forward.
 __device__ __forceinline__ void sh_backward(const int deg, const float* sh, const float* dcol, const uint32_t clamped,
@@ -182,42 +210,31 @@ __device__ __forceinline__ void sh_backward(const int deg, const float* sh, cons
 {
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-#define SH(k) sh[3 * (k) + c]
 #define DSH(k) dsh[3 * (k) + c]
         float dL_dRGB = dcol[c] * (((clamped >> c) & 1u) ? 0.0f : 1.0f);
-        float dRGBdx = 0, dRGBdy = 0, dRGBdz = 0;
         DSH(0) = SH_C0 * dL_dRGB;
         if (deg > 0) {
             DSH(1) = (-SH_C1 * y) * dL_dRGB; DSH(2) = (SH_C1 * z) * dL_dRGB; DSH(3) = (-SH_C1 * x) * dL_dRGB;
-            dRGBdx = -SH_C1 * SH(3); dRGBdy = -SH_C1 * SH(1); dRGBdz = SH_C1 * SH(2);
             if (deg > 1) {
                 float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
                 DSH(4) = (SH_C2[0] * xy) * dL_dRGB; DSH(5) = (SH_C2[1] * yz) * dL_dRGB;
                 DSH(6) = (SH_C2[2] * (2.f * zz - xx - yy)) * dL_dRGB; DSH(7) = (SH_C2[3] * xz) * dL_dRGB;
                 DSH(8) = (SH_C2[4] * (xx - yy)) * dL_dRGB;
-                dRGBdx += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8);
-                dRGBdy += SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) + SH_C2[4] * 2.f * -y * SH(8);
-                dRGBdz += SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7);
                 if (deg > 2) {
                     DSH(9) = (SH_C3[0] * y * (3.f * xx - yy)) * dL_dRGB; DSH(10) = (SH_C3[1] * xy * z) * dL_dRGB;
                     DSH(11) = (SH_C3[2] * y * (4.f * zz - xx - yy)) * dL_dRGB;
                     DSH(12) = (SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * dL_dRGB;
                     DSH(13) = (SH_C3[4] * x * (4.f * zz - xx - yy)) * dL_dRGB;
                     DSH(14) = (SH_C3[5] * z * (xx - yy)) * dL_dRGB; DSH(15) = (SH_C3[6] * x * (xx - 3.f * yy)) * dL_dRGB;
-                    dRGBdx += (SH_C3[0] * SH(9) * 3.f * 2.f * xy + SH_C3[1] * SH(10) * yz + SH_C3[2] * SH(11) * -2.f * xy +
-                               SH_C3[3] * SH(12) * -3.f * 2.f * xz + SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
-                               SH_C3[5] * SH(14) * 2.f * xz + SH_C3[6] * SH(15) * 3.f * (xx - yy));
-                    dRGBdy += (SH_C3[0] * SH(9) * 3.f * (xx - yy) + SH_C3[1] * SH(10) * xz +
-                               SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * SH(12) * -3.f * 2.f * yz +
-                               SH_C3[4] * SH(13) * -2.f * xy + SH_C3[5] * SH(14) * -2.f * yz + SH_C3[6] * SH(15) * -3.f * 2.f * xy);
-                    dRGBdz += (SH_C3[1] * SH(10) * xy + SH_C3[2] * SH(11) * 4.f * 2.f * yz +
-                               SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * SH(13) * 4.f * 2.f * xz +
-                               SH_C3[5] * SH(14) * (xx - yy));
                 }
             }
         }
-#undef SH
 #undef DSH
+        float h[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) h[k] = sh[3 * k + c];
+        float dRGBdx, dRGBdy, dRGBdz;
+        sh_dir_channel(deg, h, x, y, z, dRGBdx, dRGBdy, dRGBdz);
         dL_ddir[0] += dRGBdx * dL_dRGB; dL_ddir[1] += dRGBdy * dL_dRGB; dL_ddir[2] += dRGBdz * dL_dRGB;
     }
 }
@@ -475,7 +492,14 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
         if (a.dL_dconic) *reinterpret_cast<float4*>(a.dL_dconic + 4 * (size_t)idx) = gc;
         // raw mode: d sigmoid = s (1 - s), the activated opacity is in the record (sgr_activations_backward's arithmetic)
         a.dL_dopacity[idx] = a.raw_params ? s0.w * op * (1.0f - op) : s0.w;
-        if (a.dL_dcolor) { a.dL_dcolor[i3] = dcol[0]; a.dL_dcolor[i3 + 1] = dcol[1]; a.dL_dcolor[i3 + 2] = dcol[2]; }
+        if (a.dL_dcolor) {
+            // (sh_dir_elsewhere: compact mode without the SH block -- the clamp-masked colour gradients leave here and
+            // k_sh_adam_from_views forms dRGB/d(view direction) -> dL/dmean next to the SH coefficients it loads anyway)
+            const bool mk = a.sh_dir_elsewhere != 0;
+            a.dL_dcolor[i3] = (mk && (clamped & 1u)) ? 0.f : dcol[0];
+            a.dL_dcolor[i3 + 1] = (mk && (clamped & 2u)) ? 0.f : dcol[1];
+            a.dL_dcolor[i3 + 2] = (mk && (clamped & 4u)) ? 0.f : dcol[2];
+        }
     }
     // ---- K9, backward.cu:144-274
     {
@@ -652,6 +676,45 @@ __global__ void __launch_bounds__(256) k_masked_colors(int P, const GeomRec* __r
     out[i3 + 2] = (clamped & 4u) ? 0.f : s0.z;
 }
 
+// dL/dmean3D through the view direction, summed over the views (the tail of the backward preprocess kernel,
+// backward.cu:99-139 + dnormvdv, moved next to the only other reader of the SH coefficients; `row` = this Gaussian's 48
+// coefficients in LDS).  Same arithmetic, operation for operation, as k_preprocess_bwd (sh_backward).  One colour channel at
+// a time, its 16 coefficients fetched from the LDS row: with all 48 in registers next to the expanded polynomial the kernel
+// needed 190 VGPRs, two waves per SIMD, and lost in bandwidth what the backward preprocess kernel saved.
+__device__ __forceinline__ void sh_dir_sum_over_views(int idx, size_t P, int V, int D, const float* __restrict__ means3D,
+                                                      const float* __restrict__ campos, const float* __restrict__ dcolor,
+                                                      const float* row, float* dm)
+{
+    const size_t i3 = 3 * (size_t)idx;
+    const float mx = means3D[i3], my = means3D[i3 + 1], mz = means3D[i3 + 2];
+    dm[0] = 0.f; dm[1] = 0.f; dm[2] = 0.f;
+    for (int v = 0; v < V; v++) {
+        const float* g = dcolor + ((size_t)v * P + idx) * 3;
+        const float g0 = g[0], g1 = g[1], g2 = g[2];
+        if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;  // culled or fully clamped in this view
+        const float dx = mx - campos[3 * v], dy = my - campos[3 * v + 1], dz = mz - campos[3 * v + 2];
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float x = dx / len, y = dy / len, z = dz / len;
+        float dL_ddir[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int c = 0; c < 3; c++) {
+            float h[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) h[k] = row[3 * k + c];
+            const float dL_dRGB = (c == 0 ? g0 : (c == 1 ? g1 : g2)) * 1.0f;  // (sh_backward's mask factor: the colours arrive masked)
+            float dRGBdx, dRGBdy, dRGBdz;
+            sh_dir_channel(D, h, x, y, z, dRGBdx, dRGBdy, dRGBdz);
+            dL_ddir[0] += dRGBdx * dL_dRGB; dL_ddir[1] += dRGBdy * dL_dRGB; dL_ddir[2] += dRGBdz * dL_dRGB;
+        }
+        // dnormvdv, auxiliary.h:107-117
+        const float sum2 = dx * dx + dy * dy + dz * dz;
+        const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+        dm[0] += ((+sum2 - dx * dx) * dL_ddir[0] - dy * dx * dL_ddir[1] - dz * dx * dL_ddir[2]) * invsum32;
+        dm[1] += (-dx * dy * dL_ddir[0] + (sum2 - dy * dy) * dL_ddir[1] - dz * dy * dL_ddir[2]) * invsum32;
+        dm[2] += (-dx * dz * dL_ddir[0] - dy * dz * dL_ddir[1] + (sum2 - dz * dz) * dL_ddir[2]) * invsum32;
+    }
+}
+
 __device__ __forceinline__ void sh_grad_sum_over_views(int idx, size_t P, int V, int D, const float* __restrict__ means3D,
                                                        const float* __restrict__ campos, const float* __restrict__ dcolor,
                                                        float* acc)
@@ -723,20 +786,52 @@ struct ShAdamArgs {
 // one contiguous stream, one float4 per lane and step (a lane-per-Gaussian walk touches 64 cache lines per instruction
 // and ran at 2 TB/s).
 #define SHA_STRIDE 52
+// DIR (dmean_extra != NULL, M == 16): phase 1 also loads the Gaussian's 48 coefficients (the wave's 12 KB block, which
+// phase 2 then streams out of the cache) and writes the view-direction part of dL/dmean3D, summed over the views, to
+// dmean_extra[P][3]; the flat Adam kernel adds it to the position gradient (sgr_adam_step_ex).
+template <bool DIR>
 __global__ void __launch_bounds__(64) k_sh_adam_from_views(int P, int V, int D, int M, size_t vstride,
                                                            const float* __restrict__ means3D,
                                                            const float* __restrict__ campos, const float* __restrict__ dcolor,
                                                            float* __restrict__ sh, float* __restrict__ exp_avg,
-                                                           float* __restrict__ exp_avg_sq, ShAdamArgs a)
+                                                           float* __restrict__ exp_avg_sq, ShAdamArgs a,
+                                                           float* __restrict__ dmean_extra)
 {
     __shared__ __attribute__((aligned(16))) float s_g[64 * SHA_STRIDE];
     const int lane = threadIdx.x;
     const int g0 = blockIdx.x * 64;
     const int idx = g0 + lane;
+    float4 pkeep[12];  // DIR: the wave's 64 x 48 coefficients in the streaming layout of phase 2 (read from memory once)
+    if (DIR) {
+        // coalesced into the panel (row = Gaussian) for the direction term, and kept in registers for the Adam update
+        // (12 loads at a 192-byte lane stride straight from memory cost this streaming kernel 25 us; re-reading the block in
+        // phase 2 gives back what the backward preprocess kernel saved)
+        const float4* p4 = reinterpret_cast<const float4*>(sh + (size_t)g0 * 48);
+        const int n4 = min(64, P - g0) * 12;
+#pragma unroll
+        for (int st = 0; st < 12; st++) pkeep[st] = p4[min(st * 64 + lane, n4 - 1)];
+#pragma unroll
+        for (int st = 0; st < 12; st++) {
+            const int e4 = st * 64 + lane;
+            if (e4 < n4) { const int g = e4 / 12; *reinterpret_cast<float4*>(s_g + g * SHA_STRIDE + 4 * (e4 - g * 12)) = pkeep[st]; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (DIR && idx < P) {
+        float dm[3];
+        sh_dir_sum_over_views(idx, vstride, V, D, means3D, campos, dcolor, s_g + lane * SHA_STRIDE, dm);
+        dmean_extra[3 * (size_t)idx] = dm[0]; dmean_extra[3 * (size_t)idx + 1] = dm[1]; dmean_extra[3 * (size_t)idx + 2] = dm[2];
+    }
+    if (DIR) {  // every lane is done with its coefficients before any lane overwrites a row with gradient sums
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     {
         float acc[48];
-        if (idx < P) sh_grad_sum_over_views(idx, vstride, V, D, means3D, campos, dcolor, acc);
-        else {
+        if (idx < P) {
+            sh_grad_sum_over_views(idx, vstride, V, D, means3D, campos, dcolor, acc);
+        } else {
 #pragma unroll
             for (int k = 0; k < 48; k++) acc[k] = 0.f;
         }
@@ -762,23 +857,37 @@ __global__ void __launch_bounds__(64) k_sh_adam_from_views(int P, int V, int D, 
         f4* m4 = reinterpret_cast<f4*>(exp_avg + base);
         f4* v4 = reinterpret_cast<f4*>(exp_avg_sq + base);
         const int n4 = live * 12;
+        // four steps at a time: their twelve loads go out together (one at a time -- loads under the lane predicate, every
+        // step waiting for its own -- a wave made twelve serial round trips; addresses are clamped instead)
+        constexpr int NB = DIR ? 2 : 4;  // (DIR holds the parameters in registers already: smaller batches keep it at 3 waves per SIMD)
 #pragma unroll
-        for (int st = 0; st < 12; st++) {
-            const int e4 = st * 64 + lane;  // float4 index inside the wave's 64 x 48 block
-            if (e4 < n4) {
-                const int g = e4 / 12, c4 = e4 - g * 12;
-                const float4 gr = *reinterpret_cast<const float4*>(s_g + g * SHA_STRIDE + 4 * c4);
+        for (int st0 = 0; st0 < 12; st0 += NB) {
+            f4 pv[NB], mv[NB], vv[NB];
+#pragma unroll
+            for (int u = 0; u < NB; u++) {
+                const int e4 = min((st0 + u) * 64 + lane, n4 - 1);  // float4 index inside the wave's 64 x 48 block
                 // the moments are touched once per step: stream them past the caches, the parameters are read again by
                 // the next forward and should stay in the last-level cache
-                const f4 pv = p4[e4], mv = __builtin_nontemporal_load(&m4[e4]), vv = __builtin_nontemporal_load(&v4[e4]);
-                float p[4] = {pv.x, pv.y, pv.z, pv.w}, m[4] = {mv.x, mv.y, mv.z, mv.w}, v[4] = {vv.x, vv.y, vv.z, vv.w};
-                const float gq[4] = {gr.x, gr.y, gr.z, gr.w};
+                if (DIR) { const float4 k = pkeep[st0 + u]; pv[u] = (f4){k.x, k.y, k.z, k.w}; }
+                else pv[u] = p4[e4];
+                mv[u] = __builtin_nontemporal_load(&m4[e4]); vv[u] = __builtin_nontemporal_load(&v4[e4]);
+            }
 #pragma unroll
-                for (int k = 0; k < 4; k++) upd(4 * c4 + k, gq[k], p[k], m[k], v[k]);
-                const f4 po = {p[0], p[1], p[2], p[3]}, mo = {m[0], m[1], m[2], m[3]}, vo = {v[0], v[1], v[2], v[3]};
-                p4[e4] = po;
-                __builtin_nontemporal_store(mo, &m4[e4]);
-                __builtin_nontemporal_store(vo, &v4[e4]);
+            for (int u = 0; u < NB; u++) {
+                const int e4 = (st0 + u) * 64 + lane;
+                if (e4 < n4) {
+                    const int g = e4 / 12, c4 = e4 - g * 12;
+                    const float4 gr = *reinterpret_cast<const float4*>(s_g + g * SHA_STRIDE + 4 * c4);
+                    float p[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w}, m[4] = {mv[u].x, mv[u].y, mv[u].z, mv[u].w};
+                    float v[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+                    const float gq[4] = {gr.x, gr.y, gr.z, gr.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) upd(4 * c4 + k, gq[k], p[k], m[k], v[k]);
+                    const f4 po = {p[0], p[1], p[2], p[3]}, mo = {m[0], m[1], m[2], m[3]}, vo = {v[0], v[1], v[2], v[3]};
+                    p4[e4] = po;
+                    __builtin_nontemporal_store(mo, &m4[e4]);
+                    __builtin_nontemporal_store(vo, &v4[e4]);
+                }
             }
         }
     } else {
@@ -911,7 +1020,7 @@ void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
 {
     if (a.P <= 0) return;
     const dim3 grid((a.P + 255) / 256);
-    const int mode = !a.shs ? 2 : (sh_fast_layout(a.shs, a.M) ? 0 : 1);
+    const int mode = (!a.shs || a.sh_dir_elsewhere) ? 2 : (sh_fast_layout(a.shs, a.M) ? 0 : 1);
     if (a.dL_dsh) {
         if (mode == 0) hipLaunchKernelGGL((k_preprocess_bwd<true, 0>), grid, dim3(256), 0, s, a);
         else if (mode == 1) hipLaunchKernelGGL((k_preprocess_bwd<true, 1>), grid, dim3(256), 0, s, a);
@@ -930,11 +1039,15 @@ void sgr_launch_masked_colors(int P, const GeomRec* rec, const float* acc, float
 
 void sgr_launch_sh_adam_from_views(int P, int V, int D, int M, size_t vstride, const float* means3D, const float* campos,
                                    const float* dcolor, float* sh, float* exp_avg, float* exp_avg_sq, float lr_dc, float lr_rest, float b1, float b2,
-                                   float eps, float bc1, float bc2_sqrt, float grad_scale, hipStream_t s)
+                                   float eps, float bc1, float bc2_sqrt, float grad_scale, float* dmean_extra, hipStream_t s)
 {
     ShAdamArgs a = {lr_dc, lr_rest, b1, b2, eps, bc1, bc2_sqrt, grad_scale};
-    hipLaunchKernelGGL(k_sh_adam_from_views, dim3((P + 63) / 64), dim3(64), 0, s, P, V, D, M, vstride, means3D, campos, dcolor, sh,
-                       exp_avg, exp_avg_sq, a);
+    if (dmean_extra)
+        hipLaunchKernelGGL(k_sh_adam_from_views<true>, dim3((P + 63) / 64), dim3(64), 0, s, P, V, D, M, vstride, means3D, campos, dcolor,
+                           sh, exp_avg, exp_avg_sq, a, dmean_extra);
+    else
+        hipLaunchKernelGGL(k_sh_adam_from_views<false>, dim3((P + 63) / 64), dim3(64), 0, s, P, V, D, M, vstride, means3D, campos, dcolor,
+                           sh, exp_avg, exp_avg_sq, a, dmean_extra);
 }
 
 void sgr_launch_sh_grad_from_views(int P, int V, int D, int M, size_t vstride, const float* means3D, const float* campos,

@@ -132,6 +132,7 @@ struct PreprocessBwdArgs {
     int W, H; float tan_fovx, tan_fovy, focal_x, focal_y;
     const GeomRec* rec;
     int raw_params;    // as in PreprocessArgs: dL_dscale / dL_drot / dL_dopacity are then gradients w.r.t. the raw parameters
+    int sh_dir_elsewhere;  // compact mode only: skip the SH block (dRGB/d(view direction) -> dL_dmean3D is formed by k_sh_adam_from_views)
     const float* acc;  // [P][SGR_ACC_STRIDE] sums from the blend backward: {dcol r,g,b, S0, Sx, Sy, Sxx, Sxy, Syy, pad x3}
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor;  // written here from acc
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
@@ -143,7 +144,7 @@ void sgr_launch_sh_grad_from_views(int P, int V, int D, int M, size_t vstride, c
 
 void sgr_launch_sh_adam_from_views(int P, int V, int D, int M, size_t vstride, const float* means3D, const float* campos,
                                    const float* dcolor, float* sh, float* exp_avg, float* exp_avg_sq, float lr_dc, float lr_rest, float b1, float b2,
-                                   float eps, float bc1, float bc2_sqrt, float grad_scale, hipStream_t s);
+                                   float eps, float bc1, float bc2_sqrt, float grad_scale, float* dmean_extra, hipStream_t s);
 
 void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_out, const uint2* rect_by_id, uint2* rects_sorted,
                               hipStream_t s);

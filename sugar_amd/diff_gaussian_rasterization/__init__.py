@@ -187,6 +187,8 @@ class _CModule:
         dL_dscales = torch.zeros(P, 3, **f) if use_cov else _sink_or_empty(grad_out, "scales", (P, 3), **f)
         dL_drotations = torch.zeros(P, 4, **f) if use_cov else _sink_or_empty(grad_out, "rotations", (P, 4), **f)
         raw_mode = 4 if (grad_out and grad_out.get("raw_params")) else 0  # SGR_MODE_RAW_PARAMS
+        if compact_sh and grad_out.get("sh_dir_elsewhere") and sh is not None and sh.numel() > 0:
+            raw_mode |= 8  # SGR_MODE_SH_DIR_ELSEWHERE: dL_dmeans3D lacks the view-direction term (sgr_sh_adam_from_views_ex forms it)
         if P != 0:
             means3D = _dev_f32(means3D, dev, "means3D")
             dL = _dev_f32(dL_dout_color, dev, "dL_dout_color")

@@ -216,6 +216,8 @@ class FlatAdam:
                 segs.append((b, e, params.LRS[k], params.LRS[k], 1, 1))
         self._seg, self._n = self._pack(segs)
         self._seg_small, self._n_small = self._pack(segs[:-1])  # everything but the SH tensor (the last segment)
+        self._dmean_extra = None  # [P,3] view-direction part of dL/dxyz written by the SH kernel (step(sh_dir=True))
+        assert params.offsets["xyz"] == 0
 
     def _pack(self, segs):
         C = self._C
@@ -224,24 +226,31 @@ class FlatAdam:
                 (C.c_float * n)(*[s[2] for s in segs]), (C.c_float * n)(*[s[3] for s in segs]),
                 (C.c_int * n)(*[s[4] for s in segs]), (C.c_int * n)(*[s[5] for s in segs])), n
 
-    def step(self, grad_scale: float = 1.0, sh_views=None, before_small=None):
+    def step(self, grad_scale: float = 1.0, sh_views=None, before_small=None, sh_dir=False):
         """One Adam step over the flat buffer.  With `sh_views = (means3D, campos_all[V,3], masked_colors[V,P,3], sh_degree)`
         the SH tensor is updated by sgr_sh_adam_from_views straight from the per-view colour gradients (its 48-float gradient
         is never materialised) and the flat kernel covers the other 11 floats per Gaussian only; `before_small` is called
-        between the two launches."""
+        between the two launches.  `sh_dir`: the rasterizer backward ran with `sh_dir_elsewhere` (its position gradient
+        lacks the term through the view direction): the SH kernel forms that term next to the coefficients it loads anyway
+        and the flat kernel adds it to the position gradient."""
         self.begin_step()
         if sh_views is not None:
-            self.step_sh(sh_views, grad_scale)
+            extra = None
+            if sh_dir:
+                if self._dmean_extra is None:
+                    self._dmean_extra = torch.empty(self.params.P, 3, dtype=torch.float32, device=self.params.flat.device)
+                extra = self._dmean_extra
+            self.step_sh(sh_views, grad_scale, dmean_extra=extra)
             if before_small is not None:
                 before_small()  # e.g. wait for the all-reduce of the small gradients, which ran next to the SH kernel
-            self.step_small(grad_scale)
+            self.step_small(grad_scale, extra=extra)
         else:
             self._flat_step(self.params.flat.numel(), self._seg, self._n, grad_scale)
 
     def begin_step(self):
         self.t += 1
 
-    def step_sh(self, sh_views, grad_scale: float = 1.0):
+    def step_sh(self, sh_views, grad_scale: float = 1.0, dmean_extra=None):
         """The SH half of the step on the CURRENT stream (a trainer may run it on a second stream, next to step_small and the
         geometry half of the next forward).  `means3D` must hold the positions the views were rendered with."""
         C, p = self._C, self.params
@@ -252,26 +261,28 @@ class FlatAdam:
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             dcol, vstride = _view_rows(dcolor_all)
-            rc = self._lib.sgr_sh_adam_from_views(
+            rc = self._lib.sgr_sh_adam_from_views_ex(
                 p.P, int(dcolor_all.shape[0]), int(sh_degree), p.M, vp(means3D), vp(campos_all.contiguous()),
                 vp(dcol), int(vstride), C.c_void_p(p.flat.data_ptr() + 4 * off),
                 C.c_void_p(self.exp_avg.data_ptr() + 4 * off), C.c_void_p(self.exp_avg_sq.data_ptr() + 4 * off),
-                p.LRS["features"], p.REST_LR, self.betas[0], self.betas[1], self.eps, self.t, float(grad_scale), stream)
+                p.LRS["features"], p.REST_LR, self.betas[0], self.betas[1], self.eps, self.t, float(grad_scale),
+                C.c_void_p(dmean_extra.data_ptr()) if dmean_extra is not None else None, stream)
         if rc < 0:
             raise RuntimeError(f"sgr_sh_adam_from_views failed ({rc})")
 
-    def step_small(self, grad_scale: float = 1.0):
+    def step_small(self, grad_scale: float = 1.0, extra=None):
         """Everything but the SH tensor: the 11 other floats per Gaussian (positions included)."""
-        self._flat_step(self.params.n_small, self._seg_small, self._n_small, grad_scale)
+        self._flat_step(self.params.n_small, self._seg_small, self._n_small, grad_scale, extra)
 
-    def _flat_step(self, n_flat, seg, n_seg, grad_scale):
+    def _flat_step(self, n_flat, seg, n_seg, grad_scale, extra=None):
         C, p = self._C, self.params
         dev = p.flat.device
         vp = lambda t: C.c_void_p(t.data_ptr())
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            rc = self._lib.sgr_adam_step(n_flat, vp(p.flat), vp(p.flat_grad), vp(self.exp_avg), vp(self.exp_avg_sq), n_seg,
-                                         *seg, self.betas[0], self.betas[1], self.eps, self.t, float(grad_scale), stream)
+            rc = self._lib.sgr_adam_step_ex(n_flat, vp(p.flat), vp(p.flat_grad), vp(self.exp_avg), vp(self.exp_avg_sq), n_seg,
+                                            *seg, self.betas[0], self.betas[1], self.eps, self.t, float(grad_scale),
+                                            vp(extra) if extra is not None else None, 3 * p.P if extra is not None else 0, stream)
         if rc < 0:
             raise RuntimeError(f"sgr_adam_step failed ({rc})")
 
@@ -341,7 +352,7 @@ class ViewShardedTrainer:
 
     def __init__(self, params: GaussianParams, rasterizer_cls, settings_cls, bg, sh_degree=3, lambda_dssim=0.2,
                  fused_loss=True, compact_sh=None, sh_grad_fn=None, grad_sink_cm=None, fused_sh_adam=None, sync_free=None,
-                 visibility=False, fuse_activations=None):
+                 visibility=False, fuse_activations=None, sh_dir_in_adam=None):
         self.fused_loss = fused_loss
         self.params = params
         self.opt = params.make_optimizer()
@@ -353,6 +364,13 @@ class ViewShardedTrainer:
         # compact mode on a ROCm device: the SH gradient is consumed by the optimiser kernel itself
         self.fused_sh_adam = (self.compact_sh and isinstance(self.opt, FlatAdam) and sh_grad_fn is None) if fused_sh_adam is None \
             else bool(fused_sh_adam)
+        # Optional (off by default): the other use of the SH coefficients in the backward, dRGB/d(view direction) -> dL/dxyz, can
+        # move into the SH-Adam kernel as well: the rasterizer backward then never reads the SH tensor
+        # (SGR_MODE_SH_DIR_ELSEWHERE), the SH-Adam kernel forms the term for all views (every rank has their colour gradients
+        # and camera centres) and the flat Adam kernel adds it to the position gradient.  Measured: the backward preprocess
+        # kernel drops from 0.085 to 0.045 ms and the SH-Adam kernel gains as much (a serial prologue per wave in a kernel
+        # that lives on 12 waves per CU): +-1 % per step depending on the box.
+        self.sh_dir_in_adam = bool(sh_dir_in_adam) and self.fused_sh_adam and params.flat.is_cuda and params.M == 16
         if grad_sink_cm is None and params.flat.is_cuda:
             from .diff_gaussian_rasterization import grad_sink as grad_sink_cm
         self.grad_sink_cm = grad_sink_cm  # context manager factory honoured by the rasterizer's backward (None: plain autograd)
@@ -421,7 +439,7 @@ class ViewShardedTrainer:
                 sinks.update(raw_params=True, scales=p.params["scaling"].grad, rotations=p.params["rotation"].grad,
                              opacities=p.params["opacity"].grad)
             if self.compact_sh:
-                sinks.update(compact_sh=True, out=holder)
+                sinks.update(compact_sh=True, out=holder, sh_dir_elsewhere=self.sh_dir_in_adam)
                 if self.world > 1:
                     # the masked colour gradients land in the send buffer of the all-gather, followed by the camera centre
                     if self._send is None:
@@ -497,7 +515,8 @@ class ViewShardedTrainer:
                 # plain path: one flat all-reduce of all 59 floats per Gaussian
                 dist.all_reduce(p.flat_grad, op=dist.ReduceOp.SUM)
         if isinstance(self.opt, FlatAdam):
-            self.opt.step(grad_scale=scale, sh_views=sh_views, before_small=wait_small)  # (the mean over views is folded in)
+            self.opt.step(grad_scale=scale, sh_views=sh_views, before_small=wait_small,  # (the mean over views is folded in)
+                          sh_dir=self.sh_dir_in_adam and sh_views is not None)
         else:
             if self.world > 1:
                 p.flat_grad.mul_(scale)

@@ -78,6 +78,42 @@ def test_trainer_compact_and_flat_paths_agree():
     assert tr.compact_sh and tr.fused_sh_adam and tr.sync_free  # the defaults on a ROCm device
 
 
+def test_view_direction_term_formed_in_the_sh_adam_kernel_is_the_same_step():
+    """SGR_MODE_SH_DIR_ELSEWHERE + sgr_sh_adam_from_views_ex + sgr_adam_step_ex: the backward never reads the SH tensor, the
+    SH-Adam kernel forms dRGB/d(view direction) -> dL/dxyz and the flat Adam kernel adds it.  Same arithmetic in the same
+    order: the parameters after three steps differ from the path that keeps the term in the backward preprocess kernel by
+    no more than two runs of that path differ from each other (the blend backward's float atomics)."""
+    from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from sugar_amd.train_step import GaussianParams, ViewShardedTrainer
+    dev = torch.device(DEV)
+    scene = syn.make_scene(30001, 5, 0.01, 0.06)
+    cams = [c._replace(viewmatrix=c.viewmatrix.to(dev), projmatrix=c.projmatrix.to(dev), campos=c.campos.to(dev))
+            for c in syn.orbit_cameras(400, 240)]
+    gts = [torch.rand(3, 240, 400, generator=torch.Generator().manual_seed(i)).to(dev) for i in range(3)]
+    flats, extras = [], []
+    for elsewhere in (False, False, True):
+        p = GaussianParams(scene, dev)
+        tr = ViewShardedTrainer(p, GaussianRasterizer, GaussianRasterizationSettings, torch.zeros(3, device=dev),
+                                sh_dir_in_adam=elsewhere)
+        assert tr.fused_sh_adam and tr.sh_dir_in_adam == elsewhere
+        for i in range(3):
+            loss, _ = tr.step(cams[i], gts[i])
+            assert torch.isfinite(loss)
+        flats.append(p.flat.clone())
+        extras.append(tr.opt._dmean_extra)
+    assert extras[0] is None and float(extras[2].abs().max()) > 0  # the term is not identically zero
+    start = GaussianParams(scene, dev).flat
+    assert float((flats[0] - start).abs().max()) > 1e-4
+    # the blend backward's float atomics make two runs of the SAME configuration differ in the last bits, and Adam turns that
+    # into +-lr for near-zero gradients: the run-to-run spread is the yardstick
+    noise = float((flats[0] - flats[1]).norm())
+    diff = float((flats[0] - flats[2]).norm())
+    assert diff <= 3.0 * noise + 1e-7 * float((flats[0] - start).norm()), (diff, noise)
+    assert diff / float((flats[0] - start).norm()) < 1e-3
+    assert not ViewShardedTrainer(GaussianParams(scene, dev), GaussianRasterizer, GaussianRasterizationSettings,
+                                  torch.zeros(3, device=dev)).sh_dir_in_adam  # an option, off by default (no net gain measured)
+
+
 def test_fused_activations_match_torch_ops():
     """exp / F.normalize / sigmoid of the raw parameters (gaussian_model.py:92-117) and their autograd gradients"""
     from sugar_amd.train_step import GaussianParams
