@@ -108,8 +108,8 @@ def test_view_direction_term_formed_in_the_sh_adam_kernel_is_the_same_step():
     # into +-lr for near-zero gradients: the run-to-run spread is the yardstick
     noise = float((flats[0] - flats[1]).norm())
     diff = float((flats[0] - flats[2]).norm())
-    assert diff <= 3.0 * noise + 1e-7 * float((flats[0] - start).norm()), (diff, noise)
-    assert diff / float((flats[0] - start).norm()) < 1e-3
+    upd = float((flats[0] - start).norm())
+    assert diff <= max(3.0 * noise, 3e-4 * upd), (diff, noise, upd)
     assert not ViewShardedTrainer(GaussianParams(scene, dev), GaussianRasterizer, GaussianRasterizationSettings,
                                   torch.zeros(3, device=dev)).sh_dir_in_adam  # an option, off by default (no net gain measured)
 
