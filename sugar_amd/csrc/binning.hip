@@ -13,7 +13,8 @@
 //   gsort      : stable LSD radix sort (8-bit passes) of (depth_bits, gaussian_id) over the P Gaussians.  Culled
 //                Gaussians carry key 0xFFFFFFFF and sink to the end.  Ties keep ascending id.  The digits are taken from
 //                key - min(key) (culled: max + 1 - min), and when that range fits 24 bits -- depths within two or three
-//                binades, the rule -- the fourth pass is an identity and its kernels return at once.
+//                binades, the rule -- the fourth pass is an identity and its kernel returns at once.  One kernel per pass
+//                (chunk tickets + look-back through published per-digit counts), one histogram kernel for all passes.
 //                The last pass also carries each Gaussian's packed tile rectangle (8 bytes, written by the preprocess
 //                kernel) into sorted order: the walks below stream it.
 //   bin_count  : workgroup b owns a contiguous slice of the sorted order and a private histogram over all T tiles in LDS;
@@ -30,7 +31,8 @@
 // oracle and against the reference's own code (tests/test_gpu_parity.py, tests/test_gpu_reference.py).
 //
 // HBM traffic: ~100 B per Gaussian for the sort, 4 B per instance for point_list, 16 B per (workgroup, tile) of histogram
-// traffic -- versus ~144 B per INSTANCE for the reference's 6-pass radix sort of 12-byte pairs.  No global atomics.
+// traffic -- versus ~144 B per INSTANCE for the reference's 6-pass radix sort of 12-byte pairs.  Global atomics only in the
+// sort: 1024 digit counters and one ticket per workgroup and pass.
 #include "sgr_device.h"
 #include <cstdlib>
 
