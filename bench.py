@@ -117,12 +117,20 @@ def main():
     off_walk = lib.sgr_img_tile_walked_offset(W, H)
     off_maxc = lib.sgr_img_tile_maxc_offset(W, H)
     BLEND_FWD = STAGES.index("blend_fwd")
+    # Everything allocated so far (torch, numpy, the scene) goes to the collector's permanent generation: a full collection
+    # of the interpreter's ~10^6 tracked objects takes 50-120 ms, and one landing inside a 20-step window (it did, in about
+    # one run out of ten: ms_per_step 2.7-5.1 instead of 1.2, the excess independent of the step count) is not a property
+    # of the step.  The collector stays enabled; it just has nothing old to walk.
+    import gc
+    gc.collect()
+    gc.freeze()
     # ---- timed region: HIP events only around the graded kernel (every event pair costs GPU pipeline time)
     lib.sgr_profile_enable(0 if args.no_stage_events else (1 << BLEND_FWD))
     sync_all()
     t0 = time.perf_counter()
     for s in range(args.warmup, args.warmup + args.steps):
         trainer.step(cams_d[cam_index(s)], gts[cam_index(s)])
+    t_enq = time.perf_counter()  # (diagnostic: when the host finished enqueueing; equal to t1 means the loop was host-bound)
     sync_all()
     t1 = time.perf_counter()
     lib.sgr_profile_enable(0)
@@ -193,6 +201,7 @@ def main():
                 "instances_per_view": R, "instances_walked_fwd": R_f, "instances_walked_bwd": R_b,
             },
             "ms_fwd_bwd": sum(stages.values()),
+            "host_enqueue_ms_per_step": 1e3 * (t_enq - t0) / K,  # below ms_per_step: the GPU, not the Python loop, set the pace
             "stages_ms": stages,
             "roofline": {
                 "kernel": "k_blend_fwd_w", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
