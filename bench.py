@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="skip the per-stage HIP events (debug: measures their cost)")
     ap.add_argument("--no-fuse-activations", action="store_true", help="stand-alone activation kernels (A/B of the raw-parameter mode)")
+    ap.add_argument("--preroll", type=int, default=600, help="untimed steps before the warm-up steps (parameters restored afterwards); 0: none")
     ap.add_argument("--sh-dir-in-adam", action="store_true", help="form dRGB/d(view direction) -> dL/dxyz in the SH-Adam kernel instead of the backward preprocess kernel (A/B)")
     ap.add_argument("--host-sync", action="store_true", help="forward with the host round trip for num_rendered (A/B of the sync-free forward)")
     args = ap.parse_args()
@@ -107,10 +108,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # pre-roll (untimed, before the W warm-up steps): every camera once, so that the caching allocator has seen the scratch
-    # sizes of all views and the list capacity of the sync-free forward has settled before anything is timed
-    for s in range(len(cams)):
-        trainer.step(cams_d[(s * world + rank) % len(cams)], gts[(s * world + rank) % len(cams)])
+    # Pre-roll (untimed, before the W warm-up steps).  A process reaches this point with the GPU idle for the ~15 s of imports
+    # and scene generation, and the first few hundred milliseconds of load after that can run well below the steady rate
+    # (scripts/sustained.py: the first 20-step window at 4.5 ms/step and the next 250 steps 15 % slow in one process, 1.26
+    # and nominal in the next; bench.py itself: about one run in ten at 2.7-5.1 ms/step).  So the step is run for ~0.7 s
+    # first -- which also shows the caching allocator the scratch sizes of every view and settles the list capacity of the
+    # sync-free forward -- and then parameters and optimiser state are put back: the timed steps see the scene as defined,
+    # not one that 600 Adam steps towards random targets have changed (R drops 18.7M -> 14M and the walked depth grows).
+    if args.preroll > 0:
+        opt = trainer.opt
+        snap = (params.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.t) if hasattr(opt, "exp_avg") else None
+        for s in range(max(args.preroll, len(cams))):
+            trainer.step(cams_d[(s * world + rank) % len(cams)], gts[(s * world + rank) % len(cams)])
+        if snap is not None:
+            with torch.no_grad():
+                params.flat.copy_(snap[0]); opt.exp_avg.copy_(snap[1]); opt.exp_avg_sq.copy_(snap[2])
+            opt.t = snap[3]
+            del snap
     for s in range(args.warmup):
         trainer.step(cams_d[cam_index(s)], gts[cam_index(s)])
     T = ((W + 15) // 16) * ((H + 15) // 16)
