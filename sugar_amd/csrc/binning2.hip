@@ -129,16 +129,25 @@ __global__ void __launch_bounds__(64) k_sup_scatter(int P, int sgx, int T1, int 
     uint32_t* s_pair = s_cnt + T1;
     const int lane = threadIdx.x;
     const uint32_t* row = hist1 + (size_t)blockIdx.x * T1;
-    for (int t = lane; t < T1; t += 64) s_cnt[t] = sup_start[t] + row[t];
+    for (int tb = 0; tb < T1; tb += 256) {  // (four loads of each table in flight: a plain loop waits for every pair)
+        uint32_t a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const int t = min(tb + 64 * j + lane, T1 - 1); a[j] = sup_start[t]; b[j] = row[t]; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const int t = tb + 64 * j + lane; if (t < T1) s_cnt[t] = a[j] + b[j]; }
+    }
     WAVE_FENCE();
     const int begin = blockIdx.x * per_slice;
     const int end = min(P, begin + per_slice);
+    uint2 r_next = rects[min(begin + lane, P - 1)];  // the next step's rectangle travels while this step is scattered
     for (int base = begin; base < end; base += 64) {
         const int s = base + lane;
+        const uint2 r_cur = r_next;
+        r_next = rects[min(s + 64, P - 1)];
         int t0 = 0, w = 1, n = 0;
         if (s < end) {
             int sx0, sy0, w1, h1;
-            if (sup_rect(rects[s], sx0, sy0, w1, h1)) { w = w1; n = w1 * h1; t0 = sy0 * sgx + sx0; }
+            if (sup_rect(r_cur, sx0, sy0, w1, h1)) { w = w1; n = w1 * h1; t0 = sy0 * sgx + sx0; }
         }
         if (__ballot(n > SGR_B2_MAXN) == 0ull) {
             // exclusive prefix of n over the lanes: the pairs of this step, ordered by Gaussian
