@@ -125,11 +125,14 @@ __global__ void __launch_bounds__(256) k_rs_prepare(int n, const uint32_t* __res
 #pragma unroll
     for (int p = 0; p < 4; p++) status[((size_t)p * n_chunks + blockIdx.x) * 256 + threadIdx.x] = 0u;
     const int base = blockIdx.x * RS_ITEMS;
+    uint32_t kk[RS_ITEMS / 256];  // (all of the chunk's keys requested before the first is used)
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS / 256; i++) kk[i] = keys[min(base + i * 256 + (int)threadIdx.x, n - 1)];
 #pragma unroll
     for (int i = 0; i < RS_ITEMS / 256; i++) {
         const int k = base + i * 256 + threadIdx.x;
         if (k < n) {
-            const uint32_t key = keys[k];
+            const uint32_t key = kk[i];
             const uint32_t nk = (key == 0xFFFFFFFFu ? kmax1 : key) - kmin;
             atomicAdd(&s_h[0][nk & 255u], 1u);
             atomicAdd(&s_h[1][(nk >> 8) & 255u], 1u);
