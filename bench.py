@@ -132,9 +132,9 @@ def main():
     off_maxc = lib.sgr_img_tile_maxc_offset(W, H)
     BLEND_FWD = STAGES.index("blend_fwd")
     # Everything allocated so far (torch, numpy, the scene) goes to the collector's permanent generation: a full collection
-    # of the interpreter's ~10^6 tracked objects takes 50-120 ms, and one landing inside a 20-step window (it did, in about
-    # one run out of ten: ms_per_step 2.7-5.1 instead of 1.2, the excess independent of the step count) is not a property
-    # of the step.  The collector stays enabled; it just has nothing old to walk.
+    # of the interpreter's 2 x 10^5 tracked objects takes tens of ms, and one landing inside a 20-step window would not be a
+    # property of the step.  (A precaution: scripts/gc_outliers.py saw no full collection in 1200 steps; the intermittent slow
+    # windows were the start-up transient handled by the pre-roll above.)  The collector stays enabled.
     import gc
     gc.collect()
     gc.freeze()
