@@ -27,6 +27,23 @@ namespace {
 
 struct Win { float w[11]; };
 
+// Workgroup b runs on XCD b % 8 (its own L2).  With the tiles handed out in raster order no two neighbouring tiles ever share
+// an L2 and every tile fetches its whole halo from the fabric (rocprofv3 FETCH_SIZE: 2.2x the image bytes in the forward, 1.7x
+// the maps in the backward).  Here XCD k takes the k-th eighth of the (channel, row, column) tile order instead, so that the
+// tiles it works on at about the same time are neighbours.  Returns false for the padding workgroups.
+__device__ __forceinline__ bool xcd_tile(int tiles_x, int tiles_y, int n_tiles, int& tile, int& c, int& ty, int& tx)
+{
+    const int per = (n_tiles + 7) >> 3;
+    const int b = blockIdx.x, j = b >> 3;
+    tile = (b & 7) * per + j;
+    if (j >= per || tile >= n_tiles) return false;
+    c = tile / (tiles_x * tiles_y);
+    const int r = tile - c * (tiles_x * tiles_y);
+    ty = r / tiles_x;
+    tx = r - ty * tiles_x;
+    return true;
+}
+
 // conv2d(padding=5) reads zeros outside the image: loads go to the clamped pixel (always a valid address, so they can
 // be issued unconditionally and in a batch) and the value is replaced by zero afterwards
 __device__ __forceinline__ bool in_image(int W, int H, int x, int y) { return x >= 0 && x < W && y >= 0 && y < H; }
@@ -45,7 +62,7 @@ __device__ __forceinline__ unsigned ld_clamped(int W, int H, int x, int y)  // o
 // halves the instruction count of a kernel that is bound by how fast its few resident waves issue.
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-__global__ void __launch_bounds__(256, 4) k_l1_ssim_fwd(int W, int H, const float* __restrict__ X,
+__global__ void __launch_bounds__(256, 4) k_l1_ssim_fwd(int W, int H, int tiles_x, int tiles_y, int n_tiles, const float* __restrict__ X,
                                                              const float* __restrict__ Y, Win win, float* __restrict__ dm1,
                                                              float* __restrict__ ds1, float* __restrict__ ds12,
                                                              float2* __restrict__ partial)
@@ -56,9 +73,10 @@ __global__ void __launch_bounds__(256, 4) k_l1_ssim_fwd(int W, int H, const floa
     __shared__ f2 hm[LRY][LTP];       // rows filtered: {mu1, mu2}
     __shared__ f2 hs[LRY][LTP];       //                {E[x^2 + y^2], E[xy]}
     __shared__ float red[2][4];
-    const int c = blockIdx.z;
+    int tile, c, tby, tbx;
+    if (!xcd_tile(tiles_x, tiles_y, n_tiles, tile, c, tby, tbx)) return;
     const size_t plane = (size_t)c * W * H;
-    const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LTY;
+    const int x0 = tbx * LT, y0 = tby * LTY;
     const int tid = threadIdx.x;
     {
         // Staging: wave w takes the staged rows w, w + 4, ..., lane = staged column.  The row part of every address and of
@@ -153,8 +171,7 @@ __global__ void __launch_bounds__(256, 4) k_l1_ssim_fwd(int W, int H, const floa
     __syncthreads();
     // one partial per workgroup; k_l1_ssim_finish adds them in double (same-address device atomics cost 0.5 ms)
     if (tid == 0) {
-        const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        partial[blk] = make_float2(red[0][0] + red[0][1] + red[0][2] + red[0][3], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        partial[tile] = make_float2(red[0][0] + red[0][1] + red[0][2] + red[0][3], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
     }
 }
 
@@ -179,7 +196,8 @@ __global__ void __launch_bounds__(1024) k_l1_ssim_finish(const float2* __restric
 
 // (the backward keeps 32 x 32 tiles: with 28 rows it was 11 % slower)  Three maps are windowed: {dS/dmu1, dS/dE[x^2]} travel
 // as a float2 pair (packed multiply-adds, 8-byte LDS accesses), dS/dE[xy] on its own.
-__global__ void __launch_bounds__(256) k_l1_ssim_bwd(int W, int H, const float* __restrict__ X, const float* __restrict__ Y,
+__global__ void __launch_bounds__(256) k_l1_ssim_bwd(int W, int H, int tiles_x, int tiles_y, int n_tiles, const float* __restrict__ X,
+                                                     const float* __restrict__ Y,
                                                      Win win, const float* __restrict__ dm1, const float* __restrict__ ds1,
                                                      const float* __restrict__ ds12, const float* __restrict__ grad_loss,
                                                      float lambda, float inv_n, float* __restrict__ dX)
@@ -188,9 +206,10 @@ __global__ void __launch_bounds__(256) k_l1_ssim_bwd(int W, int H, const float* 
     __shared__ float sq[LR][LRP];
     __shared__ f2 hp[LR][LTP];
     __shared__ float hq[LR][LTP];
-    const int c = blockIdx.z;
+    int tile, c, tby, tbx;
+    if (!xcd_tile(tiles_x, tiles_y, n_tiles, tile, c, tby, tbx)) return;
     const size_t plane = (size_t)c * W * H;
-    const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
+    const int x0 = tbx * LT, y0 = tby * LT;
     const int tid = threadIdx.x;
     const int lx = tid & 31, lg = tid >> 5;
     const int px = x0 + lx;
@@ -297,10 +316,11 @@ int sgr_l1_ssim_forward(int channels, int width, int height, const float* img, c
     float* ds1 = reinterpret_cast<float*>(scratch + plane);
     float* ds12 = reinterpret_cast<float*>(scratch + 2 * plane);
     float2* partial = reinterpret_cast<float2*>(scratch + 3 * plane);
-    dim3 grid((width + LT - 1) / LT, (height + LTY - 1) / LTY, channels);
-    hipLaunchKernelGGL(k_l1_ssim_fwd, grid, dim3(256), 0, s, width, height, img, gt, make_window(), dm1, ds1, ds12, partial);
-    hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(1024), 0, s, partial, (int)(grid.x * grid.y * grid.z),
-                       (double)channels * width * height, lambda, loss_out);
+    const int tiles_x = (width + LT - 1) / LT, tiles_y = (height + LTY - 1) / LTY, n_tiles = tiles_x * tiles_y * channels;
+    hipLaunchKernelGGL(k_l1_ssim_fwd, dim3(8 * ((n_tiles + 7) / 8)), dim3(256), 0, s, width, height, tiles_x, tiles_y, n_tiles, img, gt,
+                       make_window(), dm1, ds1, ds12, partial);
+    hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(1024), 0, s, partial, n_tiles, (double)channels * width * height, lambda,
+                       loss_out);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 
@@ -313,10 +333,10 @@ int sgr_l1_ssim_backward(int channels, int width, int height, const float* img, 
     const float* dm1 = reinterpret_cast<const float*>(scratch);
     const float* ds1 = reinterpret_cast<const float*>(scratch + plane);
     const float* ds12 = reinterpret_cast<const float*>(scratch + 2 * plane);
-    dim3 grid((width + LT - 1) / LT, (height + LT - 1) / LT, channels);
+    const int tiles_x = (width + LT - 1) / LT, tiles_y = (height + LT - 1) / LT, n_tiles = tiles_x * tiles_y * channels;
     const float inv_n = (float)(1.0 / ((double)channels * width * height));
-    hipLaunchKernelGGL(k_l1_ssim_bwd, grid, dim3(256), 0, s, width, height, img, gt, make_window(), dm1, ds1, ds12, grad_loss,
-                       lambda, inv_n, grad_img);
+    hipLaunchKernelGGL(k_l1_ssim_bwd, dim3(8 * ((n_tiles + 7) / 8)), dim3(256), 0, s, width, height, tiles_x, tiles_y, n_tiles, img, gt,
+                       make_window(), dm1, ds1, ds12, grad_loss, lambda, inv_n, grad_img);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 
