@@ -120,9 +120,10 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m)  // set bi
 // batches are sequential: a super-tile's list comes out in depth order.  The entry is the Gaussian's position in the
 // depth order (rects[] and order[] are indexed by it).
 __global__ void __launch_bounds__(64) k_sup_scatter(int P, int sgx, int T1, int key_bits, int per_slice,
-                                                    const uint2* __restrict__ rects, const uint32_t* __restrict__ sup_start,
+                                                    const uint2* __restrict__ rects, const uint32_t* __restrict__ order,
+                                                    const uint32_t* __restrict__ sup_start,
                                                     const uint32_t* __restrict__ hist1, const uint32_t* __restrict__ hdr,
-                                                    uint32_t* __restrict__ L1)
+                                                    uint4* __restrict__ L1)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_cnt[];  // [T1] running slots, then [64 * SGR_B2_MAXN] pairs
     if (hdr[SGR_B2_HDR_OVERFLOW]) return;
@@ -139,11 +140,15 @@ __global__ void __launch_bounds__(64) k_sup_scatter(int P, int sgx, int T1, int 
     WAVE_FENCE();
     const int begin = blockIdx.x * per_slice;
     const int end = min(P, begin + per_slice);
-    uint2 r_next = rects[min(begin + lane, P - 1)];  // the next step's rectangle travels while this step is scattered
+    // (the next step's rectangle and id travel while this step is scattered)
+    uint2 r_next = rects[min(begin + lane, P - 1)];
+    uint32_t id_next = order[min(begin + lane, P - 1)];
     for (int base = begin; base < end; base += 64) {
         const int s = base + lane;
         const uint2 r_cur = r_next;
+        const uint32_t id_cur = id_next;
         r_next = rects[min(s + 64, P - 1)];
+        id_next = order[min(s + 64, P - 1)];
         int t0 = 0, w = 1, n = 0;
         if (s < end) {
             int sx0, sy0, w1, h1;
@@ -179,7 +184,13 @@ __global__ void __launch_bounds__(64) k_sup_scatter(int P, int sgx, int T1, int 
                 if (on && rank == 0) slot = atomicAdd(&s_cnt[key], (uint32_t)__popcll(mm));
                 const int leader = on ? (int)__builtin_ctzll(mm) : lane;
                 slot = (uint32_t)__shfl((int)slot, leader);
-                if (on) L1[slot + rank] = (uint32_t)base + (v & 0xFFu);
+                // the entry is self-contained -- {packed rectangle, Gaussian id} of the lane that owns the pair -- so the tile
+                // passes stream 16 bytes per entry instead of chasing position -> rectangle -> id through two gathers (4- and
+                // 8-byte reads of 64-byte sectors: 330 MiB fetched for 40 MB of data, rocprofv3 FETCH_SIZE)
+                const int owner = (int)(v & 0xFFu);
+                const uint4 ent = make_uint4((uint32_t)__shfl((int)r_cur.x, owner), (uint32_t)__shfl((int)r_cur.y, owner),
+                                             (uint32_t)__shfl((int)id_cur, owner), 0u);
+                if (on) L1[slot + rank] = ent;
                 asm volatile("" ::: "memory");  // keep the batches' atomics in program order (compiler only)
             }
             WAVE_FENCE();  // s_pair is rewritten by the next step
@@ -191,10 +202,12 @@ __global__ void __launch_bounds__(64) k_sup_scatter(int P, int sgx, int T1, int 
                 todo &= todo - 1;
                 const int jn = __builtin_amdgcn_readlane(n, j), jw = __builtin_amdgcn_readlane(w, j);
                 const int jt = __builtin_amdgcn_readlane(t0, j);
+                const uint4 ent = make_uint4((uint32_t)__builtin_amdgcn_readlane((int)r_cur.x, j), (uint32_t)__builtin_amdgcn_readlane((int)r_cur.y, j),
+                                             (uint32_t)__builtin_amdgcn_readlane((int)id_cur, j), 0u);
                 for (int k = lane; k < jn; k += 64) {
                     const int ty = k / jw;
                     const uint32_t sl = atomicAdd(&s_cnt[jt + ty * sgx + (k - ty * jw)], 1u);
-                    L1[sl] = (uint32_t)(base + j);
+                    L1[sl] = ent;
                 }
                 asm volatile("" ::: "memory");
             }
@@ -228,9 +241,8 @@ __device__ __forceinline__ void tile_mask(uint2 r, int ox, int oy, uint32_t& lo,
 template <bool WRITE>
 __global__ void __launch_bounds__(64) k_tile_pass(int gx, int gy, int sgx, int T1, const uint32_t* __restrict__ sup_start,
                                                   const uint32_t* __restrict__ chunk_base, const uint32_t* __restrict__ chunk_sup,
-                                                  const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ L1,
-                                                  const uint2* __restrict__ rects,
-                                                  const uint32_t* __restrict__ order, uint32_t* __restrict__ cnt2,
+                                                  const uint32_t* __restrict__ hdr, const uint4* __restrict__ L1,
+                                                  uint32_t* __restrict__ cnt2,
                                                   const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ point_list,
                                                   uint32_t list_cap)
 {
@@ -247,7 +259,7 @@ __global__ void __launch_bounds__(64) k_tile_pass(int gx, int gy, int sgx, int T
             uint32_t run = 0;  // lane t: entries of this chunk covering tile t
             for (int b = 0; b < n; b += 64) {
                 uint32_t lo = 0u, hi = 0u;
-                if (b + lane < n) tile_mask(rects[L1[e0 + b + lane]], ox, oy, lo, hi);
+                if (b + lane < n) { const uint4 e = L1[e0 + b + lane]; tile_mask(make_uint2(e.x, e.y), ox, oy, lo, hi); }
                 uint32_t add = 0;
 #pragma unroll
                 for (int t = 0; t < 32; t++) {
@@ -268,9 +280,9 @@ __global__ void __launch_bounds__(64) k_tile_pass(int gx, int gy, int sgx, int T
             for (int b = 0; b < SGR_B2_BATCHES; b++) {
                 lo[b] = 0u; hi[b] = 0u; id[b] = 0u;
                 if (b * 64 + lane < n) {
-                    const uint32_t i = L1[e0 + b * 64 + lane];
-                    tile_mask(rects[i], ox, oy, lo[b], hi[b]);
-                    id[b] = order[i];
+                    const uint4 e = L1[e0 + b * 64 + lane];
+                    tile_mask(make_uint2(e.x, e.y), ox, oy, lo[b], hi[b]);
+                    id[b] = e.z;
                 }
             }
             // lane t: first slot of tile t's segment for this chunk
@@ -389,7 +401,7 @@ Bin2Layout sgr_bin2_layout(int P, int gx, int gy)
     L.sup_start = off;  off = sgr_align(off + (size_t)(L.T1 + 1) * 4);
     L.chunk_base = off; off = sgr_align(off + (size_t)(L.T1 + 1) * 4);
     L.hdr = off;        off = sgr_align(off + 64);
-    L.L1 = off;         off = sgr_align(off + (size_t)L.cap1 * 4);
+    L.L1 = off;         off = sgr_align(off + (size_t)L.cap1 * 16);  // {packed rectangle, id, -} per entry
     L.cnt2 = off;       off = sgr_align(off + (size_t)L.chunk_cap * 64 * 4);
     L.chunk_sup = off;  off = sgr_align(off + (size_t)L.chunk_cap * 4);
     L.total = off;
@@ -398,13 +410,13 @@ Bin2Layout sgr_bin2_layout(int P, int gx, int gy)
 
 // level 1 + the counting half of level 2: leaves tile_count[T] (consumed by sgr_launch_tile_scan) and the header
 void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scratch, uint32_t* hdr, const uint2* rects,
-                           uint32_t* tile_count, hipStream_t s)
+                           const uint32_t* order, uint32_t* tile_count, hipStream_t s)
 {
     uint32_t* hist1 = reinterpret_cast<uint32_t*>(scratch + L.hist1);
     uint32_t* sup_count = reinterpret_cast<uint32_t*>(scratch + L.sup_count);
     uint32_t* sup_start = reinterpret_cast<uint32_t*>(scratch + L.sup_start);
     uint32_t* chunk_base = reinterpret_cast<uint32_t*>(scratch + L.chunk_base);
-    uint32_t* L1 = reinterpret_cast<uint32_t*>(scratch + L.L1);
+    uint4* L1 = reinterpret_cast<uint4*>(scratch + L.L1);
     uint32_t* cnt2 = reinterpret_cast<uint32_t*>(scratch + L.cnt2);
     uint32_t* chunk_sup = reinterpret_cast<uint32_t*>(scratch + L.chunk_sup);
     static size_t conf_a = 0, conf_b = 0;
@@ -417,11 +429,11 @@ void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scr
     hipLaunchKernelGGL(k_sup_hist_scan, dim3(L.T1), dim3(256), 0, s, L.T1, hist1, sup_count);
     hipLaunchKernelGGL(k_sup_scan, dim3(1), dim3(1024), 0, s, L.T1, L.cap1, L.chunk_cap, sup_count, sup_start, chunk_base,
                        chunk_sup, hdr);
-    hipLaunchKernelGGL(k_sup_scatter, dim3(SGR_B2_SLICES), dim3(64), lds_sc, s, P, L.sgx, L.T1, key_bits, L.per_slice, rects,
+    hipLaunchKernelGGL(k_sup_scatter, dim3(SGR_B2_SLICES), dim3(64), lds_sc, s, P, L.sgx, L.T1, key_bits, L.per_slice, rects, order,
                        sup_start, hist1, hdr, L1);
     const uint32_t grid = L.chunk_cap < 8192u ? L.chunk_cap : 8192u;  // the chunk count lives on the device: grid-stride
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_pass<false>), dim3(grid), dim3(64), 0, s, gx, gy, L.sgx, L.T1, sup_start, chunk_base,
-                       chunk_sup, hdr, L1, rects, (const uint32_t*)nullptr, cnt2, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
+                       chunk_sup, hdr, L1, cnt2, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
     hipLaunchKernelGGL(k_tile_scan2, dim3(L.T1), dim3(64), 0, s, gx, gy, L.sgx, chunk_base, hdr, cnt2, tile_count);
 }
 
@@ -431,9 +443,9 @@ void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, c
     if (n_chunks == 0) return;
     const uint32_t* sup_start = reinterpret_cast<const uint32_t*>(scratch + L.sup_start);
     const uint32_t* chunk_base = reinterpret_cast<const uint32_t*>(scratch + L.chunk_base);
-    const uint32_t* L1 = reinterpret_cast<const uint32_t*>(scratch + L.L1);
+    const uint4* L1 = reinterpret_cast<const uint4*>(scratch + L.L1);
     uint32_t* cnt2 = reinterpret_cast<uint32_t*>(scratch + L.cnt2);
     const uint32_t* chunk_sup = reinterpret_cast<const uint32_t*>(scratch + L.chunk_sup);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_pass<true>), dim3(n_chunks), dim3(64), 0, s, gx, gy, L.sgx, L.T1, sup_start,
-                       chunk_base, chunk_sup, hdr, L1, rects, order, cnt2, tile_start, point_list, list_cap);
+                       chunk_base, chunk_sup, hdr, L1, cnt2, tile_start, point_list, list_cap);
 }

@@ -221,7 +221,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     {
         StageTimer t(s, SGR_STAGE_SCAN);
         if (two_level) {
-            sgr_launch_bin2_count(P, IL.gx, IL.gy, B2, bin2, header + 4, rects, tile_cursor, s);
+            sgr_launch_bin2_count(P, IL.gx, IL.gy, B2, bin2, header + 4, rects, order, tile_cursor, s);
         } else {
             sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, blk_hist, s);
             sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
