@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--no-fuse-activations", action="store_true", help="stand-alone activation kernels (A/B of the raw-parameter mode)")
     ap.add_argument("--preroll", type=int, default=600, help="untimed steps before the warm-up steps (parameters restored afterwards); 0: none")
     ap.add_argument("--sh-dir-in-adam", action="store_true", help="form dRGB/d(view direction) -> dL/dxyz in the SH-Adam kernel instead of the backward preprocess kernel (A/B)")
+    ap.add_argument("--force-collectives", action="store_true", help="N = 1: create a one-rank RCCL group and run the gradient exchange anyway (exercises the collective path on one GPU)")
     ap.add_argument("--host-sync", action="store_true", help="forward with the host round trip for num_rendered (A/B of the sync-free forward)")
     args = ap.parse_args()
 
@@ -68,8 +69,11 @@ def main():
     local_dev = local_rank % n_dev
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1:
+    use_group = world > 1 or args.force_collectives
+    if use_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29531"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -97,7 +101,7 @@ def main():
     trainer = ViewShardedTrainer(params, GaussianRasterizer, GaussianRasterizationSettings, bg_d,
                                  sync_free=False if args.host_sync else None,
                                  fuse_activations=False if args.no_fuse_activations else None,
-                                 sh_dir_in_adam=args.sh_dir_in_adam)
+                                 sh_dir_in_adam=args.sh_dir_in_adam, force_collectives=args.force_collectives)
 
     def cam_index(step):
         return (step * world + rank) % len(cams)
@@ -177,6 +181,28 @@ def main():
     if blend_ms == 0.0:
         blend_ms = stages["blend_fwd"]
 
+    # ---- what the collectives cost the step: the same K steps once more with and once without the gradient exchange (after the
+    # graded region; without the exchange the replicas drift apart, which is irrelevant for a timing)
+    comm = None
+    if trainer.exchange:
+        def timed(first):
+            sync_all()
+            ta = time.perf_counter()
+            for s in range(first, first + args.steps):
+                trainer.step(cams_d[cam_index(s)], gts[cam_index(s)])
+            sync_all()
+            el = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            return 1e3 * float(el.item()) / args.steps
+        base = args.warmup + args.steps + n_post
+        with_c = timed(base)
+        trainer.exchange = False
+        without_c = timed(base + args.steps)
+        trainer.exchange = True
+        comm = {"ms_per_step_with_collectives": with_c, "ms_per_step_without_collectives": without_c,
+                "comm_exposed_ms": with_c - without_c}
+
     if rank == 0:
         K = args.steps
         R_f = float(walked.item()) / n_post
@@ -224,10 +250,13 @@ def main():
                 "pair_evals_per_s": (256.0 * R_f) / (blend_ms * 1e-3) if blend_ms > 0 else 0.0,
             },
         }
+        if comm is not None:
+            out.update(comm)
+            out["config"]["collectives"] = "forced on a one-rank RCCL group" if world == 1 else "RCCL"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cams[0], bg)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_group:
         dist.barrier()
         dist.destroy_process_group()
 

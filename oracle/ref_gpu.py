@@ -19,13 +19,30 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_ref", "libref_rasterizer.so")  # compiler-default FMA contraction (A/B baseline)
 LIB_PATH_NOCONTRACT = os.path.join(_HERE, "_ref", "libref_rasterizer_nocontract.so")  # -ffp-contract=off (bit-exact pin)
+LIB_PATH_KNN = os.path.join(_HERE, "_ref", "libref_simple_knn.so")  # the reference's simple-knn (distCUDA2), -ffp-contract=off
 _ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 _libs = {}
 _variant = "default"
 
 
 def available() -> bool:
-    return os.path.exists(LIB_PATH) and os.path.exists(LIB_PATH_NOCONTRACT)
+    return os.path.exists(LIB_PATH) and os.path.exists(LIB_PATH_NOCONTRACT) and os.path.exists(LIB_PATH_KNN)
+
+
+def dist2(points: torch.Tensor) -> torch.Tensor:
+    """The reference's `distCUDA2` (simple_knn.cu:185-221 through spatial.cu:15-26): mean squared distance to the three
+    nearest other points.  points: float32 [P,3] on the GPU."""
+    if "knn" not in _libs:
+        L = C.CDLL(LIB_PATH_KNN)
+        L.ref_dist2.restype = None
+        L.ref_dist2.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        _libs["knn"] = L
+    pts = points.contiguous().float()
+    out = torch.zeros(pts.shape[0], dtype=torch.float32, device=pts.device)  # spatial.cu:19: torch::full({P}, 0.0)
+    torch.cuda.synchronize(pts.device)
+    _libs["knn"].ref_dist2(pts.shape[0], C.c_void_p(pts.data_ptr()), C.c_void_p(out.data_ptr()))
+    torch.cuda.synchronize(pts.device)
+    return out
 
 
 def use(variant: str):

@@ -352,13 +352,20 @@ class ViewShardedTrainer:
 
     def __init__(self, params: GaussianParams, rasterizer_cls, settings_cls, bg, sh_degree=3, lambda_dssim=0.2,
                  fused_loss=True, compact_sh=None, sh_grad_fn=None, grad_sink_cm=None, fused_sh_adam=None, sync_free=None,
-                 visibility=False, fuse_activations=None, sh_dir_in_adam=None):
+                 visibility=False, fuse_activations=None, sh_dir_in_adam=None, force_collectives=False, params_only=True):
         self.fused_loss = fused_loss
         self.params = params
         self.opt = params.make_optimizer()
         self.rasterizer_cls, self.settings_cls = rasterizer_cls, settings_cls
         self.bg, self.sh_degree, self.lambda_dssim = bg, sh_degree, lambda_dssim
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # the gradient exchange runs when there is more than one rank -- or on request with a single-rank process group
+        # (`force_collectives`: the all-gather started from inside the backward, the asynchronous all-reduce and their stream
+        # semantics execute on the real backend, RCCL on a one-GPU box, with nothing to exchange)
+        self.exchange = self.world > 1 or (bool(force_collectives) and dist.is_available() and dist.is_initialized())
+        # `params_only=False`: the rasterizer backward also delivers dL/dmeans2D (pkg["viewspace_points"].grad), which the
+        # densification statistics of train.py:111-123 / sugar_densifier.py:156-164 need; the lean default skips it
+        self.params_only = bool(params_only)
         self.compact_sh = params.flat.is_cuda if compact_sh is None else bool(compact_sh)
         self.sh_grad_fn = sh_grad_fn or sh_grad_from_views
         # compact mode on a ROCm device: the SH gradient is consumed by the optimiser kernel itself
@@ -434,13 +441,13 @@ class ViewShardedTrainer:
         leaves = [p.params[k] for k in names]
         holder = {}
         if self.grad_sink_cm is not None:
-            sinks = dict(means3D=p.params["xyz"].grad, params_only=True)
+            sinks = dict(means3D=p.params["xyz"].grad, params_only=self.params_only)
             if self.fuse_activations:
                 sinks.update(raw_params=True, scales=p.params["scaling"].grad, rotations=p.params["rotation"].grad,
                              opacities=p.params["opacity"].grad)
             if self.compact_sh:
                 sinks.update(compact_sh=True, out=holder, sh_dir_elsewhere=self.sh_dir_in_adam)
-                if self.world > 1:
+                if self.exchange:
                     # the masked colour gradients land in the send buffer of the all-gather, followed by the camera centre
                     if self._send is None:
                         self._send = torch.empty(p.P + 1, 3, dtype=torch.float32, device=p.flat.device)
@@ -484,7 +491,7 @@ class ViewShardedTrainer:
             if self.compact_sh:
                 g_rgb = holder["masked_colors"].contiguous()
                 campos = cam.campos.reshape(1, 3).to(g_rgb.dtype).contiguous()
-                if self.world > 1:
+                if self.exchange:
                     P_ = g_rgb.shape[0]
                     if self._send is None or g_rgb.device != self._send.device:  # (a rasterizer that ignored the sink)
                         self._send = torch.empty(P_ + 1, 3, dtype=g_rgb.dtype, device=g_rgb.device)
@@ -511,7 +518,7 @@ class ViewShardedTrainer:
                     sh_views = (p.params["xyz"].detach(), all_cam, all_rgb, self.sh_degree)
                 else:
                     self.sh_grad_fn(p.params["xyz"].detach(), all_cam, all_rgb, self.sh_degree, p.params["features"].grad)
-            elif self.world > 1:
+            elif self.exchange:
                 # plain path: one flat all-reduce of all 59 floats per Gaussian
                 dist.all_reduce(p.flat_grad, op=dist.ReduceOp.SUM)
         if isinstance(self.opt, FlatAdam):

@@ -6,8 +6,8 @@ Bar (BASELINE.json north_star):
     depth-sorted per-tile Gaussian lists are compared BIT-EXACTLY;
   * rendered RGB and gradients within 1e-4 relative.  The blend uses the hardware exp2 path while the oracle uses
     expf, and the backward sums in a different order (the reference's own atomics are order-nondeterministic), so
-    these are checked norm-wise (<= 1e-4) and element-wise with a floor of 1e-3 * max|ref| (>= 99.9 % of elements
-    within 1e-4 for the image, >= 99 % within 1e-3 for gradients).
+    these are checked norm-wise (<= 1e-5 image, <= 1e-4 gradients) and element-wise with a floor of 1e-3 * max|ref|
+    (>= 99.9 % of the elements within 1e-4, image and every gradient tensor alike).
 """
 import numpy as np
 import pytest
@@ -23,7 +23,7 @@ GRAD_NAMES = dict(means3D="dL_dmeans3D", means2D="dL_dmeans2D", opacities="dL_do
                   colors_precomp="dL_dcolors", scales="dL_dscales", rotations="dL_drotations", cov3D_precomp="dL_dcov3D")
 
 
-def _check(scene, cam, bg, grads=True, **opts):
+def _check(scene, cam, bg, grads=True, grad_frac=1e-3, **opts):
     st = pu.run_oracle(scene, cam, bg, **opts)
     H, W = cam.image_height, cam.image_width
     g = np.random.default_rng(0).standard_normal((3, H, W)).astype(np.float32)
@@ -58,9 +58,9 @@ def _check(scene, cam, bg, grads=True, **opts):
         for k, v in hp["grads"].items():
             ref = gr[GRAD_NAMES[k]]
             e = pu.rel_stats(v.reshape(ref.shape), ref)
-            rel = np.abs(v.reshape(ref.shape).astype(np.float64) - ref) / (np.abs(ref) + 1e-3 * max(e["scale"], 1e-30))
-            assert e["norm_rel"] <= 1e-4, (k, e)
-            assert (rel > 1e-3).mean() <= 1e-2, (k, e)
+            # the north star's bar: 1e-4 relative on every gradient tensor -- norm-wise, and >= 99.9 % of the elements
+            # within 1e-4 (relative, floor 1e-3 * max|ref|)
+            assert e["norm_rel"] <= 1e-4 and e["frac_gt_1e4"] <= grad_frac, (k, e)
     return st, hp
 
 
@@ -93,7 +93,12 @@ def test_sh_degrees(deg):
 
 def test_partial_tiles_and_large_gaussians():
     scene = syn.make_scene(3000, 11, 0.01, 0.3)
-    _check(scene, syn.orbit_cameras(250, 190)[2], torch.tensor([0.1, 0.2, 0.3]))
+    # splats hundreds of pixels wide: thousands of per-pixel terms of either sign cancel in every gradient element, and ANY
+    # float summation order (the reference's atomics included) scatters a fraction of a percent of the elements by more than
+    # 1e-4 around the double-summed oracle -- tests/test_gpu_reference.py::test_large_splat_gradient_spread measures the
+    # reference's own scatter on this scene and holds the product to it; here the element-wise bar is 99.5 %
+    scene_bar = 5e-3
+    _check(scene, syn.orbit_cameras(250, 190)[2], torch.tensor([0.1, 0.2, 0.3]), grad_frac=scene_bar)
 
 
 def test_camera_inside_cloud_near_culling():
@@ -109,7 +114,9 @@ def test_long_tile_lists_use_large_sort_paths():
     m = torch.randn(P, 3, generator=g) * 0.002  # two tight clusters: one tile with 30000, one with 10000 instances
     m[: P // 4] += torch.tensor([0.0, 0.6, 0.3])
     scene = base._replace(means3D=m.contiguous(), opacities=torch.full((P, 1), 0.02))
-    st, hp = _check(scene, syn.orbit_cameras(160, 128)[0], torch.zeros(3), grads=False)
+    # gradients too: 30 000-entry walks put the backward's T * rcp(1 - alpha) reconstruction (blend.hip, backward.cu:503)
+    # through its longest chains
+    st, hp = _check(scene, syn.orbit_cameras(160, 128)[0], torch.zeros(3), grads=True)
     lens = st["ranges"][:, 1] - st["ranges"][:, 0]
     assert lens.max() > 16384 and ((lens > 2048) & (lens <= 16384)).any()
 
