@@ -53,6 +53,11 @@ def main():
     ap.add_argument("--preroll", type=int, default=600, help="untimed steps before the warm-up steps (parameters restored afterwards); 0: none")
     ap.add_argument("--sh-dir-in-adam", action="store_true", help="form dRGB/d(view direction) -> dL/dxyz in the SH-Adam kernel instead of the backward preprocess kernel (A/B)")
     ap.add_argument("--force-collectives", action="store_true", help="N = 1: create a one-rank RCCL group and run the gradient exchange anyway (exercises the collective path on one GPU)")
+    ap.add_argument("--python-step", action="store_true", help="the autograd-based ViewShardedTrainer (Python between the kernels) instead of the native step (A/B)")
+    ap.add_argument("--no-walk-hint", action="store_true", help="native step without the walk hint of the list-write pass (A/B)")
+    ap.add_argument("--forward-only", action="store_true", help="a step = one rasterizer forward through the reference-shaped API (BASELINE config 5 is quoted forward-only; implied by --workload config5)")
+    ap.add_argument("--drift-steps", type=int, default=1000, help="after the graded region: train this many steps on WITHOUT restoring the parameters and time K steps of the drifted scene (0: skip)")
+    ap.add_argument("--no-densify-variant", action="store_true", help="skip the extra timing of the step with dL/dmeans2D + fused densification statistics")
     ap.add_argument("--host-sync", action="store_true", help="forward with the host round trip for num_rendered (A/B of the sync-free forward)")
     args = ap.parse_args()
 
@@ -88,7 +93,8 @@ def main():
         dist.barrier()
     lib = _lib.load()
     from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
-    from sugar_amd.train_step import GaussianParams, ViewShardedTrainer
+    from sugar_amd.train_step import GaussianParams, NativeTrainer, ViewShardedTrainer
+    forward_only = args.forward_only or args.workload == "config5"
 
     scene, cams, bg = syn.make_config(args.workload, P=args.gaussians)
     P = scene.means3D.shape[0]
@@ -98,15 +104,30 @@ def main():
     gtor = torch.Generator().manual_seed(1234)
     gts = [torch.rand(3, H, W, generator=gtor).to(dev) for _ in range(len(cams))]
     params = GaussianParams(scene, dev)
-    trainer = ViewShardedTrainer(params, GaussianRasterizer, GaussianRasterizationSettings, bg_d,
-                                 sync_free=False if args.host_sync else None,
-                                 fuse_activations=False if args.no_fuse_activations else None,
-                                 sh_dir_in_adam=args.sh_dir_in_adam, force_collectives=args.force_collectives)
+    native = not (args.python_step or forward_only)
+    if forward_only:
+        trainer = ForwardOnly(scene, dev, bg_d, GaussianRasterizer, GaussianRasterizationSettings, _C)
+    elif native:
+        trainer = NativeTrainer(params, bg_d, W, H, force_collectives=args.force_collectives, walk_hint=not args.no_walk_hint)
+    else:
+        trainer = ViewShardedTrainer(params, GaussianRasterizer, GaussianRasterizationSettings, bg_d,
+                                     sync_free=False if args.host_sync else None,
+                                     fuse_activations=False if args.no_fuse_activations else None,
+                                     sh_dir_in_adam=args.sh_dir_in_adam, force_collectives=args.force_collectives)
 
     def cam_index(step):
         return (step * world + rank) % len(cams)
 
+    def do_step(tr, s):
+        k = cam_index(s)
+        if isinstance(tr, NativeTrainer):
+            tr.step(cams_d[k], gts[k], cam_key=k)
+        else:
+            tr.step(cams_d[k], gts[k])
+
     def sync_all():
+        if isinstance(trainer, NativeTrainer):
+            trainer.synchronize()  # (validates the step still in flight)
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -119,18 +140,41 @@ def main():
     # first -- which also shows the caching allocator the scratch sizes of every view and settles the list capacity of the
     # sync-free forward -- and then parameters and optimiser state are put back: the timed steps see the scene as defined,
     # not one that 600 Adam steps towards random targets have changed (R drops 18.7M -> 14M and the walked depth grows).
-    if args.preroll > 0:
-        opt = trainer.opt
-        snap = (params.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.t) if hasattr(opt, "exp_avg") else None
+    def opt_state(tr):
+        if isinstance(tr, NativeTrainer):
+            return tr
+        return tr.opt if hasattr(getattr(tr, "opt", None), "exp_avg") else None
+
+    def snapshot(tr):
+        o = opt_state(tr)
+        return None if o is None else (params.flat.clone(), o.exp_avg.clone(), o.exp_avg_sq.clone(), o.t)
+
+    def restore(tr, snap):
+        if snap is None:
+            return
+        sync_all()
+        o = opt_state(tr)
+        with torch.no_grad():
+            params.flat.copy_(snap[0]); o.exp_avg.copy_(snap[1]); o.exp_avg_sq.copy_(snap[2])
+        o.t = snap[3]
+
+    if args.preroll > 0 and not forward_only:
+        snap = snapshot(trainer)
         for s in range(max(args.preroll, len(cams))):
-            trainer.step(cams_d[(s * world + rank) % len(cams)], gts[(s * world + rank) % len(cams)])
-        if snap is not None:
-            with torch.no_grad():
-                params.flat.copy_(snap[0]); opt.exp_avg.copy_(snap[1]); opt.exp_avg_sq.copy_(snap[2])
-            opt.t = snap[3]
-            del snap
+            do_step(trainer, s)
+        restore(trainer, snap)
+        if native and trainer.walk_hint:
+            # the walk hints now describe the pre-rolled scene: one more pass over the cameras from the restored state
+            # leaves the hints of the scene as defined, then the state is put back once more
+            for s in range(len(cams)):
+                do_step(trainer, s)
+            restore(trainer, snap)
+        del snap
+    elif forward_only:
+        for s in range(max(8, len(cams))):
+            do_step(trainer, s)
     for s in range(args.warmup):
-        trainer.step(cams_d[cam_index(s)], gts[cam_index(s)])
+        do_step(trainer, s)
     T = ((W + 15) // 16) * ((H + 15) // 16)
     off_walk = lib.sgr_img_tile_walked_offset(W, H)
     off_maxc = lib.sgr_img_tile_maxc_offset(W, H)
@@ -147,7 +191,7 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for s in range(args.warmup, args.warmup + args.steps):
-        trainer.step(cams_d[cam_index(s)], gts[cam_index(s)])
+        do_step(trainer, s)
     t_enq = time.perf_counter()  # (diagnostic: when the host finished enqueueing; equal to t1 means the loop was host-bound)
     sync_all()
     t1 = time.perf_counter()
@@ -168,11 +212,12 @@ def main():
     n_post = len(cams)
     lib.sgr_profile_enable((1 << len(STAGES)) - 1)
     for s in range(args.warmup + args.steps, args.warmup + args.steps + n_post):
-        trainer.step(cams_d[cam_index(s)], gts[cam_index(s)])
-        lf = _C.last_forward
-        img = lf["img"]
+        do_step(trainer, s)
+        img = trainer._img if isinstance(trainer, NativeTrainer) else _C.last_forward["img"]
         walked += img[off_walk: off_walk + 4 * T].view(torch.int32).sum()
         walked_b += img[off_maxc: off_maxc + 4 * T].view(torch.int32).sum()
+        if isinstance(trainer, NativeTrainer):
+            trainer.synchronize()
         rendered += trainer.last_num_rendered
     torch.cuda.synchronize(dev)
     lib.sgr_profile_enable(0)
@@ -184,12 +229,12 @@ def main():
     # ---- what the collectives cost the step: the same K steps once more with and once without the gradient exchange (after the
     # graded region; without the exchange the replicas drift apart, which is irrelevant for a timing)
     comm = None
-    if trainer.exchange:
+    if getattr(trainer, "exchange", False):
         def timed(first):
             sync_all()
             ta = time.perf_counter()
             for s in range(first, first + args.steps):
-                trainer.step(cams_d[cam_index(s)], gts[cam_index(s)])
+                do_step(trainer, s)
             sync_all()
             el = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device=dev)
             if world > 1:
@@ -202,6 +247,45 @@ def main():
         trainer.exchange = True
         comm = {"ms_per_step_with_collectives": with_c, "ms_per_step_without_collectives": without_c,
                 "comm_exposed_ms": with_c - without_c}
+
+    def time_steps(tr, first):
+        sync_all()
+        if isinstance(tr, NativeTrainer):
+            tr.synchronize()
+        ta = time.perf_counter()
+        for s in range(first, first + args.steps):
+            do_step(tr, s)
+        if isinstance(tr, NativeTrainer):
+            tr.synchronize()
+        sync_all()
+        return 1e3 * (time.perf_counter() - ta) / args.steps
+
+    extras = {}
+    base = args.warmup + 3 * args.steps + n_post
+    if world == 1 and native and not args.no_densify_variant:
+        # the step a densifying trainer runs for half its schedule (train.py:111-123, sugar_densifier.py:156-164): dL/dmeans2D
+        # written, visibility / radii kept, the three statistics updated inside the backward preprocess kernel
+        snap = snapshot(trainer)
+        dtr = NativeTrainer(params, bg_d, W, H, densify_stats=True, walk_hint=not args.no_walk_hint, capacity=trainer.capacity)
+        dtr.exp_avg.copy_(trainer.exp_avg); dtr.exp_avg_sq.copy_(trainer.exp_avg_sq); dtr.t = trainer.t
+        for s in range(2 * len(cams)):
+            do_step(dtr, s)
+        ms_d = time_steps(dtr, base)
+        restore(trainer, snap)
+        ms_plain = time_steps(trainer, base)
+        restore(trainer, snap)
+        extras["densify_stats_variant"] = {"ms_per_step": ms_d, "ms_per_step_plain_same_moment": ms_plain,
+                                           "delta_ms": ms_d - ms_plain,
+                                           "what": "dL/dmeans2D written + radii kept + max_radii2D / xyz_gradient_accum / denom updated in the backward preprocess kernel"}
+        del dtr, snap
+    if world == 1 and not forward_only and args.drift_steps > 0:
+        # the headline is the scene as defined (parameters restored after the pre-roll); this is the same step after the
+        # optimiser has moved the scene towards the (random) target images for a while: R shrinks, the walked depth grows
+        for s in range(args.drift_steps):
+            do_step(trainer, base + s)
+        ms_drift = time_steps(trainer, base + args.drift_steps)
+        extras["after_training"] = {"untimed_steps_before": args.drift_steps, "ms_per_step": ms_drift,
+                                    "images_per_sec": 1e3 / ms_drift, "num_rendered": trainer.last_num_rendered}
 
     if rank == 0:
         K = args.steps
@@ -231,8 +315,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: {P} Gaussians @ {W}x{H}, SH degree 3, 3DGS train step "
-                            "(raster fwd -> 0.8 L1 + 0.2 DSSIM -> bwd -> Adam, 59 floats/Gaussian), 8 orbit cameras cycled",
+                "workload": (f"{args.workload}: {P} Gaussians @ {W}x{H}, SH degree 3, rasterizer FORWARD only through the "
+                             "reference-shaped API, 8 orbit cameras cycled" if forward_only else
+                             f"{args.workload}: {P} Gaussians @ {W}x{H}, SH degree 3, 3DGS train step "
+                             "(raster fwd -> 0.8 L1 + 0.2 DSSIM -> bwd -> Adam, 59 floats/Gaussian), 8 orbit cameras cycled"),
+                "step_driver": ("reference-shaped Python API" if forward_only else
+                                "native (sgr_trainer_step: one call per step, sync-free forward, walk hint "
+                                + ("on" if getattr(trainer, "walk_hint", False) else "off") + ")" if native
+                                else "python (autograd-based ViewShardedTrainer)"),
                 "views_per_step": world,
                 "parallelism": (f"view-sharded dp{world}: all-gather of 3 masked colour grads per Gaussian and view + all-reduce of "
                                 "the 11 non-SH floats per Gaussian (RCCL), SH gradient summed over views inside the Adam kernel"
@@ -246,24 +336,47 @@ def main():
             "roofline": {
                 "kernel": "k_blend_fwd_w", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": "profiles/pmc_blend_fwd.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command taken earlier (scripts/pmc_on_box.sh), NOT measured in this run",
                 "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": blend_ms,
                 "pair_evals_per_s": (256.0 * R_f) / (blend_ms * 1e-3) if blend_ms > 0 else 0.0,
             },
         }
+        out.update(extras)
+        if isinstance(trainer, NativeTrainer):
+            out["forwards_repeated"] = trainer.redone
         if comm is not None:
             out.update(comm)
             out["config"]["collectives"] = "forced on a one-rank RCCL group" if world == 1 else "RCCL"
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, cams[0], bg)
+            out["cpu_baseline"] = cpu_baseline(scene, cams[0], bg, forward_only)
         print(json.dumps(out), flush=True)
     if use_group:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(scene, cam, bg):
+class ForwardOnly:
+    """a "step" = one rasterizer forward through the reference-shaped API (BASELINE config 5 is quoted forward-only)"""
+
+    def __init__(self, scene, dev, bg, rasterizer_cls, settings_cls, cmod):
+        self.t = {k: getattr(scene, k).to(dev) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        self.m2 = torch.zeros_like(self.t["means3D"])
+        self.bg, self.R, self.S, self.cmod = bg, rasterizer_cls, settings_cls, cmod
+        self.last_num_rendered = 0
+
+    def step(self, cam, gt):
+        st = self.S(image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=self.bg,
+                    scale_modifier=1.0, viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix, sh_degree=3, campos=cam.campos,
+                    prefiltered=False, debug=False)
+        t = self.t
+        with torch.no_grad():
+            self.R(st)(t["means3D"], self.m2, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+        self.last_num_rendered = self.cmod.last_forward["num_rendered"]
+
+
+def cpu_baseline(scene, cam, bg, forward_only=False):
     """The CPU oracle (a port of the reference rasterizer, oracle/cpu_rasterizer.c) on the host cores: rasterizer
-    forward + backward of ONE view of the same workload."""
+    forward + backward of ONE view of the same workload; one warm-up run, then the median of three."""
     from oracle import cpu_oracle as orc
     cores = os.cpu_count() or 1
     orc.set_threads(cores)
@@ -272,15 +385,24 @@ def cpu_baseline(scene, cam, bg):
     kw = dict(shs=scene.shs.numpy(), scales=scene.scales.numpy(), rotations=scene.rotations.numpy(),
               viewmatrix=cam.viewmatrix.numpy(), projmatrix=cam.projmatrix.numpy(), campos=cam.campos.numpy(),
               bg=bg.numpy(), W=W, H=H, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy)
-    t0 = time.perf_counter()
-    st = orc.forward(scene.means3D.numpy(), scene.opacities.numpy(), **kw)
-    t1 = time.perf_counter()
-    orc.backward(st, g)
-    t2 = time.perf_counter()
-    return {"value": 1.0 / (t2 - t0), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 view, rasterizer forward ({t1 - t0:.2f} s) + backward ({t2 - t1:.2f} s) only (no loss/Adam), "
-                      f"{scene.means3D.shape[0]} Gaussians @ {W}x{H}, OpenMP over {cores} threads "
-                      "(binning sort is single-threaded)"}
+    runs = []
+    for it in range(4):
+        t0 = time.perf_counter()
+        st = orc.forward(scene.means3D.numpy(), scene.opacities.numpy(), **kw)
+        t1 = time.perf_counter()
+        if not forward_only:
+            orc.backward(st, g)
+        t2 = time.perf_counter()
+        if it > 0:  # (the first run is the warm-up)
+            runs.append((t2 - t0, t1 - t0, t2 - t1))
+        if it == 1 and runs[0][0] > 12.0:
+            break   # bounded sample: a workload this slow on the host gets one timed run
+    runs.sort()
+    tot, tf, tb = runs[len(runs) // 2]
+    return {"value": 1.0 / tot, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 view, rasterizer forward ({tf:.2f} s)" + ("" if forward_only else f" + backward ({tb:.2f} s)") +
+                      f" only (no loss/Adam), {scene.means3D.shape[0]} Gaussians @ {W}x{H}, OpenMP over {cores} threads "
+                      f"(binning sort is single-threaded); 1 warm-up run, median of {len(runs)}"}
 
 
 if __name__ == "__main__":

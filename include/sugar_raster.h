@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 1
+#define SGR_ABI_VERSION 2 /* 2: sgr_forward_ex takes an options struct, binning mode per call, trainer API */
 
 #define SGR_E_INVALID (-1) /* bad argument (e.g. NUM_CHANNELS != 3 path, rasterizer_impl.cu:242-245) */
 #define SGR_E_HIP (-2)     /* a HIP runtime call or kernel failed (CHECK_CUDA, auxiliary.h:166-173) */
@@ -59,14 +59,46 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user,
                     float tan_fovx, float tan_fovy, int prefiltered,
                     float* out_color, int* radii, int debug, void* stream);
 
-/* sgr_forward without the host round trip (extension).  The reference copies num_rendered to the host in the middle of
- * the forward to size the instance list (rasterizer_impl.cu:280-281): the GPU idles for the round trip.
- * binning_capacity > 0 selects the SYNC-FREE forward: the list is allocated for `binning_capacity` instances, nothing is
- * copied back and the call returns binning_capacity (pass it to sgr_backward as R).  The device-side header (8 uint32 at
- * sgr_img_header_offset() of the image scratch: word 0 = the real num_rendered, word 6 != 0 = level-1 binning overflow)
- * tells whether the forward is VALID: if word 0 > capacity or word 6 != 0 the blend kernel has returned without touching
- * its outputs, and the caller must discard this forward and repeat it (binning_capacity = 0, or a larger one) BEFORE running
- * the backward.  binning_capacity == 0, or the single-level binning selected: exactly sgr_forward. */
+/* sgr_forward with options (extension; every field may be zero / NULL: then exactly sgr_forward).
+ *
+ * binning_capacity > 0 selects the SYNC-FREE forward.  The reference copies num_rendered to the host in the middle of the
+ *   forward to size the instance list (rasterizer_impl.cu:280-281): the GPU idles for the round trip.  Here the list is
+ *   allocated for `binning_capacity` instances, nothing is waited for and the call returns binning_capacity (pass it to
+ *   sgr_backward as R).  The device-side header (8 uint32 at sgr_img_header_offset() of the image scratch, SGR_HDR_*) tells
+ *   whether the forward is VALID: word 0 = the real num_rendered; if it exceeds the capacity, or word 6 != 0 (level-1 binning
+ *   overflow), the blend kernel has returned without touching its outputs and the caller must discard this forward and
+ *   repeat it (binning_capacity = 0, or a larger one).  sgr_backward on an invalid forward is a no-op on the device (its
+ *   kernels read the same header), so a caller may check late.
+ * header_host (pinned HOST memory, 16 uint32) / header_event (a hipEvent_t): the header is copied to header_host[0..7]
+ *   right behind the tile scan -- before the list write and the blend -- and once more to header_host[8..15] behind the
+ *   blend (word 3, the hint-miss flag, is only final there); header_event, if given, is recorded behind the second copy.
+ * tile_need (device, uint32 per tile, extension): WALK HINT.  The lists are depth ordered and a tile stops walking once all
+ *   its pixels are saturated -- at the metric workload 88 % of the instances written are never read.  With tile_need[t] = the
+ *   number of list entries tile t is expected to walk (e.g. its tile_walked of the previous visit of the same camera, plus a
+ *   margin), the list-write pass skips every 512-entry chunk of a super-tile none of whose tiles needs it, and the blend
+ *   walks at most tile_need[t] entries of tile t.  Ranges, num_rendered and the written prefix of every list are unchanged
+ *   (bit-identical to rasterizer_impl.cu:70-138).  If a tile would have walked further, header word 3 (SGR_HDR_HINT_MISS) is
+ *   set: the forward is then INVALID exactly like a capacity overflow (repeat it without the hint).
+ * tile_need_out (device, uint32 per tile): receives the hint for the next visit: tile_walked + 25 % + 64.
+ * info (host, may be NULL): what the call did (binning path taken). */
+#define SGR_HDR_R 0          /* header words (device): total instances */
+#define SGR_HDR_MAXCOUNT 1   /* largest per-tile instance count */
+#define SGR_HDR_R_HI 2
+#define SGR_HDR_HINT_MISS 3  /* != 0: a tile needed more entries than its walk hint allowed */
+#define SGR_HDR_L1_OVERFLOW 6 /* != 0: the level-1 (super-tile) list overflowed its capacity */
+typedef struct sgr_forward_info {
+    int binning_mode;        /* 0: two-level binning, 1: single-level */
+    int sync_free;           /* 1: the call did not wait for the device */
+} sgr_forward_info;
+typedef struct sgr_forward_opts {
+    int64_t binning_capacity;
+    int flags;               /* SGR_FLAG_* */
+    uint32_t* header_host;
+    void* header_event;
+    const uint32_t* tile_need;
+    uint32_t* tile_need_out;
+    sgr_forward_info* info;
+} sgr_forward_opts;
 int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user,
                        sgr_alloc_fn binning_alloc, void* binning_user,
                        sgr_alloc_fn img_alloc, void* img_user,
@@ -77,7 +109,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user,
                        const float* rotations, const float* cov3D_precomp,
                        const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                        float tan_fovx, float tan_fovy, int prefiltered,
-                       float* out_color, int* radii, int debug, void* stream, int64_t binning_capacity, int flags);
+                       float* out_color, int* radii, int debug, void* stream, const sgr_forward_opts* opts);
 
 /* flags of sgr_forward_ex.  SGR_FLAG_RAW_PARAMS: `scales`, `rotations` and `opacities` are the RAW parameters of the 3DGS model
  * (log scale, unnormalised quaternion, opacity logit) and the activations of gaussian_model.py:92-117 (exp, F.normalize,
@@ -85,6 +117,11 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user,
  * through memory.  The matching backward is sgr_backward_phase with SGR_MODE_RAW_PARAMS: dL_dscale, dL_drot and dL_dopacity
  * are then the gradients w.r.t. the raw parameters (sgr_activations_backward folded in).  Ignored with cov3D_precomp. */
 #define SGR_FLAG_RAW_PARAMS 1
+/* SGR_FLAG_SINGLE_LEVEL_BINNING: take the single-level ordered scatter (binning.hip) instead of the default two-level
+ * binning (super-tiles of 8x8 tiles, then tiles; falls back to the single level by itself when the level-1 list would
+ * overflow).  Both produce bit-identical lists and ranges; the single level needs one LDS counter per tile (at most about
+ * 38 000 tiles) and always takes the host round trip. */
+#define SGR_FLAG_SINGLE_LEVEL_BINNING 2
 #define SGR_MODE_RAW_PARAMS 4 /* or-ed into the `phase` argument of sgr_backward_phase (phases 0, 1, 2 as before) */
 /* Compact SH mode only (dL_dsh == NULL): the backward skips the SH block altogether -- no read of shs, and dL_dmean3D
  * comes out WITHOUT the term through the view direction; sgr_sh_adam_from_views_ex forms that term. */
@@ -131,6 +168,27 @@ int sgr_backward_phase(int phase, int P, int D, int M, int64_t R,
                        float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                        float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                        int debug, void* stream);
+
+/* sgr_backward_phase with options.  Densification statistics of the train loop (gaussian_splatting/train.py:111-123,
+ * sugar_scene/sugar_densifier.py:156-164), fused into the backward preprocess: for every Gaussian with radius > 0
+ *   max_radii2D[i] = max(max_radii2D[i], radius_i);  grad_accum[i] += |dL_dmean2D[i].xy|;  denom[i] += 1
+ * (all float[P], updated in place; NULL = not wanted).  dL_dmean2D itself need not be written for that. */
+typedef struct sgr_backward_opts {
+    float* max_radii2D;
+    float* grad_accum;
+    float* denom;
+} sgr_backward_opts;
+int sgr_backward_ex(int phase, int P, int D, int M, int64_t R,
+                    const float* background, int width, int height,
+                    const float* means3D, const float* shs, const float* colors_precomp,
+                    const float* scales, float scale_modifier, const float* rotations,
+                    const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                    const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii,
+                    char* geom_buffer, char* binning_buffer, char* img_buffer,
+                    const float* dL_dpix,
+                    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                    float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                    int debug, void* stream, const sgr_backward_opts* opts);
 
 /* SH gradient from per-view masked colour gradients (view-sharded training exchanges 12 B per Gaussian and view instead
  * of 12*M B):  dL_dsh[P*M*3] = sum_v basis(normalize(means3D - campos_all[v])) (x) dcolor_all[v][P*3]   (the per-view
@@ -219,7 +277,7 @@ int sgr_dist2_grid(int P, const float* points, float* meanDists, char* scratch, 
  * sugar_trainers/coarse_sdf.py:456-457.  img, gt: [channels, height, width] float32.
  *   forward : loss_out[3] = {loss, l1 mean, ssim mean}; `scratch` (sgr_l1_ssim_scratch_bytes) keeps the per-pixel SSIM
  *             partials for the backward.
- *   backward: grad_img[c,h,w] = grad_loss[0] * dloss/dimg (grad_loss is a device scalar; gt receives no gradient). */
+ *   backward: grad_img[c,h,w] = grad_loss[0] * dloss/dimg (grad_loss is a device scalar, NULL = 1; gt receives no gradient). */
 size_t sgr_l1_ssim_scratch_bytes(int channels, int width, int height);
 int sgr_l1_ssim_forward(int channels, int width, int height, const float* img, const float* gt, float lambda,
                         char* scratch, float* loss_out, void* stream);
@@ -243,6 +301,73 @@ int sgr_adam_step_ex(long long n, float* params, const float* grads, float* exp_
                      const long long* seg_begin, const long long* seg_end, const float* seg_lr_a, const float* seg_lr_b,
                      const int* seg_period, const int* seg_split, float beta1, float beta2, float eps, int step,
                      float grad_scale, const float* extra, long long extra_n, void* stream);
+
+/* ---- the train step as ONE native call per phase ---------------------------------------------------------------------
+ * gaussian_splatting/train.py:86-128 (render -> 0.8 L1 + 0.2 (1 - SSIM) -> backward -> Adam) enqueued by this library on the
+ * caller's stream: no Python between the kernels, no host round trip (sync-free forward), no allocation (every buffer is
+ * the caller's, sized once).  All pointers are DEVICE pointers owned by the caller unless said otherwise.
+ *
+ * Parameters: ONE flat float buffer (and equally laid out gradient / moment buffers), raw 3DGS parameters
+ * (gaussian_model.py:92-117: log scale, unnormalised quaternion, opacity logit; activated inside the kernels):
+ *   flat[off_xyz .. +3P] positions, [off_opacity .. +P], [off_scaling .. +3P], [off_rotation .. +4P] -- these four are the
+ *   prefix flat[0 .. n_small) -- and [off_features .. +3MP] the SH tensor [P,M,3].
+ * A step has four phases (bit mask), so that a view-sharded trainer can put its collectives between them:
+ *   1  forward, loss, loss backward, blend backward; the clamp-masked colour gradients land in colors[0..3P) followed by the
+ *      camera centre in colors[3P..3P+3): the send buffer of the all-gather;
+ *   2  backward preprocess: gradients of the small parameters into flat_grad (+ the densification statistics, if given);
+ *   4  Adam on the SH tensor straight from the per-view colour gradients (sgr_sh_adam_from_views);
+ *   8  Adam on flat[0 .. n_small).
+ * Validity: the forward is sync-free (binning capacity, optional walk hint).  An invalid forward (header words 0 / 3 / 6, see
+ * sgr_forward_ex) turns every later kernel of the step -- backward AND Adam -- into a no-op on the device; the host learns
+ * about it from sgr_trainer_forward_valid() whenever it chooses to look (typically one step later, when the header copy has
+ * long arrived) and repeats the step with a larger capacity / without the hint. */
+typedef struct sgr_train_config {
+    int P, D, M, width, height;
+    float* flat; float* flat_grad; float* exp_avg; float* exp_avg_sq;
+    long long off_xyz, off_opacity, off_scaling, off_rotation, off_features, n_small;
+    float lr_xyz, lr_opacity, lr_scaling, lr_rotation, lr_features_dc, lr_features_rest;
+    float beta1, beta2, eps, lambda_dssim;
+    const float* background;     /* [3] */
+    char* geom; size_t geom_bytes;       /* >= sgr_geom_bytes(P) */
+    char* img; size_t img_bytes;         /* >= sgr_img_bytes(width, height) + sgr_bin2_bytes(P, width, height) */
+    char* binning; size_t binning_bytes; /* >= sgr_binning_bytes(binning_capacity, width, height) */
+    int64_t binning_capacity;
+    char* loss_scratch;          /* sgr_l1_ssim_scratch_bytes(3, width, height) */
+    float* image;                /* [3,H,W] rendered image (output) */
+    float* grad_image;           /* [3,H,W] dL/dimage (scratch) */
+    float* loss_out;             /* [3]: loss, l1 mean, ssim mean (output) */
+    float* colors;               /* [(P + 1) * 3] */
+    int* radii;                  /* [P] or NULL */
+    uint32_t* header_host;       /* pinned HOST memory, 16 uint32 */
+    float* dL_dmean2D;           /* [P,3] or NULL: the gradient the densifier reads (viewspace_points.grad) */
+    float* max_radii2D; float* grad_accum; float* denom; /* [P] each or NULL: fused densification statistics */
+} sgr_train_config;
+typedef struct sgr_train_view {
+    const float* viewmatrix; const float* projmatrix; const float* campos; /* device: [16], [16], [3] */
+    float tan_fovx, tan_fovy;
+    const float* gt_image;       /* [3,H,W] */
+    const uint32_t* tile_need;   /* walk hint of this camera (device, [tiles]) or NULL */
+    uint32_t* tile_need_out;     /* receives the hint for its next visit, or NULL */
+} sgr_train_view;
+typedef struct sgr_train_exchange { /* phases 4 and 8 */
+    int n_views;                 /* views whose colour gradients are summed (1: this rank's own) */
+    const float* all_colors;     /* [n_views][view_stride][3]; NULL: cfg.colors */
+    int64_t view_stride;         /* rows between views (0: P) */
+    const float* all_campos;     /* [n_views][3]; NULL: this view's campos */
+    float grad_scale;            /* 1 / n_views: the mean over the views is folded into the Adam kernels */
+    int step;                    /* 1-based Adam step (bias correction) */
+} sgr_train_exchange;
+typedef struct sgr_trainer sgr_trainer;
+sgr_trainer* sgr_trainer_create(const sgr_train_config* cfg); /* copies cfg; NULL on a bad configuration (sgr_last_error) */
+void sgr_trainer_destroy(sgr_trainer* t);
+int sgr_trainer_set_binning(sgr_trainer* t, char* binning, size_t bytes, int64_t capacity); /* after a capacity overflow */
+int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* view, int phases, const sgr_train_exchange* ex, void* stream);
+/* Waits for the header copy of the most recent phase-1 call (the copy sits behind the forward's blend kernel) and returns
+ * 1 if that forward was valid, 0 if the step was a no-op on the device and has to be repeated; header_out[16] (may be NULL)
+ * receives the two header copies (word 0: the real num_rendered, word 3: hint miss, word 6: level-1 overflow). */
+int sgr_trainer_forward_valid(sgr_trainer* t, uint32_t* header_out);
+const char* sgr_trainer_last_error(void);
+size_t sgr_bin2_bytes(int P, int width, int height); /* scratch of the two-level binning appended to the image scratch */
 
 /* ---- SuGaR density field and level-set surface sampler (share the Gaussian buffers) --------------
  * B_g = R_g diag(1 / max(s_g, 1e-8)) is SuGaR's get_covariance(return_full_matrix=True, return_sqrt=True,
@@ -291,14 +416,6 @@ int sgr_level_set_points(int N, int K, const float* world_points, const int64_t*
                          const float* centers, const float* inv_scaled_rot, const float* strengths,
                          const float* gaussian_std, int n_levels, const float* levels_host, int n_range, float range_size,
                          float density_factor, uint8_t* valid, float* points, float* normals, const float* packed, void* stream);
-
-/* ---- binning path selection (debug / tests) ------------------------------------------------------------------------
- * mode 0 (default): two-level depth-ordered binning (super-tiles of 8x8 tiles, then tiles) with an automatic fall-back
- * to mode 1 when the level-1 list would overflow; mode 1: single-level ordered scatter.  Both produce bit-identical lists
- * and ranges.  sgr_set_binning_mode returns the previous mode; sgr_last_binning_mode the path the last forward took. */
-int sgr_set_binning_mode(int mode);
-int sgr_last_binning_mode(void);
-int sgr_set_blend_variant(int variant); /* development switch between blend kernel variants; returns the old value */
 
 /* ---- SuGaR.get_points_rgb, sugar_scene/sugar_model.py:839-883 (with sugar_utils/spherical_harmonics.py:117-172) -----
  * colors[P,3] = clamp_min(eval_sh(D, sh, dir) + 0.5, 0),  dir = F.normalize(positions - camera_centers) when positions is

@@ -21,12 +21,21 @@ SIGNATURES = {
     "sgr_forward": (_i64, [ALLOC_FN, _vp, ALLOC_FN, _vp, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp,
                            _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp]),
     "sgr_forward_ex": (_i64, [ALLOC_FN, _vp, ALLOC_FN, _vp, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp,
-                              _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp, _i64, _i]),
+                              _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp, _vp]),
     "sgr_backward": (_i, [_i, _i, _i, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp,
                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sgr_backward_phase": (_i, [_i, _i, _i, _i, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "sgr_backward_ex": (_i, [_i, _i, _i, _i, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp,
+                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "sgr_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    "sgr_trainer_create": (_vp, [_vp]),
+    "sgr_trainer_destroy": (None, [_vp]),
+    "sgr_trainer_set_binning": (_i, [_vp, _vp, _sz, _i64]),
+    "sgr_trainer_step": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "sgr_trainer_forward_valid": (_i, [_vp, _vp]),
+    "sgr_trainer_last_error": (C.c_char_p, []),
+    "sgr_bin2_bytes": (_sz, [_i, _i, _i]),
     "sgr_sh_grad_from_views": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp]),
     "sgr_sh_adam_from_views": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "sgr_sh_adam_from_views_ex": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
@@ -60,15 +69,54 @@ SIGNATURES = {
     "sgr_sh_to_rgb_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgr_activations_forward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgr_activations_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "sgr_set_binning_mode": (_i, [_i]),
-    "sgr_last_binning_mode": (_i, []),
-    "sgr_set_blend_variant": (_i, [_i]),
     "sgr_dist2": (_i, [_i, _vp, _vp, _vp]),
     "sgr_knn": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "sgr_knn_grid_scratch_bytes": (_sz, [_i]),
     "sgr_knn_grid": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "sgr_dist2_grid": (_i, [_i, _vp, _vp, _vp, _vp]),
 }
+
+ABI_VERSION = 2  # SGR_ABI_VERSION of include/sugar_raster.h these bindings were written for
+
+
+# ---- structs of include/sugar_raster.h
+class ForwardInfo(C.Structure):
+    _fields_ = [("binning_mode", _i), ("sync_free", _i)]
+
+
+class ForwardOpts(C.Structure):
+    _fields_ = [("binning_capacity", _i64), ("flags", _i), ("header_host", _vp), ("header_event", _vp), ("tile_need", _vp),
+                ("tile_need_out", _vp), ("info", C.POINTER(ForwardInfo))]
+
+
+class BackwardOpts(C.Structure):
+    _fields_ = [("max_radii2D", _vp), ("grad_accum", _vp), ("denom", _vp)]
+
+
+class TrainConfig(C.Structure):
+    _fields_ = [("P", _i), ("D", _i), ("M", _i), ("width", _i), ("height", _i),
+                ("flat", _vp), ("flat_grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp),
+                ("off_xyz", C.c_longlong), ("off_opacity", C.c_longlong), ("off_scaling", C.c_longlong),
+                ("off_rotation", C.c_longlong), ("off_features", C.c_longlong), ("n_small", C.c_longlong),
+                ("lr_xyz", _f), ("lr_opacity", _f), ("lr_scaling", _f), ("lr_rotation", _f), ("lr_features_dc", _f),
+                ("lr_features_rest", _f), ("beta1", _f), ("beta2", _f), ("eps", _f), ("lambda_dssim", _f),
+                ("background", _vp), ("geom", _vp), ("geom_bytes", _sz), ("img", _vp), ("img_bytes", _sz), ("binning", _vp),
+                ("binning_bytes", _sz), ("binning_capacity", _i64), ("loss_scratch", _vp), ("image", _vp), ("grad_image", _vp),
+                ("loss_out", _vp), ("colors", _vp), ("radii", _vp), ("header_host", _vp), ("dL_dmean2D", _vp),
+                ("max_radii2D", _vp), ("grad_accum", _vp), ("denom", _vp)]
+
+
+class TrainView(C.Structure):
+    _fields_ = [("viewmatrix", _vp), ("projmatrix", _vp), ("campos", _vp), ("tan_fovx", _f), ("tan_fovy", _f), ("gt_image", _vp),
+                ("tile_need", _vp), ("tile_need_out", _vp)]
+
+
+class TrainExchange(C.Structure):
+    _fields_ = [("n_views", _i), ("all_colors", _vp), ("view_stride", _i64), ("all_campos", _vp), ("grad_scale", _f), ("step", _i)]
+
+
+SGR_FLAG_RAW_PARAMS, SGR_FLAG_SINGLE_LEVEL_BINNING = 1, 2
+HDR_R, HDR_HINT_MISS, HDR_L1_OVERFLOW = 0, 3, 6
 
 _lib = None
 
@@ -89,10 +137,8 @@ def load() -> C.CDLL:
             raise ImportError(f"{LIB_PATH} does not export `{name}` (ABI mismatch; rebuild)") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.sgr_abi_version() != 1:
-        raise ImportError("sugar_raster ABI version mismatch")
-    if os.environ.get("SGR_BLEND_VARIANT"):  # development switch, see sgr_set_blend_variant
-        lib.sgr_set_blend_variant(int(os.environ["SGR_BLEND_VARIANT"]))
+    if lib.sgr_abi_version() != ABI_VERSION:
+        raise ImportError(f"sugar_raster ABI version mismatch: library {lib.sgr_abi_version()}, bindings {ABI_VERSION} (rebuild)")
     _lib = lib
     return lib
 

@@ -31,6 +31,7 @@ SOURCES = {
     "activations.hip": [],
     "field.hip": [],
     "capi.hip": [],
+    "train.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

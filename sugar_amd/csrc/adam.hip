@@ -67,8 +67,10 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) k_adam(long long n4, f4* __restrict__ p, const f4* __restrict__ g,
                                               f4* __restrict__ m, f4* __restrict__ v, AdamSegs sg, float b1, float b2,
                                               float eps, float bc1, float bc2_sqrt, float grad_scale,
-                                              const float* __restrict__ extra, long long extra_n)
+                                              const float* __restrict__ extra, long long extra_n,
+                                              const uint32_t* __restrict__ guard, uint32_t guard_cap)
 {
+    if (guard && SGR_FORWARD_INVALID(guard, guard_cap)) return;  // the step's forward was a no-op: so is its optimiser step
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         // g, m and v are touched once per step: stream them past the caches (p is read again by the next forward)
         f4 gg = __builtin_nontemporal_load(&g[i]);
@@ -101,10 +103,10 @@ __global__ void __launch_bounds__(256) k_adam(long long n4, f4* __restrict__ p, 
 
 }  // namespace
 
-extern "C" int sgr_adam_step_ex(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n_seg,
-                                const long long* seg_begin, const long long* seg_end, const float* seg_lr_a,
-                                const float* seg_lr_b, const int* seg_period, const int* seg_split, float beta1, float beta2,
-                                float eps, int step, float grad_scale, const float* extra, long long extra_n, void* stream)
+int sgr_adam_launch(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n_seg,
+                    const long long* seg_begin, const long long* seg_end, const float* seg_lr_a, const float* seg_lr_b,
+                    const int* seg_period, const int* seg_split, float beta1, float beta2, float eps, int step, float grad_scale,
+                    const float* extra, long long extra_n, const uint32_t* guard, uint32_t guard_cap, hipStream_t stream)
 {
     if (n <= 0) return 0;
     if (extra_n < 0 || extra_n > n || (extra_n > 0 && !extra)) return SGR_E_INVALID;
@@ -121,10 +123,20 @@ extern "C" int sgr_adam_step_ex(long long n, float* params, const float* grads, 
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     const long long n4 = n / 4;
     const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n4, reinterpret_cast<f4*>(params),
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, stream, n4, reinterpret_cast<f4*>(params),
                        reinterpret_cast<const f4*>(grads), reinterpret_cast<f4*>(exp_avg),
-                       reinterpret_cast<f4*>(exp_avg_sq), sg, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale, extra, extra_n);
+                       reinterpret_cast<f4*>(exp_avg_sq), sg, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale, extra, extra_n, guard,
+                       guard_cap);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
+}
+
+extern "C" int sgr_adam_step_ex(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n_seg,
+                                const long long* seg_begin, const long long* seg_end, const float* seg_lr_a,
+                                const float* seg_lr_b, const int* seg_period, const int* seg_split, float beta1, float beta2,
+                                float eps, int step, float grad_scale, const float* extra, long long extra_n, void* stream)
+{
+    return sgr_adam_launch(n, params, grads, exp_avg, exp_avg_sq, n_seg, seg_begin, seg_end, seg_lr_a, seg_lr_b, seg_period, seg_split,
+                           beta1, beta2, eps, step, grad_scale, extra, extra_n, nullptr, 0, (hipStream_t)stream);
 }
 
 extern "C" int sgr_adam_step(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n_seg,

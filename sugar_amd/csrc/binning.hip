@@ -423,7 +423,8 @@ __global__ void __launch_bounds__(64) k_hist_scan(int T, int n_blocks, uint32_t*
 // CONSECUTIVE tiles the one CU this runs on spent 17 us mostly on 32-byte-strided stores.)
 __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __restrict__ tile_count,
                                                     uint32_t* __restrict__ tile_start, uint32_t* __restrict__ header,
-                                                    uint32_t* __restrict__ tile_maxc, uint32_t* __restrict__ tile_walked)
+                                                    uint32_t* __restrict__ tile_maxc, uint32_t* __restrict__ tile_walked,
+                                                    int clear_b2_words)
 {
     __shared__ uint32_t s_seg[128];
     __shared__ uint32_t s_max[16];
@@ -468,6 +469,9 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __res
         header[SGR_HDR_R] = carry;
         header[SGR_HDR_R_HI] = 0;
         header[SGR_HDR_MAXCOUNT] = m;
+        header[SGR_HDR_HINT_MISS] = 0;
+        if (clear_b2_words) { header[4] = 0; header[5] = 0; header[6] = 0; }  // single-level path: k_sup_scan did not run
+        header[7] = 0;
     }
 }
 
@@ -587,7 +591,8 @@ void sgr_launch_hist_scan(int T, int n_blocks, uint32_t* blk_hist, uint32_t* til
 }
 
 void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* header, uint32_t* tile_maxc,
-                          uint32_t* tile_walked, hipStream_t s)
+                          uint32_t* tile_walked, int clear_b2_words, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, tile_count, tile_start, header, tile_maxc, tile_walked);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, tile_count, tile_start, header, tile_maxc, tile_walked,
+                       clear_b2_words);
 }

@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(64) k_tile_pass(int gx, int gy, int sgx, int T
                                                   const uint32_t* __restrict__ hdr, const uint4* __restrict__ L1,
                                                   uint32_t* __restrict__ cnt2,
                                                   const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ point_list,
-                                                  uint32_t list_cap)
+                                                  uint32_t list_cap, const uint32_t* __restrict__ tile_need)
 {
     __shared__ uint32_t s_row[WRITE ? SGR_B2_CHUNK : 1];
     if (hdr[SGR_B2_HDR_OVERFLOW]) return;
@@ -275,6 +275,19 @@ __global__ void __launch_bounds__(64) k_tile_pass(int gx, int gy, int sgx, int T
             }
             cnt2[(size_t)c * 64 + lane] = run;
         } else {
+            // lane t: first slot of tile t's segment for this chunk
+            uint32_t base = 0, before = 0, need = 0;
+            {
+                const int tx = ox + (lane & (SGR_SUP - 1)), ty = oy + (lane >> SGR_SUP_SHIFT);
+                if (tx < gx && ty < gy) {
+                    before = cnt2[(size_t)c * 64 + lane];  // entries of the tile in the earlier chunks of this super-tile
+                    base = tile_start[ty * gx + tx] + before;
+                    need = tile_need ? tile_need[ty * gx + tx] : 0xFFFFFFFFu;
+                }
+            }
+            // walk hint: the lists are in depth order and so are the chunks -- if every tile of the super-tile already holds
+            // the entries it is expected to walk, this chunk (and every later one) is never read: nothing to write
+            if (__ballot(before < need) == 0ull) continue;
             uint32_t lo[SGR_B2_BATCHES], hi[SGR_B2_BATCHES], id[SGR_B2_BATCHES];
 #pragma unroll
             for (int b = 0; b < SGR_B2_BATCHES; b++) {
@@ -284,12 +297,6 @@ __global__ void __launch_bounds__(64) k_tile_pass(int gx, int gy, int sgx, int T
                     tile_mask(make_uint2(e.x, e.y), ox, oy, lo[b], hi[b]);
                     id[b] = e.z;
                 }
-            }
-            // lane t: first slot of tile t's segment for this chunk
-            uint32_t base = 0;
-            {
-                const int tx = ox + (lane & (SGR_SUP - 1)), ty = oy + (lane >> SGR_SUP_SHIFT);
-                if (tx < gx && ty < gy) base = tile_start[ty * gx + tx] + cnt2[(size_t)c * 64 + lane];
             }
 #pragma unroll
             for (int half = 0; half < 2; half++) {
@@ -433,12 +440,13 @@ void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scr
                        sup_start, hist1, hdr, L1);
     const uint32_t grid = L.chunk_cap < 8192u ? L.chunk_cap : 8192u;  // the chunk count lives on the device: grid-stride
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_pass<false>), dim3(grid), dim3(64), 0, s, gx, gy, L.sgx, L.T1, sup_start, chunk_base,
-                       chunk_sup, hdr, L1, cnt2, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
+                       chunk_sup, hdr, L1, cnt2, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_tile_scan2, dim3(L.T1), dim3(64), 0, s, gx, gy, L.sgx, chunk_base, hdr, cnt2, tile_count);
 }
 
 void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, const uint32_t* hdr, uint32_t n_chunks, const uint2* rects,
-                           const uint32_t* order, const uint32_t* tile_start, uint32_t* point_list, uint32_t list_cap, hipStream_t s)
+                           const uint32_t* order, const uint32_t* tile_start, uint32_t* point_list, uint32_t list_cap,
+                           const uint32_t* tile_need, hipStream_t s)
 {
     if (n_chunks == 0) return;
     const uint32_t* sup_start = reinterpret_cast<const uint32_t*>(scratch + L.sup_start);
@@ -447,5 +455,5 @@ void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, c
     uint32_t* cnt2 = reinterpret_cast<uint32_t*>(scratch + L.cnt2);
     const uint32_t* chunk_sup = reinterpret_cast<const uint32_t*>(scratch + L.chunk_sup);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_pass<true>), dim3(n_chunks), dim3(64), 0, s, gx, gy, L.sgx, L.T1, sup_start,
-                       chunk_base, chunk_sup, hdr, L1, cnt2, tile_start, point_list, list_cap);
+                       chunk_base, chunk_sup, hdr, L1, cnt2, tile_start, point_list, list_cap, tile_need);
 }

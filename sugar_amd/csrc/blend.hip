@@ -18,14 +18,6 @@
 // 36-byte atomic request into a 64-byte accumulator record instead of the reference's up to 64 x 9 float atomics
 // (backward.cu:523-554).
 #include "sgr_common.h"
-#include <cstdlib>
-
-int g_sgr_blend_variant = 0;  // development switch between kernel variants under test (sgr_set_blend_variant); unused at present
-
-#ifdef SGR_COUNT
-__device__ unsigned long long g_sgr_count[8];
-extern "C" void sgr_debug_counts(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sgr_count), sizeof(g_sgr_count)); unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_sgr_count), z, sizeof(z)); }
-#endif
 
 namespace {
 
@@ -77,7 +69,7 @@ __device__ __forceinline__ bool block_hit(float gxc, float gyc, float cx, float 
 }
 
 // The walk over a compacted batch, hand-scheduled (the compiler's version of this loop carries ~30 VALU and ~23 SALU
-// instructions per entry; this one 22 and 9).  Lanes whose pixel is finished are simply removed from EXEC for the whole walk,
+// instructions per entry; this one 21 and 9).  Lanes whose pixel is finished are simply removed from EXEC for the whole walk,
 // the reference's three skip tests (forward.cu:336-351) narrow EXEC further inside an iteration, and the state updates are
 // plain moves under that mask -- no v_cndmask, no per-lane bookkeeping.  The 10 dwords of entry k+1 are fetched from LDS
 // (uniform address: broadcast) while entry k is evaluated (two register sets, A = v[40:49], B = v[50:59]).
@@ -100,11 +92,10 @@ __device__ __forceinline__ bool block_hit(float gxc, float gyc, float cx, float 
     "v_min_f32 v62, 0x3f7d70a4, v62\n"  /* alpha = min(0.99, opacity * G) */                        \
     "s_and_b64 exec, exec, vcc\n"                                                                   \
     "v_cmp_ngt_f32 vcc, 0x3b808081, v62\n" /* !(alpha < 1/255) */                                   \
-    "v_sub_f32 v60, 1.0, v62\n"                                                                     \
-    "v_mul_f32 v60, %[T], v60\n"        /* test_T */                                                \
+    "v_mul_f32 v61, v62, %[T]\n"        /* alpha * T */                                             \
+    "v_sub_f32 v60, %[T], v61\n"        /* test_T = T - alpha T  (forward.cu:347: T (1 - alpha), one rounding apart) */ \
     "s_and_b64 exec, exec, vcc\n"                                                                   \
     "v_cmp_gt_f32 vcc, 0x38d1b717, v60\n" /* test_T < 0.0001: this lane is finished */              \
-    "v_mul_f32 v61, v62, %[T]\n"                                                                    \
     "s_andn2_b64 %[live], %[live], vcc\n"                                                           \
     "s_andn2_b64 exec, exec, vcc\n"                                                                 \
     "v_mov_b32 %[T], v60\n"                                                                         \
@@ -164,9 +155,12 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
                                                     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_maxc,
                                                     uint32_t* __restrict__ tile_walked, float* __restrict__ out_color,
                                                     unsigned long long* __restrict__ blk_mask, uint32_t* __restrict__ blk_nb,
-                                                    const uint32_t* __restrict__ guard_hdr, uint32_t list_cap)
+                                                    uint32_t* __restrict__ header, uint32_t list_cap,
+                                                    const uint32_t* __restrict__ tile_need)
 {
-    if (guard_hdr && (guard_hdr[SGR_HDR_R] > list_cap || guard_hdr[4 + SGR_B2_HDR_OVERFLOW])) return;
+    // sync-free forward: the list did not fit the caller's capacity (or the level-1 binning overflowed) -> leave everything
+    // untouched; the caller repeats the forward and every later kernel of the step reads the same header
+    if (header[SGR_HDR_R] > list_cap || header[4 + SGR_B2_HDR_OVERFLOW]) return;
     // entry k: {x, y, -0.5*conic.x*log2e, -conic.y*log2e | -0.5*conic.z*log2e, opacity, r, g | b, bitcast(1-based list position), -, -}
     // (one spare entry: the walk's look-ahead reads one entry past the last)
     __shared__ __attribute__((aligned(16))) float s_e[65 * (SGR_FWD_ENTRY_BYTES / 4)];
@@ -182,7 +176,9 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
     const bool inside = px < W && py < H;
     const float pixfx = (float)px, pixfy = (float)py;
     const uint32_t r0 = tile_start[tile];
-    const int total = (int)(tile_start[tile + 1] - r0);
+    const int total_all = (int)(tile_start[tile + 1] - r0);
+    // walk hint: only the first tile_need[tile] entries of the list are guaranteed to have been written
+    const int total = tile_need ? (int)min((uint32_t)total_all, tile_need[tile]) : total_all;
 
     float T = 1.0f;
     uint32_t last_contributor = 0;
@@ -232,6 +228,8 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    // the hint was too short: pixels of this block are still accumulating where the written prefix ends
+    if (total < total_all && live != 0ull && lane == 0) atomicOr(&header[SGR_HDR_HINT_MISS], 1u);
     if (inside) {
         const size_t pix_id = (size_t)W * py + px;
         const size_t HW = (size_t)H * W;
@@ -356,52 +354,15 @@ __device__ __forceinline__ void bwd_phase_a(uint32_t e_addr, uint32_t w_addr, in
           "v115", "v116", "v117", "v118", "v119", "vcc", "scc", "memory");
 }
 
-#ifdef SGR_BWD_REF_A
-// C++ restatement of bwd_phase_a (debug aid: -DSGR_BWD_REF_A)
-__device__ __forceinline__ void bwd_phase_a_ref(const float* q, float2* zw, int lane, int rows, bool inside, float pixfx, float pixfy,
-                                                float g0, float g1, float g2, float ntb, uint32_t lastc, float& T, float& acc_g,
-                                                float& lc_g, float& last_alpha)
-{
-    for (int r = 0; r < rows; r++) {
-        const float* e = q + r * BW_ENTRY_DW;
-        const float dx = e[0] - pixfx, dy = e[1] - pixfy;
-        const float power = dx * (e[2] * dx + e[3] * dy) + e[4] * dy * dy;
-        const float G = __builtin_amdgcn_exp2f(power);
-        const float alpha = fminf(0.99f, e[5] * G);
-        const bool active = inside && (__float_as_uint(e[9]) <= lastc) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-        float Z = 0.f, Wt = 0.f;
-#ifdef SGR_COUNT
-        {   // (entry, block) pairs walked by the backward, pairs with a contributing pixel, contributing lanes
-            const unsigned long long am = __ballot(active);
-            if (lane == 0) {
-                atomicAdd(&g_sgr_count[4], 1ull);
-                atomicAdd(&g_sgr_count[5], am ? 1ull : 0ull);
-                atomicAdd(&g_sgr_count[6], (unsigned long long)__popcll(am));
-            }
-        }
-#endif
-        if (active) {
-            const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
-            acc_g += last_alpha * (lc_g - acc_g);
-            T = T * inv;
-            lc_g = e[6] * g0 + e[7] * g1 + e[8] * g2;
-            Wt = alpha * T;
-            const float d = (lc_g - acc_g) * T + ntb * inv;
-            last_alpha = alpha;
-            Z = G * d;
-        }
-        zw[r * BW_ZW_STRIDE + lane] = make_float2(Z, Wt);
-    }
-}
-#endif
-
 __global__ void __launch_bounds__(64)
 k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ point_list,
               const unsigned long long* __restrict__ blk_mask, const uint32_t* __restrict__ blk_nb, const GeomRec* __restrict__ rec,
               const float* __restrict__ bg, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
-              const float* __restrict__ dL_dpix, float* __restrict__ acc, const uint32_t* __restrict__ tile_order)
+              const float* __restrict__ dL_dpix, float* __restrict__ acc, const uint32_t* __restrict__ tile_order,
+              const uint32_t* __restrict__ header, uint32_t list_cap)
 {
     __shared__ __attribute__((aligned(16))) float s_q[(BW_QCAP + 1) * BW_ENTRY_DW];  // (+1: phase A's look-ahead)
+    if (SGR_FORWARD_INVALID(header, list_cap)) return;  // the forward was a no-op (blk_nb, masks, lists are not there)
     __shared__ float2 s_zw[BW_SUB * BW_ZW_STRIDE];
     const int wg = blockIdx.x;
     const int sub = (wg >> 3) & 3;
@@ -455,15 +416,8 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
         int qs = 0;
         while (qn - qs >= BW_SUB || (last_batch && qn > qs)) {
             const int rows = min(BW_SUB, qn - qs);
-#ifdef SGR_BWD_REF_A
-            bwd_phase_a_ref(s_q + qs * BW_ENTRY_DW, s_zw, lane, rows, inside, pixfx, pixfy, g0, g1, g2, ntb, last_contributor, T, acc_g,
-                            lc_g, last_alpha);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#else
             bwd_phase_a(q_lds + (uint32_t)qs * (BW_ENTRY_DW * 4), zw_lds, rows, inside_mask, pixfx, pixfy, g0, g1, g2, ntb,
                         last_contributor, T, acc_g, lc_g, last_alpha);
-#endif
             // ---------------- phase B: lane = (panel row bg_, pixel rows 2 bq and 2 bq + 1)
             if (bg_ < rows) {
                 const float* e = s_q + (qs + bg_) * BW_ENTRY_DW;
@@ -471,9 +425,6 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
                 float s0 = 0.f, sx = 0.f, sxx = 0.f, t0 = 0.f, tx1 = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
-#ifdef SGR_BWD_HALF
-                    if (i == 8) __builtin_amdgcn_sched_barrier(0);  // two groups of eight loads: fewer registers in flight
-#endif
                     const float2 v = row[i];
                     const float xi = (float)(i & 7);
                     s0 += v.x; sx += v.x * xi; sxx += v.x * (xi * xi);
@@ -513,11 +464,7 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
                     const int g = 4 * pass + (lane >> 4);
                     if (g < rows && c < 9) {
                         const float val = tbl[g * 16 + c];
-#ifndef SGR_BWD_NO_ATOMICS
                         if (val != 0.f) atomicAdd(acc + (size_t)__float_as_uint(tbl[g * 16 + 9]) * SGR_ACC_STRIDE + c, val);
-#else
-                        if (val == 12345.f) atomicAdd(acc + (size_t)__float_as_uint(tbl[g * 16 + 9]) * SGR_ACC_STRIDE + c, val);
-#endif
                     }
                 }
             }
@@ -581,11 +528,12 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
 // lifetimes spread over an order of magnitude, raster order leaves a quarter of the chip idle at the end.)  One workgroup:
 // a counting sort over 1024 depth classes; ties land in arbitrary order.
 __global__ void __launch_bounds__(1024) k_tile_order(int T, const uint32_t* __restrict__ tile_maxc, const uint32_t* __restrict__ header,
-                                                     uint32_t* __restrict__ order)
+                                                     uint32_t list_cap, uint32_t* __restrict__ order)
 {
     __shared__ uint32_t s_cls[1024];
     __shared__ uint32_t s_w[16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (SGR_FORWARD_INVALID(header, list_cap)) return;
     const uint32_t mc = header[SGR_HDR_MAXCOUNT];
     const int shift = mc >= 1024u ? (32 - __builtin_clz(mc)) - 10 : 0;  // class = 1023 - (depth >> shift): class 0 = deepest
     s_cls[tid] = 0u;
@@ -608,27 +556,38 @@ __global__ void __launch_bounds__(1024) k_tile_order(int T, const uint32_t* __re
     for (int i = tid; i < T; i += 1024) order[atomicAdd(&s_cls[1023u - min(tile_maxc[i] >> shift, 1023u)], 1u)] = (uint32_t)i;
 }
 
+// walk hint for the next visit of this camera: what the tile walked now, plus a quarter, plus one batch
+__global__ void __launch_bounds__(256) k_make_hint(int T, const uint32_t* __restrict__ tile_walked, const uint32_t* __restrict__ header,
+                                                   uint32_t list_cap, uint32_t* __restrict__ need_out)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T || SGR_FORWARD_INVALID(header, list_cap)) return;  // (an invalid forward leaves the previous hint in place)
+    const uint32_t w = tile_walked[t];
+    need_out[t] = w + (w >> 2) + 64u;
+}
+
 }  // namespace
 
 void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
                           uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
-                          const uint32_t* guard_hdr, uint32_t list_cap, hipStream_t s)
+                          uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, uint32_t* tile_need_out, hipStream_t s)
 {
     const int T = gx * gy;  // (tile_maxc and tile_walked were zeroed by the tile scan: the blocks of a tile combine with atomicMax)
     hipLaunchKernelGGL(k_blend_fwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg, final_T,
-                       n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, guard_hdr, list_cap);
+                       n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap, tile_need);
+    if (tile_need_out)
+        hipLaunchKernelGGL(k_make_hint, dim3((T + 255) / 256), dim3(256), 0, s, T, tile_walked, header, list_cap, tile_need_out);
 }
 
 void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const unsigned long long* blk_mask, const uint32_t* blk_nb, const GeomRec* rec, const float* bg,
                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* acc,
-                          const uint32_t* tile_maxc, const uint32_t* header, uint32_t* tile_order, hipStream_t s)
+                          const uint32_t* tile_maxc, const uint32_t* header, uint32_t list_cap, uint32_t* tile_order, hipStream_t s)
 {
     const int T = gx * gy;
-    static const bool raster = getenv("SGR_BWD_RASTER_ORDER") != nullptr;  // (development: A/B of the launch order)
-    if (raster || 4 * T < 8192) tile_order = nullptr;  // (fewer waves than the chip holds at once: nothing to order)
-    else hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, T, tile_maxc, header, tile_order);
+    if (4 * T < 8192) tile_order = nullptr;  // (fewer waves than the chip holds at once: nothing to order)
+    else hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, T, tile_maxc, header, list_cap, tile_order);
     hipLaunchKernelGGL(k_blend_bwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, blk_mask, blk_nb, rec,
-                       bg, final_T, n_contrib, dL_dpix, acc, tile_order);
+                       bg, final_T, n_contrib, dL_dpix, acc, tile_order, header, list_cap);
 }

@@ -85,29 +85,10 @@ struct StageTimer {
 
 }  // namespace
 
-static int g_binning_mode = 0;   // 0: two-level binning (binning2.hip) with automatic fallback, 1: single-level (binning.hip)
-static int g_last_binning = 0;   // which path the last forward took
-
 extern "C" {
 
 int sgr_abi_version(void) { return SGR_ABI_VERSION; }
 
-int sgr_set_binning_mode(int mode)
-{
-    const int old = g_binning_mode;
-    if (mode == 0 || mode == 1) g_binning_mode = mode;
-    return old;
-}
-
-int sgr_last_binning_mode(void) { return g_last_binning; }
-
-extern int g_sgr_blend_variant;
-int sgr_set_blend_variant(int v)
-{
-    const int old = g_sgr_blend_variant;
-    g_sgr_blend_variant = v;
-    return old;
-}
 const char* sgr_last_error(void) { return g_err.c_str(); }
 
 size_t sgr_geom_bytes(int P) { return sgr_geom_total(P); }
@@ -157,10 +138,18 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
                        const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                        float tan_fovx, float tan_fovy, int prefiltered, float* out_color, int* radii, int debug,
-                       void* stream, int64_t binning_capacity, int flags)
+                       void* stream, const sgr_forward_opts* opts)
 {
-    (void)prefiltered;  // the reference only uses it to trap on an inconsistent pre-filter (auxiliary.h:156-160)
+    // prefiltered: the reference only uses it to abort the process when a Gaussian the caller promised to be visible is
+    // culled (auxiliary.h:156-160: printf + __trap); a library must not kill its host, so the promise is not checked
+    (void)prefiltered;
     hipStream_t s = (hipStream_t)stream;
+    static const sgr_forward_opts no_opts = {0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (!opts) opts = &no_opts;
+    int64_t binning_capacity = opts->binning_capacity;
+    const int flags = opts->flags;
+    const int binning_mode = (flags & SGR_FLAG_SINGLE_LEVEL_BINNING) ? 1 : 0;
+    if (opts->tile_need && binning_mode == 1) return fail(SGR_E_INVALID, "the walk hint needs the two-level binning");
     if (P <= 0 || width <= 0 || height <= 0) return fail(SGR_E_INVALID, "P, width and height must be positive");
     if (!means3D || !opacities || !viewmatrix || !projmatrix || !background || !out_color)
         return fail(SGR_E_INVALID, "null required pointer");
@@ -173,7 +162,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     const ImgLayout IL = sgr_img_layout(width, height);
     const bool legacy_ok = IL.n_blocks > 0;  // one LDS counter per tile fits (about 38 000 tiles)
     if (IL.gx > 65535 || IL.gy > 65535) return fail(SGR_E_INVALID, "image too large: more than 65535 tiles per axis");
-    if (!legacy_ok && g_binning_mode == 1)
+    if (!legacy_ok && binning_mode == 1)
         return fail(SGR_E_INVALID, "image too large for the single-level binning (one LDS counter per tile, about 38 000 tiles)");
     const Bin2Layout B2 = sgr_bin2_layout(P, IL.gx, IL.gy);
     char* geom = geom_alloc(geom_user, sgr_geom_bytes(P));
@@ -217,7 +206,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     STAGE_CHECK("gaussian_sort");
 
     char* bin2 = img + IL.total;
-    bool two_level = g_binning_mode == 0;
+    bool two_level = binning_mode == 0;
     {
         StageTimer t(s, SGR_STAGE_SCAN);
         if (two_level) {
@@ -226,9 +215,11 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
             sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, blk_hist, s);
             sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
         }
-        sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, tile_maxc, tile_walked, s);
+        sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, tile_maxc, tile_walked, two_level ? 0 : 1, s);
     }
     STAGE_CHECK("bin_count");
+    // the header for a caller that checks late: copied here, right behind the tile scan (words 0 and 6 are final)
+    if (opts->header_host) HIP_TRY(hipMemcpyAsync(opts->header_host, header, 32, hipMemcpyDeviceToHost, s));
 
     // Sync-free mode (binning_capacity > 0, two-level binning): no device-to-host copy of R and no host wait -- the
     // instance list gets the caller's capacity, the write pass clamps to it and the blend kernel returns at once when the
@@ -252,14 +243,16 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
             two_level = false;
             sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, blk_hist, s);
             sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
-            sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, tile_maxc, tile_walked, s);
+            sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, tile_maxc, tile_walked, 1, s);
+            if (opts->header_host) HIP_TRY(hipMemcpyAsync(opts->header_host, header, 32, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 16, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
         }
         R = (int64_t)g_pinned.p[SGR_HDR_R];
         n_chunks = g_pinned.p[4 + SGR_B2_HDR_CHUNKS];
     }
-    g_last_binning = two_level ? 0 : 1;
+    if (opts->info) { opts->info->binning_mode = two_level ? 0 : 1; opts->info->sync_free = nosync ? 1 : 0; }
+    if (opts->tile_need && !two_level) return fail(SGR_E_INVALID, "the walk hint needs the two-level binning (level-1 overflow on this view)");
 
     const BinLayout BL = sgr_bin_layout(R, IL.T);
     char* binning = binning_alloc(binning_user, BL.total);
@@ -271,7 +264,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
         StageTimer t(s, SGR_STAGE_SCATTER);
         if (two_level)
             sgr_launch_bin2_write(IL.gx, IL.gy, B2, bin2, header + 4, n_chunks, rects, order, tile_start, point_list,
-                                  nosync ? (uint32_t)R : 0xFFFFFFFFu, s);
+                                  nosync ? (uint32_t)R : 0xFFFFFFFFu, opts->tile_need, s);
         else
             sgr_launch_bin_scatter(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, tile_start, blk_hist, point_list, s);
     }
@@ -279,10 +272,13 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     {
         StageTimer t(s, SGR_STAGE_BLEND_FWD);
         sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
-                             tile_maxc, tile_walked, out_color, blk_mask, blk_nb, nosync ? header : nullptr,
-                             (uint32_t)(nosync ? R : 0), s);
+                             tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, (uint32_t)R, opts->tile_need,
+                             opts->tile_need_out, s);
     }
     STAGE_CHECK("blend_fwd");
+    // ... and once more behind the blend: word 3 (hint miss) is final only now
+    if (opts->header_host) HIP_TRY(hipMemcpyAsync(opts->header_host + 8, header, 32, hipMemcpyDeviceToHost, s));
+    if (opts->header_event) HIP_TRY(hipEventRecord((hipEvent_t)opts->header_event, s));
     return R;
 }
 
@@ -296,7 +292,7 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
 {
     return sgr_forward_ex(geom_alloc, geom_user, binning_alloc, binning_user, img_alloc, img_user, P, D, M, background, width, height,
                           means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
-                          projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug, stream, 0, 0);
+                          projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug, stream, nullptr);
 }
 
 // phase 0: everything; 1: the blend half (accumulator reset, blend backward, and in compact mode the masked colour
@@ -307,7 +303,7 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
                          const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, char* geom_buffer,
                          char* binning_buffer, char* img_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
                          float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                         float* dL_dscale, float* dL_drot, int debug, void* stream)
+                         float* dL_dscale, float* dL_drot, int debug, void* stream, const sgr_backward_opts* opts = nullptr)
 {
     hipStream_t s = (hipStream_t)stream;
     const int raw_params = (phase & SGR_MODE_RAW_PARAMS) ? 1 : 0;
@@ -345,7 +341,7 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
             // (the forward's per-tile counters are dead by now: their array holds the backward's launch order)
             sgr_launch_blend_bwd(width, height, IL.gx, IL.gy, tile_start, point_list, blk_mask, blk_nb, rec, background, final_T,
                                  n_contrib, dL_dpix, acc, reinterpret_cast<const uint32_t*>(img_buffer + IL.tile_maxc),
-                                 reinterpret_cast<const uint32_t*>(img_buffer + IL.header),
+                                 reinterpret_cast<const uint32_t*>(img_buffer + IL.header), (uint32_t)(R > 0xFFFFFFFFll ? 0xFFFFFFFFll : R),
                                  reinterpret_cast<uint32_t*>(img_buffer + IL.tile_cursor), s);
         }
         STAGE_CHECK("blend_bwd");
@@ -368,6 +364,9 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
     pb.raw_params = raw_params && !cov3D_precomp;
     pb.sh_dir_elsewhere = sh_dir_elsewhere && use_sh && !dL_dsh;  // (compact SH mode only: see sgr_sh_adam_from_views_ex)
     pb.acc = acc;
+    pb.dens_max_radii = opts ? opts->max_radii2D : nullptr;
+    pb.dens_accum = opts ? opts->grad_accum : nullptr;
+    pb.dens_denom = opts ? opts->denom : nullptr;
     pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dopacity = dL_dopacity;
     pb.dL_dcolor = phase == 2 ? nullptr : dL_dcolor;  // phase 2: already written (and possibly being sent) by phase 1
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_dsh = use_sh ? dL_dsh : nullptr;
@@ -405,6 +404,27 @@ int sgr_backward_phase(int phase, int P, int D, int M, int64_t R, const float* b
                          rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, geom_buffer, binning_buffer,
                          img_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
                          dL_drot, debug, stream);
+}
+
+int sgr_backward_ex(int phase, int P, int D, int M, int64_t R, const float* background, int width, int height,
+                    const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                    float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                    const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii,
+                    char* geom_buffer, char* binning_buffer, char* img_buffer, const float* dL_dpix, float* dL_dmean2D,
+                    float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                    float* dL_dscale, float* dL_drot, int debug, void* stream, const sgr_backward_opts* opts)
+{
+    (void)radii;
+    return backward_impl(phase, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier,
+                         rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, geom_buffer, binning_buffer,
+                         img_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
+                         dL_drot, debug, stream, opts);
+}
+
+size_t sgr_bin2_bytes(int P, int width, int height)
+{
+    const ImgLayout IL = sgr_img_layout(width, height);
+    return sgr_bin2_layout(P, IL.gx, IL.gy).total;
 }
 
 int sgr_sh_grad_from_views(int P, int n_views, int D, int M, const float* means3D, const float* campos_all,

@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256) k_l1_ssim_bwd(int W, int H, int tiles_x, 
             if (t >= 0 && t < 11) { gp[o] += win.w[t] * h; gq[o] += win.w[t] * h2; }
         }
     }
-    const float gl = grad_loss[0] * inv_n;
+    const float gl = (grad_loss ? grad_loss[0] : 1.0f) * inv_n;  // (NULL: d loss / d loss = 1)
 #pragma unroll
     for (int o = 0; o < 4; o++) {
         const int py = y0 + 4 * lg + o;
@@ -327,7 +327,7 @@ int sgr_l1_ssim_forward(int channels, int width, int height, const float* img, c
 int sgr_l1_ssim_backward(int channels, int width, int height, const float* img, const float* gt, float lambda,
                          const char* scratch, const float* grad_loss, float* grad_img, void* stream)
 {
-    if (channels <= 0 || width <= 0 || height <= 0 || !img || !gt || !scratch || !grad_loss || !grad_img) return SGR_E_INVALID;
+    if (channels <= 0 || width <= 0 || height <= 0 || !img || !gt || !scratch || !grad_img) return SGR_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const size_t plane = sgr_align((size_t)channels * width * height * 4);
     const float* dm1 = reinterpret_cast<const float*>(scratch);

@@ -488,6 +488,11 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
         dm2y = -(op * ddely_dy) * (cz * s1.y + cy * s1.x);
         g0 = -0.5f * op * s1.z; g1 = -0.5f * op * s1.w; g3 = -0.5f * op * s2x;
         if (a.dL_dmean2D) { a.dL_dmean2D[i3] = dm2x; a.dL_dmean2D[i3 + 1] = dm2y; a.dL_dmean2D[i3 + 2] = 0; }
+        // densification statistics of the train loop, fused (train.py:111-123 / sugar_densifier.py:156-164: over the
+        // visibility filter radii > 0 -- this branch -- max_radii2D = max(., radii), accum += |viewspace grad .xy|, denom += 1)
+        if (a.dens_accum) a.dens_accum[idx] += sqrtf(dm2x * dm2x + dm2y * dm2y);
+        if (a.dens_denom) a.dens_denom[idx] += 1.0f;
+        if (a.dens_max_radii) a.dens_max_radii[idx] = fmaxf(a.dens_max_radii[idx], (float)radius);
         float4 gc = {g0, g1, 0.f, g3};
         if (a.dL_dconic) *reinterpret_cast<float4*>(a.dL_dconic + 4 * (size_t)idx) = gc;
         // raw mode: d sigmoid = s (1 - s), the activated opacity is in the record (sgr_activations_backward's arithmetic)
@@ -779,6 +784,7 @@ __global__ void __launch_bounds__(256) k_sh_grad_from_views(int P, int V, int D,
 // values and lr_rest for the others: gaussian_model.py:157-158) without ever writing the 48-float gradient to memory.
 struct ShAdamArgs {
     float lr_dc, lr_rest, b1, b2, eps, bc1, bc2_sqrt, grad_scale;
+    const uint32_t* guard; uint32_t guard_cap;  // forward header + list capacity: the step is a no-op if that forward was invalid (NULL: no check)
 };
 
 // One wave per 64 Gaussians.  Phase 1: lane = Gaussian, the 48 sums in registers, dropped into an LDS panel (row stride 52
@@ -798,6 +804,7 @@ __global__ void __launch_bounds__(64) k_sh_adam_from_views(int P, int V, int D, 
                                                            float* __restrict__ dmean_extra)
 {
     __shared__ __attribute__((aligned(16))) float s_g[64 * SHA_STRIDE];
+    if (a.guard && SGR_FORWARD_INVALID(a.guard, a.guard_cap)) return;
     const int lane = threadIdx.x;
     const int g0 = blockIdx.x * 64;
     const int idx = g0 + lane;
@@ -1039,9 +1046,10 @@ void sgr_launch_masked_colors(int P, const GeomRec* rec, const float* acc, float
 
 void sgr_launch_sh_adam_from_views(int P, int V, int D, int M, size_t vstride, const float* means3D, const float* campos,
                                    const float* dcolor, float* sh, float* exp_avg, float* exp_avg_sq, float lr_dc, float lr_rest, float b1, float b2,
-                                   float eps, float bc1, float bc2_sqrt, float grad_scale, float* dmean_extra, hipStream_t s)
+                                   float eps, float bc1, float bc2_sqrt, float grad_scale, float* dmean_extra, hipStream_t s,
+                                   const uint32_t* guard, uint32_t guard_cap)
 {
-    ShAdamArgs a = {lr_dc, lr_rest, b1, b2, eps, bc1, bc2_sqrt, grad_scale};
+    ShAdamArgs a = {lr_dc, lr_rest, b1, b2, eps, bc1, bc2_sqrt, grad_scale, guard, guard_cap};
     if (dmean_extra)
         hipLaunchKernelGGL(k_sh_adam_from_views<true>, dim3((P + 63) / 64), dim3(64), 0, s, P, V, D, M, vstride, means3D, campos, dcolor,
                            sh, exp_avg, exp_avg_sq, a, dmean_extra);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include "../../include/sugar_raster.h"  // SGR_HDR_*, the option structs
 
 #define SGR_TILE_X 16  // BLOCK_X, DGR/cuda_rasterizer/config.h:16 (part of the pixel-exact contract)
 #define SGR_TILE_Y 16  // BLOCK_Y, DGR/cuda_rasterizer/config.h:17
@@ -82,7 +83,8 @@ Bin2Layout sgr_bin2_layout(int P, int gx, int gy);
 void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scratch, uint32_t* hdr, const uint2* rects,
                            const uint32_t* order, uint32_t* tile_count, hipStream_t s);
 void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, const uint32_t* hdr, uint32_t n_chunks, const uint2* rects,
-                           const uint32_t* order, const uint32_t* tile_start, uint32_t* point_list, uint32_t list_cap, hipStream_t s);
+                           const uint32_t* order, const uint32_t* tile_start, uint32_t* point_list, uint32_t list_cap,
+                           const uint32_t* tile_need, hipStream_t s);
 
 // binning: [ point_list u32[R] | blk_mask u64[(R/64 + T + 1) * 4] ]   blk_mask: per 64-entry batch of every tile's list and per
 //           8x8 block of the tile, the lanes (entries) that survive the block's exact cull -- written by the forward blend
@@ -98,10 +100,8 @@ static inline BinLayout sgr_bin_layout(int64_t R, int T)
     return L;
 }
 
-// header words written by the tile scan
-#define SGR_HDR_R 0        // total instances (low 32 bits)
-#define SGR_HDR_MAXCOUNT 1 // largest per-tile instance count
-#define SGR_HDR_R_HI 2     // high 32 bits of R
+// header words: SGR_HDR_* of include/sugar_raster.h (0 R, 1 largest tile count, 2 R high word, 3 hint miss; words 4-6 are
+// the two-level binning's SGR_B2_HDR_*, written by k_sup_scan and cleared by the tile scan on the single-level path)
 
 // stage ids of the optional event profile (sgr_profile_read)
 enum { SGR_STAGE_PREPROCESS = 0, SGR_STAGE_SCAN /* bin_count + scans */, SGR_STAGE_SCATTER, SGR_STAGE_SORT /* depth sort */, SGR_STAGE_BLEND_FWD,
@@ -133,6 +133,7 @@ struct PreprocessBwdArgs {
     const GeomRec* rec;
     int raw_params;    // as in PreprocessArgs: dL_dscale / dL_drot / dL_dopacity are then gradients w.r.t. the raw parameters
     int sh_dir_elsewhere;  // compact mode only: skip the SH block (dRGB/d(view direction) -> dL_dmean3D is formed by k_sh_adam_from_views)
+    float* dens_max_radii; float* dens_accum; float* dens_denom;  // fused densification statistics (sgr_backward_opts) or NULL
     const float* acc;  // [P][SGR_ACC_STRIDE] sums from the blend backward: {dcol r,g,b, S0, Sx, Sy, Sxx, Sxy, Syy, pad x3}
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor;  // written here from acc
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
@@ -144,7 +145,13 @@ void sgr_launch_sh_grad_from_views(int P, int V, int D, int M, size_t vstride, c
 
 void sgr_launch_sh_adam_from_views(int P, int V, int D, int M, size_t vstride, const float* means3D, const float* campos,
                                    const float* dcolor, float* sh, float* exp_avg, float* exp_avg_sq, float lr_dc, float lr_rest, float b1, float b2,
-                                   float eps, float bc1, float bc2_sqrt, float grad_scale, float* dmean_extra, hipStream_t s);
+                                   float eps, float bc1, float bc2_sqrt, float grad_scale, float* dmean_extra, hipStream_t s,
+                                   const uint32_t* guard = nullptr, uint32_t guard_cap = 0);
+// sgr_adam_step_ex with the same guard (adam.hip)
+int sgr_adam_launch(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n_seg,
+                    const long long* seg_begin, const long long* seg_end, const float* seg_lr_a, const float* seg_lr_b,
+                    const int* seg_period, const int* seg_split, float beta1, float beta2, float eps, int step, float grad_scale,
+                    const float* extra, long long extra_n, const uint32_t* guard, uint32_t guard_cap, hipStream_t s);
 
 void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_out, const uint2* rect_by_id, uint2* rects_sorted,
                               hipStream_t s);
@@ -158,13 +165,17 @@ void sgr_launch_bin_scatter(int P, int gx, int gy, int n_slices, int per_slice, 
                             const uint32_t* tile_start, uint32_t* blk_hist, uint32_t* point_list, hipStream_t s);
 void sgr_launch_hist_scan(int T, int n_blocks, uint32_t* blk_hist, uint32_t* tile_count, hipStream_t s);
 void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* header, uint32_t* tile_maxc,
-                          uint32_t* tile_walked, hipStream_t s);
+                          uint32_t* tile_walked, int clear_b2_words, hipStream_t s);
 
+// header: the forward's device header; list_cap: instances the list was allocated for (the forward is a no-op when the header
+// says it does not fit, the backward when the forward was one); tile_need / tile_need_out: walk hint (sgr_forward_opts)
 void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
                           uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
-                          const uint32_t* guard_hdr, uint32_t list_cap, hipStream_t s);
+                          uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, uint32_t* tile_need_out, hipStream_t s);
 void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const unsigned long long* blk_mask, const uint32_t* blk_nb, const GeomRec* rec, const float* bg,
                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* acc,
-                          const uint32_t* tile_maxc, const uint32_t* header, uint32_t* tile_order, hipStream_t s);
+                          const uint32_t* tile_maxc, const uint32_t* header, uint32_t list_cap, uint32_t* tile_order, hipStream_t s);
+// true on the device when the forward that wrote `hdr` must be treated as not having happened
+#define SGR_FORWARD_INVALID(hdr, cap) ((hdr)[SGR_HDR_R] > (cap) || (hdr)[SGR_HDR_HINT_MISS] != 0u || (hdr)[4 + SGR_B2_HDR_OVERFLOW] != 0u)

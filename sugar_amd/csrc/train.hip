@@ -1,0 +1,173 @@
+// train.hip -- the train step as native calls (sgr_trainer_*, include/sugar_raster.h).
+//
+// Restates the order of gaussian_splatting/train.py:86-128 (render -> loss -> backward -> optimizer.step) on the caller's
+// stream with the library's own kernels: sync-free rasterizer forward in raw-parameter mode, fused L1 + D-SSIM loss and its
+// backward, blend backward, backward preprocess (gradients land in the flat gradient buffer), SH-Adam from the per-view
+// colour gradients and flat Adam over the other 11 floats per Gaussian.  Host side only: ~25 launches per step and nothing
+// else -- no allocation, no host wait, no interpreter between the kernels (the Python loop this replaces finished 27 us
+// ahead of the GPU at 1.29 ms per step).
+#include "../../include/sugar_raster.h"
+#include "sgr_common.h"
+
+#include <cmath>
+#include <cstring>
+#include <string>
+
+namespace {
+
+struct FixedBuf { char* p; size_t bytes; size_t asked; };
+char* fixed_alloc(void* user, size_t bytes)
+{
+    FixedBuf* b = static_cast<FixedBuf*>(user);
+    b->asked = bytes;
+    return bytes <= b->bytes ? b->p : nullptr;
+}
+
+}  // namespace
+
+struct sgr_trainer {
+    sgr_train_config c;
+    hipEvent_t hdr_event = nullptr;
+    bool have_forward = false;
+    int64_t R = 0;              // what the last forward returned (= the capacity)
+    long long seg_begin[4], seg_end[4];
+    float seg_lr[4];
+    int seg_one[4];
+    std::string err;
+};
+
+extern "C" {
+
+static thread_local std::string g_train_err;
+static int tfail(int code, const std::string& m) { g_train_err = m; return code; }
+const char* sgr_trainer_last_error(void) { return g_train_err.c_str(); }
+
+sgr_trainer* sgr_trainer_create(const sgr_train_config* cfg)
+{
+    if (!cfg) { g_train_err = "null config"; return nullptr; }
+    const sgr_train_config& c = *cfg;
+    const bool ok = c.P > 0 && c.width > 0 && c.height > 0 && c.M >= (c.D + 1) * (c.D + 1) && c.M <= 16 && c.D >= 0 && c.D <= 3 &&
+                    c.flat && c.flat_grad && c.exp_avg && c.exp_avg_sq && c.background && c.geom && c.img && c.binning &&
+                    c.loss_scratch && c.image && c.grad_image && c.loss_out && c.colors && c.header_host &&
+                    c.binning_capacity > 0 && c.n_small > 0 && (c.n_small & 3) == 0 && (c.off_features & 3) == 0;
+    if (!ok) { g_train_err = "sgr_trainer_create: bad configuration (null pointer, size or alignment)"; return nullptr; }
+    if (c.geom_bytes < sgr_geom_bytes(c.P) || c.img_bytes < sgr_img_bytes(c.width, c.height) + sgr_bin2_bytes(c.P, c.width, c.height) ||
+        c.binning_bytes < sgr_binning_bytes(c.binning_capacity, c.width, c.height)) {
+        g_train_err = "sgr_trainer_create: a scratch buffer is smaller than sgr_geom_bytes / sgr_img_bytes + sgr_bin2_bytes / sgr_binning_bytes";
+        return nullptr;
+    }
+    sgr_trainer* t = new sgr_trainer;
+    t->c = c;
+    if (hipEventCreateWithFlags(&t->hdr_event, hipEventDisableTiming) != hipSuccess) { delete t; g_train_err = "hipEventCreate failed"; return nullptr; }
+    const long long P = c.P;
+    const long long b[4] = {c.off_xyz, c.off_opacity, c.off_scaling, c.off_rotation};
+    const long long n[4] = {3 * P, P, 3 * P, 4 * P};
+    const float lr[4] = {c.lr_xyz, c.lr_opacity, c.lr_scaling, c.lr_rotation};
+    for (int k = 0; k < 4; k++) { t->seg_begin[k] = b[k]; t->seg_end[k] = b[k] + n[k]; t->seg_lr[k] = lr[k]; t->seg_one[k] = 1; }
+    std::memset(c.header_host, 0, 64);
+    return t;
+}
+
+void sgr_trainer_destroy(sgr_trainer* t)
+{
+    if (!t) return;
+    if (t->hdr_event) (void)hipEventDestroy(t->hdr_event);
+    delete t;
+}
+
+int sgr_trainer_set_binning(sgr_trainer* t, char* binning, size_t bytes, int64_t capacity)
+{
+    if (!t || !binning || capacity <= 0 || bytes < sgr_binning_bytes(capacity, t->c.width, t->c.height))
+        return tfail(SGR_E_INVALID, "sgr_trainer_set_binning: bad buffer");
+    t->c.binning = binning; t->c.binning_bytes = bytes; t->c.binning_capacity = capacity;
+    return 0;
+}
+
+int sgr_trainer_forward_valid(sgr_trainer* t, uint32_t* header_out)
+{
+    if (!t || !t->have_forward) return tfail(SGR_E_INVALID, "sgr_trainer_forward_valid: no forward yet");
+    if (hipEventSynchronize(t->hdr_event) != hipSuccess) return tfail(SGR_E_HIP, "hipEventSynchronize failed");
+    const uint32_t* h = t->c.header_host;
+    if (header_out) std::memcpy(header_out, h, 64);
+    const bool bad = (int64_t)h[SGR_HDR_R] > t->R || h[8 + SGR_HDR_HINT_MISS] != 0u || h[SGR_HDR_L1_OVERFLOW] != 0u;
+    return bad ? 0 : 1;
+}
+
+int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* v, int phases, const sgr_train_exchange* ex, void* stream)
+{
+    if (!t || !v) return tfail(SGR_E_INVALID, "sgr_trainer_step: null argument");
+    const sgr_train_config& c = t->c;
+    hipStream_t s = (hipStream_t)stream;
+    const int P = c.P, W = c.width, H = c.height;
+    float* flat = c.flat;
+    float* grad = c.flat_grad;
+    const float* means3D = flat + c.off_xyz;
+    const float* shs = flat + c.off_features;
+    const float* opac = flat + c.off_opacity;
+    const float* scal = flat + c.off_scaling;
+    const float* rot = flat + c.off_rotation;
+    const uint32_t* header = reinterpret_cast<const uint32_t*>(c.img + sgr_img_header_offset(W, H));
+    const uint32_t cap = (uint32_t)(c.binning_capacity > 0xFFFFFFFFll ? 0xFFFFFFFFll : c.binning_capacity);
+    if (phases & 1) {
+        if (!v->viewmatrix || !v->projmatrix || !v->campos || !v->gt_image) return tfail(SGR_E_INVALID, "sgr_trainer_step: null view");
+        FixedBuf g = {c.geom, c.geom_bytes, 0}, b = {c.binning, c.binning_bytes, 0}, i = {c.img, c.img_bytes, 0};
+        sgr_forward_opts fo;
+        std::memset(&fo, 0, sizeof(fo));
+        fo.binning_capacity = c.binning_capacity;
+        fo.flags = SGR_FLAG_RAW_PARAMS;
+        fo.header_host = c.header_host;
+        fo.header_event = t->hdr_event;
+        fo.tile_need = v->tile_need;
+        fo.tile_need_out = v->tile_need_out;
+        const int64_t R = sgr_forward_ex(fixed_alloc, &g, fixed_alloc, &b, fixed_alloc, &i, P, c.D, c.M, c.background, W, H, means3D, shs,
+                                         nullptr, opac, scal, 1.0f, rot, nullptr, v->viewmatrix, v->projmatrix, v->campos,
+                                         v->tan_fovx, v->tan_fovy, 0, c.image, c.radii, 0, stream, &fo);
+        if (R < 0) return tfail((int)R, std::string("forward: ") + sgr_last_error());
+        t->R = R;
+        t->have_forward = true;
+        int rc = sgr_l1_ssim_forward(3, W, H, c.image, v->gt_image, c.lambda_dssim, c.loss_scratch, c.loss_out, stream);
+        if (rc < 0) return tfail(rc, "l1_ssim_forward failed");
+        rc = sgr_l1_ssim_backward(3, W, H, c.image, v->gt_image, c.lambda_dssim, c.loss_scratch, nullptr, c.grad_image, stream);
+        if (rc < 0) return tfail(rc, "l1_ssim_backward failed");
+    }
+    if (phases & 3) {
+        if (!t->have_forward) return tfail(SGR_E_INVALID, "sgr_trainer_step: backward before any forward");
+        sgr_backward_opts bo = {c.max_radii2D, c.grad_accum, c.denom};
+        // compact SH mode (dL_dsh == NULL), raw-parameter gradients straight into the flat gradient buffer
+        for (int ph = 1; ph <= 2; ph++) {
+            if (!(phases & ph)) continue;
+            const int rc = sgr_backward_ex(ph | SGR_MODE_RAW_PARAMS, P, c.D, c.M, t->R, c.background, W, H, means3D, shs, nullptr, scal,
+                                           1.0f, rot, nullptr, v->viewmatrix, v->projmatrix, v->campos, v->tan_fovx, v->tan_fovy,
+                                           c.radii, c.geom, c.binning, c.img, c.grad_image, c.dL_dmean2D, nullptr,
+                                           grad + c.off_opacity, c.colors, grad + c.off_xyz, nullptr, nullptr, grad + c.off_scaling,
+                                           grad + c.off_rotation, 0, stream, &bo);
+            if (rc < 0) return tfail(rc, std::string("backward: ") + sgr_last_error());
+            if (ph == 1 && hipMemcpyAsync(c.colors + 3 * (size_t)P, v->campos, 12, hipMemcpyDeviceToDevice, s) != hipSuccess)
+                return tfail(SGR_E_HIP, "camera centre copy failed");
+        }
+    }
+    if (phases & 12) {
+        if (!ex || ex->step < 1 || ex->n_views < 1) return tfail(SGR_E_INVALID, "sgr_trainer_step: exchange description missing");
+        const float bc1 = 1.f - powf(c.beta1, (float)ex->step);
+        const float bc2_sqrt = sqrtf(1.f - powf(c.beta2, (float)ex->step));
+        if (phases & 4) {
+            const float* cols = ex->all_colors ? ex->all_colors : c.colors;
+            const float* cams = ex->all_campos ? ex->all_campos : (ex->all_colors ? nullptr : c.colors + 3 * (size_t)P);
+            if (!cams) return tfail(SGR_E_INVALID, "sgr_trainer_step: all_campos missing");
+            const size_t stride = (size_t)(ex->view_stride ? ex->view_stride : (ex->all_colors ? P : P + 1));
+            sgr_launch_sh_adam_from_views(P, ex->n_views, c.D, c.M, stride, means3D, cams, cols, flat + c.off_features,
+                                          c.exp_avg + c.off_features, c.exp_avg_sq + c.off_features, c.lr_features_dc,
+                                          c.lr_features_rest, c.beta1, c.beta2, c.eps, bc1, bc2_sqrt, ex->grad_scale, nullptr, s, header, cap);
+            if (hipGetLastError() != hipSuccess) return tfail(SGR_E_HIP, "sh_adam launch failed");
+        }
+        if (phases & 8) {
+            const int rc = sgr_adam_launch(c.n_small, flat, grad, c.exp_avg, c.exp_avg_sq, 4, t->seg_begin, t->seg_end, t->seg_lr, t->seg_lr,
+                                           t->seg_one, t->seg_one, c.beta1, c.beta2, c.eps, ex->step, ex->grad_scale, nullptr, 0, header,
+                                           cap, s);
+            if (rc < 0) return tfail(rc, "adam launch failed");
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

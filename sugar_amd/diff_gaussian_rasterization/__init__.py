@@ -28,8 +28,11 @@ from .. import _lib
 # `grad_sink(compact_sh=True, out=holder)` selects the compact SH mode of sgr_backward: no SH gradient is produced (the
 # autograd gradient of `shs` is None) and holder["masked_colors"] receives the clamp-masked dL/dRGB [P,3] from which
 # sugar_amd.train_step rebuilds the SH gradient summed over all views (sgr_sh_grad_from_views).
-# `grad_sink(binning_capacity=n, header_out=pinned int32[8], header_event=torch.cuda.Event)` selects the sync-free forward
-# (sgr_forward_ex): no host round trip for num_rendered; the caller checks the header before running the backward.
+# `grad_sink(binning_capacity=n, header_out=pinned int32[16], header_event=torch.cuda.Event)` selects the sync-free forward
+# (sgr_forward_ex): no host round trip for num_rendered; the caller checks the header (a backward on an invalid forward is a
+# no-op on the device).  `tile_need=` / `tile_need_out=` (int32[tiles] device tensors): the walk hint of sgr_forward_opts.
+# `single_level_binning=True`: SGR_FLAG_SINGLE_LEVEL_BINNING.  `dens_stats=(max_radii2D, grad_accum, denom)` (float[P]
+# device tensors): the densification statistics of train.py:111-123 fused into the backward (sgr_backward_opts).
 _GRAD_SINK: dict = {}
 
 
@@ -136,28 +139,36 @@ class _CModule:
             # sync-free forward: `binning_capacity=n` (instances); the 8-word device header is copied into the pinned
             # tensor `header_out` behind the forward and `header_event` recorded: the CALLER must check it (word 0 = real
             # num_rendered <= n and word 6 == 0) before running the backward, and repeat the forward otherwise
-            capacity = int(_GRAD_SINK.get("binning_capacity") or 0) if _GRAD_SINK else 0
+            sink = _GRAD_SINK or {}
+            capacity = int(sink.get("binning_capacity") or 0)
             # `raw_params=True`: scales / rotations / opacities are the raw 3DGS parameters, activated inside the kernels
-            flags = 1 if (_GRAD_SINK and _GRAD_SINK.get("raw_params")) else 0
+            flags = (_lib.SGR_FLAG_RAW_PARAMS if sink.get("raw_params") else 0) | \
+                    (_lib.SGR_FLAG_SINGLE_LEVEL_BINNING if sink.get("single_level_binning") else 0)
+            hdr_out, hdr_ev = sink.get("header_out"), sink.get("header_event")
+            if capacity > 0 and (hdr_out is None or hdr_ev is None):
+                raise RuntimeError("binning_capacity needs header_out (pinned int32[16]) and header_event (torch.cuda.Event)")
+            if hdr_out is not None and not (hdr_out.is_pinned() and hdr_out.numel() >= 16 and hdr_out.dtype == torch.int32):
+                raise RuntimeError("header_out must be a pinned int32 tensor of 16 elements")
+            need, need_out = sink.get("tile_need"), sink.get("tile_need_out")
+            info = _lib.ForwardInfo()
+            opts = _lib.ForwardOpts(capacity, flags, hdr_out.data_ptr() if hdr_out is not None else None, None,
+                                    need.data_ptr() if need is not None else None,
+                                    need_out.data_ptr() if need_out is not None else None, C.pointer(info))
             rendered = lib.sgr_forward_ex(
                 scratch.cb("geom"), None, scratch.cb("binning"), None, scratch.cb("img"), None,
                 P, int(degree), int(M), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
                 _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
                 _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
-                _ptr(out_color), _ptr(radii), int(bool(debug)), C.c_void_p(stream), capacity, flags)
+                _ptr(out_color), _ptr(radii), int(bool(debug)), C.c_void_p(stream), C.byref(opts))
+            if rendered >= 0 and hdr_ev is not None:
+                # the library has queued the header copies (words 0-7 behind the tile scan, 8-15 behind the blend)
+                hdr_ev.record(torch.cuda.current_stream(dev))
         if rendered < 0:
             raise RuntimeError(f"sgr_forward failed ({rendered}): {_lib.last_error()}")
         t = scratch.tensors
-        if capacity > 0:
-            off = lib.sgr_img_header_offset(W, H)
-            hdr_out, hdr_ev = _GRAD_SINK.get("header_out"), _GRAD_SINK.get("header_event")
-            if hdr_out is None or hdr_ev is None:
-                raise RuntimeError("binning_capacity needs header_out (pinned int32[8]) and header_event (torch.cuda.Event)")
-            hdr_out.copy_(t["img"][off: off + 32].view(torch.int32), non_blocking=True)
-            hdr_ev.record(torch.cuda.current_stream(dev))
         # introspection only (bench.py's roofline accounting, parity tests): the most recent forward's scratch
         _CModule.last_forward = dict(num_rendered=int(rendered), W=W, H=H, P=P, geom=t["geom"], binning=t["binning"],
-                                     img=t["img"])
+                                     img=t["img"], binning_mode=int(info.binning_mode), sync_free=bool(info.sync_free))
         return int(rendered), out_color, radii, t["geom"], t["binning"], t["img"]
 
     @staticmethod
@@ -205,17 +216,22 @@ class _CModule:
                         _p(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations), int(bool(debug)),
                         C.c_void_p(stream))
                 on_colors = grad_out.get("on_colors") if (compact_sh and grad_out) else None
+                stats = grad_out.get("dens_stats") if grad_out else None
+                bopts = None
+                if stats is not None:
+                    for st in stats:
+                        if not (st.is_cuda and st.dtype == torch.float32 and st.numel() == P and st.is_contiguous()):
+                            raise RuntimeError("dens_stats: three contiguous float32 device tensors of P elements")
+                    bopts = C.byref(_lib.BackwardOpts(*[st.data_ptr() for st in stats]))
                 if on_colors is not None:
                     # two halves: the masked colour gradients are final after the blend half, so the caller can start
                     # exchanging them while the preprocess half runs
-                    rc = lib.sgr_backward_phase(1 | raw_mode, *args)
+                    rc = lib.sgr_backward_ex(1 | raw_mode, *args, bopts)
                     if rc >= 0:
                         on_colors(dL_dcolors)
-                        rc = lib.sgr_backward_phase(2 | raw_mode, *args)
-                elif raw_mode:
-                    rc = lib.sgr_backward_phase(raw_mode, *args)
+                        rc = lib.sgr_backward_ex(2 | raw_mode, *args, bopts)
                 else:
-                    rc = lib.sgr_backward(*args)
+                    rc = lib.sgr_backward_ex(raw_mode, *args, bopts)
             if rc < 0:
                 raise RuntimeError(f"sgr_backward failed ({rc}): {_lib.last_error()}")
         if compact_sh and isinstance(grad_out.get("out"), dict):

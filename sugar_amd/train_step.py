@@ -396,7 +396,7 @@ class ViewShardedTrainer:
         if self.fuse_activations and not on_hip:
             raise ValueError("fuse_activations needs the HIP rasterizer")
         self._bin_cap = 0                 # instances the binning buffer is sized for (0: next forward runs with the host round trip)
-        self._hdr = torch.zeros(8, dtype=torch.int32).pin_memory() if self.sync_free else None
+        self._hdr = torch.zeros(16, dtype=torch.int32).pin_memory() if self.sync_free else None
         self._ev_hdr = torch.cuda.Event() if self.sync_free else None
         self.last_num_rendered = 0
         self.redone = 0                   # forwards repeated because the capacity was too small
@@ -464,10 +464,10 @@ class ViewShardedTrainer:
         with ctxm:
             pkg, loss = self._forward(cam, gt_image, cap)
             if cap:
-                # the header was copied right behind the tile scan: long done by the time the loss is enqueued
+                # the header travels behind the forward's blend kernel (the loss kernels are already queued behind it)
                 self._ev_hdr.synchronize()
                 R = int(self._hdr[0]) & 0xFFFFFFFF
-                if R > cap or int(self._hdr[6]) != 0:
+                if R > cap or int(self._hdr[6]) != 0 or int(self._hdr[8 + 3]) != 0:
                     self.redone += 1
                     pkg, loss = self._forward(cam, gt_image, 0)  # with the host round trip: any size
                     R = self._last_forward_R()
@@ -529,3 +529,182 @@ class ViewShardedTrainer:
                 p.flat_grad.mul_(scale)
             self.opt.step()
         return loss.detach(), pkg
+
+
+class NativeTrainer:
+    """ViewShardedTrainer.step with the interpreter taken out: one `sgr_trainer_step` call (include/sugar_raster.h) enqueues the
+    whole step -- sync-free rasterizer forward in raw-parameter mode, fused loss and its backward, rasterizer backward into
+    the flat gradient buffer, SH-Adam from the colour gradients, flat Adam over the other 11 floats per Gaussian -- on the
+    current stream, from buffers allocated once.  Same arithmetic, same kernels, same parameter layout (GaussianParams).
+
+    Validity without a host wait.  The forward runs with a list capacity and, from a camera's second visit on, with a WALK
+    HINT (per tile: how many list entries it walked last time + 25 % + 64): the list-write pass then skips the chunks nobody
+    will read.  A forward that outgrew the capacity or the hint makes every later kernel of the step -- backward and Adam
+    included -- a no-op on the device; the host finds out when it next looks at the pinned header (before enqueueing the
+    following step, when the copy has long arrived), enlarges the capacity / drops the hint and repeats the step.
+
+    With a gradient exchange (several ranks, or `force_collectives` on a one-rank group) the step is enqueued in its four
+    phases with the collectives between them, exactly where ViewShardedTrainer puts them, and the validity check is made
+    right behind the forward (the loss and the blend backward are queued by then), before anything is sent."""
+
+    def __init__(self, params: GaussianParams, bg, width, height, sh_degree=3, lambda_dssim=0.2, densify_stats=False,
+                 force_collectives=False, walk_hint=True, capacity=None, betas=(0.9, 0.999), eps=1e-15):
+        import ctypes as C
+        from . import _lib
+        if not params.flat.is_cuda:
+            raise RuntimeError("NativeTrainer needs the parameters on a ROCm device; there is no CPU path")
+        self._C, self._L, self._lib = C, _lib, _lib.load()
+        lib = self._lib
+        self.params, self.bg = params, bg.to(params.flat.device).float().contiguous()
+        self.W, self.H, self.sh_degree = int(width), int(height), int(sh_degree)
+        dev = params.flat.device
+        self.dev = dev
+        P, M = params.P, params.M
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.exchange = self.world > 1 or (bool(force_collectives) and dist.is_available() and dist.is_initialized())
+        self.walk_hint = bool(walk_hint)
+        self.exp_avg = torch.zeros_like(params.flat)
+        self.exp_avg_sq = torch.zeros_like(params.flat)
+        self.t = 0
+        u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
+        self.T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+        self._geom = u8(lib.sgr_geom_bytes(P))
+        self._img = u8(lib.sgr_img_bytes(self.W, self.H) + lib.sgr_bin2_bytes(P, self.W, self.H))
+        self.capacity = int(capacity) if capacity else 24 * P + (1 << 20)
+        self._binning = u8(lib.sgr_binning_bytes(self.capacity, self.W, self.H))
+        self._loss_scratch = u8(lib.sgr_l1_ssim_scratch_bytes(3, self.W, self.H))
+        self.image = torch.empty(3, self.H, self.W, device=dev)
+        self._grad_image = torch.empty(3, self.H, self.W, device=dev)
+        self.loss_out = torch.zeros(3, device=dev)
+        self._send = torch.zeros(P + 1, 3, device=dev)
+        self._recv = torch.empty(self.world * (P + 1), 3, device=dev) if self.exchange else None
+        self._hdr = torch.zeros(16, dtype=torch.int32).pin_memory()
+        self.radii = torch.zeros(P, dtype=torch.int32, device=dev)
+        self.densify_stats = bool(densify_stats)
+        if self.densify_stats:  # gaussian_model.py:125-127 / sugar_densifier.py:152-154
+            self.viewspace_grad = torch.zeros(P, 3, device=dev)
+            self.max_radii2D = torch.zeros(P, device=dev)
+            self.xyz_gradient_accum = torch.zeros(P, device=dev)
+            self.denom = torch.zeros(P, device=dev)
+        self._hints = {}       # camera key -> int32[T] walk hint
+        self._pending = None   # (cam, gt, key) of the step whose forward has not been validated yet
+        self.redone = 0
+        self.last_num_rendered = 0
+        o, vp = params.offsets, (lambda t: t.data_ptr() if t is not None else None)
+        st = (lambda name: vp(getattr(self, name))) if self.densify_stats else (lambda name: None)
+        self._cfg = _lib.TrainConfig(
+            P, self.sh_degree, M, self.W, self.H, vp(params.flat), vp(params.flat_grad), vp(self.exp_avg), vp(self.exp_avg_sq),
+            o["xyz"], o["opacity"], o["scaling"], o["rotation"], o["features"], params.n_small,
+            params.LRS["xyz"], params.LRS["opacity"], params.LRS["scaling"], params.LRS["rotation"], params.LRS["features"],
+            params.REST_LR, betas[0], betas[1], eps, lambda_dssim, vp(self.bg), vp(self._geom), self._geom.numel(), vp(self._img),
+            self._img.numel(), vp(self._binning), self._binning.numel(), self.capacity, vp(self._loss_scratch), vp(self.image),
+            vp(self._grad_image), vp(self.loss_out), vp(self._send), vp(self.radii), vp(self._hdr), st("viewspace_grad"),
+            st("max_radii2D"), st("xyz_gradient_accum"), st("denom"))
+        self._h = lib.sgr_trainer_create(C.byref(self._cfg))
+        if not self._h:
+            raise RuntimeError("sgr_trainer_create failed: " + lib.sgr_trainer_last_error().decode(errors="replace"))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.sgr_trainer_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- one phase mask, one call
+    def _call(self, cam, gt, key, phases, ex, use_hint=True):
+        C, L = self._C, self._L
+        need = need_out = None
+        if self.walk_hint and (phases & 1):
+            ent = self._hints.get(key)
+            if ent is None:
+                ent = self._hints[key] = [torch.zeros(self.T, dtype=torch.int32, device=self.dev), False]
+            need = ent[0].data_ptr() if (ent[1] and use_hint) else None  # (usable once a forward that wrote it was validated)
+            need_out = ent[0].data_ptr()
+        view = L.TrainView(cam.viewmatrix.data_ptr(), cam.projmatrix.data_ptr(), cam.campos.data_ptr(), cam.tanfovx, cam.tanfovy,
+                           gt.data_ptr(), need, need_out)
+        with torch.cuda.device(self.dev):
+            rc = self._lib.sgr_trainer_step(self._h, C.byref(view), phases, C.byref(ex) if ex is not None else None,
+                                            C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream))
+        if rc < 0:
+            raise RuntimeError(f"sgr_trainer_step failed ({rc}): " + self._lib.sgr_trainer_last_error().decode(errors="replace"))
+
+    def _grow(self, R):
+        self.capacity = int(R) + int(R) // 2 + 65536
+        self._binning = torch.empty(int(self._lib.sgr_binning_bytes(self.capacity, self.W, self.H)), dtype=torch.uint8, device=self.dev)
+        rc = self._lib.sgr_trainer_set_binning(self._h, self._binning.data_ptr(), self._binning.numel(), self.capacity)
+        if rc < 0:
+            raise RuntimeError("sgr_trainer_set_binning failed")
+
+    def _valid(self):
+        """waits for the header of the most recent forward; returns (ok, overflow R or 0, hint missed)"""
+        hdr = (self._C.c_uint32 * 16)()
+        ok = self._lib.sgr_trainer_forward_valid(self._h, hdr)
+        if ok < 0:
+            raise RuntimeError("sgr_trainer_forward_valid failed")
+        self.last_num_rendered = int(hdr[0])
+        return bool(ok), (int(hdr[0]) if int(hdr[0]) > self.capacity else 0), bool(hdr[8 + 3])
+
+    def _repair(self, key, R, missed):
+        self.redone += 1
+        if R:
+            torch.cuda.synchronize(self.dev)  # (the old list buffer may still be in use by queued kernels)
+            self._grow(R)
+        if missed and key in self._hints:
+            self._hints[key][1] = False  # the next forward of this camera runs unhinted and leaves a fresh hint
+
+    def _resolve(self):
+        """validate the step that is still in flight; repeat it until its forward is valid"""
+        while self._pending is not None:
+            cam, gt, key = self._pending
+            ok, R, missed = self._valid()
+            if ok:
+                if key in self._hints:
+                    self._hints[key][1] = True
+                self._pending = None
+                return
+            if not (R or missed):
+                raise RuntimeError("level-1 binning overflow: this view needs the single-level binning (use ViewShardedTrainer)")
+            self._repair(key, R, missed)
+            ex = self._L.TrainExchange(1, None, 0, None, 1.0, self.t)
+            self._call(cam, gt, key, 15, ex)
+
+    def step(self, cam, gt_image, cam_key=None):
+        """One optimisation step on `cam` (device tensors) against `gt_image` [3,H,W]; returns the loss as a device scalar
+        (a view of `self.loss_out`: read it before the next step, or clone it)."""
+        key = id(cam) if cam_key is None else cam_key
+        if not self.exchange:
+            self._resolve()
+            self.t += 1
+            ex = self._L.TrainExchange(1, None, 0, None, 1.0, self.t)
+            self._call(cam, gt_image, key, 15, ex)
+            self._pending = (cam, gt_image, key)
+            return self.loss_out[0]
+        # ---- with the gradient exchange: phases with the collectives between them
+        P, world = self.params.P, self.world
+        self.t += 1
+        while True:
+            self._call(cam, gt_image, key, 1, None)
+            ok, R, missed = self._valid()
+            if ok:
+                if key in self._hints:
+                    self._hints[key][1] = True
+                break
+            if not (R or missed):
+                raise RuntimeError("level-1 binning overflow: this view needs the single-level binning (use ViewShardedTrainer)")
+            self._repair(key, R, missed)
+        work = dist.all_gather_into_tensor(self._recv, self._send, async_op=True)  # colours + camera centre: one collective
+        self._call(cam, gt_image, key, 2, None)
+        small = dist.all_reduce(self.params.flat_grad[: self.params.n_small], op=dist.ReduceOp.SUM, async_op=True)
+        work.wait()
+        cams = self._recv.view(world, P + 1, 3)[:, P].contiguous()
+        ex = self._L.TrainExchange(world, self._recv.data_ptr(), P + 1, cams.data_ptr(), 1.0 / world, self.t)
+        self._call(cam, gt_image, key, 4, ex)
+        small.wait()
+        self._call(cam, gt_image, key, 8, ex)
+        return self.loss_out[0]
+
+    def synchronize(self):
+        self._resolve()
+        torch.cuda.synchronize(self.dev)

@@ -21,6 +21,29 @@ def _declared_functions():
     return sorted(set(n for n in names if n != "sgr_alloc_fn"))
 
 
+def _declared_struct(name):
+    """field names of `typedef struct name { ... } name;` in include/sugar_raster.h, in order"""
+    src = open(os.path.join(ROOT, "include", "sugar_raster.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), src, flags=re.S).group(1)
+    fields = []
+    for stmt in body.split(";"):
+        stmt = stmt.strip()
+        if not stmt:
+            continue
+        for part in stmt.split(","):
+            fields.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", part)[-1])
+    return fields
+
+
+def test_ctypes_structs_mirror_the_header():
+    from sugar_amd import _lib
+    for cname, cls in (("sgr_forward_opts", _lib.ForwardOpts), ("sgr_forward_info", _lib.ForwardInfo),
+                       ("sgr_backward_opts", _lib.BackwardOpts), ("sgr_train_config", _lib.TrainConfig),
+                       ("sgr_train_view", _lib.TrainView), ("sgr_train_exchange", _lib.TrainExchange)):
+        assert [f[0] for f in cls._fields_] == _declared_struct(cname), cname
+
+
 def test_library_exports_every_declared_symbol(hip_lib):
     raw = ctypes.CDLL(os.path.join(ROOT, "sugar_amd", "libsugar_raster.so"))
     decl = _declared_functions()
@@ -29,7 +52,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert not missing, missing
     from sugar_amd import _lib
     assert sorted(_lib.SIGNATURES) == decl, "ctypes signature table and header disagree"
-    assert hip_lib.sgr_abi_version() == 1
+    assert hip_lib.sgr_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_scratch_layout_queries(hip_lib):

@@ -30,33 +30,45 @@ def _setup(dev):
     return scene, cams, gts
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, native=False):
     from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-    from sugar_amd.train_step import GaussianParams, ViewShardedTrainer
+    from sugar_amd.train_step import GaussianParams, NativeTrainer, ViewShardedTrainer
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
     scene, cams, gts = _setup(dev)
     params = GaussianParams(scene, dev)
-    tr = ViewShardedTrainer(params, GaussianRasterizer, GaussianRasterizationSettings, torch.zeros(3, device=dev))
-    assert tr.compact_sh and tr.fused_sh_adam and tr.world == world
-    started = []
-    orig = tr._start_gather
-    tr._start_gather = lambda c: (started.append(1), orig(c))[1]
-    for s in range(STEPS):
-        k = (s * world + rank) % len(cams)
-        tr.step(cams[k], gts[k])
-    assert len(started) == STEPS  # the all-gather was launched from inside the rasterizer backward every step
+    if native:
+        tr = NativeTrainer(params, torch.zeros(3), W, H, capacity=50000 if rank == 1 else None)  # rank 1 starts too small
+        assert tr.exchange and tr.world == world
+        for s in range(STEPS):
+            k = (s * world + rank) % len(cams)
+            tr.step(cams[k], gts[k], cam_key=k)
+        tr.synchronize()
+        assert (tr.redone >= 1) == (rank == 1)
+    else:
+        tr = ViewShardedTrainer(params, GaussianRasterizer, GaussianRasterizationSettings, torch.zeros(3, device=dev))
+        assert tr.compact_sh and tr.fused_sh_adam and tr.world == world
+        started = []
+        orig = tr._start_gather
+        tr._start_gather = lambda c: (started.append(1), orig(c))[1]
+        for s in range(STEPS):
+            k = (s * world + rank) % len(cams)
+            tr.step(cams[k], gts[k])
+        assert len(started) == STEPS  # the all-gather was launched from inside the rasterizer backward every step
     torch.cuda.synchronize()
     np.save(os.path.join(out_dir, f"flat_{rank}.npy"), params.flat.detach().cpu().numpy())
     dist.destroy_process_group()
 
 
-def test_two_ranks_match_sequential_accumulation(tmp_path):
+@pytest.mark.parametrize("native", [False, True])
+def test_two_ranks_match_sequential_accumulation(tmp_path, native):
+    """native=True: the same exchange driven by NativeTrainer (sgr_trainer_step in its four phases, the collectives between
+    them); rank 1 starts with a list capacity that is too small and must repair it BEFORE anything is sent."""
     from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     from sugar_amd.train_step import GaussianParams, render, train_loss
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), native), nprocs=world, join=True)
     flats = [np.load(tmp_path / f"flat_{r}.npy") for r in range(world)]
     assert np.array_equal(flats[0], flats[1]), "replicas diverged"
     # single-process reference: plain autograd accumulation of the same views, mean gradient, one flat Adam step per batch
@@ -120,6 +132,15 @@ def _rccl_worker(rank, world, port, out_dir):
     for s in range(3):
         tr.step(cams[s % len(cams)], gts[s % len(cams)])
     torch.cuda.synchronize()
+    # and the native step with its phases around the same collectives
+    from sugar_amd.train_step import NativeTrainer
+    pn = GaussianParams(scene, dev)
+    nt = NativeTrainer(pn, torch.zeros(3), W, H, force_collectives=True)
+    assert nt.exchange
+    for s in range(3):
+        nt.step(cams[s % len(cams)], gts[s % len(cams)], cam_key=s)
+    nt.synchronize()
+    np.save(os.path.join(out_dir, "rccl_native.npy"), pn.flat.detach().cpu().numpy())
     np.save(os.path.join(out_dir, "rccl_forced.npy"), flats[True])
     np.save(os.path.join(out_dir, "rccl_plain.npy"), flats[False])
     np.save(os.path.join(out_dir, "rccl_flat_exchange.npy"), params.flat.detach().cpu().numpy())
@@ -129,12 +150,12 @@ def _rccl_worker(rank, world, port, out_dir):
 def test_single_rank_rccl_group_runs_the_collective_path(tmp_path):
     scene = syn.make_scene(P, 17, 0.01, 0.08)
     mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
-    a, b, c = (np.load(tmp_path / f"rccl_{n}.npy") for n in ("forced", "plain", "flat_exchange"))
+    a, b, c, d = (np.load(tmp_path / f"rccl_{n}.npy") for n in ("forced", "plain", "flat_exchange", "native"))
     from sugar_amd.train_step import GaussianParams
     start = GaussianParams(scene, torch.device("cuda:0")).flat.detach().cpu().numpy()
     upd = np.abs(b - start).max()
     assert upd > 1e-4
-    for other in (a, c):
+    for other in (a, c, d):
         # (float atomics in the blend backward: the sign of a near-zero gradient may flip a +-lr Adam step)
         assert float((np.abs(other - b) > 1e-2 * upd).mean()) < 1e-4
         assert float(np.linalg.norm(other - b) / np.linalg.norm(b - start)) < 1e-3

@@ -1,0 +1,172 @@
+"""GPU tests of the native train step (sgr_trainer_*, sugar_amd.train_step.NativeTrainer), the walk hint of the list-write
+pass (sgr_forward_opts.tile_need) and the fused densification statistics (sgr_backward_opts)."""
+import numpy as np
+import pytest
+import torch
+
+from sugar_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cams(W, H):
+    dev = torch.device(DEV)
+    return [c._replace(viewmatrix=c.viewmatrix.to(dev), projmatrix=c.projmatrix.to(dev), campos=c.campos.to(dev))
+            for c in syn.orbit_cameras(W, H)]
+
+
+def _close(a, b, start):
+    """two runs of the same steps: equal up to the float-atomic order of the blend backward (Adam turns the sign of a
+    near-zero gradient into a +-lr step, so a handful of parameters may sit a full update apart)"""
+    upd = float((b - start).abs().max())
+    assert upd > 1e-4
+    assert float(((a - b).abs() > 1e-2 * upd).float().mean()) < 1e-4
+    assert float((a - b).norm() / (b - start).norm()) < 1e-3
+
+
+def test_native_step_equals_the_autograd_trainer_and_repairs_itself():
+    """Twelve steps over eight cameras (every camera is revisited: the second visits run with the walk hint), started with a
+    list capacity that is far too small (the first forward overflows, the device skips that step, the host repeats it)."""
+    from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from sugar_amd.train_step import GaussianParams, NativeTrainer, ViewShardedTrainer
+    dev = torch.device(DEV)
+    W, H = 400, 240
+    scene = syn.make_scene(30000, 5, 0.01, 0.06)
+    cams = _cams(W, H)
+    gts = [torch.rand(3, H, W, generator=torch.Generator().manual_seed(i)).to(dev) for i in range(8)]
+    pa = GaussianParams(scene, dev)
+    start = pa.flat.clone()
+    ref = ViewShardedTrainer(pa, GaussianRasterizer, GaussianRasterizationSettings, torch.zeros(3, device=dev))
+    ref_losses = [float(ref.step(cams[i % 8], gts[i % 8])[0]) for i in range(12)]
+    results = {}
+    for name, kw in (("hint", dict(capacity=1000)), ("nohint", dict(walk_hint=False))):
+        pb = GaussianParams(scene, dev)
+        nt = NativeTrainer(pb, torch.zeros(3), W, H, **kw)
+        losses = []
+        for i in range(12):
+            loss = nt.step(cams[i % 8], gts[i % 8], cam_key=i % 8)
+            nt.synchronize()  # (validates the step, so that the loss read here belongs to a valid forward)
+            losses.append(float(loss))
+        if name == "hint":
+            assert nt.redone >= 1 and nt.capacity > 1000          # the capacity repair ran
+            assert all(ent[1] for ent in nt._hints.values())     # hints in use from the second visit on
+        assert np.allclose(losses, ref_losses, rtol=2e-4), (losses, ref_losses)
+        _close(pb.flat, pa.flat, start)
+        results[name] = pb.flat.clone()
+    _close(results["hint"], results["nohint"], start)
+
+
+def test_lagged_validation_skips_and_repeats_an_invalid_step():
+    """Without synchronising after every step the validity check lags one step behind; a hint that has become too short
+    (forced here) makes that step a no-op on the device and the trainer repeats it before the next one."""
+    from sugar_amd.train_step import GaussianParams, NativeTrainer
+    dev = torch.device(DEV)
+    W, H = 400, 240
+    scene = syn.make_scene(30000, 6, 0.01, 0.06)
+    cams = _cams(W, H)
+    gts = [torch.rand(3, H, W, generator=torch.Generator().manual_seed(i)).to(dev) for i in range(8)]
+    flats = []
+    for sabotage in (False, True):
+        p = GaussianParams(scene, dev)
+        start = p.flat.clone()
+        nt = NativeTrainer(p, torch.zeros(3), W, H)
+        for i in range(16):
+            if sabotage and i == 10:
+                nt.synchronize()
+                for ent in nt._hints.values():
+                    ent[0].fill_(1)  # every tile may walk ONE entry: the hinted forwards must notice and be repeated
+            nt.step(cams[i % 8], gts[i % 8], cam_key=i % 8)
+        nt.synchronize()
+        assert (nt.redone >= 6) if sabotage else (nt.redone == 0)
+        flats.append(p.flat.clone())
+    _close(flats[1], flats[0], start)
+
+
+def test_walk_hint_leaves_ranges_and_the_walked_prefix_bit_identical():
+    """sgr_forward_opts.tile_need through the reference-shaped API: same image bit for bit, same ranges and num_rendered, and
+    every tile's list identical to the unhinted one over the entries the tile walks (rasterizer_impl.cu:70-138 order)."""
+    from sugar_amd import _lib
+    from sugar_amd.diff_gaussian_rasterization import _C, grad_sink
+    from tests import parity_utils as pu
+    lib = _lib.load()
+    dev = torch.device(DEV)
+    scene = syn.make_scene(150000, 21, 0.004, 0.05)
+    cam = syn.orbit_cameras(1000, 600)[3]
+    W, H = 1000, 600
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    hint = torch.zeros(T, dtype=torch.int32, device=dev)
+    hdr = torch.zeros(16, dtype=torch.int32).pin_memory()
+    ev = torch.cuda.Event()
+    with grad_sink(tile_need_out=hint, header_out=hdr, header_event=ev):
+        a = pu.run_hip(scene, cam, bg)
+    off = lib.sgr_img_tile_walked_offset(W, H)
+    walked = _C.last_forward["img"][off: off + 4 * T].view(torch.int32).clone()
+    assert torch.equal(hint, walked + (walked >> 2) + 64)
+    g = np.random.default_rng(0).standard_normal((3, H, W)).astype(np.float32)
+    with grad_sink(tile_need=hint, header_out=hdr, header_event=ev):
+        b = pu.run_hip(scene, cam, bg, grad_out=g)
+    ev.synchronize()
+    assert int(hdr[8 + 3]) == 0 and int(hdr[0]) == a["num_rendered"]
+    assert b["num_rendered"] == a["num_rendered"] and np.array_equal(a["tile_start"], b["tile_start"])
+    assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["n_contrib"], b["n_contrib"])
+    ts, w = a["tile_start"].astype(np.int64), walked.cpu().numpy().astype(np.int64)
+    keep = np.zeros(a["num_rendered"], dtype=bool)
+    for t in np.nonzero(w)[0]:
+        keep[ts[t]: ts[t] + w[t]] = True
+    assert keep.sum() < 0.9 * keep.size  # the hint is worth something on this scene
+    assert np.array_equal(a["point_list"][keep], b["point_list"][keep])
+    # gradients agree with the unhinted forward's (the backward only reads what the forward walked)
+    c = pu.run_hip(scene, cam, bg, grad_out=g)
+    for k in c["grads"]:
+        assert pu.rel_stats(b["grads"][k], c["grads"][k])["norm_rel"] < 2e-5, k
+    # a hint that is too short is reported, not rendered wrongly
+    short = torch.ones_like(hint)
+    with grad_sink(tile_need=short, header_out=hdr, header_event=ev):
+        pu.run_hip(scene, cam, bg)
+    ev.synchronize()
+    assert int(hdr[8 + 3]) != 0
+
+
+def test_fused_densification_statistics():
+    """sgr_backward_opts against the reference's own bookkeeping (gaussian_splatting/train.py:111-123,
+    scene/gaussian_model.py:405-407) applied to the gradients the plain API returns"""
+    from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, grad_sink
+    from sugar_amd.train_step import GaussianParams, NativeTrainer
+    dev = torch.device(DEV)
+    W, H = 320, 200
+    scene = syn.make_scene(20000, 9, 0.01, 0.08)
+    cams = _cams(W, H)
+    gts = [torch.rand(3, H, W, generator=torch.Generator().manual_seed(i)).to(dev) for i in range(3)]
+    P = 20000
+    # reference bookkeeping on the plain API: two views, parameters fixed
+    max_radii, accum, denom = torch.zeros(P, device=dev), torch.zeros(P, 1, device=dev), torch.zeros(P, 1, device=dev)
+    m, op, sh, sc, ro = (t.to(dev).requires_grad_(True) for t in (scene.means3D, scene.opacities, scene.shs, scene.scales, scene.rotations))
+    fused = [torch.zeros(P, device=dev) for _ in range(3)]
+    for i in range(2):
+        cam = cams[i]
+        st = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, torch.zeros(3, device=dev), 1.0, cam.viewmatrix, cam.projmatrix, 3,
+                                           cam.campos, False, False)
+        for use_fused in (False, True):
+            vs = torch.zeros(P, 3, device=dev, requires_grad=True)
+            with grad_sink(dens_stats=tuple(fused) if use_fused else None):
+                img, radii = GaussianRasterizer(st)(m, vs, op, shs=sh, scales=sc, rotations=ro)
+                ((img - gts[i]) ** 2).sum().backward()
+            if not use_fused:
+                vis = radii > 0
+                max_radii[vis] = torch.max(max_radii[vis], radii[vis].float())                 # train.py:114
+                accum[vis] += torch.norm(vs.grad[vis, :2], dim=-1, keepdim=True)               # gaussian_model.py:406
+                denom[vis] += 1                                                                # gaussian_model.py:407
+    assert torch.equal(fused[0], max_radii) and torch.equal(fused[2], denom[:, 0])
+    assert float((fused[1] - accum[:, 0]).norm() / accum.norm()) < 2e-5  # (two backward runs: atomic order)
+    assert float(denom.sum()) > P // 4
+    # and through the native trainer
+    p = GaussianParams(scene, dev)
+    nt = NativeTrainer(p, torch.zeros(3), W, H, densify_stats=True)
+    nt.step(cams[0], gts[0], cam_key=0)
+    nt.synchronize()
+    assert float(nt.denom.sum()) == float((nt.radii > 0).sum()) > 0
+    assert torch.equal(nt.max_radii2D, nt.radii.float().clamp_min(0))
+    ref = nt.viewspace_grad[:, :2].norm(dim=-1)
+    assert float((nt.xyz_gradient_accum - ref).abs().max()) <= 1e-6 * float(ref.max())

@@ -248,15 +248,12 @@ def test_8k_image_runs_on_the_two_level_binning_only():
     from sugar_amd import _lib
     scene = syn.make_scene(20000, 35, 0.002, 0.01)
     cam = syn.orbit_cameras(7680, 4320)[2]
+    from sugar_amd.diff_gaussian_rasterization import _C, grad_sink
     _check(scene, cam, torch.zeros(3), grads=False)
-    lib = _lib.load()
-    assert lib.sgr_last_binning_mode() == 0
-    old = lib.sgr_set_binning_mode(1)
-    try:
+    assert _C.last_forward["binning_mode"] == 0
+    with grad_sink(single_level_binning=True):
         with pytest.raises(RuntimeError, match="too large for the single-level"):
             pu.run_hip(scene, cam, torch.zeros(3))
-    finally:
-        lib.sgr_set_binning_mode(old)
 
 
 def test_knn_with_an_uninstantiated_k_is_a_prefix_of_the_next_one():
@@ -302,27 +299,21 @@ def test_grid_knn_is_identical_to_exhaustive(dist):
     assert torch.equal(distCUDA2(p, method="brute"), distCUDA2(p, method="grid"))
 
 
-def _lists(scene, cam, bg):
-    from sugar_amd import _lib
-    h = pu.run_hip(scene, cam, bg)
-    return h, _lib.load().sgr_last_binning_mode()
+def _lists(scene, cam, bg, single_level=False):
+    from sugar_amd.diff_gaussian_rasterization import _C, grad_sink
+    with grad_sink(single_level_binning=single_level):
+        h = pu.run_hip(scene, cam, bg)
+    return h, _C.last_forward["binning_mode"]
 
 
 def test_two_level_and_single_level_binning_give_identical_lists():
     """binning2.hip (super-tiles, then tiles) against binning.hip (single-level ordered scatter): same ranges, same lists,
     same image -- at a size where every level-2 code path runs (several chunks per super-tile, partial border super-tiles)."""
-    from sugar_amd import _lib
-    lib = _lib.load()
     scene = syn.make_scene(120000, 21, 0.004, 0.05)
     cam = syn.orbit_cameras(1000, 600)[3]   # 63 x 38 tiles: the last super-tile column / row are partial
     bg = torch.tensor([0.1, 0.2, 0.3])
-    old = lib.sgr_set_binning_mode(0)
-    try:
-        a, mode_a = _lists(scene, cam, bg)
-        lib.sgr_set_binning_mode(1)
-        b, mode_b = _lists(scene, cam, bg)
-    finally:
-        lib.sgr_set_binning_mode(old)
+    a, mode_a = _lists(scene, cam, bg)
+    b, mode_b = _lists(scene, cam, bg, single_level=True)  # per call (SGR_FLAG_SINGLE_LEVEL_BINNING): no process-wide switch
     assert (mode_a, mode_b) == (0, 1)
     assert a["num_rendered"] == b["num_rendered"] and a["num_rendered"] > 1_000_000
     assert np.array_equal(a["tile_start"], b["tile_start"])

@@ -54,8 +54,13 @@ def test_out_of_scope_classes_import_and_raise(p3d):
         from pytorch3d.renderer.cameras import _get_sfm_calibration_matrix
         with pytest.raises(NotImplementedError):
             Meshes(verts=[], faces=[])
+        # the camera algebra is functional (sugar_scene/cameras.py:311-324 builds its cameras from it) ...
+        K = _get_sfm_calibration_matrix(1, "cpu", torch.tensor([[1.5, 2.0]]), torch.tensor([[0.1, -0.2]]))
+        assert K.shape == (1, 4, 4) and float(K[0, 0, 0]) == 1.5 and abs(float(K[0, 1, 2]) + 0.2) < 1e-6 and float(K[0, 3, 2]) == 1.0
+        # ... and the mesh rasterizer can be constructed (SuGaR does so unconditionally, sugar_model.py:1880-1893) but not run
+        r = MeshRasterizer(cameras=None, raster_settings=RasterizationSettings(image_size=(8, 8), faces_per_pixel=10))
         with pytest.raises(NotImplementedError):
-            _get_sfm_calibration_matrix(1, "cpu", None, None)
+            r(None)
         from pytorch3d.ops import knn_points
         with pytest.raises(RuntimeError):  # HIP only, no CPU fallback
             knn_points(torch.zeros(1, 10, 3), torch.zeros(1, 10, 3), K=4)
@@ -83,3 +88,44 @@ def test_unmodified_sugar_model_renders_through_the_boundary(p3d):
     assert sm.GaussianRasterizationSettings is GaussianRasterizationSettings
     import simple_knn._C as knn_c
     assert sm.distCUDA2 is knn_c.distCUDA2
+
+
+def test_camera_algebra_round_trips_and_matches_the_gaussian_splatting_camera(p3d):
+    """The stand-in FoVPerspectiveCameras (parity-unpinned against pytorch3d itself, which is absent): unproject(project(x))
+    = x, the camera centre is where the view transform maps to the origin, and a camera built the way
+    sugar_scene/cameras.py:convert_camera_from_gs_to_pytorch3d builds it sees a world point at the pixel the rasterizer's
+    viewmatrix / projmatrix (synthetic.look_at_camera, a restatement of sugar_scene/cameras.py:203-212) puts it."""
+    if not getattr(p3d, "__version__", "").endswith("sugar_amd.shim"):
+        pytest.skip("real pytorch3d installed")
+    from pytorch3d.renderer import FoVPerspectiveCameras
+    from pytorch3d.renderer.cameras import _get_sfm_calibration_matrix
+    from sugar_amd import synthetic as syn
+    W, H = 200, 152
+    cam = syn.orbit_cameras(W, H)[3]
+    w2c = cam.viewmatrix.t().double()                       # COLMAP-convention world-to-camera (x right, y down, z forward)
+    fx, fy = W / (2 * cam.tanfovx), H / (2 * cam.tanfovy)
+    scale = min(W, H) / 2.0
+    K = _get_sfm_calibration_matrix(1, "cpu", torch.tensor([[fx / scale, fy / scale]]), torch.zeros(1, 2))
+    # cameras.py:319-322: pytorch3d looks along +z with x LEFT and y UP: flip x and y of the COLMAP camera frame
+    flip = torch.tensor([-1.0, -1.0, 1.0], dtype=torch.float64)
+    R = (w2c[:3, :3].t() * flip)[None].float()              # row-vector convention: X_view = X_world @ R + T
+    T = (w2c[:3, 3] * flip)[None].float()
+    p3 = FoVPerspectiveCameras(R=R, T=T, K=K, znear=0.0001)
+    assert torch.allclose(p3.get_camera_center()[0], cam.campos, atol=1e-5)
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(50, 3, generator=g) - 0.5)
+    view = p3.get_world_to_view_transform().transform_points(x)
+    ndc = p3.transform_points(x)
+    back = p3.unproject_points(torch.cat([ndc[:, :2], view[:, 2:3]], dim=1)[None], scaled_depth_input=False)[0]
+    assert torch.allclose(back, x, atol=1e-5)
+    # the Gaussian-splatting projection of the same points: pixel = ((ndc + 1) * S - 1) / 2 (auxiliary.h:41-44)
+    hom = torch.cat([x, torch.ones(50, 1)], dim=1) @ cam.projmatrix
+    gs = hom[:, :2] / hom[:, 3:4]
+    px_gs = ((gs[:, 0] + 1) * W - 1) / 2
+    py_gs = ((gs[:, 1] + 1) * H - 1) / 2
+    # pytorch3d NDC: +x left, +y up, the SHORTER side spans [-1, 1] (sugar_model.py:1937-1944 maps pixel j to
+    # W / min - 2 j / (min - 1))
+    px_p3 = (W / min(W, H) - ndc[:, 0]) * (min(W, H) - 1) / 2
+    py_p3 = (H / min(W, H) - ndc[:, 1]) * (min(W, H) - 1) / 2
+    # the two pixel conventions differ by the (min - 1) / min factor SuGaR's table uses: within a pixel over the image
+    assert float((px_p3 - px_gs).abs().max()) < 1.0 and float((py_p3 - py_gs).abs().max()) < 1.0
