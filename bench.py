@@ -173,8 +173,15 @@ def main():
     elif forward_only:
         for s in range(max(8, len(cams))):
             do_step(trainer, s)
+    marks = {}
+    def mark(name):
+        if isinstance(trainer, NativeTrainer):
+            trainer.synchronize()
+            marks[name] = trainer.redone
+    mark("after_preroll")
     for s in range(args.warmup):
         do_step(trainer, s)
+    mark("after_warmup")
     T = ((W + 15) // 16) * ((H + 15) // 16)
     off_walk = lib.sgr_img_tile_walked_offset(W, H)
     off_maxc = lib.sgr_img_tile_maxc_offset(W, H)
@@ -195,6 +202,7 @@ def main():
     t_enq = time.perf_counter()  # (diagnostic: when the host finished enqueueing; equal to t1 means the loop was host-bound)
     sync_all()
     t1 = time.perf_counter()
+    mark("after_timed")
     lib.sgr_profile_enable(0)
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
@@ -326,7 +334,7 @@ def main():
                 "views_per_step": world,
                 "parallelism": (f"view-sharded dp{world}: all-gather of 3 masked colour grads per Gaussian and view + all-reduce of "
                                 "the 11 non-SH floats per Gaussian (RCCL), SH gradient summed over views inside the Adam kernel"
-                                if trainer.compact_sh and world > 1 else f"view-sharded dp{world}" if world > 1
+                                if getattr(trainer, 'compact_sh', True) and world > 1 else f"view-sharded dp{world}" if world > 1
                                 else f"view-sharded dp{world}, single process, no collective"),
                 "instances_per_view": R, "instances_walked_fwd": R_f, "instances_walked_bwd": R_b,
             },
@@ -343,7 +351,8 @@ def main():
         }
         out.update(extras)
         if isinstance(trainer, NativeTrainer):
-            out["forwards_repeated"] = trainer.redone
+            out["forwards_repeated"] = {"in_timed_region": marks.get("after_timed", 0) - marks.get("after_warmup", 0),
+                                        "pre_roll_and_warmup": marks.get("after_warmup", 0), "whole_run": trainer.redone}
         if comm is not None:
             out.update(comm)
             out["config"]["collectives"] = "forced on a one-rank RCCL group" if world == 1 else "RCCL"

@@ -19,8 +19,22 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def install() -> str:
-    """Returns "patched" (real pytorch3d found, knn_points redirected) or "shim" (stand-in package activated)."""
+def install(patch_sugar=False) -> str:
+    """Returns "patched" (real pytorch3d found, knn_points redirected) or "shim" (stand-in package activated).
+
+    `patch_sugar`: also route SuGaR's own Gaussian-buffer-sharing tensor code -- `get_points_rgb`, `get_covariance(return_sqrt)`,
+    `get_field_values`, `compute_level_surface_points_from_camera_fast(use_gaussian_depth=True)` -- to the HIP kernels
+    (sugar_amd.sugar_patch), without touching the reference's files.  Pass the imported `sugar_scene.sugar_model` module, or
+    True to import it (the reference must then be on sys.path)."""
+    mode = _install_pytorch3d()
+    if patch_sugar:
+        from .. import sugar_patch
+        module = importlib.import_module("sugar_scene.sugar_model") if patch_sugar is True else patch_sugar
+        sugar_patch.install(module)
+    return mode
+
+
+def _install_pytorch3d() -> str:
     spec = None
     try:
         spec = importlib.util.find_spec("pytorch3d")

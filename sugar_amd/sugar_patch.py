@@ -1,0 +1,219 @@
+"""Routes SuGaR's Gaussian-buffer-sharing tensor code to the HIP kernels of this package WITHOUT touching the reference's
+files: `install(sm)` replaces four methods of the `SuGaR` class of an imported `sugar_scene.sugar_model` module
+
+    SuGaR.get_points_rgb                                   sugar_model.py:839-883    -> sgr_sh_to_rgb_*        (shcolor.py)
+    SuGaR.get_covariance(return_sqrt=True, ...)            sugar_model.py:729-736    -> sgr_scaled_rotation_*  (field.py)
+    SuGaR.get_field_values                                 sugar_model.py:1247-1316  -> sgr_density_field_*    (field.py)
+    SuGaR.compute_level_surface_points_from_camera_fast    sugar_model.py:1848-2083  -> sgr_level_set_points + the rasterizer
+                                                                                        + the HIP k-NN (use_gaussian_depth=True)
+
+with functions of the same signature and return values.  Each replacement takes over only what it implements -- tensors on a
+ROCm device and the argument combinations listed below -- and hands every other call to the reference's own method, which
+stays reachable as `SuGaR._sugar_amd_original[name]`.  `uninstall(sm)` puts the originals back.
+
+The replacements are written against the attributes SuGaR exposes (`points`, `scaling`, `quaternions`, `strengths`,
+`sh_coordinates`, `knn_idx`, `knn_to_track`, `image_height`, `image_width`, `get_beta`, `render_image_gaussian_rasterizer`,
+`get_gaussians_closest_to_samples`), so the GPU tests can drive them with a small stand-in object holding a fixture of the
+reference model's state (the reference tree does not exist on the GPU box).
+"""
+from __future__ import annotations
+
+import functools
+
+import numpy as np
+import torch
+
+PATCHED = ("get_points_rgb", "get_covariance", "get_field_values", "compute_level_surface_points_from_camera_fast")
+
+
+def _on_gpu(*ts):
+    return all(t is None or (torch.is_tensor(t) and t.is_cuda) for t in ts) and any(t is not None for t in ts)
+
+
+# ----------------------------------------------------------------------------------------------- get_points_rgb
+def get_points_rgb(self, positions=None, camera_centers=None, directions=None, sh_levels=None, sh_coordinates=None, _orig=None):
+    pos = self.points if positions is None else positions
+    if _orig is not None and (sh_levels is None or not _on_gpu(pos) or (camera_centers is None and directions is None)):
+        return _orig(self, positions=positions, camera_centers=camera_centers, directions=directions, sh_levels=sh_levels,
+                     sh_coordinates=sh_coordinates)
+    from .shcolor import get_points_rgb as hip
+    return hip(self, positions=positions, camera_centers=camera_centers, directions=directions, sh_levels=sh_levels,
+               sh_coordinates=sh_coordinates)
+
+
+# ----------------------------------------------------------------------------------------------- get_covariance
+def get_covariance(self, return_full_matrix=False, return_sqrt=False, inverse_scales=False, _orig=None):
+    q = self.quaternions
+    if return_sqrt and q.is_cuda:
+        from .field import scaled_rotation
+        return scaled_rotation(q, self.scaling, inverse_scales)  # sugar_model.py:730-736
+    return _orig(self, return_full_matrix=return_full_matrix, return_sqrt=return_sqrt, inverse_scales=inverse_scales)
+
+
+# ----------------------------------------------------------------------------------------------- get_field_values
+def get_field_values(self, x, gaussian_idx=None, closest_gaussians_idx=None, gaussian_strengths=None, gaussian_centers=None,
+                     gaussian_inv_scaled_rotation=None, return_sdf=True, density_threshold=1., density_factor=1.,
+                     return_sdf_grad=False, sdf_grad_max_value=10., opacity_min_clamp=1e-16,
+                     return_closest_gaussian_opacities=False, return_beta=False, _orig=None, _density_field=None):
+    """sugar_model.py:1247-1316.  The neighbour gather, the warp, the exponentials and their sum (and, in the backward, the
+    scatter of their gradients) are the fused kernels; everything after the densities is the reference's own arithmetic on
+    [N] / [N,K] tensors.  `return_sdf_grad=True` needs the per-neighbour warped shifts and goes to the reference's code."""
+    if _orig is not None and (return_sdf_grad or not x.is_cuda):
+        return _orig(self, x, gaussian_idx=gaussian_idx, closest_gaussians_idx=closest_gaussians_idx,
+                     gaussian_strengths=gaussian_strengths, gaussian_centers=gaussian_centers,
+                     gaussian_inv_scaled_rotation=gaussian_inv_scaled_rotation, return_sdf=return_sdf,
+                     density_threshold=density_threshold, density_factor=density_factor, return_sdf_grad=return_sdf_grad,
+                     sdf_grad_max_value=sdf_grad_max_value, opacity_min_clamp=opacity_min_clamp,
+                     return_closest_gaussian_opacities=return_closest_gaussian_opacities, return_beta=return_beta)
+    if return_sdf_grad:
+        raise NotImplementedError("return_sdf_grad=True is served by the reference's own method")
+    if _density_field is None:
+        from .field import density_field as _density_field
+    if gaussian_strengths is None:
+        gaussian_strengths = self.strengths
+    if gaussian_centers is None:
+        gaussian_centers = self.points
+    if gaussian_inv_scaled_rotation is None:
+        gaussian_inv_scaled_rotation = self.get_covariance(return_full_matrix=True, return_sqrt=True, inverse_scales=True)
+    if closest_gaussians_idx is None:
+        closest_gaussians_idx = self.knn_idx[gaussian_idx]
+    fields = {}
+    neighbor_opacities, densities = _density_field(x, closest_gaussians_idx, gaussian_centers, gaussian_inv_scaled_rotation,
+                                                   gaussian_strengths, density_factor)                       # :1266-1276
+    fields['density'] = densities.clone()
+    density_mask = densities >= 1.
+    densities = torch.where(density_mask, densities / (densities.detach() + 1e-12), densities)               # :1278-1279
+    if return_closest_gaussian_opacities:
+        fields['closest_gaussian_opacities'] = neighbor_opacities
+    if return_sdf or return_sdf_grad or return_beta:
+        beta = self.get_beta(x, closest_gaussians_idx=closest_gaussians_idx, closest_gaussians_opacities=neighbor_opacities,
+                             densities=densities, opacity_min_clamp=opacity_min_clamp)
+        clamped_densities = densities.clamp(min=opacity_min_clamp)
+    if return_beta:
+        fields['beta'] = beta
+    if return_sdf:
+        fields['sdf'] = beta * (torch.sqrt(-2. * torch.log(clamped_densities))
+                                - np.sqrt(-2. * np.log(min(density_threshold, 1.))))                         # :1301-1306
+    return fields
+
+
+# ------------------------------------------------------------------------- compute_level_surface_points_from_camera_fast
+def compute_level_surface_points_from_camera_fast(
+        self, nerf_cameras=None, cam_idx=0, rasterizer=None, surface_levels=[0.1, 0.3, 0.5], n_surface_points=-1,
+        primitive_types=None, triangle_scale=None, splat_mesh=True, n_points_in_range=21, range_size=3.,
+        n_points_per_pass=2_000_000, density_factor=1., return_pixel_idx=False, return_gaussian_idx=False, return_normals=False,
+        compute_flat_normals=False, compute_intersection_for_flat_gaussian=False, use_gaussian_depth=False,
+        just_use_depth_as_level=False, _orig=None, _level_set_points=None):
+    """sugar_model.py:1848-2083 on the Gaussian-depth path (`use_gaussian_depth=True`, :1901-1911, :1962-1964): the depth map
+    is a render of the rasterizer with the view-space depth as colour, the pixels are unprojected with the camera, their 16
+    nearest Gaussians come from the k-NN query, and the 21 ray samples x 16 neighbours per pixel, the level crossings and
+    the normals are ONE kernel (the reference materialises [n * 21, 16, 3, 3] tensors in passes of 2M samples).  The
+    mesh-rasterizer path (`use_gaussian_depth=False`) and the flat-Gaussian variants go to the reference's own method."""
+    on_gpu = self.points.is_cuda
+    if _orig is not None and (not use_gaussian_depth or not on_gpu or compute_flat_normals or compute_intersection_for_flat_gaussian
+                              or just_use_depth_as_level):
+        return _orig(self, nerf_cameras=nerf_cameras, cam_idx=cam_idx, rasterizer=rasterizer, surface_levels=surface_levels,
+                     n_surface_points=n_surface_points, primitive_types=primitive_types, triangle_scale=triangle_scale,
+                     splat_mesh=splat_mesh, n_points_in_range=n_points_in_range, range_size=range_size,
+                     n_points_per_pass=n_points_per_pass, density_factor=density_factor, return_pixel_idx=return_pixel_idx,
+                     return_gaussian_idx=return_gaussian_idx, return_normals=return_normals,
+                     compute_flat_normals=compute_flat_normals,
+                     compute_intersection_for_flat_gaussian=compute_intersection_for_flat_gaussian,
+                     use_gaussian_depth=use_gaussian_depth, just_use_depth_as_level=just_use_depth_as_level)
+    if not use_gaussian_depth or compute_flat_normals or compute_intersection_for_flat_gaussian or just_use_depth_as_level:
+        raise NotImplementedError("only the Gaussian-depth path is implemented here; the others run the reference's own method")
+    if _level_set_points is None:
+        from .field import level_set_points as _level_set_points
+    from pytorch3d.transforms import quaternion_apply, quaternion_invert
+    if nerf_cameras is None:
+        nerf_cameras = self.nerfmodel.training_cameras
+    if primitive_types is not None:
+        self.primitive_types = primitive_types
+    if triangle_scale is not None:
+        self.triangle_scale = triangle_scale
+    p3d_cameras = nerf_cameras.p3d_cameras[cam_idx]
+    device = self.points.device
+    H, W = self.image_height, self.image_width
+    # splatted depth (:1901-1911)
+    point_depth = p3d_cameras.get_world_to_view_transform().transform_points(self.points)[..., 2:].expand(-1, 3)
+    depth = self.render_image_gaussian_rasterizer(camera_indices=cam_idx, bg_color=torch.Tensor([-1., -1., -1.]).to(device),
+                                                  sh_deg=0, compute_covariance_in_rasterizer=True, return_2d_radii=False,
+                                                  use_same_scale_in_all_directions=False,
+                                                  point_colors=point_depth).contiguous()[..., 0]
+    no_depth_mask = depth < 0.
+    depth[no_depth_mask] = depth.max() * 1.05
+    # back-projection (:1932-1959); the pixel tables of the reference (:1934-1941) as index arithmetic
+    m = min(W, H)
+    rows = torch.arange(H, device=device, dtype=torch.float32)[:, None].expand(H, W)
+    cols = torch.arange(W, device=device, dtype=torch.float32)[None, :].expand(H, W)
+    ndc_x = W / m - (cols / (m - 1)) * 2
+    ndc_y = H / m - (rows / (m - 1)) * 2
+    ndc_points = torch.stack((ndc_x.reshape(-1), ndc_y.reshape(-1), depth.reshape(-1)), dim=-1)
+    no_proj_mask = no_depth_mask.view(-1)
+    ndc_points = ndc_points[~no_proj_mask][None]
+    if n_surface_points == -1:
+        n_surface_points = ndc_points.shape[1]
+        ndc_points_idx = torch.arange(n_surface_points)
+    else:
+        n_surface_points = min(n_surface_points, ndc_points.shape[1])
+        ndc_points_idx = torch.randperm(ndc_points.shape[1])[:n_surface_points]
+        ndc_points = ndc_points[:, ndc_points_idx]
+    all_world_points = p3d_cameras.unproject_points(ndc_points, scaled_depth_input=False).view(-1, 3)
+    closest_gaussians_idx = self.get_gaussians_closest_to_samples(all_world_points)                    # :1963 (HIP k-NN)
+    gaussian_idx = closest_gaussians_idx[..., 0]
+    cam_center = p3d_cameras.get_camera_center()
+    gaussian_to_camera = torch.nn.functional.normalize(cam_center - self.points, dim=-1)               # :1971-1972
+    gaussian_standard_deviations = (self.scaling * quaternion_apply(quaternion_invert(self.quaternions), gaussian_to_camera)).norm(dim=-1)
+    B = self.get_covariance(return_full_matrix=True, return_sqrt=True, inverse_scales=True)
+    with torch.no_grad():
+        res = _level_set_points(all_world_points.detach(), closest_gaussians_idx, cam_center.detach(), self.points.detach(),
+                                B.detach(), self.strengths.detach(), gaussian_standard_deviations.detach(),
+                                surface_levels=tuple(surface_levels), n_points_in_range=n_points_in_range, range_size=range_size,
+                                density_factor=density_factor, return_normals=return_normals)
+    all_outputs = {}
+    pixel_idx_all = None
+    if return_pixel_idx:
+        pixel_idx_all = torch.arange(H * W, dtype=torch.long, device=device)[~no_proj_mask][ndc_points_idx.to(device)]
+    for surface_level in surface_levels:
+        r = res[surface_level]
+        outputs = {'intersection_points': r['intersection_points']}
+        if return_pixel_idx:
+            outputs['pixel_idx'] = pixel_idx_all[r['valid']]
+        if return_gaussian_idx:
+            outputs['gaussian_idx'] = gaussian_idx[r['valid']]
+        if return_normals:
+            outputs['normals'] = r['normals']
+        all_outputs[surface_level] = outputs
+    return all_outputs
+
+
+_IMPL = dict(get_points_rgb=get_points_rgb, get_covariance=get_covariance, get_field_values=get_field_values,
+             compute_level_surface_points_from_camera_fast=compute_level_surface_points_from_camera_fast)
+
+
+def install(sugar_model_module, names=PATCHED):
+    """Patch `sugar_model_module.SuGaR` (the imported reference module).  Idempotent; returns the patched names."""
+    cls = sugar_model_module.SuGaR
+    saved = cls.__dict__.get("_sugar_amd_original")
+    if saved is None:
+        saved = {}
+        cls._sugar_amd_original = saved
+    done = []
+    for name in names:
+        if name in saved:
+            done.append(name)
+            continue
+        orig = getattr(cls, name)
+        impl = _IMPL[name]
+        wrapped = functools.partialmethod(impl, _orig=orig)
+        saved[name] = orig
+        setattr(cls, name, wrapped)
+        done.append(name)
+    return done
+
+
+def uninstall(sugar_model_module):
+    cls = sugar_model_module.SuGaR
+    for name, orig in list(cls.__dict__.get("_sugar_amd_original", {}).items()):
+        setattr(cls, name, orig)
+    cls._sugar_amd_original = {}

@@ -208,16 +208,24 @@ def test_sync_free_forward_matches_and_recovers_from_a_small_capacity():
         color0, _ = GaussianRasterizer(st)(**args)
     R = _C.last_forward["num_rendered"]
     list0 = _C.last_forward["binning"][: 4 * R].clone()
-    hdr, ev = torch.zeros(8, dtype=torch.int32).pin_memory(), torch.cuda.Event()
+    hdr, ev = torch.zeros(16, dtype=torch.int32).pin_memory(), torch.cuda.Event()
     for cap, ok in ((R + 1000, True), (R, True), (R - 1, False), (R // 3, False)):
         with torch.no_grad(), grad_sink(binning_capacity=cap, header_out=hdr, header_event=ev):
             color, _ = GaussianRasterizer(st)(**args)
         ev.synchronize()
-        assert int(hdr[0]) == R and int(hdr[6]) == 0
-        assert _C.last_forward["num_rendered"] == cap
+        assert int(hdr[0]) == R and int(hdr[6]) == 0 and int(hdr[8]) == R and int(hdr[8 + 3]) == 0  # both header copies
+        assert _C.last_forward["num_rendered"] == cap and _C.last_forward["sync_free"]
         if ok:
             assert torch.equal(color, color0)
             assert torch.equal(_C.last_forward["binning"][: 4 * R], list0)
+        else:
+            # a backward on the invalid forward is a no-op on the device: no fault, no atomics into the accumulators
+            leaves = {k: v.clone().requires_grad_(True) for k, v in args.items()}
+            with grad_sink(binning_capacity=cap, header_out=hdr, header_event=ev):
+                c2, _ = GaussianRasterizer(st)(**leaves)
+                c2.sum().backward()
+            torch.cuda.synchronize()
+            assert float(leaves["opacities"].grad.abs().max()) == 0.0 and float(leaves["means3D"].grad.abs().max()) == 0.0
     # the trainer notices and repeats the forward
     from sugar_amd.train_step import GaussianParams, ViewShardedTrainer
     cams = [c._replace(viewmatrix=c.viewmatrix.to(dev), projmatrix=c.projmatrix.to(dev), campos=c.campos.to(dev))
