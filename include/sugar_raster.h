@@ -79,7 +79,8 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user,
  *   walks at most tile_need[t] entries of tile t.  Ranges, num_rendered and the written prefix of every list are unchanged
  *   (bit-identical to rasterizer_impl.cu:70-138).  If a tile would have walked further, header word 3 (SGR_HDR_HINT_MISS) is
  *   set: the forward is then INVALID exactly like a capacity overflow (repeat it without the hint).
- * tile_need_out (device, uint32 per tile): receives the hint for the next visit: tile_walked + 25 % + 64.
+ * tile_need_out (device, uint32 per tile): receives the hint for the next visit: tile_walked * (1 + hint_margin) + 64
+ *   (hint_margin <= 0: 0.25).
  * info (host, may be NULL): what the call did (binning path taken). */
 #define SGR_HDR_R 0          /* header words (device): total instances */
 #define SGR_HDR_MAXCOUNT 1   /* largest per-tile instance count */
@@ -97,6 +98,7 @@ typedef struct sgr_forward_opts {
     void* header_event;
     const uint32_t* tile_need;
     uint32_t* tile_need_out;
+    float hint_margin;
     sgr_forward_info* info;
 } sgr_forward_opts;
 int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user,
@@ -348,6 +350,7 @@ typedef struct sgr_train_view {
     const float* gt_image;       /* [3,H,W] */
     const uint32_t* tile_need;   /* walk hint of this camera (device, [tiles]) or NULL */
     uint32_t* tile_need_out;     /* receives the hint for its next visit, or NULL */
+    float hint_margin;           /* see sgr_forward_opts */
 } sgr_train_view;
 typedef struct sgr_train_exchange { /* phases 4 and 8 */
     int n_views;                 /* views whose colour gradients are summed (1: this rank's own) */

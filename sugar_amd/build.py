@@ -15,7 +15,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libsugar_raster.so")
+OUT = os.environ.get("SGR_BUILD_OUT") or os.path.join(HERE, "libsugar_raster.so")  # (SGR_BUILD_OUT + SGR_EXTRA_DEFS: variant builds for A/B runs)
 ARCH = "gfx950"
 
 # translation unit -> extra flags.  The per-Gaussian and binning kernels carry the pixel-exact contract
@@ -33,7 +33,8 @@ SOURCES = {
     "capi.hip": [],
     "train.hip": [],
 }
-COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+COMMON = (["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+          + os.environ.get("SGR_EXTRA_DEFS", "").split())
 
 
 def _hipcc() -> str:
@@ -60,7 +61,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == dig:
         return OUT
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build") if OUT.endswith("libsugar_raster.so") else OUT + ".build"
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []

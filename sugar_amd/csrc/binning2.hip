@@ -9,8 +9,8 @@
 // (rocprofv3 WRITE_SIZE) and the kernel is latency-bound with one wave per SIMD.  Here a Gaussian is first appended, in
 // depth order, to the lists of the 8x8-tile SUPER-TILES its rectangle touches (135 bins at 1080p, ~2 entries per
 // Gaussian: the ordered scatter is cheap and runs 2048 waves), and each super-tile list is then cut into chunks of 512
-// entries.  One wave per chunk walks its entries in order with lane = tile of the super-tile, tests rectangle vs tile and
-// appends the id to its own tile's list: 64 sequential write streams per wave, full lines, no atomics.
+// entries.  A workgroup per chunk walks its entries in order with lane = entry, one ballot per tile of the super-tile, and
+// appends the ids to the tiles' lists: sequential write streams, full lines, no atomics.
 //
 //   sup_count   : slice b of the depth order histograms its super-tiles in LDS (one lane per Gaussian)
 //   sup_hist_scan: exclusive scan over slices, per-super-tile totals
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) k_sup_count(int P, int sgx, int T1, int p
 // one 1024-thread workgroup: list starts, chunk table, totals
 __global__ void __launch_bounds__(1024) k_sup_scan(int T1, uint32_t cap1, uint32_t chunk_cap, const uint32_t* __restrict__ sup_count,
                                                    uint32_t* __restrict__ sup_start, uint32_t* __restrict__ chunk_base,
-                                                   uint32_t* __restrict__ chunk_sup, uint32_t* __restrict__ hdr)
+                                                   uint4* __restrict__ chunk_info, uint32_t* __restrict__ hdr)
 {
     __shared__ uint32_t s_a[1024], s_b[1024];
     const int tid = threadIdx.x;
@@ -94,7 +94,10 @@ __global__ void __launch_bounds__(1024) k_sup_scan(int T1, uint32_t cap1, uint32
         const uint32_t c = sup_count[i];
         sup_start[i] = ra; chunk_base[i] = rb;
         const uint32_t nc = (c + SGR_B2_CHUNK - 1) / SGR_B2_CHUNK;
-        for (uint32_t k = 0; k < nc && rb + k < chunk_cap; k++) chunk_sup[rb + k] = (uint32_t)i;  // chunk -> super-tile
+        // chunk -> {super-tile, first level-1 entry, entries}: ONE 16-byte load per chunk in the tile passes (the chain
+        // chunk -> super-tile -> list start / first chunk -> entry range was three dependent round trips per wave)
+        for (uint32_t k = 0; k < nc && rb + k < chunk_cap; k++)
+            chunk_info[rb + k] = make_uint4((uint32_t)i, ra + k * SGR_B2_CHUNK, min((uint32_t)SGR_B2_CHUNK, c - k * SGR_B2_CHUNK), 0u);
         ra += c; rb += nc;
     }
     if (tid == 1023) {
@@ -215,7 +218,7 @@ __global__ void __launch_bounds__(64) k_sup_scatter(int P, int sgx, int T1, int 
     }
 }
 
-// One wave per chunk of a super-tile list (<= 512 entries = 8 batches of one entry per lane).  A lane turns the rectangle
+// Per chunk of a super-tile list (<= 512 entries = 8 batches of one entry per lane): a lane turns the rectangle
 // of its entry into the 64-bit mask of the super-tile's 8 x 8 tiles it covers (a dozen instructions for 64 entries).
 // Then, per tile t, one ballot of bit t per batch gives the entries that cover it, in list order:
 //   WRITE = false: the popcounts are the tile's count for this chunk (kept in lane t of one register);
@@ -238,88 +241,103 @@ __device__ __forceinline__ void tile_mask(uint2 r, int ox, int oy, uint32_t& lo,
 
 #define SGR_B2_BATCHES (SGR_B2_CHUNK / 64)
 
-template <bool WRITE>
-__global__ void __launch_bounds__(64) k_tile_pass(int gx, int gy, int sgx, int T1, const uint32_t* __restrict__ sup_start,
-                                                  const uint32_t* __restrict__ chunk_base, const uint32_t* __restrict__ chunk_sup,
-                                                  const uint32_t* __restrict__ hdr, const uint4* __restrict__ L1,
-                                                  uint32_t* __restrict__ cnt2,
-                                                  const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ point_list,
-                                                  uint32_t list_cap, const uint32_t* __restrict__ tile_need)
+// SEVERAL waves per chunk (one workgroup), an equal share of the super-tile's 64 tiles each.  One wave walking all 64 tiles of a
+// chunk is a serial chain of ~5000 instructions (64 tiles x 8 batches of ballot / rank / LDS store): ~40 us by itself, however
+// few chunks there are -- the walk hint below skips four chunks in five at the metric workload and the pass did not get
+// any shorter until the chain was cut up.  Every wave loads the chunk's 512 entries and turns them into tile masks (a
+// dozen instructions per batch, repeated by every wave) and then keeps the half of the masks its tiles live in.
+// How many waves: measured at the metric workload (3661 chunks) -- count pass 28 / 21 / 23 / 29 / 44 us with 1 / 2 / 4 / 8 / 16
+// waves per chunk (its chain is short, the repeated loads cost more); write pass without a hint 52 / 48 / 45 / 46 / 62 us and
+// with nearly every chunk skipped 40 / 24 / 17 / 14 / 18 us.
+#define SGR_B2_COUNT_WAVES 2
+#define SGR_B2_WRITE_WAVES 8
+template <bool WRITE, int SGR_B2_WAVES>
+__global__ void __launch_bounds__(64 * SGR_B2_WAVES) k_tile_pass(int gx, int gy, int sgx, int T1, const uint4* __restrict__ chunk_info,
+                                                                 const uint32_t* __restrict__ hdr, const uint4* __restrict__ L1,
+                                                                 uint32_t* __restrict__ cnt2,
+                                                                 const uint32_t* __restrict__ tile_start,
+                                                                 uint32_t* __restrict__ point_list, uint32_t list_cap,
+                                                                 const uint32_t* __restrict__ tile_need)
 {
-    __shared__ uint32_t s_row[WRITE ? SGR_B2_CHUNK : 1];
+    constexpr int SGR_B2_TILES_PER_WAVE = 64 / SGR_B2_WAVES;
+    __shared__ uint32_t s_rows[WRITE ? SGR_B2_WAVES * SGR_B2_CHUNK : 1];
     if (hdr[SGR_B2_HDR_OVERFLOW]) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t* s_row = s_rows + (WRITE ? wave * SGR_B2_CHUNK : 0);
     const int n_chunks = (int)hdr[SGR_B2_HDR_CHUNKS];
     for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        const int sup = (int)chunk_sup[c];
-        const uint32_t e0 = sup_start[sup] + (uint32_t)(c - (int)chunk_base[sup]) * SGR_B2_CHUNK;
-        const int n = (int)min((uint32_t)SGR_B2_CHUNK, sup_start[sup + 1] - e0);
+        const uint4 ci = chunk_info[c];
+        const int sup = (int)ci.x;
+        const uint32_t e0 = ci.y;
+        const int n = (int)ci.z;
         const int ox = (sup % sgx) * SGR_SUP, oy = (sup / sgx) * SGR_SUP;
+        uint32_t base = 0;
+        if (WRITE) {
+            // lane t: first slot of tile t's segment for this chunk
+            uint32_t before = 0, need = 0, total = 0;
+            const int tx = ox + (lane & (SGR_SUP - 1)), ty = oy + (lane >> SGR_SUP_SHIFT);
+            if (tx < gx && ty < gy) {
+                const int t = ty * gx + tx;
+                before = cnt2[(size_t)c * 64 + lane];  // entries of the tile in the earlier chunks of this super-tile
+                const uint32_t t0 = tile_start[t];
+                total = tile_start[t + 1] - t0;
+                base = t0 + before;
+                need = tile_need ? tile_need[t] : 0xFFFFFFFFu;
+            }
+            // walk hint: the lists are in depth order and so are the chunks -- if every tile of the super-tile already holds
+            // the entries it is expected to walk (or all it has), this chunk and every later one is never read: nothing to
+            // write.  (All four waves evaluate the same test.)
+            if (__ballot(before < min(need, total)) == 0ull) continue;
+        }
+        const int half = (wave * SGR_B2_TILES_PER_WAVE) >> 5;           // this wave's tiles sit in the low or the high mask word
+        const int t_first = (wave * SGR_B2_TILES_PER_WAVE) & 31;
+        uint32_t msk[SGR_B2_BATCHES], id[SGR_B2_BATCHES];
+#pragma unroll
+        for (int b = 0; b < SGR_B2_BATCHES; b++) {
+            msk[b] = 0u; id[b] = 0u;
+            if (b * 64 + lane < n) {  // (requesting all eight up front at clamped indices made no difference here: measured)
+                const uint4 e = L1[e0 + b * 64 + lane];
+                uint32_t lo, hi;
+                tile_mask(make_uint2(e.x, e.y), ox, oy, lo, hi);
+                msk[b] = half ? hi : lo;
+                id[b] = e.z;
+            }
+        }
         if (!WRITE) {
-            uint32_t run = 0;  // lane t: entries of this chunk covering tile t
-            for (int b = 0; b < n; b += 64) {
-                uint32_t lo = 0u, hi = 0u;
-                if (b + lane < n) { const uint4 e = L1[e0 + b + lane]; tile_mask(make_uint2(e.x, e.y), ox, oy, lo, hi); }
+            uint32_t run = 0;  // lane 16 wave + tt: entries of this chunk covering that tile
+#pragma unroll
+            for (int b = 0; b < SGR_B2_BATCHES; b++) {
+                if (b * 64 >= n) break;  // (uniform)
                 uint32_t add = 0;
 #pragma unroll
-                for (int t = 0; t < 32; t++) {
-                    const unsigned long long M = __ballot((lo & (1u << t)) != 0u);
-                    add = (lane == t) ? (uint32_t)__popcll(M) : add;
-                }
-#pragma unroll
-                for (int t = 0; t < 32; t++) {
-                    const unsigned long long M = __ballot((hi & (1u << t)) != 0u);
-                    add = (lane == t + 32) ? (uint32_t)__popcll(M) : add;
+                for (int tt = 0; tt < SGR_B2_TILES_PER_WAVE; tt++) {
+                    const unsigned long long M = __ballot((msk[b] & (1u << (t_first + tt))) != 0u);
+                    add = (lane == wave * SGR_B2_TILES_PER_WAVE + tt) ? (uint32_t)__popcll(M) : add;
                 }
                 run += add;
             }
-            cnt2[(size_t)c * 64 + lane] = run;
+            if (lane / SGR_B2_TILES_PER_WAVE == wave) cnt2[(size_t)c * 64 + lane] = run;
         } else {
-            // lane t: first slot of tile t's segment for this chunk
-            uint32_t base = 0, before = 0, need = 0;
-            {
-                const int tx = ox + (lane & (SGR_SUP - 1)), ty = oy + (lane >> SGR_SUP_SHIFT);
-                if (tx < gx && ty < gy) {
-                    before = cnt2[(size_t)c * 64 + lane];  // entries of the tile in the earlier chunks of this super-tile
-                    base = tile_start[ty * gx + tx] + before;
-                    need = tile_need ? tile_need[ty * gx + tx] : 0xFFFFFFFFu;
+            for (int tt = 0; tt < SGR_B2_TILES_PER_WAVE; tt++) {
+                const uint32_t sel = 1u << (t_first + tt);
+                uint32_t cnt = 0;  // wave-uniform
+#pragma unroll
+                for (int b = 0; b < SGR_B2_BATCHES; b++) {
+                    const bool bit = (msk[b] & sel) != 0u;
+                    const unsigned long long M = __ballot(bit);
+                    if (bit) s_row[cnt + lanes_below(M)] = id[b];
+                    cnt += (uint32_t)__popcll(M);
                 }
-            }
-            // walk hint: the lists are in depth order and so are the chunks -- if every tile of the super-tile already holds
-            // the entries it is expected to walk, this chunk (and every later one) is never read: nothing to write
-            if (__ballot(before < need) == 0ull) continue;
-            uint32_t lo[SGR_B2_BATCHES], hi[SGR_B2_BATCHES], id[SGR_B2_BATCHES];
-#pragma unroll
-            for (int b = 0; b < SGR_B2_BATCHES; b++) {
-                lo[b] = 0u; hi[b] = 0u; id[b] = 0u;
-                if (b * 64 + lane < n) {
-                    const uint4 e = L1[e0 + b * 64 + lane];
-                    tile_mask(make_uint2(e.x, e.y), ox, oy, lo[b], hi[b]);
-                    id[b] = e.z;
-                }
-            }
-#pragma unroll
-            for (int half = 0; half < 2; half++) {
-                for (int t = 0; t < 32; t++) {
-                    const uint32_t sel = 1u << t;
-                    uint32_t cnt = 0;  // wave-uniform
-#pragma unroll
-                    for (int b = 0; b < SGR_B2_BATCHES; b++) {
-                        const bool bit = ((half ? hi[b] : lo[b]) & sel) != 0u;
-                        const unsigned long long M = __ballot(bit);
-                        if (bit) s_row[cnt + lanes_below(M)] = id[b];
-                        cnt += (uint32_t)__popcll(M);
-                    }
-                    if (cnt) {
-                        // the LDS pipeline of a wave is in order: the row's writes land before these reads, and the reads
-                        // before the next tile's writes; only the compiler has to keep that order (a fence would drain
-                        // the stores)
-                        LDS_ORDER();
-                        const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)base, t + 32 * half);
-                        for (uint32_t j = lane; j < cnt; j += 64)
-                            if (dst + j < list_cap) point_list[dst + j] = s_row[j];  // (sync-free mode: the list has the caller's capacity)
-                        LDS_ORDER();
-                    }
+                if (cnt) {
+                    // the LDS pipeline of a wave is in order: the row's writes land before these reads, and the reads
+                    // before the next tile's writes; only the compiler has to keep that order (a fence would drain
+                    // the stores)
+                    LDS_ORDER();
+                    const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)base, wave * SGR_B2_TILES_PER_WAVE + tt);
+                    for (uint32_t j = lane; j < cnt; j += 64)
+                        if (dst + j < list_cap) point_list[dst + j] = s_row[j];  // (sync-free mode: the list has the caller's capacity)
+                    LDS_ORDER();
                 }
             }
         }
@@ -410,7 +428,7 @@ Bin2Layout sgr_bin2_layout(int P, int gx, int gy)
     L.hdr = off;        off = sgr_align(off + 64);
     L.L1 = off;         off = sgr_align(off + (size_t)L.cap1 * 16);  // {packed rectangle, id, -} per entry
     L.cnt2 = off;       off = sgr_align(off + (size_t)L.chunk_cap * 64 * 4);
-    L.chunk_sup = off;  off = sgr_align(off + (size_t)L.chunk_cap * 4);
+    L.chunk_sup = off;  off = sgr_align(off + (size_t)L.chunk_cap * 16);  // chunk -> {super-tile, first entry, entries, -}
     L.total = off;
     return L;
 }
@@ -425,7 +443,7 @@ void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scr
     uint32_t* chunk_base = reinterpret_cast<uint32_t*>(scratch + L.chunk_base);
     uint4* L1 = reinterpret_cast<uint4*>(scratch + L.L1);
     uint32_t* cnt2 = reinterpret_cast<uint32_t*>(scratch + L.cnt2);
-    uint32_t* chunk_sup = reinterpret_cast<uint32_t*>(scratch + L.chunk_sup);
+    uint4* chunk_info = reinterpret_cast<uint4*>(scratch + L.chunk_sup);
     static size_t conf_a = 0, conf_b = 0;
     const size_t lds = (size_t)L.T1 * 4, lds_sc = lds + 64 * SGR_B2_MAXN * 4;
     int key_bits = 1;
@@ -435,12 +453,12 @@ void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scr
     hipLaunchKernelGGL(k_sup_count, dim3(SGR_B2_SLICES), dim3(256), lds, s, P, L.sgx, L.T1, L.per_slice, rects, hist1);
     hipLaunchKernelGGL(k_sup_hist_scan, dim3(L.T1), dim3(256), 0, s, L.T1, hist1, sup_count);
     hipLaunchKernelGGL(k_sup_scan, dim3(1), dim3(1024), 0, s, L.T1, L.cap1, L.chunk_cap, sup_count, sup_start, chunk_base,
-                       chunk_sup, hdr);
+                       chunk_info, hdr);
     hipLaunchKernelGGL(k_sup_scatter, dim3(SGR_B2_SLICES), dim3(64), lds_sc, s, P, L.sgx, L.T1, key_bits, L.per_slice, rects, order,
                        sup_start, hist1, hdr, L1);
     const uint32_t grid = L.chunk_cap < 8192u ? L.chunk_cap : 8192u;  // the chunk count lives on the device: grid-stride
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_pass<false>), dim3(grid), dim3(64), 0, s, gx, gy, L.sgx, L.T1, sup_start, chunk_base,
-                       chunk_sup, hdr, L1, cnt2, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_pass<false, SGR_B2_COUNT_WAVES>), dim3(grid), dim3(64 * SGR_B2_COUNT_WAVES), 0, s, gx, gy, L.sgx, L.T1, chunk_info, hdr, L1,
+                       cnt2, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_tile_scan2, dim3(L.T1), dim3(64), 0, s, gx, gy, L.sgx, chunk_base, hdr, cnt2, tile_count);
 }
 
@@ -449,11 +467,9 @@ void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, c
                            const uint32_t* tile_need, hipStream_t s)
 {
     if (n_chunks == 0) return;
-    const uint32_t* sup_start = reinterpret_cast<const uint32_t*>(scratch + L.sup_start);
-    const uint32_t* chunk_base = reinterpret_cast<const uint32_t*>(scratch + L.chunk_base);
     const uint4* L1 = reinterpret_cast<const uint4*>(scratch + L.L1);
     uint32_t* cnt2 = reinterpret_cast<uint32_t*>(scratch + L.cnt2);
-    const uint32_t* chunk_sup = reinterpret_cast<const uint32_t*>(scratch + L.chunk_sup);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_pass<true>), dim3(n_chunks), dim3(64), 0, s, gx, gy, L.sgx, L.T1, sup_start,
-                       chunk_base, chunk_sup, hdr, L1, cnt2, tile_start, point_list, list_cap, tile_need);
+    const uint4* chunk_info = reinterpret_cast<const uint4*>(scratch + L.chunk_sup);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_pass<true, SGR_B2_WRITE_WAVES>), dim3(n_chunks), dim3(64 * SGR_B2_WRITE_WAVES), 0, s, gx, gy, L.sgx, L.T1, chunk_info, hdr, L1,
+                       cnt2, tile_start, point_list, list_cap, tile_need);
 }

@@ -144,7 +144,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     // culled (auxiliary.h:156-160: printf + __trap); a library must not kill its host, so the promise is not checked
     (void)prefiltered;
     hipStream_t s = (hipStream_t)stream;
-    static const sgr_forward_opts no_opts = {0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static const sgr_forward_opts no_opts = {0, 0, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr};
     if (!opts) opts = &no_opts;
     int64_t binning_capacity = opts->binning_capacity;
     const int flags = opts->flags;
@@ -273,7 +273,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
         StageTimer t(s, SGR_STAGE_BLEND_FWD);
         sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
                              tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, (uint32_t)R, opts->tile_need,
-                             opts->tile_need_out, s);
+                             opts->tile_need_out, opts->hint_margin, s);
     }
     STAGE_CHECK("blend_fwd");
     // ... and once more behind the blend: word 3 (hint miss) is final only now
@@ -419,6 +419,15 @@ int sgr_backward_ex(int phase, int P, int D, int M, int64_t R, const float* back
                          rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, geom_buffer, binning_buffer,
                          img_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
                          dL_drot, debug, stream, opts);
+}
+
+// (introspection for the developer scripts: byte offsets of the two-level binning tables inside the image scratch)
+void sgr_debug_bin2_offsets(int P, int width, int height, size_t* out)
+{
+    const ImgLayout IL = sgr_img_layout(width, height);
+    const Bin2Layout B = sgr_bin2_layout(P, IL.gx, IL.gy);
+    out[0] = IL.total + B.sup_start; out[1] = IL.total + B.chunk_base; out[2] = IL.total + B.cnt2; out[3] = IL.total + B.chunk_sup;
+    out[4] = (size_t)B.T1; out[5] = (size_t)B.sgx; out[6] = (size_t)B.chunk_cap; out[7] = IL.header;
 }
 
 size_t sgr_bin2_bytes(int P, int width, int height)

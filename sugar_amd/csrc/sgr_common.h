@@ -172,7 +172,8 @@ void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_star
 void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
                           uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
-                          uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, uint32_t* tile_need_out, hipStream_t s);
+                          uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, uint32_t* tile_need_out, float hint_margin,
+                          hipStream_t s);
 void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const unsigned long long* blk_mask, const uint32_t* blk_nb, const GeomRec* rec, const float* bg,
                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* acc,

@@ -548,7 +548,7 @@ class NativeTrainer:
     right behind the forward (the loss and the blend backward are queued by then), before anything is sent."""
 
     def __init__(self, params: GaussianParams, bg, width, height, sh_degree=3, lambda_dssim=0.2, densify_stats=False,
-                 force_collectives=False, walk_hint=True, capacity=None, betas=(0.9, 0.999), eps=1e-15):
+                 force_collectives=False, walk_hint=True, capacity=None, betas=(0.9, 0.999), eps=1e-15, hint_margin=None):
         import ctypes as C
         from . import _lib
         if not params.flat.is_cuda:
@@ -563,6 +563,8 @@ class NativeTrainer:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.exchange = self.world > 1 or (bool(force_collectives) and dist.is_available() and dist.is_initialized())
         self.walk_hint = bool(walk_hint)
+        import os as _os
+        self.hint_margin = float(hint_margin if hint_margin is not None else _os.environ.get("SGR_HINT_MARGIN", 0.25))
         self.exp_avg = torch.zeros_like(params.flat)
         self.exp_avg_sq = torch.zeros_like(params.flat)
         self.t = 0
@@ -623,7 +625,7 @@ class NativeTrainer:
             need = ent[0].data_ptr() if (ent[1] and use_hint) else None  # (usable once a forward that wrote it was validated)
             need_out = ent[0].data_ptr()
         view = L.TrainView(cam.viewmatrix.data_ptr(), cam.projmatrix.data_ptr(), cam.campos.data_ptr(), cam.tanfovx, cam.tanfovy,
-                           gt.data_ptr(), need, need_out)
+                           gt.data_ptr(), need, need_out, self.hint_margin)
         with torch.cuda.device(self.dev):
             rc = self._lib.sgr_trainer_step(self._h, C.byref(view), phases, C.byref(ex) if ex is not None else None,
                                             C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream))
