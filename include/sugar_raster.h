@@ -81,11 +81,13 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user,
  *   set: the forward is then INVALID exactly like a capacity overflow (repeat it without the hint).
  * tile_need_out (device, uint32 per tile): receives the hint for the next visit: tile_walked * (1 + hint_margin) + 64
  *   (hint_margin <= 0: 0.25).
- * info (host, may be NULL): what the call did (binning path taken). */
+ * info (host, may be NULL): what the call did (binning path taken).
+ * Header word 5 (SGR_HDR_CHUNKS): level-2 chunks of this view (see chunk_grid). */
 #define SGR_HDR_R 0          /* header words (device): total instances */
 #define SGR_HDR_MAXCOUNT 1   /* largest per-tile instance count */
 #define SGR_HDR_R_HI 2
 #define SGR_HDR_HINT_MISS 3  /* != 0: a tile needed more entries than its walk hint allowed */
+#define SGR_HDR_CHUNKS 5      /* 512-entry chunks of the super-tile lists (two-level binning) */
 #define SGR_HDR_L1_OVERFLOW 6 /* != 0: the level-1 (super-tile) list overflowed its capacity */
 typedef struct sgr_forward_info {
     int binning_mode;        /* 0: two-level binning, 1: single-level */
@@ -99,6 +101,10 @@ typedef struct sgr_forward_opts {
     const uint32_t* tile_need;
     uint32_t* tile_need_out;
     float hint_margin;
+    uint32_t chunk_grid;     /* sync-free forward: workgroups to launch for the level-2 tile passes (their count lives on the
+                                device; the passes are grid-stride loops, so any value is correct).  0: the capacity bound,
+                                about twice what a typical view needs; a trainer passes header word 5 of the camera's
+                                previous visit plus a margin */
     sgr_forward_info* info;
 } sgr_forward_opts;
 int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user,
@@ -351,6 +357,7 @@ typedef struct sgr_train_view {
     const uint32_t* tile_need;   /* walk hint of this camera (device, [tiles]) or NULL */
     uint32_t* tile_need_out;     /* receives the hint for its next visit, or NULL */
     float hint_margin;           /* see sgr_forward_opts */
+    uint32_t chunk_grid;         /* see sgr_forward_opts */
 } sgr_train_view;
 typedef struct sgr_train_exchange { /* phases 4 and 8 */
     int n_views;                 /* views whose colour gradients are summed (1: this rank's own) */

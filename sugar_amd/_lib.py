@@ -86,7 +86,7 @@ class ForwardInfo(C.Structure):
 
 class ForwardOpts(C.Structure):
     _fields_ = [("binning_capacity", _i64), ("flags", _i), ("header_host", _vp), ("header_event", _vp), ("tile_need", _vp),
-                ("tile_need_out", _vp), ("hint_margin", _f), ("info", C.POINTER(ForwardInfo))]
+                ("tile_need_out", _vp), ("hint_margin", _f), ("chunk_grid", C.c_uint32), ("info", C.POINTER(ForwardInfo))]
 
 
 class BackwardOpts(C.Structure):
@@ -108,7 +108,7 @@ class TrainConfig(C.Structure):
 
 class TrainView(C.Structure):
     _fields_ = [("viewmatrix", _vp), ("projmatrix", _vp), ("campos", _vp), ("tan_fovx", _f), ("tan_fovy", _f), ("gt_image", _vp),
-                ("tile_need", _vp), ("tile_need_out", _vp), ("hint_margin", _f)]
+                ("tile_need", _vp), ("tile_need_out", _vp), ("hint_margin", _f), ("chunk_grid", C.c_uint32)]
 
 
 class TrainExchange(C.Structure):

@@ -435,7 +435,7 @@ Bin2Layout sgr_bin2_layout(int P, int gx, int gy)
 
 // level 1 + the counting half of level 2: leaves tile_count[T] (consumed by sgr_launch_tile_scan) and the header
 void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scratch, uint32_t* hdr, const uint2* rects,
-                           const uint32_t* order, uint32_t* tile_count, hipStream_t s)
+                           const uint32_t* order, uint32_t* tile_count, uint32_t chunk_grid, hipStream_t s)
 {
     uint32_t* hist1 = reinterpret_cast<uint32_t*>(scratch + L.hist1);
     uint32_t* sup_count = reinterpret_cast<uint32_t*>(scratch + L.sup_count);
@@ -456,7 +456,8 @@ void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scr
                        chunk_info, hdr);
     hipLaunchKernelGGL(k_sup_scatter, dim3(SGR_B2_SLICES), dim3(64), lds_sc, s, P, L.sgx, L.T1, key_bits, L.per_slice, rects, order,
                        sup_start, hist1, hdr, L1);
-    const uint32_t grid = L.chunk_cap < 8192u ? L.chunk_cap : 8192u;  // the chunk count lives on the device: grid-stride
+    uint32_t grid = L.chunk_cap < 8192u ? L.chunk_cap : 8192u;  // the chunk count lives on the device: grid-stride
+    if (chunk_grid && chunk_grid < grid) grid = chunk_grid;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_pass<false, SGR_B2_COUNT_WAVES>), dim3(grid), dim3(64 * SGR_B2_COUNT_WAVES), 0, s, gx, gy, L.sgx, L.T1, chunk_info, hdr, L1,
                        cnt2, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_tile_scan2, dim3(L.T1), dim3(64), 0, s, gx, gy, L.sgx, chunk_base, hdr, cnt2, tile_count);

@@ -144,7 +144,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     // culled (auxiliary.h:156-160: printf + __trap); a library must not kill its host, so the promise is not checked
     (void)prefiltered;
     hipStream_t s = (hipStream_t)stream;
-    static const sgr_forward_opts no_opts = {0, 0, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr};
+    static const sgr_forward_opts no_opts = {0, 0, nullptr, nullptr, nullptr, nullptr, 0.f, 0u, nullptr};
     if (!opts) opts = &no_opts;
     int64_t binning_capacity = opts->binning_capacity;
     const int flags = opts->flags;
@@ -210,7 +210,8 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     {
         StageTimer t(s, SGR_STAGE_SCAN);
         if (two_level) {
-            sgr_launch_bin2_count(P, IL.gx, IL.gy, B2, bin2, header + 4, rects, order, tile_cursor, s);
+            sgr_launch_bin2_count(P, IL.gx, IL.gy, B2, bin2, header + 4, rects, order, tile_cursor,
+                                  binning_capacity > 0 ? opts->chunk_grid : 0u, s);
         } else {
             sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, blk_hist, s);
             sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
@@ -230,7 +231,10 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     uint32_t n_chunks = 0;
     if (nosync) {
         R = binning_capacity;
-        n_chunks = B2.chunk_cap < 8192u ? B2.chunk_cap : 8192u;  // the chunk count lives on the device: grid-stride
+        // the chunk count lives on the device: the passes are grid-stride loops over it; the caller may know better than the
+        // capacity bound how many workgroups are worth launching (idle 512-thread workgroups are not free to dispatch)
+        n_chunks = B2.chunk_cap < 8192u ? B2.chunk_cap : 8192u;
+        if (opts->chunk_grid && opts->chunk_grid < n_chunks) n_chunks = opts->chunk_grid;
     } else {
         if (!g_pinned.p) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_pinned.p), 64, hipHostMallocDefault));
         // words 0-3: the tile scan's header (R, ...); words 4-6: the two-level binning's (R1, chunks, overflow) -- one copy

@@ -81,7 +81,7 @@ struct Bin2Layout {
 Bin2Layout sgr_bin2_layout(int P, int gx, int gy);
 // hdr: three words (SGR_B2_HDR_*) next to the image header, so that one device-to-host copy brings both
 void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scratch, uint32_t* hdr, const uint2* rects,
-                           const uint32_t* order, uint32_t* tile_count, hipStream_t s);
+                           const uint32_t* order, uint32_t* tile_count, uint32_t chunk_grid, hipStream_t s);
 void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, const uint32_t* hdr, uint32_t n_chunks, const uint2* rects,
                            const uint32_t* order, const uint32_t* tile_start, uint32_t* point_list, uint32_t list_cap,
                            const uint32_t* tile_need, hipStream_t s);

@@ -120,6 +120,7 @@ int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* v, int phases, const 
         fo.tile_need = v->tile_need;
         fo.tile_need_out = v->tile_need_out;
         fo.hint_margin = v->hint_margin;
+        fo.chunk_grid = v->chunk_grid;
         const int64_t R = sgr_forward_ex(fixed_alloc, &g, fixed_alloc, &b, fixed_alloc, &i, P, c.D, c.M, c.background, W, H, means3D, shs,
                                          nullptr, opac, scal, 1.0f, rot, nullptr, v->viewmatrix, v->projmatrix, v->campos,
                                          v->tan_fovx, v->tan_fovy, 0, c.image, c.radii, 0, stream, &fo);

@@ -154,7 +154,7 @@ class _CModule:
             opts = _lib.ForwardOpts(capacity, flags, hdr_out.data_ptr() if hdr_out is not None else None, None,
                                     need.data_ptr() if need is not None else None,
                                     need_out.data_ptr() if need_out is not None else None, float(sink.get("hint_margin") or 0.0),
-                                    C.pointer(info))
+                                    int(sink.get("chunk_grid") or 0), C.pointer(info))
             rendered = lib.sgr_forward_ex(
                 scratch.cb("geom"), None, scratch.cb("binning"), None, scratch.cb("img"), None,
                 P, int(degree), int(M), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),

@@ -538,8 +538,9 @@ class NativeTrainer:
     current stream, from buffers allocated once.  Same arithmetic, same kernels, same parameter layout (GaussianParams).
 
     Validity without a host wait.  The forward runs with a list capacity and, from a camera's second visit on, with a WALK
-    HINT (per tile: how many list entries it walked last time + 25 % + 64): the list-write pass then skips the chunks nobody
-    will read.  A forward that outgrew the capacity or the hint makes every later kernel of the step -- backward and Adam
+    HINT (per tile: how many list entries it walked last time, times 1 + hint_margin, + 64): the list-write pass then skips the
+    chunks nobody will read.  Three misses within 32 forwards switch the hints off for the next 64 (a scene that changes this
+    fast is cheaper to bin in full than to render twice).  A forward that outgrew the capacity or the hint makes every later kernel of the step -- backward and Adam
     included -- a no-op on the device; the host finds out when it next looks at the pinned header (before enqueueing the
     following step, when the copy has long arrived), enlarges the capacity / drops the hint and repeats the step.
 
@@ -564,7 +565,12 @@ class NativeTrainer:
         self.exchange = self.world > 1 or (bool(force_collectives) and dist.is_available() and dist.is_initialized())
         self.walk_hint = bool(walk_hint)
         import os as _os
-        self.hint_margin = float(hint_margin if hint_margin is not None else _os.environ.get("SGR_HINT_MARGIN", 0.25))
+        # measured on the metric scene while Adam's first steps move it (bench.py, 600 steps): margin 0.25 -> 24 forwards
+        # repeated, 0.5 -> 13, 1.0 -> 4; list-write pass 57 -> 37 us at 0.5 (a wider margin skips less)
+        self.hint_margin = float(hint_margin if hint_margin is not None else _os.environ.get("SGR_HINT_MARGIN", 0.5))
+        self._recent_misses = []   # step numbers of the latest hint misses
+        self._hint_pause_until = 0
+        self._calls = 0            # forwards enqueued so far (the clock of the hint policy; `t` is Adam's and may be reset)
         self.exp_avg = torch.zeros_like(params.flat)
         self.exp_avg_sq = torch.zeros_like(params.flat)
         self.t = 0
@@ -618,19 +624,29 @@ class NativeTrainer:
     def _call(self, cam, gt, key, phases, ex, use_hint=True):
         C, L = self._C, self._L
         need = need_out = None
-        if self.walk_hint and (phases & 1):
+        if phases & 1:
             ent = self._hints.get(key)
-            if ent is None:
-                ent = self._hints[key] = [torch.zeros(self.T, dtype=torch.int32, device=self.dev), False]
-            need = ent[0].data_ptr() if (ent[1] and use_hint) else None  # (usable once a forward that wrote it was validated)
-            need_out = ent[0].data_ptr()
+            if ent is None:  # per camera: [walk hint, hint usable, level-2 chunks of the last validated visit]
+                ent = self._hints[key] = [torch.zeros(self.T, dtype=torch.int32, device=self.dev), False, 0]
+            if self.walk_hint:
+                # (usable once a forward that wrote it was validated, and not while the hints are paused)
+                need = ent[0].data_ptr() if (ent[1] and use_hint and self._calls >= self._hint_pause_until) else None
+                need_out = ent[0].data_ptr()
+            self._last_hinted = need is not None
+            self._calls += 1
         view = L.TrainView(cam.viewmatrix.data_ptr(), cam.projmatrix.data_ptr(), cam.campos.data_ptr(), cam.tanfovx, cam.tanfovy,
-                           gt.data_ptr(), need, need_out, self.hint_margin)
+                           gt.data_ptr(), need, need_out, self.hint_margin, self._chunk_grid(key))
         with torch.cuda.device(self.dev):
             rc = self._lib.sgr_trainer_step(self._h, C.byref(view), phases, C.byref(ex) if ex is not None else None,
                                             C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream))
         if rc < 0:
             raise RuntimeError(f"sgr_trainer_step failed ({rc}): " + self._lib.sgr_trainer_last_error().decode(errors="replace"))
+
+    def _chunk_grid(self, key):
+        """workgroups worth launching for the level-2 tile passes: what this camera's last visit had, plus a quarter"""
+        ent = self._hints.get(key)
+        n = ent[2] if ent is not None else 0
+        return (n + n // 4 + 64) if n else 0
 
     def _grow(self, R):
         self.capacity = int(R) + int(R) // 2 + 65536
@@ -646,10 +662,19 @@ class NativeTrainer:
         if ok < 0:
             raise RuntimeError("sgr_trainer_forward_valid failed")
         self.last_num_rendered = int(hdr[0])
+        self._last_chunks = int(hdr[5])
         return bool(ok), (int(hdr[0]) if int(hdr[0]) > self.capacity else 0), bool(hdr[8 + 3])
+
+    def _hint_feedback(self, missed):
+        if missed:
+            self._recent_misses = [t for t in self._recent_misses if t > self._calls - 32] + [self._calls]
+            if len(self._recent_misses) >= 3:
+                self._hint_pause_until = self._calls + 64
+                self._recent_misses = []
 
     def _repair(self, key, R, missed):
         self.redone += 1
+        self._hint_feedback(missed)
         if R:
             torch.cuda.synchronize(self.dev)  # (the old list buffer may still be in use by queued kernels)
             self._grow(R)
@@ -664,6 +689,8 @@ class NativeTrainer:
             if ok:
                 if key in self._hints:
                     self._hints[key][1] = True
+                    self._hints[key][2] = self._last_chunks
+                self._hint_feedback(False)
                 self._pending = None
                 return
             if not (R or missed):
@@ -692,6 +719,8 @@ class NativeTrainer:
             if ok:
                 if key in self._hints:
                     self._hints[key][1] = True
+                    self._hints[key][2] = self._last_chunks
+                self._hint_feedback(False)
                 break
             if not (R or missed):
                 raise RuntimeError("level-1 binning overflow: this view needs the single-level binning (use ViewShardedTrainer)")

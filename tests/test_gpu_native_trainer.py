@@ -78,7 +78,8 @@ def test_lagged_validation_skips_and_repeats_an_invalid_step():
                     ent[0].fill_(1)  # every tile may walk ONE entry: the hinted forwards must notice and be repeated
             nt.step(cams[i % 8], gts[i % 8], cam_key=i % 8)
         nt.synchronize()
-        assert (nt.redone >= 6) if sabotage else (nt.redone == 0)
+        # (three misses within 32 steps pause the hints for 64 steps: the remaining sabotaged hints are not even tried)
+        assert (3 <= nt.redone <= 6) if sabotage else (nt.redone == 0)
         flats.append(p.flat.clone())
     _close(flats[1], flats[0], start)
 
