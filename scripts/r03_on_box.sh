@@ -7,7 +7,10 @@ OUT="$R/gpurun_out/r03"
 mkdir -p "$OUT"
 cd "$R"
 { echo "# rocm-smi before"; rocm-smi --showclocks --showpower --showtemp --showmemuse --showperflevel 2>&1 | grep -v "^=\|^$" | head -40; } > "$OUT/box_state.txt"
+( for i in $(seq 1 60); do rocm-smi --showclocks --showpower 2>&1 | grep -i "sclk\|mclk\|fclk\|Power (W)" | tr -s "\t " " " | tr "\n" "|"; echo; sleep 0.25; done ) > "$OUT/box_clocks_during_bench.txt" &
+SAMPLER=$!
 python bench.py --steps 20 --warmup 5 > "$OUT/bench_metric.json" 2> "$OUT/bench_metric.err"
+kill $SAMPLER 2>/dev/null; wait $SAMPLER 2>/dev/null
 { echo "# rocm-smi right after the metric bench"; rocm-smi --showclocks --showpower --showtemp 2>&1 | grep -v "^=\|^$" | head -30; } >> "$OUT/box_state.txt"
 for w in config2 config3 config5; do
   python bench.py --workload $w --steps 20 --warmup 5 --preroll 64 --drift-steps 0 --no-densify-variant > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"

@@ -135,16 +135,19 @@ int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* v, int phases, const 
     if (phases & 3) {
         if (!t->have_forward) return tfail(SGR_E_INVALID, "sgr_trainer_step: backward before any forward");
         sgr_backward_opts bo = {c.max_radii2D, c.grad_accum, c.denom};
-        // compact SH mode (dL_dsh == NULL), raw-parameter gradients straight into the flat gradient buffer
-        for (int ph = 1; ph <= 2; ph++) {
-            if (!(phases & ph)) continue;
+        // compact SH mode (dL_dsh == NULL), raw-parameter gradients straight into the flat gradient buffer.  Both halves asked
+        // for at once (no collective to start in between): ONE pass, the preprocess kernel writes the masked colour gradients
+        // itself (the split costs a 23 us kernel of its own)
+        const int first = (phases & 3) == 3 ? 0 : ((phases & 1) ? 1 : 2);
+        const int last = (phases & 3) == 3 ? 0 : ((phases & 2) ? 2 : 1);
+        for (int ph = first; ph <= last; ph++) {
             const int rc = sgr_backward_ex(ph | SGR_MODE_RAW_PARAMS, P, c.D, c.M, t->R, c.background, W, H, means3D, shs, nullptr, scal,
                                            1.0f, rot, nullptr, v->viewmatrix, v->projmatrix, v->campos, v->tan_fovx, v->tan_fovy,
                                            c.radii, c.geom, c.binning, c.img, c.grad_image, c.dL_dmean2D, nullptr,
                                            grad + c.off_opacity, c.colors, grad + c.off_xyz, nullptr, nullptr, grad + c.off_scaling,
                                            grad + c.off_rotation, 0, stream, &bo);
             if (rc < 0) return tfail(rc, std::string("backward: ") + sgr_last_error());
-            if (ph == 1 && hipMemcpyAsync(c.colors + 3 * (size_t)P, v->campos, 12, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            if (ph != 2 && hipMemcpyAsync(c.colors + 3 * (size_t)P, v->campos, 12, hipMemcpyDeviceToDevice, s) != hipSuccess)
                 return tfail(SGR_E_HIP, "camera centre copy failed");
         }
     }

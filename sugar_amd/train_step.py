@@ -570,6 +570,7 @@ class NativeTrainer:
         self.hint_margin = float(hint_margin if hint_margin is not None else _os.environ.get("SGR_HINT_MARGIN", 0.5))
         self._recent_misses = []   # step numbers of the latest hint misses
         self._hint_pause_until = 0
+        self.host_work_s = 0.0     # time spent preparing and enqueueing steps (the waits for the header are not in it)
         self._calls = 0            # forwards enqueued so far (the clock of the hint policy; `t` is Adam's and may be reset)
         self.exp_avg = torch.zeros_like(params.flat)
         self.exp_avg_sq = torch.zeros_like(params.flat)
@@ -622,6 +623,8 @@ class NativeTrainer:
 
     # ---- one phase mask, one call
     def _call(self, cam, gt, key, phases, ex, use_hint=True):
+        import time as _time
+        _t0 = _time.perf_counter()
         C, L = self._C, self._L
         need = need_out = None
         if phases & 1:
@@ -639,6 +642,7 @@ class NativeTrainer:
         with torch.cuda.device(self.dev):
             rc = self._lib.sgr_trainer_step(self._h, C.byref(view), phases, C.byref(ex) if ex is not None else None,
                                             C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream))
+        self.host_work_s += _time.perf_counter() - _t0
         if rc < 0:
             raise RuntimeError(f"sgr_trainer_step failed ({rc}): " + self._lib.sgr_trainer_last_error().decode(errors="replace"))
 
