@@ -205,6 +205,7 @@ def main():
     for s in range(args.warmup, args.warmup + args.steps):
         do_step(trainer, s)
     t_enq = time.perf_counter()  # (diagnostic: when the host finished enqueueing; equal to t1 means the loop was host-bound)
+    hw1 = getattr(trainer, "host_work_s", 0.0)
     sync_all()
     t1 = time.perf_counter()
     mark("after_timed")
@@ -347,7 +348,7 @@ def main():
             # wall time of the host loop; the native trainer spends most of it WAITING for the previous step's header (it runs one
             # step ahead of the GPU by design): host_work_ms_per_step is what it actually computes and enqueues
             "host_enqueue_ms_per_step": 1e3 * (t_enq - t0) / K,
-            "host_work_ms_per_step": (1e3 * (trainer.host_work_s - hw0) / K) if isinstance(trainer, NativeTrainer) else None,
+            "host_work_ms_per_step": (1e3 * (hw1 - hw0) / K) if isinstance(trainer, NativeTrainer) else None,
             "stages_ms": stages,
             "roofline": {
                 "kernel": "k_blend_fwd_w", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -374,22 +375,48 @@ def main():
 
 
 class ForwardOnly:
-    """a "step" = one rasterizer forward through the reference-shaped API (BASELINE config 5 is quoted forward-only)"""
+    """a "step" = one rasterizer forward through the reference-shaped API (BASELINE config 5 is quoted forward-only).  After
+    one pass over the cameras with the reference's host round trip (which tells the largest num_rendered), the forwards run
+    sync-free with a fixed list capacity: no wait for the GPU in the middle of the call, and scratch buffers of constant size
+    (with num_rendered differing per camera the caching allocator otherwise returns to hipMalloc every call: 19 ms per forward
+    at 6M Gaussians @ 4K against 1.7 ms of kernels)."""
 
     def __init__(self, scene, dev, bg, rasterizer_cls, settings_cls, cmod):
         self.t = {k: getattr(scene, k).to(dev) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
         self.m2 = torch.zeros_like(self.t["means3D"])
         self.bg, self.R, self.S, self.cmod = bg, rasterizer_cls, settings_cls, cmod
         self.last_num_rendered = 0
+        self.calls, self.max_R, self.capacity = 0, 0, 0
+        self.hdr = torch.zeros(16, dtype=torch.int32).pin_memory()
+        self.ev = torch.cuda.Event()
+        self.redone = 0
 
-    def step(self, cam, gt):
+    def _forward(self, cam, capacity):
+        import contextlib
+        from sugar_amd.diff_gaussian_rasterization import grad_sink
         st = self.S(image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=self.bg,
                     scale_modifier=1.0, viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix, sh_degree=3, campos=cam.campos,
                     prefiltered=False, debug=False)
         t = self.t
-        with torch.no_grad():
+        cm = grad_sink(binning_capacity=capacity, header_out=self.hdr, header_event=self.ev) if capacity else contextlib.nullcontext()
+        with torch.no_grad(), cm:
             self.R(st)(t["means3D"], self.m2, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
-        self.last_num_rendered = self.cmod.last_forward["num_rendered"]
+
+    def step(self, cam, gt):
+        self.calls += 1
+        if self.calls <= 8:
+            self._forward(cam, 0)
+            self.last_num_rendered = self.cmod.last_forward["num_rendered"]
+            self.max_R = max(self.max_R, self.last_num_rendered)
+            self.capacity = self.max_R + self.max_R // 4 + 65536
+            return
+        if self.calls > 9:  # the previous sync-free forward: valid?  (checked one call later: its header has long arrived)
+            self.ev.synchronize()
+            self.last_num_rendered = int(self.hdr[0]) & 0xFFFFFFFF
+            if self.last_num_rendered > self.capacity or int(self.hdr[6]):
+                self.redone += 1
+                self.capacity = self.last_num_rendered + self.last_num_rendered // 2
+        self._forward(cam, self.capacity)
 
 
 def cpu_baseline(scene, cam, bg, forward_only=False):

@@ -15,6 +15,7 @@ kill $SAMPLER 2>/dev/null; wait $SAMPLER 2>/dev/null
 for w in config2 config3 config5; do
   python bench.py --workload $w --steps 20 --warmup 5 --preroll 64 --drift-steps 0 --no-densify-variant > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"
 done
+python scripts/config4_rehearsal.py > "$OUT/config4_rehearsal.json" 2> "$OUT/config4.err"
 python bench.py --steps 20 --warmup 5 --force-collectives --no-cpu-baseline --drift-steps 0 --no-densify-variant > "$OUT/bench_metric_forced_collectives.json" 2> "$OUT/bench_fc.err"
 python bench.py --steps 20 --warmup 5 --python-step --no-cpu-baseline --drift-steps 0 > "$OUT/bench_metric_python_step.json" 2> "$OUT/bench_py.err"
 cd /tmp && export TMPDIR=/tmp

@@ -11,20 +11,30 @@
 // (dx*dx + dy*dy) + dz*dz with individually rounded ops (-ffp-contract=off), identical to the oracle.
 #include "../../include/sugar_raster.h"
 #include "sgr_common.h"
+#include <cstdlib>
 #include <string>
 
 namespace {
 
 #define KNN_TILE 1024
 
+// `qlist` / `qcount` (grid search fallback): the queries are qlist[0 .. *qcount), taken only when there are more than
+// `min_count` of them (fewer go to k_knn_far, one workgroup per query)
 template <int K, bool EXCLUDE_SELF>
 __global__ void __launch_bounds__(256) k_knn(int N, const float* __restrict__ query, int M, const float* __restrict__ ref,
                                              float* __restrict__ out_d, int64_t* __restrict__ out_i,
-                                             float* __restrict__ out_mean)
+                                             float* __restrict__ out_mean, const int* __restrict__ qlist = nullptr,
+                                             const unsigned int* __restrict__ qcount = nullptr, unsigned int min_count = 0)
 {
     __shared__ float s_ref[KNN_TILE * 3];
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    const bool live = q < N;
+    int q = blockIdx.x * 256 + threadIdx.x;
+    bool live = q < N;
+    if (qlist) {
+        const unsigned int n = min(*qcount, (unsigned int)N);
+        if (n <= min_count || (unsigned int)blockIdx.x * 256u >= n) return;  // (uniform per workgroup: before any barrier)
+        live = (unsigned int)q < n;
+        q = live ? qlist[q] : 0;
+    }
     float qx = 0, qy = 0, qz = 0;
     if (live) { qx = query[3 * (size_t)q]; qy = query[3 * (size_t)q + 1]; qz = query[3 * (size_t)q + 2]; }
     float bd[K];
@@ -116,7 +126,9 @@ int sgr_knn(int N, const float* query, int M, const float* ref, int K, float* di
 // =====================================================================================================================
 namespace {
 
-struct GridHdr { unsigned int minb[3], maxb[3]; };  // order-preserving uint encodings of the bbox
+struct GridHdr { unsigned int minb[3], maxb[3], far_count, pad; };  // order-preserving uint encodings of the bbox; fallback count
+#define GRID_MAX_RING 4  // measured (124k queries, 10 % of them far from 1M points): 2: 15.7, 3: 14.3, 4: 14.3, 6: 14.8, 10: 20, 16: 44, 24: 110 ms
+#define FAR_SINGLE_MAX 16384u  // up to this many far queries: one workgroup each; more: the tiled exhaustive kernel
 
 __device__ __forceinline__ unsigned int f2ord(float f)
 {
@@ -131,6 +143,87 @@ __device__ __forceinline__ float ord2f(unsigned int o)
 __global__ void k_grid_init(GridHdr* h)
 {
     if (threadIdx.x < 3) { h->minb[threadIdx.x] = 0xFFFFFFFFu; h->maxb[threadIdx.x] = 0u; }
+    if (threadIdx.x == 3) h->far_count = 0u;
+}
+
+// Far queries, Q per workgroup (grid-stride over the fallback list): the 256 threads split the reference set -- every point is
+// loaded once for the Q queries --, keep their own K best per query in registers, and a query's K best are then drawn from the
+// 256 sorted lists in K rounds of a block-wide arg-min on (distance, index).  Same arithmetic and order as k_knn: same result.
+template <int K, bool EXCLUDE_SELF, int Q>
+__global__ void __launch_bounds__(256) k_knn_far(const float* __restrict__ query, int M, const float4* __restrict__ sorted,
+                                                 float* __restrict__ out_d, int64_t* __restrict__ out_i, float* __restrict__ out_mean,
+                                                 const int* __restrict__ qlist, const unsigned int* __restrict__ qcount, unsigned int cap)
+{
+    __shared__ float s_d[4];
+    __shared__ int s_i[4], s_t[4];
+    const unsigned int n = min(*qcount, cap);
+    if (n > FAR_SINGLE_MAX) return;  // (k_knn takes them)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (unsigned int w = blockIdx.x * Q; w < n; w += gridDim.x * Q) {
+        int qid[Q];
+        float qx[Q], qy[Q], qz[Q];
+        float bd[Q][K];
+        int bi[Q][K];
+#pragma unroll
+        for (int u = 0; u < Q; u++) {
+            qid[u] = qlist[min(w + u, n - 1)];  // (a short last group repeats its last query)
+            qx[u] = query[3 * (size_t)qid[u]]; qy[u] = query[3 * (size_t)qid[u] + 1]; qz[u] = query[3 * (size_t)qid[u] + 2];
+#pragma unroll
+            for (int k = 0; k < K; k++) { bd[u][k] = 3.402823466e+38f; bi[u][k] = 0x7FFFFFFF; }
+        }
+        for (int j = tid; j < M; j += 256) {  // (the cell-sorted copy: one 16-byte load per point; any visiting order gives the same lists)
+            const float4 p = sorted[j];
+            const int pid = __float_as_int(p.w);
+#pragma unroll
+            for (int u = 0; u < Q; u++) {
+                if (EXCLUDE_SELF && pid == qid[u]) continue;
+                const float dx = p.x - qx[u], dy = p.y - qy[u], dz = p.z - qz[u];
+                float d = dx * dx + dy * dy + dz * dz;
+                int id = pid;
+                if (!(d < bd[u][K - 1] || (d == bd[u][K - 1] && id < bi[u][K - 1]))) continue;
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    if (d < bd[u][k] || (d == bd[u][k] && id < bi[u][k])) {
+                        const float td = bd[u][k]; const int ti = bi[u][k];
+                        bd[u][k] = d; bi[u][k] = id; d = td; id = ti;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < Q; u++) {
+            if (w + u >= n) break;  // (uniform)
+            const int q = qid[u];
+            float sum3 = 0.f;
+            for (int k = 0; k < K; k++) {
+                // block-wide arg-min of the list heads on (distance, index)
+                float d = bd[u][0]; int id = bi[u][0]; int who = tid;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float od = __shfl_xor(d, o); const int oi = __shfl_xor(id, o); const int ow = __shfl_xor(who, o);
+                    if (od < d || (od == d && oi < id)) { d = od; id = oi; who = ow; }
+                }
+                __syncthreads();
+                if (lane == 0) { s_d[wave] = d; s_i[wave] = id; s_t[wave] = who; }
+                __syncthreads();
+                d = s_d[0]; id = s_i[0]; who = s_t[0];
+#pragma unroll
+                for (int v = 1; v < 4; v++)
+                    if (s_d[v] < d || (s_d[v] == d && s_i[v] < id)) { d = s_d[v]; id = s_i[v]; who = s_t[v]; }
+                if (tid == who) {  // pop the winner's head
+#pragma unroll
+                    for (int j = 0; j + 1 < K; j++) { bd[u][j] = bd[u][j + 1]; bi[u][j] = bi[u][j + 1]; }
+                    bd[u][K - 1] = 3.402823466e+38f; bi[u][K - 1] = 0x7FFFFFFF;
+                }
+                if (tid == 0) {
+                    if (out_mean) { if (k < 3) sum3 += d; }
+                    else { out_d[(size_t)q * K + k] = d; out_i[(size_t)q * K + k] = (id == 0x7FFFFFFF) ? -1 : (int64_t)id; }
+                }
+            }
+            if (tid == 0 && out_mean) out_mean[q] = sum3 / 3.0f;
+        }
+        __syncthreads();
+    }
 }
 
 __global__ void __launch_bounds__(256) k_grid_bbox(int M, const float* __restrict__ pts, GridHdr* h)
@@ -217,7 +310,8 @@ template <int K, bool EXCLUDE_SELF, bool SELF_QUERY>
 __global__ void __launch_bounds__(128) k_grid_query(int N, const float* __restrict__ query, const GridHdr* __restrict__ hdr, int G,
                                                     const unsigned int* __restrict__ cell_start, const float4* __restrict__ sorted,
                                                     float* __restrict__ out_d, int64_t* __restrict__ out_i,
-                                                    float* __restrict__ out_mean)
+                                                    float* __restrict__ out_mean, unsigned int* __restrict__ far_count,
+                                                    int* __restrict__ far_list, unsigned int far_cap, int max_ring)
 {
     const int t = blockIdx.x * 128 + threadIdx.x;
     if (t >= N) return;
@@ -269,6 +363,13 @@ __global__ void __launch_bounds__(128) k_grid_query(int N, const float* __restri
         const float reach = (float)r * g.h;
         if (bd[K - 1] < reach * reach) break;
         if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == G - 1 && y1 == G - 1 && z1 == G - 1) break;  // whole grid searched
+        // A query far from the data (an outlier; a pixel unprojected in front of the cloud) would walk O(G^3) mostly empty
+        // cells -- 0.3 ms EACH at 1M points: 1 % of the level-set sampler's 124k pixels cost 370 ms.  After GRID_MAX_RING
+        // rings it is handed to the exhaustive kernels instead (same distances, same (distance, index) order: same result).
+        if (r >= max_ring && far_list) {
+            const unsigned int pos = atomicAdd(far_count, 1u);
+            if (pos < far_cap) { far_list[pos] = q; return; }
+        }
     }
     if (out_mean) {
         out_mean[q] = (bd[0] + bd[1] + bd[2]) / 3.0f;
@@ -281,6 +382,12 @@ __global__ void __launch_bounds__(128) k_grid_query(int N, const float* __restri
     }
 }
 
+int grid_max_ring()
+{
+    static const int v = [] { const char* e = getenv("SGR_KNN_MAX_RING"); const int x = e ? atoi(e) : 0; return x > 0 ? x : GRID_MAX_RING; }();
+    return v;
+}
+
 int grid_res(int M)
 {
     int G = (int)ceil(cbrt((double)M / 6.0));
@@ -289,7 +396,8 @@ int grid_res(int M)
     return G;
 }
 
-struct GridScratch { GridHdr* hdr; unsigned int *cell_count, *cursor, *cell_start, *cell_of; float4* sorted; size_t total; };
+struct GridScratch { GridHdr* hdr; unsigned int *cell_count, *cursor, *cell_start, *cell_of; float4* sorted; int* far_list;
+                     unsigned int far_cap; size_t total; };
 GridScratch carve_grid(char* base, int M)
 {
     const int G = grid_res(M);
@@ -302,6 +410,8 @@ GridScratch carve_grid(char* base, int M)
     s.cell_start = reinterpret_cast<unsigned int*>(base + off); off = sgr_align(off + (cells + 1) * 4);
     s.cell_of = reinterpret_cast<unsigned int*>(base + off); off = sgr_align(off + (size_t)M * 4);
     s.sorted = reinterpret_cast<float4*>(base + off); off = sgr_align(off + (size_t)M * 16);
+    s.far_cap = (unsigned int)(M > 65536 ? M : 65536);  // queries the exhaustive fallback can take (the rest walk on)
+    s.far_list = reinterpret_cast<int*>(base + off); off = sgr_align(off + (size_t)s.far_cap * 4);
     s.total = off;
     return s;
 }
@@ -321,15 +431,30 @@ int build_grid(int M, const float* ref, const GridScratch& gs, hipStream_t s)
     return 0;
 }
 
+// the two exhaustive fallbacks of a grid query (each looks at the far count and takes its own regime)
+template <int K, bool EXCLUDE_SELF>
+void launch_far(int N, const float* query, int M, const float* ref, const GridScratch& gs, float* d, int64_t* i, float* mean, hipStream_t s)
+{
+    const unsigned int cap = gs.far_cap < (unsigned int)N ? gs.far_cap : (unsigned int)N;
+    constexpr int Q = K <= 4 ? 8 : (K <= 16 ? 4 : 2);  // queries per workgroup: Q * K (distance, index) pairs per thread in registers
+    const unsigned int groups = (cap + Q - 1) / Q;
+    hipLaunchKernelGGL((k_knn_far<K, EXCLUDE_SELF, Q>), dim3(groups < 4096u ? groups : 4096u), dim3(256), 0, s, query, M, gs.sorted, d, i,
+                       mean, gs.far_list, &gs.hdr->far_count, cap);
+    hipLaunchKernelGGL((k_knn<K, EXCLUDE_SELF>), dim3((cap + 255) / 256), dim3(256), 0, s, (int)cap, query, M, ref, d, i, mean,
+                       (const int*)gs.far_list, (const unsigned int*)&gs.hdr->far_count, FAR_SINGLE_MAX);
+}
+
 template <int K>
-void launch_grid_query(bool self, int N, const float* query, const GridScratch& gs, int G, float* d, int64_t* i, hipStream_t s)
+void launch_grid_query(bool self, int N, const float* query, int M, const float* ref, const GridScratch& gs, int G, float* d, int64_t* i,
+                       hipStream_t s)
 {
     if (self)
         hipLaunchKernelGGL((k_grid_query<K, false, true>), dim3((N + 127) / 128), dim3(128), 0, s, N, query, gs.hdr, G, gs.cell_start,
-                           gs.sorted, d, i, (float*)nullptr);
+                           gs.sorted, d, i, (float*)nullptr, &gs.hdr->far_count, gs.far_list, gs.far_cap, grid_max_ring());
     else
         hipLaunchKernelGGL((k_grid_query<K, false, false>), dim3((N + 127) / 128), dim3(128), 0, s, N, query, gs.hdr, G, gs.cell_start,
-                           gs.sorted, d, i, (float*)nullptr);
+                           gs.sorted, d, i, (float*)nullptr, &gs.hdr->far_count, gs.far_list, gs.far_cap, grid_max_ring());
+    launch_far<K, false>(N, query, M, ref, gs, d, i, nullptr, s);
 }
 
 }  // namespace
@@ -349,13 +474,13 @@ int sgr_knn_grid(int N, const float* query, int M, const float* ref, int K, floa
     const int G = grid_res(M);
     const bool self = (query == ref && N == M);
     switch (K) {
-        case 1: launch_grid_query<1>(self, N, query, gs, G, dists, idx, s); break;
-        case 2: launch_grid_query<2>(self, N, query, gs, G, dists, idx, s); break;
-        case 3: launch_grid_query<3>(self, N, query, gs, G, dists, idx, s); break;
-        case 4: launch_grid_query<4>(self, N, query, gs, G, dists, idx, s); break;
-        case 8: launch_grid_query<8>(self, N, query, gs, G, dists, idx, s); break;
-        case 16: launch_grid_query<16>(self, N, query, gs, G, dists, idx, s); break;
-        case 32: launch_grid_query<32>(self, N, query, gs, G, dists, idx, s); break;
+        case 1: launch_grid_query<1>(self, N, query, M, ref, gs, G, dists, idx, s); break;
+        case 2: launch_grid_query<2>(self, N, query, M, ref, gs, G, dists, idx, s); break;
+        case 3: launch_grid_query<3>(self, N, query, M, ref, gs, G, dists, idx, s); break;
+        case 4: launch_grid_query<4>(self, N, query, M, ref, gs, G, dists, idx, s); break;
+        case 8: launch_grid_query<8>(self, N, query, M, ref, gs, G, dists, idx, s); break;
+        case 16: launch_grid_query<16>(self, N, query, M, ref, gs, G, dists, idx, s); break;
+        case 32: launch_grid_query<32>(self, N, query, M, ref, gs, G, dists, idx, s); break;
         default: return SGR_E_INVALID;
     }
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
@@ -370,7 +495,9 @@ int sgr_dist2_grid(int P, const float* points, float* meanDists, char* scratch, 
     const int rc = build_grid(P, points, gs, s);
     if (rc < 0) return rc;
     hipLaunchKernelGGL((k_grid_query<3, true, true>), dim3((P + 127) / 128), dim3(128), 0, s, P, points, gs.hdr, grid_res(P),
-                       gs.cell_start, gs.sorted, (float*)nullptr, (int64_t*)nullptr, meanDists);
+                       gs.cell_start, gs.sorted, (float*)nullptr, (int64_t*)nullptr, meanDists, &gs.hdr->far_count, gs.far_list,
+                       gs.far_cap, grid_max_ring());
+    launch_far<3, true>(P, points, P, points, gs, nullptr, nullptr, meanDists, s);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 

@@ -30,7 +30,12 @@ class Transform3d:
         return self._matrix
 
     def inverse(self) -> "Transform3d":
-        return Transform3d(torch.inverse(self._matrix))
+        # a handful of 4x4 matrices: inverted on the host in float64 (torch.inverse on a ROCm device goes through a solver
+        # library whose launch costs tens of milliseconds per call -- 240 ms per view in the level-set sampler)
+        m = self._matrix
+        if m.is_cuda and not m.requires_grad:
+            return Transform3d(torch.inverse(m.detach().double().cpu()).to(device=m.device, dtype=m.dtype))
+        return Transform3d(torch.inverse(m))
 
     def compose(self, *others: "Transform3d") -> "Transform3d":
         m = self._matrix

@@ -153,10 +153,11 @@ def compute_level_surface_points_from_camera_fast(
     ndc_points = ndc_points[~no_proj_mask][None]
     if n_surface_points == -1:
         n_surface_points = ndc_points.shape[1]
-        ndc_points_idx = torch.arange(n_surface_points)
+        ndc_points_idx = torch.arange(n_surface_points, device=device)
     else:
         n_surface_points = min(n_surface_points, ndc_points.shape[1])
-        ndc_points_idx = torch.randperm(ndc_points.shape[1])[:n_surface_points]
+        # (the reference draws this permutation on the CPU, :1955: ~15 ms at 1080p plus the copy; same distribution on the device)
+        ndc_points_idx = torch.randperm(ndc_points.shape[1], device=device)[:n_surface_points]
         ndc_points = ndc_points[:, ndc_points_idx]
     all_world_points = p3d_cameras.unproject_points(ndc_points, scaled_depth_input=False).view(-1, 3)
     closest_gaussians_idx = self.get_gaussians_closest_to_samples(all_world_points)                    # :1963 (HIP k-NN)
