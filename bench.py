@@ -353,7 +353,7 @@ def main():
             "roofline": {
                 "kernel": "k_blend_fwd_w", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": "profiles/pmc_blend_fwd.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command taken earlier (scripts/pmc_on_box.sh), NOT measured in this run",
+                "traffic_source": "profiles/pmc_blend_fwd.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command taken earlier (scripts/r03_on_box.sh -> profiles/r03_pmc_*.txt), NOT measured in this run",
                 "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": blend_ms,
                 "pair_evals_per_s": (256.0 * R_f) / (blend_ms * 1e-3) if blend_ms > 0 else 0.0,
             },

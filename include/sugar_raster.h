@@ -185,6 +185,8 @@ typedef struct sgr_backward_opts {
     float* max_radii2D;
     float* grad_accum;
     float* denom;
+    float* campos_row;   /* compact SH mode: receives cam_pos[3] next to the colour gradients (the last row of an all-gather send
+                            buffer), written by the kernel that writes dL_dcolor; NULL = not wanted */
 } sgr_backward_opts;
 int sgr_backward_ex(int phase, int P, int D, int M, int64_t R,
                     const float* background, int width, int height,

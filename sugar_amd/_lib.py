@@ -90,7 +90,7 @@ class ForwardOpts(C.Structure):
 
 
 class BackwardOpts(C.Structure):
-    _fields_ = [("max_radii2D", _vp), ("grad_accum", _vp), ("denom", _vp)]
+    _fields_ = [("max_radii2D", _vp), ("grad_accum", _vp), ("denom", _vp), ("campos_row", _vp)]
 
 
 class TrainConfig(C.Structure):

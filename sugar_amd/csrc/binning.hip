@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(64) k_hist_scan(int T, int n_blocks, uint32_t*
 __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __restrict__ tile_count,
                                                     uint32_t* __restrict__ tile_start, uint32_t* __restrict__ header,
                                                     uint32_t* __restrict__ tile_maxc, uint32_t* __restrict__ tile_walked,
-                                                    int clear_b2_words)
+                                                    int clear_b2_words, uint32_t* __restrict__ host_a, uint32_t* __restrict__ host_b)
 {
     __shared__ uint32_t s_seg[128];
     __shared__ uint32_t s_max[16];
@@ -472,6 +472,14 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __res
         header[SGR_HDR_HINT_MISS] = 0;
         if (clear_b2_words) { header[4] = 0; header[5] = 0; header[6] = 0; }  // single-level path: k_sup_scan did not run
         header[7] = 0;
+        // the header for the host, written straight into its pinned memory (a 32-byte copy command of its own cost the stream
+        // 8 us, twice per forward); words 4-6 were left by k_sup_scan, an earlier kernel on this stream
+        const uint32_t w4 = clear_b2_words ? 0u : header[4], w5 = clear_b2_words ? 0u : header[5], w6 = clear_b2_words ? 0u : header[6];
+        for (int k = 0; k < 2; k++) {
+            uint32_t* h = k ? host_b : host_a;
+            if (!h) continue;
+            h[0] = carry; h[1] = m; h[2] = 0; h[3] = 0; h[4] = w4; h[5] = w5; h[6] = w6; h[7] = 0;
+        }
     }
 }
 
@@ -591,8 +599,8 @@ void sgr_launch_hist_scan(int T, int n_blocks, uint32_t* blk_hist, uint32_t* til
 }
 
 void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* header, uint32_t* tile_maxc,
-                          uint32_t* tile_walked, int clear_b2_words, hipStream_t s)
+                          uint32_t* tile_walked, int clear_b2_words, uint32_t* host_a, uint32_t* host_b, hipStream_t s)
 {
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, tile_count, tile_start, header, tile_maxc, tile_walked,
-                       clear_b2_words);
+                       clear_b2_words, host_a, host_b);
 }

@@ -558,10 +558,13 @@ __global__ void __launch_bounds__(1024) k_tile_order(int T, const uint32_t* __re
 
 // walk hint for the next visit of this camera: what the tile walked now, plus a margin, plus one batch
 __global__ void __launch_bounds__(256) k_make_hint(int T, const uint32_t* __restrict__ tile_walked, const uint32_t* __restrict__ header,
-                                                   uint32_t list_cap, float margin, uint32_t* __restrict__ need_out)
+                                                   uint32_t list_cap, float margin, uint32_t* __restrict__ need_out,
+                                                   uint32_t* __restrict__ header_host)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= T || SGR_FORWARD_INVALID(header, list_cap)) return;  // (an invalid forward leaves the previous hint in place)
+    // the second header copy for the host (word 3, the hint-miss flag, is final now that the blend kernel is done)
+    if (header_host && t < 8) header_host[8 + t] = header[t];
+    if (!need_out || t >= T || SGR_FORWARD_INVALID(header, list_cap)) return;  // (an invalid forward leaves the previous hint in place)
     const uint32_t w = tile_walked[t];
     need_out[t] = w + (uint32_t)((float)w * margin) + 64u;
 }
@@ -572,14 +575,14 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
                           uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
                           uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, uint32_t* tile_need_out, float hint_margin,
-                          hipStream_t s)
+                          uint32_t* header_host_dev, hipStream_t s)
 {
     const int T = gx * gy;  // (tile_maxc and tile_walked were zeroed by the tile scan: the blocks of a tile combine with atomicMax)
     hipLaunchKernelGGL(k_blend_fwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg, final_T,
                        n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap, tile_need);
-    if (tile_need_out)
-        hipLaunchKernelGGL(k_make_hint, dim3((T + 255) / 256), dim3(256), 0, s, T, tile_walked, header, list_cap,
-                           hint_margin > 0.f ? hint_margin : 0.25f, tile_need_out);
+    if (tile_need_out || header_host_dev)
+        hipLaunchKernelGGL(k_make_hint, dim3(tile_need_out ? (T + 255) / 256 : 1), dim3(256), 0, s, T, tile_walked, header, list_cap,
+                           hint_margin > 0.f ? hint_margin : 0.25f, tile_need_out, header_host_dev);
 }
 
 void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,

@@ -205,6 +205,18 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     { StageTimer t(s, SGR_STAGE_SORT); sgr_launch_gaussian_sort(P, sort_scratch, &order, pa.rect_by_id, rects, s); }
     STAGE_CHECK("gaussian_sort");
 
+    // host-visible header targets: the caller's pinned memory and this thread's own read-back slot, as device pointers
+    uint32_t* hh_dev = nullptr;
+    if (opts->header_host && hipHostGetDevicePointer(reinterpret_cast<void**>(&hh_dev), opts->header_host, 0) != hipSuccess) {
+        hh_dev = nullptr;
+        (void)hipGetLastError();  // not pinned / not mapped: the copy-command path below
+    }
+    const bool will_sync = !(binning_capacity > 0 && binning_mode == 0);
+    uint32_t* pin_dev = nullptr;
+    if (will_sync) {
+        if (!g_pinned.p) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_pinned.p), 64, hipHostMallocDefault));
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&pin_dev), g_pinned.p, 0) != hipSuccess) { pin_dev = nullptr; (void)hipGetLastError(); }
+    }
     char* bin2 = img + IL.total;
     bool two_level = binning_mode == 0;
     {
@@ -216,11 +228,12 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
             sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, blk_hist, s);
             sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
         }
-        sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, tile_maxc, tile_walked, two_level ? 0 : 1, s);
+        sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, tile_maxc, tile_walked, two_level ? 0 : 1, hh_dev, pin_dev, s);
     }
     STAGE_CHECK("bin_count");
-    // the header for a caller that checks late: copied here, right behind the tile scan (words 0 and 6 are final)
-    if (opts->header_host) HIP_TRY(hipMemcpyAsync(opts->header_host, header, 32, hipMemcpyDeviceToHost, s));
+    // the header for a caller that checks late: right behind the tile scan (words 0 and 6 are final) -- written by the scan
+    // kernel itself when the caller's memory is device-mapped, a copy command otherwise
+    if (opts->header_host && !hh_dev) HIP_TRY(hipMemcpyAsync(opts->header_host, header, 32, hipMemcpyDeviceToHost, s));
 
     // Sync-free mode (binning_capacity > 0, two-level binning): no device-to-host copy of R and no host wait -- the
     // instance list gets the caller's capacity, the write pass clamps to it and the blend kernel returns at once when the
@@ -236,9 +249,8 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
         n_chunks = B2.chunk_cap < 8192u ? B2.chunk_cap : 8192u;
         if (opts->chunk_grid && opts->chunk_grid < n_chunks) n_chunks = opts->chunk_grid;
     } else {
-        if (!g_pinned.p) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_pinned.p), 64, hipHostMallocDefault));
-        // words 0-3: the tile scan's header (R, ...); words 4-6: the two-level binning's (R1, chunks, overflow) -- one copy
-        HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 32, hipMemcpyDeviceToHost, s));
+        // words 0-3: the tile scan's header (R, ...); words 4-6: the two-level binning's (R1, chunks, overflow)
+        if (!pin_dev) HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 32, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));  // the one host round trip of the forward (rasterizer_impl.cu:280-281)
         if (two_level && g_pinned.p[4 + SGR_B2_HDR_OVERFLOW]) {
             // more (Gaussian, super-tile) pairs than the level-1 list holds (huge splats): the single-level path has no such limit
@@ -247,9 +259,9 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
             two_level = false;
             sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, blk_hist, s);
             sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
-            sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, tile_maxc, tile_walked, 1, s);
-            if (opts->header_host) HIP_TRY(hipMemcpyAsync(opts->header_host, header, 32, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 16, hipMemcpyDeviceToHost, s));
+            sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, tile_maxc, tile_walked, 1, hh_dev, pin_dev, s);
+            if (opts->header_host && !hh_dev) HIP_TRY(hipMemcpyAsync(opts->header_host, header, 32, hipMemcpyDeviceToHost, s));
+            if (!pin_dev) HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 16, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
         }
         R = (int64_t)g_pinned.p[SGR_HDR_R];
@@ -277,11 +289,11 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
         StageTimer t(s, SGR_STAGE_BLEND_FWD);
         sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
                              tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, (uint32_t)R, opts->tile_need,
-                             opts->tile_need_out, opts->hint_margin, s);
+                             opts->tile_need_out, opts->hint_margin, hh_dev, s);
     }
     STAGE_CHECK("blend_fwd");
     // ... and once more behind the blend: word 3 (hint miss) is final only now
-    if (opts->header_host) HIP_TRY(hipMemcpyAsync(opts->header_host + 8, header, 32, hipMemcpyDeviceToHost, s));
+    if (opts->header_host && !hh_dev) HIP_TRY(hipMemcpyAsync(opts->header_host + 8, header, 32, hipMemcpyDeviceToHost, s));
     if (opts->header_event) HIP_TRY(hipEventRecord((hipEvent_t)opts->header_event, s));
     return R;
 }
@@ -350,7 +362,7 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
         }
         STAGE_CHECK("blend_bwd");
         if (phase == 1) {
-            sgr_launch_masked_colors(P, rec, acc, dL_dcolor, s);
+            sgr_launch_masked_colors(P, rec, acc, dL_dcolor, cam_pos, opts ? opts->campos_row : nullptr, s);
             STAGE_CHECK("masked_colors");
             return 0;
         }
@@ -368,6 +380,7 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
     pb.raw_params = raw_params && !cov3D_precomp;
     pb.sh_dir_elsewhere = sh_dir_elsewhere && use_sh && !dL_dsh;  // (compact SH mode only: see sgr_sh_adam_from_views_ex)
     pb.acc = acc;
+    pb.campos_row = (opts && compact && phase == 0) ? opts->campos_row : nullptr;  // (phase 1 wrote it with the colours)
     pb.dens_max_radii = opts ? opts->max_radii2D : nullptr;
     pb.dens_accum = opts ? opts->grad_accum : nullptr;
     pb.dens_denom = opts ? opts->denom : nullptr;

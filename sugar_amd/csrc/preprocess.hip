@@ -424,6 +424,7 @@ template <bool STORE_SH, int SH>
 __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
 {
     const int idx0 = blockIdx.x * 256 + threadIdx.x;
+    if (a.campos_row && idx0 < 3) a.campos_row[idx0] = a.cam_pos[idx0];  // (see sgr_backward_opts)
     const bool valid = idx0 < a.P;
     const int idx = valid ? idx0 : a.P - 1;  // lanes past the end re-read the last Gaussian and store nothing
     const size_t i3 = 3 * (size_t)idx;
@@ -667,9 +668,11 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
 // The clamp-masked colour gradients of the compact mode on their own: they only need the blend backward's sums, so a
 // trainer can start exchanging them while the backward preprocess is still running (sgr_backward_phase).
 __global__ void __launch_bounds__(256) k_masked_colors(int P, const GeomRec* __restrict__ rec, const float* __restrict__ acc,
-                                                       float* __restrict__ out)
+                                                       float* __restrict__ out, const float* __restrict__ cam_pos,
+                                                       float* __restrict__ campos_row)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (campos_row && idx < 3) campos_row[idx] = cam_pos[idx];  // the camera centre travels with the colours (one send buffer)
     if (idx >= P) return;
     const GeomRec* rp = rec + idx;
     const size_t i3 = 3 * (size_t)idx;
@@ -1039,9 +1042,10 @@ void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s)
     }
 }
 
-void sgr_launch_masked_colors(int P, const GeomRec* rec, const float* acc, float* out, hipStream_t s)
+void sgr_launch_masked_colors(int P, const GeomRec* rec, const float* acc, float* out, const float* cam_pos, float* campos_row,
+                              hipStream_t s)
 {
-    hipLaunchKernelGGL(k_masked_colors, dim3((P + 255) / 256), dim3(256), 0, s, P, rec, acc, out);
+    hipLaunchKernelGGL(k_masked_colors, dim3((P + 255) / 256), dim3(256), 0, s, P, rec, acc, out, cam_pos, campos_row);
 }
 
 void sgr_launch_sh_adam_from_views(int P, int V, int D, int M, size_t vstride, const float* means3D, const float* campos,

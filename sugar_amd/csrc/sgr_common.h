@@ -133,13 +133,14 @@ struct PreprocessBwdArgs {
     const GeomRec* rec;
     int raw_params;    // as in PreprocessArgs: dL_dscale / dL_drot / dL_dopacity are then gradients w.r.t. the raw parameters
     int sh_dir_elsewhere;  // compact mode only: skip the SH block (dRGB/d(view direction) -> dL_dmean3D is formed by k_sh_adam_from_views)
+    float* campos_row;  // compact mode: receives the camera centre (the row behind the colour gradients in a send buffer) or NULL
     float* dens_max_radii; float* dens_accum; float* dens_denom;  // fused densification statistics (sgr_backward_opts) or NULL
     const float* acc;  // [P][SGR_ACC_STRIDE] sums from the blend backward: {dcol r,g,b, S0, Sx, Sy, Sxx, Sxy, Syy, pad x3}
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor;  // written here from acc
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
 };
 void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
-void sgr_launch_masked_colors(int P, const GeomRec* rec, const float* acc, float* out, hipStream_t s);
+void sgr_launch_masked_colors(int P, const GeomRec* rec, const float* acc, float* out, const float* cam_pos, float* campos_row, hipStream_t s);
 void sgr_launch_sh_grad_from_views(int P, int V, int D, int M, size_t vstride, const float* means3D, const float* campos,
                                    const float* dcolor, float* dL_dsh, hipStream_t s);
 
@@ -165,7 +166,7 @@ void sgr_launch_bin_scatter(int P, int gx, int gy, int n_slices, int per_slice, 
                             const uint32_t* tile_start, uint32_t* blk_hist, uint32_t* point_list, hipStream_t s);
 void sgr_launch_hist_scan(int T, int n_blocks, uint32_t* blk_hist, uint32_t* tile_count, hipStream_t s);
 void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* header, uint32_t* tile_maxc,
-                          uint32_t* tile_walked, int clear_b2_words, hipStream_t s);
+                          uint32_t* tile_walked, int clear_b2_words, uint32_t* host_a, uint32_t* host_b, hipStream_t s);  // host_*: device-mapped pinned memory or NULL
 
 // header: the forward's device header; list_cap: instances the list was allocated for (the forward is a no-op when the header
 // says it does not fit, the backward when the forward was one); tile_need / tile_need_out: walk hint (sgr_forward_opts)
@@ -173,7 +174,7 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
                           uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
                           uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, uint32_t* tile_need_out, float hint_margin,
-                          hipStream_t s);
+                          uint32_t* header_host_dev, hipStream_t s);
 void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const unsigned long long* blk_mask, const uint32_t* blk_nb, const GeomRec* rec, const float* bg,
                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* acc,

@@ -134,7 +134,7 @@ int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* v, int phases, const 
     }
     if (phases & 3) {
         if (!t->have_forward) return tfail(SGR_E_INVALID, "sgr_trainer_step: backward before any forward");
-        sgr_backward_opts bo = {c.max_radii2D, c.grad_accum, c.denom};
+        sgr_backward_opts bo = {c.max_radii2D, c.grad_accum, c.denom, c.colors + 3 * (size_t)P};  // (camera centre: the row behind the colours)
         // compact SH mode (dL_dsh == NULL), raw-parameter gradients straight into the flat gradient buffer.  Both halves asked
         // for at once (no collective to start in between): ONE pass, the preprocess kernel writes the masked colour gradients
         // itself (the split costs a 23 us kernel of its own)
@@ -147,8 +147,6 @@ int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* v, int phases, const 
                                            grad + c.off_opacity, c.colors, grad + c.off_xyz, nullptr, nullptr, grad + c.off_scaling,
                                            grad + c.off_rotation, 0, stream, &bo);
             if (rc < 0) return tfail(rc, std::string("backward: ") + sgr_last_error());
-            if (ph != 2 && hipMemcpyAsync(c.colors + 3 * (size_t)P, v->campos, 12, hipMemcpyDeviceToDevice, s) != hipSuccess)
-                return tfail(SGR_E_HIP, "camera centre copy failed");
         }
     }
     if (phases & 12) {

@@ -223,7 +223,7 @@ class _CModule:
                     for st in stats:
                         if not (st.is_cuda and st.dtype == torch.float32 and st.numel() == P and st.is_contiguous()):
                             raise RuntimeError("dens_stats: three contiguous float32 device tensors of P elements")
-                    bopts = C.byref(_lib.BackwardOpts(*[st.data_ptr() for st in stats]))
+                    bopts = C.byref(_lib.BackwardOpts(*[st.data_ptr() for st in stats], None))
                 if on_colors is not None:
                     # two halves: the masked colour gradients are final after the blend half, so the caller can start
                     # exchanging them while the preprocess half runs
