@@ -6,7 +6,7 @@ R="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT="$R/gpurun_out/r03"
 mkdir -p "$OUT"
 cd "$R"
-{ echo "# rocm-smi before"; rocm-smi --showclocks --showpower --showtemp --showmemuse --showperflevel 2>&1 | grep -v "^=\|^$" | head -40; } > "$OUT/box_state.txt"
+{ echo "# partition modes"; rocm-smi --showcomputepartition --showmemorypartition 2>&1 | grep -v "^=\|^$" | head -8; echo "# rocm-smi before"; rocm-smi --showclocks --showpower --showtemp --showmemuse --showperflevel 2>&1 | grep -v "^=\|^$" | head -40; } > "$OUT/box_state.txt"
 ( for i in $(seq 1 60); do rocm-smi --showclocks --showpower 2>&1 | grep -i "sclk\|mclk\|fclk\|Power (W)" | tr -s "\t " " " | tr "\n" "|"; echo; sleep 0.25; done ) > "$OUT/box_clocks_during_bench.txt" &
 SAMPLER=$!
 python bench.py --steps 20 --warmup 5 > "$OUT/bench_metric.json" 2> "$OUT/bench_metric.err"
