@@ -58,9 +58,16 @@ def main():
     ap.add_argument("--forward-only", action="store_true", help="a step = one rasterizer forward through the reference-shaped API (BASELINE config 5 is quoted forward-only; implied by --workload config5)")
     ap.add_argument("--drift-steps", type=int, default=1000, help="after the graded region: train this many steps on WITHOUT restoring the parameters and time K steps of the drifted scene (0: skip)")
     ap.add_argument("--no-densify-variant", action="store_true", help="skip the extra timing of the step with dL/dmeans2D + fused densification statistics")
+    ap.add_argument("--watchdog-sec", type=int, default=0, help="dump every thread's stack to stderr and exit if the run takes longer than this (0: off at one rank, 900 s with several)")
     ap.add_argument("--host-sync", action="store_true", help="forward with the host round trip for num_rendered (A/B of the sync-free forward)")
     args = ap.parse_args()
 
+    wd = args.watchdog_sec or (900 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 0)
+    if wd > 0:
+        # (a multi-rank run that stops making progress should leave its stacks on stderr, not sit in a collective until the
+        # caller's own limit: one two-rank gloo rehearsal did exactly that once this round and could not be reproduced)
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True)
     # stdout carries ONE line, the JSON: whatever libraries print there meanwhile (RCCL's version banner, for one) goes to stderr
     sys.stdout.flush()
     json_fd = os.dup(1)
