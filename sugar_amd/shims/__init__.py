@@ -5,9 +5,11 @@ package:
   * pytorch3d is installed  -> its `ops.knn_points` is replaced by `sugar_amd.knn.knn_points` for the call shape SuGaR uses
                                (everything else stays pytorch3d's own);
   * pytorch3d is absent     -> the minimal `pytorch3d` package under this directory is put on `sys.path`: `ops.knn_points`,
-                               `ops.estimate_pointcloud_normals`, the quaternion helpers of `transforms` that SuGaR uses, and
-                               placeholders for the mesh classes (`renderer`, `structures`, `loss`) that raise on use --
-                               mesh rasterization / extraction is outside this package's scope.
+                               `ops.estimate_pointcloud_normals`, the quaternion helpers of `transforms` that SuGaR uses, the
+                               camera algebra of `renderer.cameras`, the `structures.Meshes` container and the two
+                               `loss` mesh regularisers the surface-bound (refine) model needs, texture containers, and
+                               a mesh rasterizer that raises on use -- mesh rasterization / extraction is outside this
+                               package's scope.
 """
 from __future__ import annotations
 

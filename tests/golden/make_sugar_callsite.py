@@ -167,9 +167,103 @@ def run():
         torch.Tensor.cuda = real_cuda
 
 
+class _TriangleMesh:
+    """the attributes of an open3d TriangleMesh that SuGaR.__init__ reads when binding (:160, :213-216)"""
+    def __init__(self, vertices, triangles, vertex_colors):
+        self.vertices, self.triangles, self.vertex_colors = vertices, triangles, vertex_colors
+
+
+def _bumpy_sphere(n_lat=14, n_lon=24, seed=3):
+    """a closed, consistently oriented triangle mesh: latitude rings between two poles, radius modulated"""
+    rng = np.random.default_rng(seed)
+    verts = [[0.0, 0.0, 1.0]]
+    for i in range(1, n_lat):
+        th = math.pi * i / n_lat
+        for j in range(n_lon):
+            ph = 2 * math.pi * j / n_lon
+            verts.append([math.sin(th) * math.cos(ph), math.sin(th) * math.sin(ph), math.cos(th)])
+    verts.append([0.0, 0.0, -1.0])
+    v = np.asarray(verts)
+    r = 0.6 + 0.08 * np.sin(3 * v[:, :1]) * np.cos(2 * v[:, 1:2]) + 0.01 * rng.standard_normal((len(v), 1))
+    v = v * r
+    ring = lambda i, j: 1 + (i - 1) * n_lon + (j % n_lon)
+    tris = []
+    for j in range(n_lon):
+        tris.append([0, ring(1, j), ring(1, j + 1)])
+        tris.append([len(v) - 1, ring(n_lat - 1, j + 1), ring(n_lat - 1, j)])
+    for i in range(1, n_lat - 1):
+        for j in range(n_lon):
+            a, b, c, d = ring(i, j), ring(i, j + 1), ring(i + 1, j), ring(i + 1, j + 1)
+            tris.append([a, c, d]); tris.append([a, d, b])
+    return _TriangleMesh(v.astype(np.float64), np.asarray(tris, dtype=np.int64), rng.random((len(v), 3)))
+
+
+def run_bound():
+    """The refine-mode model (BASELINE.json config 4): Gaussians bound to the triangles of a surface mesh
+    (SuGaR.__init__(surface_mesh_to_bind=...), :150-226, :326-350; positions from barycentric coordinates :384-397, flat
+    scales :399-430, rotations from the face frame + a learned in-plane complex number :432-475), rendered through the same
+    boundary.  `Meshes` / `TexturesVertex` are the stand-ins of sugar_amd.shims (parity-unpinned against pytorch3d)."""
+    sm = _import_reference_model()
+    from sugar_amd import synthetic as syn
+    torch.manual_seed(0)
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sm.knn_points = _scipy_knn_points
+    sm.GaussianRasterizer = _Recorder
+    _Recorder.calls = []
+    try:
+        cams = syn.orbit_cameras(W, H)
+        nerf = types.SimpleNamespace(device=torch.device("cpu"), training_cameras=_Cameras(cams))
+        mesh = _bumpy_sphere()
+        g = torch.Generator().manual_seed(78)
+        model = sm.SuGaR(nerfmodel=nerf, points=None, colors=None, initialize=False, sh_levels=4, keep_track_of_knn=False,
+                         surface_mesh_to_bind=mesh, n_gaussians_per_surface_triangle=6, learn_surface_mesh_positions=True,
+                         learn_surface_mesh_opacity=True, learn_surface_mesh_scales=True)
+        n = model._n_points
+        assert model.binded_to_surface_mesh and n == 6 * len(mesh.triangles)
+        with torch.no_grad():  # a mid-refinement state
+            model._scales += 0.3 * torch.randn(n, 2, generator=g) + 0.5
+            model._quaternions += 0.7 * torch.randn(n, 2, generator=g)
+            model.all_densities += 2.0 * torch.randn(n, 1, generator=g) + 2.5
+            model._sh_coordinates_rest += 0.15 * torch.randn(n, 15, 3, generator=g)
+        wimg = torch.randn(H, W, 3, generator=g)
+        out = {"W": np.int32(W), "H": np.int32(H), "dL_dimage_hw3": wimg.numpy(), "n_faces": np.int32(len(mesh.triangles))}
+        for ci, (cam_idx, in_rast) in enumerate(((2, False), (6, True))):
+            model.zero_grad(set_to_none=True)
+            res = model.render_image_gaussian_rasterizer(camera_indices=cam_idx, bg_color=None, sh_deg=3,
+                                                         compute_color_in_rasterizer=in_rast, return_2d_radii=True)
+            (res["image"] * wimg).sum().backward()
+            call = _Recorder.calls[-1]
+            s = call["settings"]
+            pre = f"c{ci}_"
+            out[pre + "tanfov"] = np.array([s.tanfovx, s.tanfovy], dtype=np.float64)
+            out[pre + "sh_degree"] = np.int32(s.sh_degree)
+            for k in ("bg", "viewmatrix", "projmatrix", "campos"):
+                out[pre + k] = getattr(s, k).detach().numpy().astype(np.float32)
+            for k, v in call["inputs"].items():
+                if v is None:
+                    continue
+                out[pre + "in_" + k] = v.detach().numpy()
+                if v.grad is not None:
+                    out[pre + "grad_" + k] = v.grad.detach().numpy()
+            out[pre + "image_hw3"] = res["image"].detach().numpy()
+            out[pre + "radii"] = res["radii"].numpy()
+            # gradients on the bound model's own parameters: mesh vertices, in-plane scales, in-plane rotation
+            for name in ("_points", "_scales", "_quaternions", "all_densities", "_sh_coordinates_dc", "_sh_coordinates_rest"):
+                out[pre + "param_grad" + name] = getattr(model, name).grad.detach().numpy()
+        assert out["c0_in_scales"].shape == (n, 3) and float(out["c0_in_scales"][:, 0].max()) < 1e-5  # flat Gaussians
+        return out
+    finally:
+        torch.Tensor.cuda = real_cuda
+
+
 def main():
-    out = run()
-    path = os.path.join(HERE, "sugar_callsite.npz")
+    for fn, name in ((run, "sugar_callsite.npz"), (run_bound, "sugar_callsite_bound.npz")):
+        _write(fn(), name)
+
+
+def _write(out, name):
+    path = os.path.join(HERE, name)
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
     for k in sorted(out):

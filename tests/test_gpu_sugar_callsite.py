@@ -1,7 +1,9 @@
 """GPU replay of the reference's real call site: tests/golden/sugar_callsite.npz holds the tensors the UNMODIFIED
 SuGaR.render_image_gaussian_rasterizer (sugar_scene/sugar_model.py:2085-2294) handed to the GaussianRasterizer boundary
 (once with colours from get_points_rgb as `colors_precomp`, once with SH evaluated in the rasterizer) together with the image
-and gradients the CPU oracle returned.  The HIP rasterizer must reproduce them from the same boundary inputs."""
+and gradients the CPU oracle returned.  The HIP rasterizer must reproduce them from the same boundary inputs.
+sugar_callsite_bound.npz is the same for the refine-mode model (BASELINE.json config 4: six flat Gaussians per triangle of a
+surface mesh, thickness 3e-6 -- covariances of rank 2 up to rounding, the hardest conditioning this boundary sees)."""
 import os
 
 import numpy as np
@@ -9,7 +11,8 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "sugar_callsite.npz"))
+GOLDS = {name: np.load(os.path.join(os.path.dirname(__file__), "golden", f"sugar_callsite{suffix}.npz"))
+         for name, suffix in (("free", ""), ("bound", "_bound"))}
 DEV = "cuda:0"
 
 
@@ -19,7 +22,9 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("call", [0, 1])
-def test_replay_of_the_sugar_call_site(call):
+@pytest.mark.parametrize("model", ["free", "bound"])
+def test_replay_of_the_sugar_call_site(model, call):
+    GOLD = GOLDS[model]
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer  # the drop-in package name
     pre = f"c{call}_"
     t = lambda k: torch.tensor(GOLD[pre + k], device=DEV)
