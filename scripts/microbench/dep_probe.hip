@@ -1,0 +1,92 @@
+// dep_probe.hip -- gfx950: how fast does ONE wave issue dependent vs independent VALU instructions, and how many waves per
+// SIMD does it take to fill the vector pipe with either?  (developer tool; the blend kernels' inner loops are one dependent chain
+// per wave: this prices what interleaving two entries would buy)
+// Build: hipcc -O2 --offload-arch=gfx950 dep_probe.hip -o dep_probe ; run: ./dep_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+enum Mode { DEP1, DEP2, DEP4, DEP8, EXPDEP1, EXPDEP2, RCPDEP1, CMPMASK, LDSBCAST, MODE_COUNT };
+static const char* mode_name[] = {"48 v_fma, 1 chain", "48 v_fma, 2 chains", "48 v_fma, 4 chains", "48 v_fma, 8 chains",
+                                  "24 x (v_exp + v_fma), 1 chain", "24 x (v_exp + v_fma), 2 chains", "24 x (v_rcp + v_fma), 1 chain",
+                                  "16 x (v_cmp + s_and exec + v_fma + s_mov exec)", "16 x (3 broadcast ds_read 40 B + 3 v_fma on them)"};
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_rate(int iters, float a, float b, float* out)
+{
+    __shared__ float lds[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) lds[i] = a + i;
+    __syncthreads();
+    float x[8];
+    for (int c = 0; c < 8; c++) x[c] = a + c + threadIdx.x;
+    const uint32_t base = (uint32_t)(uintptr_t)lds;
+    for (int it = 0; it < iters; it++) {
+        if constexpr (MODE == DEP1 || MODE == DEP2 || MODE == DEP4 || MODE == DEP8) {
+            constexpr int NC = MODE == DEP1 ? 1 : MODE == DEP2 ? 2 : MODE == DEP4 ? 4 : 8;
+#pragma unroll
+            for (int u = 0; u < 48 / NC; u++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(b));
+        }
+        if constexpr (MODE == EXPDEP1)
+#pragma unroll
+            for (int u = 0; u < 24; u++) asm volatile("v_exp_f32 %0, %0\n v_fma_f32 %0, %0, %1, %2" : "+v"(x[0]) : "v"(a), "v"(b));
+        if constexpr (MODE == EXPDEP2)
+#pragma unroll
+            for (int u = 0; u < 12; u++)
+                asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3"
+                             : "+v"(x[0]), "+v"(x[1]) : "v"(a), "v"(b));
+        if constexpr (MODE == RCPDEP1)
+#pragma unroll
+            for (int u = 0; u < 24; u++) asm volatile("v_rcp_f32 %0, %0\n v_fma_f32 %0, %0, %1, %2" : "+v"(x[0]) : "v"(a), "v"(b));
+        if constexpr (MODE == CMPMASK) {
+            unsigned long long full;
+#pragma unroll
+            for (int u = 0; u < 16; u++)
+                asm volatile("s_mov_b64 %1, exec\n v_cmp_ngt_f32 vcc, 0x3b808081, %0\n s_and_b64 exec, exec, vcc\n"
+                             "v_fma_f32 %0, %0, %2, %3\n s_mov_b64 exec, %1" : "+v"(x[0]), "=&s"(full) : "v"(a), "v"(b) : "vcc");
+        }
+        if constexpr (MODE == LDSBCAST) {
+#pragma unroll
+            for (int u = 0; u < 16; u++)
+                asm volatile("ds_read_b128 v[40:43], %1\n ds_read_b128 v[44:47], %1 offset:16\n ds_read_b64 v[48:49], %1 offset:32\n"
+                             "s_waitcnt lgkmcnt(0)\n v_fma_f32 %0, %0, v40, v44\n v_fma_f32 %0, %0, v41, v48\n v_fma_f32 %0, %0, v43, v49"
+                             : "+v"(x[0]) : "v"(base + 48u * u)
+                             : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49");
+        }
+    }
+    float s = 0.f;
+    for (int c = 0; c < 8; c++) s += x[c];
+    if (s == 12345.678f) out[0] = s;
+}
+
+template <int MODE>
+void rate(int waves_per_simd, int n_instr)
+{
+    static float* out = nullptr;
+    if (!out) hipMalloc(&out, 64);
+    const int iters = 4096;
+    const int grid = 256 * waves_per_simd;
+    hipLaunchKernelGGL((k_rate<MODE>), dim3(grid), dim3(256), 0, 0, 16, 1.0001f, 0.5f, out);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k_rate<MODE>), dim3(grid), dim3(256), 0, 0, iters, 1.0001f, 0.5f, out);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double ns_per_iter = ms * 1e6 / iters;
+    printf("%-52s waves/SIMD=%d  wall %.3f ms   per wave: %.2f ns per VALU instr   per SIMD: %.2f ns per VALU instr\n", mode_name[MODE],
+           waves_per_simd, ms, ns_per_iter / n_instr, ns_per_iter / n_instr / waves_per_simd);
+}
+
+template <int MODE>
+void sweep(int n_instr) { for (int w : {1, 2, 3, 4, 6}) rate<MODE>(w, n_instr); }
+
+int main()
+{
+    sweep<DEP1>(48); sweep<DEP2>(48); sweep<DEP4>(48); sweep<DEP8>(48);
+    sweep<EXPDEP1>(48); sweep<EXPDEP2>(48); sweep<RCPDEP1>(48); sweep<CMPMASK>(32); sweep<LDSBCAST>(48);
+    return 0;
+}

@@ -34,6 +34,12 @@ __device__ __forceinline__ float sum_over_rows(float x)
     return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
+// the value of the lane 8 lanes away inside the same 16-lane row (DPP row rotate: folds into the add)
+__device__ __forceinline__ float pair_in_row(float x)
+{
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x128, 0xF, 0xF, false));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Forward blend.
 //
@@ -255,7 +261,7 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
 // Two lane mappings alternate over groups of 16 Gaussians of the block's list (walked back to front):
 //   phase A  lane = pixel.  The per-pixel recurrence of backward.cu:486-534 (T /= 1-alpha, accum_rec, dL_dalpha) runs
 //            sequentially over the 16 Gaussians; for each pair the lane stores just Z = G * dL_dalpha and Wt = alpha * T into
-//            a wave-private LDS panel zw[g][pixel].  Hand-scheduled like the forward walk: ~30 VALU per entry, the
+//            a wave-private LDS panel zw[g][pixel].  Hand-scheduled like the forward walk: 27.5 VALU per entry, the
 //            reference's tests as EXEC masks.
 //   phase B  lane = (Gaussian g, pixel rows 2q and 2q+1).  Each lane streams its 16 pixels out of the panel and accumulates,
 //            in registers, the colour sums  sum Wt*dL_dpix  and the raw moments of Z about the block origin; one
@@ -269,15 +275,24 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
 // Which list entries to take comes from the forward: it leaves one 64-bit mask per (64-entry batch, block) -- the lanes that
 // survived the block's exact cull -- so the backward neither culls again nor gathers records it will not use; the
 // survivors of several batches are collected in a small LDS queue so that phase B always sees full groups of 16.
-#define BW_QCAP 80          // queue entries: at most 15 left over + 64 new
-#define BW_SUB 16
+#ifndef BW_SUB
+#define BW_SUB 8            // Gaussians per group (panel rows)
+#endif
+#define BW_QCAP (BW_SUB + 64)  // queue entries: at most BW_SUB - 1 left over + 64 new
 #define BW_ZW_STRIDE 65     // float2 units: conflict-free for the phase-A writes and the phase-B reads
 #define BW_ENTRY_DW 12      // x, y, A, B | C, opacity, r, g | b, list position (1-based), id, -
 
 // The ten registers of an entry are reused in place as it is evaluated (no further temporaries):
 //   X -> dx -> Z        Y -> dy -> Wt       A -> G         B -> t -> 1/(1-alpha)       CZ -> power -> dL_dalpha     OP -> alpha
+//   R -> colour . g
 // (X, Y must be an even-aligned register pair: they leave as the (Z, Wt) panel entry.)
-#define SGR_BWD_BODY(X, Y, A, B, CZ, OP, R, G_, BL, POS, XY)                                      \
+// accum_rec (backward.cu:514-516) is advanced at the END of the entry that produced (alpha, colour) instead of at the start of
+// the next contributing one: the difference colour.g - accum_rec.g it needs is the one dL_dalpha uses anyway, and no copy of
+// alpha or of the colour term has to be carried.  Same operations on the same values: bit-identical sums.
+// (Measured, same box: the walk is bound by the latency of this dependent chain at the 3 waves per SIMD the LDS footprint allows,
+// not by instruction issue -- removing 2.5 of 30 instructions that sit beside the chain changed the kernel by < 1 %, zeroing the
+// panel row with a second LDS write instead of the two v_mov cost 1.5 %.)
+#define SGR_BWD_BODY(X, Y, A, B, CZ, OP, R, G_, BL, POS, XY, OFF)                                 \
     "v_sub_f32 " X ", " X ", %[px]\n"                                                             \
     "v_sub_f32 " Y ", " Y ", %[py]\n"                                                             \
     "v_mul_f32 " B ", " B ", " Y "\n"                                                             \
@@ -298,60 +313,58 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
     "s_and_b64 exec, %[m0], vcc\n"                                                                \
     "v_sub_f32 " B ", 1.0, " OP "\n"                                                              \
     "v_rcp_f32 " B ", " B "\n"           /* 1 / (1 - alpha) */                                    \
-    "v_sub_f32 " CZ ", %[lc], %[acc]\n"                                                           \
-    "v_fmac_f32 %[acc], %[la], " CZ "\n" /* accum_rec . g  (backward.cu:514-516) */               \
+    "v_mul_f32 " R ", " R ", %[g0]\n"                                                             \
+    "v_fmac_f32 " R ", " G_ ", %[g1]\n"                                                           \
+    "v_fmac_f32 " R ", " BL ", %[g2]\n"  /* colour . g */                                         \
     "v_mul_f32 %[T], %[T], " B "\n"                                                               \
-    "v_mul_f32 %[lc], " R ", %[g0]\n"                                                             \
-    "v_fmac_f32 %[lc], " G_ ", %[g1]\n"                                                           \
-    "v_fmac_f32 %[lc], " BL ", %[g2]\n"  /* last_color . g */                                     \
     "v_mul_f32 " Y ", " OP ", %[T]\n"    /* Wt = alpha * T */                                     \
-    "v_sub_f32 " CZ ", %[lc], %[acc]\n"                                                           \
+    "v_sub_f32 " CZ ", " R ", %[acc]\n"  /* (colour - accum_rec) . g */                           \
+    "v_fmac_f32 %[acc], " OP ", " CZ "\n" /* accum_rec . g as the next contributing entry sees it */ \
     "v_mul_f32 " CZ ", " CZ ", %[T]\n"                                                            \
     "v_fmac_f32 " CZ ", %[ntb], " B "\n" /* dL_dalpha (backward.cu:523-529) */                    \
-    "v_mov_b32 %[la], " OP "\n"                                                                   \
     "v_mul_f32 " X ", " A ", " CZ "\n"   /* Z = G * dL_dalpha */                                  \
     "s_mov_b64 exec, %[full]\n"                                                                   \
-    "ds_write_b64 %[waddr], " XY "\n"                                                             \
-    "v_add_u32 %[waddr], 520, %[waddr]\n"
+    "ds_write_b64 %[waddr], " XY OFF "\n"
 
-// rows (1..16) queue entries starting at LDS address e_addr -> panel rows 0..rows-1 at w_addr (+ 8 * lane already added)
+// rows (1..BW_SUB) queue entries starting at LDS address e_addr -> panel rows 0..rows-1 at w_addr (+ 8 * lane already added)
 __device__ __forceinline__ void bwd_phase_a(uint32_t e_addr, uint32_t w_addr, int rows, unsigned long long inside_mask, float pixfx,
                                             float pixfy, float g0, float g1, float g2, float ntb, uint32_t lastc, float& T,
-                                            float& acc_g, float& lc_g, float& last_alpha)
+                                            float& acc_g)
 {
     unsigned long long full, m0, m1;
     asm volatile(
         "s_mov_b64 %[full], exec\n"
         "s_waitcnt lgkmcnt(0)\n"
-        "ds_read_b128 v[100:103], %[eaddr]\n"
-        "ds_read_b128 v[104:107], %[eaddr] offset:16\n"
-        "ds_read_b64 v[108:109], %[eaddr] offset:32\n"
+        "ds_read_b128 v[64:67], %[eaddr]\n"
+        "ds_read_b128 v[68:71], %[eaddr] offset:16\n"
+        "ds_read_b64 v[72:73], %[eaddr] offset:32\n"
         "1:\n"
-        "ds_read_b128 v[110:113], %[eaddr] offset:48\n"
-        "ds_read_b128 v[114:117], %[eaddr] offset:64\n"
-        "ds_read_b64 v[118:119], %[eaddr] offset:80\n"
+        "ds_read_b128 v[74:77], %[eaddr] offset:48\n"
+        "ds_read_b128 v[78:81], %[eaddr] offset:64\n"
+        "ds_read_b64 v[82:83], %[eaddr] offset:80\n"
         "s_waitcnt lgkmcnt(3)\n"
-        SGR_BWD_BODY("v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v[100:101]")
+        SGR_BWD_BODY("v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v[64:65]", "")
         "s_add_i32 %[n], %[n], -1\n"
         "s_cmp_eq_u32 %[n], 0\n"
         "s_cbranch_scc1 3f\n"
-        "ds_read_b128 v[100:103], %[eaddr] offset:96\n"
-        "ds_read_b128 v[104:107], %[eaddr] offset:112\n"
-        "ds_read_b64 v[108:109], %[eaddr] offset:128\n"
+        "ds_read_b128 v[64:67], %[eaddr] offset:96\n"
+        "ds_read_b128 v[68:71], %[eaddr] offset:112\n"
+        "ds_read_b64 v[72:73], %[eaddr] offset:128\n"
         "v_add_u32 %[eaddr], 96, %[eaddr]\n"
         "s_waitcnt lgkmcnt(4)\n"  /* the panel write of the previous entry may still be counted */
-        SGR_BWD_BODY("v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v[110:111]")
+        SGR_BWD_BODY("v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v[74:75]", " offset:520")
+        "v_add_u32 %[waddr], 1040, %[waddr]\n"
         "s_add_i32 %[n], %[n], -1\n"
         "s_cmp_eq_u32 %[n], 0\n"
         "s_cbranch_scc0 1b\n"
         "3:\n"
         "s_waitcnt lgkmcnt(0)\n"
-        : [T] "+v"(T), [acc] "+v"(acc_g), [lc] "+v"(lc_g), [la] "+v"(last_alpha), [eaddr] "+v"(e_addr), [waddr] "+v"(w_addr),
-          [n] "+s"(rows), [full] "=&s"(full), [m0] "=&s"(m0), [m1] "=&s"(m1)
+        : [T] "+v"(T), [acc] "+v"(acc_g), [eaddr] "+v"(e_addr), [waddr] "+v"(w_addr), [n] "+s"(rows), [full] "=&s"(full),
+          [m0] "=&s"(m0), [m1] "=&s"(m1)
         : [px] "v"(pixfx), [py] "v"(pixfy), [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [ntb] "v"(ntb), [lastc] "v"(lastc),
           [inside] "s"(inside_mask)
-        : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114",
-          "v115", "v116", "v117", "v118", "v119", "vcc", "scc", "memory");
+        : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78",
+          "v79", "v80", "v81", "v82", "v83", "vcc", "scc", "memory");
 }
 
 __global__ void __launch_bounds__(64)
@@ -392,18 +405,25 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (inside) { g0 = dL_dpix[pix_id]; g1 = dL_dpix[HW + pix_id]; g2 = dL_dpix[2 * HW + pix_id]; }
     const float ntb = -T_final * (bg[0] * g0 + bg[1] * g1 + bg[2] * g2);
-    float acc_g = 0.f, lc_g = 0.f, last_alpha = 0.f;
+    float acc_g = 0.f;
 
+#if BW_SUB == 16
     // phase-B role: panel row bg_ (Gaussian), pixels 16 bq .. 16 bq + 15 of the block (rows 2 bq and 2 bq + 1)
     const int bg_ = lane & 15, bq = lane >> 4;
-    float rg0[16], rg1[16], rg2[16];
+    constexpr int BPIX = 16;
+#else
+    // phase-B role: panel row bg_ (Gaussian), pixel row bq of the block (pixels 8 bq .. 8 bq + 7)
+    const int bg_ = lane & 7, bq = lane >> 3;
+    constexpr int BPIX = 8;
+#endif
+    float rg0[BPIX], rg1[BPIX], rg2[BPIX];
     {
         float* gp = reinterpret_cast<float*>(s_zw);
         gp[lane] = g0; gp[64 + lane] = g1; gp[128 + lane] = g2;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int i = 0; i < 16; i++) { rg0[i] = gp[16 * bq + i]; rg1[i] = gp[64 + 16 * bq + i]; rg2[i] = gp[128 + 16 * bq + i]; }
+        for (int i = 0; i < BPIX; i++) { rg0[i] = gp[BPIX * bq + i]; rg1[i] = gp[64 + BPIX * bq + i]; rg2[i] = gp[128 + BPIX * bq + i]; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -417,11 +437,12 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
         while (qn - qs >= BW_SUB || (last_batch && qn > qs)) {
             const int rows = min(BW_SUB, qn - qs);
             bwd_phase_a(q_lds + (uint32_t)qs * (BW_ENTRY_DW * 4), zw_lds, rows, inside_mask, pixfx, pixfy, g0, g1, g2, ntb,
-                        last_contributor, T, acc_g, lc_g, last_alpha);
+                        last_contributor, T, acc_g);
             // ---------------- phase B: lane = (panel row bg_, pixel rows 2 bq and 2 bq + 1)
             if (bg_ < rows) {
                 const float* e = s_q + (qs + bg_) * BW_ENTRY_DW;
-                const float2* row = s_zw + bg_ * BW_ZW_STRIDE + 16 * bq;
+                const float2* row = s_zw + bg_ * BW_ZW_STRIDE + BPIX * bq;
+#if BW_SUB == 16
                 float s0 = 0.f, sx = 0.f, sxx = 0.f, t0 = 0.f, tx1 = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
@@ -436,6 +457,21 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
                 float o[9] = {k0, k1, k2, s0, sx, y0 * s0 + t0, sxx, y0 * sx + tx1, y0 * y0 * s0 + (2.f * y0 + 1.f) * t0};
 #pragma unroll
                 for (int v = 0; v < 9; v++) o[v] = sum_over_rows(o[v]);
+#else
+                float s0 = 0.f, sx = 0.f, sxx = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float2 v = row[i];
+                    const float xi = (float)i;
+                    s0 += v.x; sx += v.x * xi; sxx += v.x * (xi * xi);
+                    k0 += v.y * rg0[i]; k1 += v.y * rg1[i]; k2 += v.y * rg2[i];
+                }
+                // raw moments about the block origin: this lane's pixels all have y = bq
+                const float y0 = (float)bq;
+                float o[9] = {k0, k1, k2, s0, sx, y0 * s0, sxx, y0 * sx, y0 * y0 * s0};
+#pragma unroll
+                for (int v = 0; v < 9; v++) o[v] = sum_over_rows(o[v] + pair_in_row(o[v]));
+#endif
                 {
                     // d = centre - pixel = (xb - x, yb - y): shift the raw moments to the Gaussian's centre (every lane: the
                     // four lanes of a Gaussian hold the same sums after the reduction)
@@ -451,7 +487,7 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
                     float* tb = reinterpret_cast<float*>(s_zw) + bg_ * 16;
                     if (bq == 0) { tb[0] = o[0]; tb[1] = o[1]; tb[2] = o[2]; tb[3] = S0; }
                     else if (bq == 1) { tb[4] = dxs; tb[5] = dys; tb[6] = dxx; tb[7] = dxy; }
-                    else if (bq == 2) { tb[8] = dyy; tb[9] = e[10]; }
+                    else if (bq == 2) { tb[8] = dyy; tb[9] = e[10]; }  // (bq > 2: these lanes only took part in the sums)
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -460,7 +496,7 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
                 const float* tbl = reinterpret_cast<const float*>(s_zw);
                 const int c = lane & 15;
 #pragma unroll
-                for (int pass = 0; pass < 4; pass++) {
+                for (int pass = 0; pass < BW_SUB / 4; pass++) {
                     const int g = 4 * pass + (lane >> 4);
                     if (g < rows && c < 9) {
                         const float val = tbl[g * 16 + c];
