@@ -23,14 +23,19 @@ namespace {
 
 #define LOG2E 1.4426950408889634f
 
-// x summed over the four 16-lane rows of the wave (lanes l, l+16, l+32, l+48), result in every lane: two gfx950 lane-swap
-// VALU ops instead of two ds_bpermute round trips through the LDS pipeline.
-__device__ __forceinline__ float sum_over_rows(float x)
+// Sums over the four 16-lane rows of the wave, TWO values per gfx950 lane swap.  v_permlane16_swap exchanges the odd rows of its
+// first operand with the even rows of its second, so after one swap and one add rows 0 and 2 hold a's sums over the row pairs
+// (0,1) and (2,3) and rows 1 and 3 hold b's; v_permlane32_swap exchanges the upper half of the first operand with the lower half
+// of the second, so the same step on two such results leaves the total of a in row 0, of b in row 1, and those of the second
+// pair in rows 2 and 3.  Four totals for three swaps and three adds (one value at a time: four instructions and two copies each).
+__device__ __forceinline__ float pairsum16(float a, float b)
 {
-    const uint32_t u = __float_as_uint(x);
-    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // {r0,r0,r2,r2} , {r1,r1,r3,r3}
-    const uint32_t y = __float_as_uint(__uint_as_float(r[0]) + __uint_as_float(r[1]));
-    auto q = __builtin_amdgcn_permlane32_swap(y, y, false, false);      // {lo,lo} , {hi,hi}
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float pairsum32(float c, float d)
+{
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(c), __float_as_uint(d), false, false);
     return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
@@ -275,9 +280,7 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
 // Which list entries to take comes from the forward: it leaves one 64-bit mask per (64-entry batch, block) -- the lanes that
 // survived the block's exact cull -- so the backward neither culls again nor gathers records it will not use; the
 // survivors of several batches are collected in a small LDS queue so that phase B always sees full groups of 16.
-#ifndef BW_SUB
-#define BW_SUB 8            // Gaussians per group (panel rows)
-#endif
+#define BW_SUB 8            // Gaussians per group (panel rows); phase B's lane roles are written for 8
 #define BW_QCAP (BW_SUB + 64)  // queue entries: at most BW_SUB - 1 left over + 64 new
 #define BW_ZW_STRIDE 65     // float2 units: conflict-free for the phase-A writes and the phase-B reads
 #define BW_ENTRY_DW 12      // x, y, A, B | C, opacity, r, g | b, list position (1-based), id, -
@@ -407,15 +410,9 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
     const float ntb = -T_final * (bg[0] * g0 + bg[1] * g1 + bg[2] * g2);
     float acc_g = 0.f;
 
-#if BW_SUB == 16
-    // phase-B role: panel row bg_ (Gaussian), pixels 16 bq .. 16 bq + 15 of the block (rows 2 bq and 2 bq + 1)
-    const int bg_ = lane & 15, bq = lane >> 4;
-    constexpr int BPIX = 16;
-#else
     // phase-B role: panel row bg_ (Gaussian), pixel row bq of the block (pixels 8 bq .. 8 bq + 7)
     const int bg_ = lane & 7, bq = lane >> 3;
     constexpr int BPIX = 8;
-#endif
     float rg0[BPIX], rg1[BPIX], rg2[BPIX];
     {
         float* gp = reinterpret_cast<float*>(s_zw);
@@ -442,22 +439,6 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
             if (bg_ < rows) {
                 const float* e = s_q + (qs + bg_) * BW_ENTRY_DW;
                 const float2* row = s_zw + bg_ * BW_ZW_STRIDE + BPIX * bq;
-#if BW_SUB == 16
-                float s0 = 0.f, sx = 0.f, sxx = 0.f, t0 = 0.f, tx1 = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const float2 v = row[i];
-                    const float xi = (float)(i & 7);
-                    s0 += v.x; sx += v.x * xi; sxx += v.x * (xi * xi);
-                    if (i >= 8) { t0 += v.x; tx1 += v.x * xi; }
-                    k0 += v.y * rg0[i]; k1 += v.y * rg1[i]; k2 += v.y * rg2[i];
-                }
-                // raw moments about the block origin: y = 2 bq + (i >> 3)
-                const float y0 = (float)(2 * bq);
-                float o[9] = {k0, k1, k2, s0, sx, y0 * s0 + t0, sxx, y0 * sx + tx1, y0 * y0 * s0 + (2.f * y0 + 1.f) * t0};
-#pragma unroll
-                for (int v = 0; v < 9; v++) o[v] = sum_over_rows(o[v]);
-#else
                 float s0 = 0.f, sx = 0.f, sxx = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
@@ -466,28 +447,33 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
                     s0 += v.x; sx += v.x * xi; sxx += v.x * (xi * xi);
                     k0 += v.y * rg0[i]; k1 += v.y * rg1[i]; k2 += v.y * rg2[i];
                 }
-                // raw moments about the block origin: this lane's pixels all have y = bq
+                // this lane's share of the raw moments about the block origin (its pixels all have y = bq), shifted to the
+                // Gaussian's centre, d = centre - pixel = (xb - x, yb - y) -- the shift is linear in the moments, so it is applied
+                // to the shares and the shifted shares are summed over the eight lanes of the Gaussian
                 const float y0 = (float)bq;
-                float o[9] = {k0, k1, k2, s0, sx, y0 * s0, sxx, y0 * sx, y0 * y0 * s0};
+                const float sy = y0 * s0, sxy = y0 * sx, syy = y0 * sy;
+                const float xb = e[0] - (float)bx0, yb = e[1] - (float)by0;
+                const float dxs = xb * s0 - sx, dys = yb * s0 - sy;
+                const float dxx = xb * (xb * s0 - 2.f * sx) + sxx;
+                const float dyy = yb * (yb * s0 - 2.f * sy) + syy;
+                const float dxy = xb * dys - yb * sx + sxy;  // xb yb S0 - xb Sy - yb Sx + Sxy
+                float o[9] = {k0, k1, k2, s0, dxs, dys, dxx, dxy, dyy};
 #pragma unroll
-                for (int v = 0; v < 9; v++) o[v] = sum_over_rows(o[v] + pair_in_row(o[v]));
-#endif
-                {
-                    // d = centre - pixel = (xb - x, yb - y): shift the raw moments to the Gaussian's centre (every lane: the
-                    // four lanes of a Gaussian hold the same sums after the reduction)
-                    const float xb = e[0] - (float)bx0, yb = e[1] - (float)by0;
-                    const float S0 = o[3], Sx = o[4], Sy = o[5], Sxx = o[6], Sxy = o[7], Syy = o[8];
-                    const float dxs = xb * S0 - Sx, dys = yb * S0 - Sy;
-                    const float dxx = xb * (xb * S0 - 2.f * Sx) + Sxx;
-                    const float dyy = yb * (yb * S0 - 2.f * Sy) + Syy;
-                    const float dxy = xb * dys - yb * Sx + Sxy;  // xb yb S0 - xb Sy - yb Sx + Sxy
-                    // the nine sums of a pair are handed to nine neighbouring lanes through LDS (the panel is free now), so
-                    // that one atomic instruction carries whole 36-byte records (four Gaussians at a time) and the memory
-                    // system sees ONE request per (block, Gaussian) pair instead of nine
+                for (int v = 0; v < 9; v++) o[v] += pair_in_row(o[v]);  // lanes bq and bq ^ 1
+                // ... and over the four 16-lane rows, two values per lane swap: row r of q0 ends up with the total of o[r], row r
+                // of q1 with that of o[4 + r], row 0 of q2 with that of o[8]
+                const float q0 = pairsum32(pairsum16(o[0], o[1]), pairsum16(o[2], o[3]));
+                const float q1 = pairsum32(pairsum16(o[4], o[5]), pairsum16(o[6], o[7]));
+                const float q2 = pairsum32(pairsum16(o[8], 0.f), 0.f);
+                // the nine sums of a pair are handed to nine neighbouring lanes through LDS (the panel is free now), so that one
+                // atomic instruction carries whole 36-byte records (four Gaussians at a time) and the memory system sees ONE
+                // request per (block, Gaussian) pair instead of nine
+                if ((lane & 8) == 0) {
                     float* tb = reinterpret_cast<float*>(s_zw) + bg_ * 16;
-                    if (bq == 0) { tb[0] = o[0]; tb[1] = o[1]; tb[2] = o[2]; tb[3] = S0; }
-                    else if (bq == 1) { tb[4] = dxs; tb[5] = dys; tb[6] = dxx; tb[7] = dxy; }
-                    else if (bq == 2) { tb[8] = dyy; tb[9] = e[10]; }  // (bq > 2: these lanes only took part in the sums)
+                    const int r = lane >> 4;
+                    tb[r] = q0;
+                    tb[4 + r] = q1;
+                    if (r == 0) { tb[8] = q2; tb[9] = e[10]; }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
