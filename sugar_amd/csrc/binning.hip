@@ -83,7 +83,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 #define RS_FLAG_A 0x40000000u
 #define RS_FLAG_P 0x80000000u
 #define RS_VALUE 0x3FFFFFFFu
-#define RS_COUNTER_WORDS (4 * 256 + 4)  // global digit histograms of the four passes + one chunk ticket per pass
+#define RS_COUNTER_WORDS (4 * 256 + 4)
+#ifndef RS_LOOKBACK
+#define RS_LOOKBACK 8       // published words a digit's thread requests per round trip of the look-back
+#endif  // global digit histograms of the four passes + one chunk ticket per pass
 
 __device__ __forceinline__ uint32_t rs_peek(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void rs_post(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -234,13 +237,13 @@ __global__ void __launch_bounds__(256) k_rs_pass(int n, const uint32_t* __restri
         int k = chunk - 1;
         bool done = k < 0;
         while (!done) {
-            uint32_t v[8];
+            uint32_t v[RS_LOOKBACK];
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = (k - j >= 0) ? rs_peek(st + (size_t)(k - j) * 256) : RS_FLAG_P;
+            for (int j = 0; j < RS_LOOKBACK; j++) v[j] = (k - j >= 0) ? rs_peek(st + (size_t)(k - j) * 256) : RS_FLAG_P;
             bool stalled = false;
             int adv = 0;
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
+            for (int j = 0; j < RS_LOOKBACK; j++) {
                 if (!done && !stalled) {
                     if (v[j] == 0u) stalled = true;  // not published yet: ask again from here
                     else { prefix += v[j] & RS_VALUE; adv++; done = (v[j] & RS_FLAG_P) != 0u; }

@@ -420,8 +420,11 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreprocessArgs a)
 // blend backward, mean, scale, rotation, the camera) is requested in one batch, the SH block as soon as the radius says the
 // Gaussian was rendered.  STORE_SH = false is the compact mode (dL_dsh == NULL): the 48 basis products are not formed at all.
 // SH: 0 = fast layout, 1 = any layout, 2 = no SH (precomputed colours), compile-time for the reason given at the forward.
+#ifndef SGR_PRE_BWD_BLOCKS
+#define SGR_PRE_BWD_BLOCKS 3
+#endif
 template <bool STORE_SH, int SH>
-__global__ void __launch_bounds__(256) k_preprocess_bwd(PreprocessBwdArgs a)
+__global__ void __launch_bounds__(256, SGR_PRE_BWD_BLOCKS) k_preprocess_bwd(PreprocessBwdArgs a)
 {
     const int idx0 = blockIdx.x * 256 + threadIdx.x;
     if (a.campos_row && idx0 < 3) a.campos_row[idx0] = a.cam_pos[idx0];  // (see sgr_backward_opts)
