@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--force-collectives", action="store_true", help="N = 1: create a one-rank RCCL group and run the gradient exchange anyway (exercises the collective path on one GPU)")
     ap.add_argument("--python-step", action="store_true", help="the autograd-based ViewShardedTrainer (Python between the kernels) instead of the native step (A/B)")
     ap.add_argument("--no-walk-hint", action="store_true", help="native step without the walk hint of the list-write pass (A/B)")
+    ap.add_argument("--no-launch-order", action="store_true", help="native step with the blend kernels' workgroups in raster order instead of the camera's previous depth order (A/B)")
     ap.add_argument("--forward-only", action="store_true", help="a step = one rasterizer forward through the reference-shaped API (BASELINE config 5 is quoted forward-only; implied by --workload config5)")
     ap.add_argument("--drift-steps", type=int, default=1000, help="after the graded region: train this many steps on WITHOUT restoring the parameters and time K steps of the drifted scene (0: skip)")
     ap.add_argument("--no-densify-variant", action="store_true", help="skip the extra timing of the step with dL/dmeans2D + fused densification statistics")
@@ -119,7 +120,8 @@ def main():
     if forward_only:
         trainer = ForwardOnly(scene, dev, bg_d, GaussianRasterizer, GaussianRasterizationSettings, _C)
     elif native:
-        trainer = NativeTrainer(params, bg_d, W, H, force_collectives=args.force_collectives, walk_hint=not args.no_walk_hint)
+        trainer = NativeTrainer(params, bg_d, W, H, force_collectives=args.force_collectives, walk_hint=not args.no_walk_hint,
+                                launch_order=not args.no_launch_order)
     else:
         trainer = ViewShardedTrainer(params, GaussianRasterizer, GaussianRasterizationSettings, bg_d,
                                      sync_free=False if args.host_sync else None,
@@ -287,7 +289,8 @@ def main():
         # the step a densifying trainer runs for half its schedule (train.py:111-123, sugar_densifier.py:156-164): dL/dmeans2D
         # written, visibility / radii kept, the three statistics updated inside the backward preprocess kernel
         snap = snapshot(trainer)
-        dtr = NativeTrainer(params, bg_d, W, H, densify_stats=True, walk_hint=not args.no_walk_hint, capacity=trainer.capacity)
+        dtr = NativeTrainer(params, bg_d, W, H, densify_stats=True, walk_hint=not args.no_walk_hint, capacity=trainer.capacity,
+                            launch_order=not args.no_launch_order)
         dtr.exp_avg.copy_(trainer.exp_avg); dtr.exp_avg_sq.copy_(trainer.exp_avg_sq); dtr.t = trainer.t
         for s in range(2 * len(cams)):
             do_step(dtr, s)
@@ -342,7 +345,8 @@ def main():
                              "(raster fwd -> 0.8 L1 + 0.2 DSSIM -> bwd -> Adam, 59 floats/Gaussian), 8 orbit cameras cycled"),
                 "step_driver": ("reference-shaped Python API" if forward_only else
                                 "native (sgr_trainer_step: one call per step, sync-free forward, walk hint "
-                                + ("on" if getattr(trainer, "walk_hint", False) else "off") + ")" if native
+                                + ("on" if getattr(trainer, "walk_hint", False) else "off") + ", blend launch order "
+                                + ("by depth" if getattr(trainer, "launch_order", False) else "raster") + ")" if native
                                 else "python (autograd-based ViewShardedTrainer)"),
                 "views_per_step": world,
                 "parallelism": (f"view-sharded dp{world}: all-gather of 3 masked colour grads per Gaussian and view + all-reduce of "

@@ -81,6 +81,15 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user,
  *   set: the forward is then INVALID exactly like a capacity overflow (repeat it without the hint).
  * tile_need_out (device, uint32 per tile): receives the hint for the next visit: tile_walked * (1 + hint_margin) + 64
  *   (hint_margin <= 0: 0.25).
+ * tile_order (device, uint32 per tile, extension): LAUNCH ORDER of the blend kernel.  A permutation of 0..tiles-1; the blend
+ *   kernel hands its workgroups to the tiles in this order.  With the deepest tiles first the waves still running when the grid
+ *   drains are the short ones (raster order: 118 us, the order of the camera's previous visit: 110 us at the metric workload).
+ *   The image does not depend on it.  It must be a permutation (as written by tile_order_out); anything else leaves tiles
+ *   unrendered.
+ * tile_order_out (device, uint32 per tile): receives this view's tiles sorted by the depth of their deepest contributor,
+ *   deepest first (a counting sort over 1024 depth classes; ties in arbitrary order) -- the order the backward of this view
+ *   uses (pass SGR_BWD_TILE_ORDER_READY to sgr_backward_ex and it does not sort again) and a good tile_order for the next
+ *   visit of the same camera.  May alias tile_order.
  * info (host, may be NULL): what the call did (binning path taken).
  * Header word 5 (SGR_HDR_CHUNKS): level-2 chunks of this view (see chunk_grid). */
 #define SGR_HDR_R 0          /* header words (device): total instances */
@@ -106,6 +115,8 @@ typedef struct sgr_forward_opts {
                                 about twice what a typical view needs; a trainer passes header word 5 of the camera's
                                 previous visit plus a margin */
     sgr_forward_info* info;
+    const uint32_t* tile_order;
+    uint32_t* tile_order_out;
 } sgr_forward_opts;
 int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user,
                        sgr_alloc_fn binning_alloc, void* binning_user,
@@ -187,7 +198,9 @@ typedef struct sgr_backward_opts {
     float* denom;
     float* campos_row;   /* compact SH mode: receives cam_pos[3] next to the colour gradients (the last row of an all-gather send
                             buffer), written by the kernel that writes dL_dcolor; NULL = not wanted */
+    int flags;           /* SGR_BWD_* */
 } sgr_backward_opts;
+#define SGR_BWD_TILE_ORDER_READY 1 /* the forward of this view was given tile_order_out: its launch order is in the image scratch */
 int sgr_backward_ex(int phase, int P, int D, int M, int64_t R,
                     const float* background, int width, int height,
                     const float* means3D, const float* shs, const float* colors_precomp,
@@ -287,12 +300,16 @@ int sgr_dist2_grid(int P, const float* points, float* meanDists, char* scratch, 
  * sugar_trainers/coarse_sdf.py:456-457.  img, gt: [channels, height, width] float32.
  *   forward : loss_out[3] = {loss, l1 mean, ssim mean}; `scratch` (sgr_l1_ssim_scratch_bytes) keeps the per-pixel SSIM
  *             partials for the backward.
- *   backward: grad_img[c,h,w] = grad_loss[0] * dloss/dimg (grad_loss is a device scalar, NULL = 1; gt receives no gradient). */
+ *   backward: grad_img[c,h,w] = grad_loss[0] * dloss/dimg (grad_loss is a device scalar, NULL = 1; gt receives no gradient).
+ *   sgr_l1_ssim_forward with loss_out == NULL leaves the value to sgr_l1_ssim_backward_ex(..., loss_out): one spare workgroup of
+ *   the backward kernel adds the forward's per-tile sums (one launch less on the train step's chain). */
 size_t sgr_l1_ssim_scratch_bytes(int channels, int width, int height);
 int sgr_l1_ssim_forward(int channels, int width, int height, const float* img, const float* gt, float lambda,
                         char* scratch, float* loss_out, void* stream);
 int sgr_l1_ssim_backward(int channels, int width, int height, const float* img, const float* gt, float lambda,
                          const char* scratch, const float* grad_loss, float* grad_img, void* stream);
+int sgr_l1_ssim_backward_ex(int channels, int width, int height, const float* img, const float* gt, float lambda,
+                            const char* scratch, const float* grad_loss, float* grad_img, float* loss_out, void* stream);
 
 /* ---- one-launch Adam over a flat parameter buffer -----------------------------------------------
  * torch.optim.Adam semantics (eps inside the bias-corrected denominator, no weight decay / amsgrad) as configured by
@@ -360,6 +377,8 @@ typedef struct sgr_train_view {
     uint32_t* tile_need_out;     /* receives the hint for its next visit, or NULL */
     float hint_margin;           /* see sgr_forward_opts */
     uint32_t chunk_grid;         /* see sgr_forward_opts */
+    const uint32_t* tile_order;  /* launch order of this camera's previous visit (device, [tiles]) or NULL */
+    uint32_t* tile_order_out;    /* receives this visit's order (also used by this step's backward), or NULL */
 } sgr_train_view;
 typedef struct sgr_train_exchange { /* phases 4 and 8 */
     int n_views;                 /* views whose colour gradients are summed (1: this rank's own) */

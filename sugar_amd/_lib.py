@@ -55,6 +55,7 @@ SIGNATURES = {
     "sgr_l1_ssim_scratch_bytes": (_sz, [_i, _i, _i]),
     "sgr_l1_ssim_forward": (_i, [_i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "sgr_l1_ssim_backward": (_i, [_i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    "sgr_l1_ssim_backward_ex": (_i, [_i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "sgr_adam_step": (_i, [C.c_longlong, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _i, _f, _vp]),
     "sgr_adam_step_ex": (_i, [C.c_longlong, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _i, _f, _vp, C.c_longlong, _vp]),
     "sgr_density_field_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
@@ -86,11 +87,12 @@ class ForwardInfo(C.Structure):
 
 class ForwardOpts(C.Structure):
     _fields_ = [("binning_capacity", _i64), ("flags", _i), ("header_host", _vp), ("header_event", _vp), ("tile_need", _vp),
-                ("tile_need_out", _vp), ("hint_margin", _f), ("chunk_grid", C.c_uint32), ("info", C.POINTER(ForwardInfo))]
+                ("tile_need_out", _vp), ("hint_margin", _f), ("chunk_grid", C.c_uint32), ("info", C.POINTER(ForwardInfo)),
+                ("tile_order", _vp), ("tile_order_out", _vp)]
 
 
 class BackwardOpts(C.Structure):
-    _fields_ = [("max_radii2D", _vp), ("grad_accum", _vp), ("denom", _vp), ("campos_row", _vp)]
+    _fields_ = [("max_radii2D", _vp), ("grad_accum", _vp), ("denom", _vp), ("campos_row", _vp), ("flags", _i)]
 
 
 class TrainConfig(C.Structure):
@@ -108,7 +110,8 @@ class TrainConfig(C.Structure):
 
 class TrainView(C.Structure):
     _fields_ = [("viewmatrix", _vp), ("projmatrix", _vp), ("campos", _vp), ("tan_fovx", _f), ("tan_fovy", _f), ("gt_image", _vp),
-                ("tile_need", _vp), ("tile_need_out", _vp), ("hint_margin", _f), ("chunk_grid", C.c_uint32)]
+                ("tile_need", _vp), ("tile_need_out", _vp), ("hint_margin", _f), ("chunk_grid", C.c_uint32),
+                ("tile_order", _vp), ("tile_order_out", _vp)]
 
 
 class TrainExchange(C.Structure):
@@ -116,6 +119,7 @@ class TrainExchange(C.Structure):
 
 
 SGR_FLAG_RAW_PARAMS, SGR_FLAG_SINGLE_LEVEL_BINNING = 1, 2
+SGR_BWD_TILE_ORDER_READY = 1
 HDR_R, HDR_HINT_MISS, HDR_L1_OVERFLOW = 0, 3, 6
 
 _lib = None

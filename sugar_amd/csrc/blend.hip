@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
                                                     uint32_t* __restrict__ tile_walked, float* __restrict__ out_color,
                                                     unsigned long long* __restrict__ blk_mask, uint32_t* __restrict__ blk_nb,
                                                     uint32_t* __restrict__ header, uint32_t list_cap,
-                                                    const uint32_t* __restrict__ tile_need)
+                                                    const uint32_t* __restrict__ tile_need, const uint32_t* __restrict__ launch_order)
 {
     // sync-free forward: the list did not fit the caller's capacity (or the level-1 binning overflowed) -> leave everything
     // untouched; the caller repeats the forward and every later kernel of the step reads the same header
@@ -178,8 +178,11 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
     // workgroup b runs on XCD b % 8: the four blocks of a tile share an XCD (and its L2)
     const int wg = blockIdx.x;
     const int sub = (wg >> 3) & 3;
-    const int tile = ((wg >> 5) << 3) + (wg & 7);
-    if (tile >= T_tiles) return;
+    const int slot = ((wg >> 5) << 3) + (wg & 7);
+    if (slot >= T_tiles) return;
+    // (launch_order: the camera's previous visit, deepest tiles first -- sgr_forward_opts.tile_order; clamped, so a buffer that
+    // is not a permutation costs tiles, not memory safety)
+    const int tile = launch_order ? (int)min(launch_order[slot], (uint32_t)(T_tiles - 1)) : slot;
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
     const int bx0 = tx * SGR_TILE_X + 8 * (sub & 1), by0 = ty * SGR_TILE_Y + 8 * (sub >> 1);
@@ -549,13 +552,22 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
 // running when the grid drains are the short ones.  (Workgroups start in index order; with ~2.5 dispatch rounds of waves whose
 // lifetimes spread over an order of magnitude, raster order leaves a quarter of the chip idle at the end.)  One workgroup:
 // a counting sort over 1024 depth classes; ties land in arbitrary order.
+// (behind a forward that keeps the order, the same launch also does k_make_hint's work: tile_walked != NULL)
 __global__ void __launch_bounds__(1024) k_tile_order(int T, const uint32_t* __restrict__ tile_maxc, const uint32_t* __restrict__ header,
-                                                     uint32_t list_cap, uint32_t* __restrict__ order)
+                                                     uint32_t list_cap, uint32_t* __restrict__ order, uint32_t* __restrict__ order_copy,
+                                                     const uint32_t* __restrict__ tile_walked, float margin,
+                                                     uint32_t* __restrict__ need_out, uint32_t* __restrict__ header_host)
 {
     __shared__ uint32_t s_cls[1024];
     __shared__ uint32_t s_w[16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (header_host && tid < 8) header_host[8 + tid] = header[tid];  // (see k_make_hint)
     if (SGR_FORWARD_INVALID(header, list_cap)) return;
+    if (need_out)
+        for (int i = tid; i < T; i += 1024) {
+            const uint32_t w = tile_walked[i];
+            need_out[i] = w + (uint32_t)((float)w * margin) + 64u;
+        }
     const uint32_t mc = header[SGR_HDR_MAXCOUNT];
     const int shift = mc >= 1024u ? (32 - __builtin_clz(mc)) - 10 : 0;  // class = 1023 - (depth >> shift): class 0 = deepest
     s_cls[tid] = 0u;
@@ -575,7 +587,11 @@ __global__ void __launch_bounds__(1024) k_tile_order(int T, const uint32_t* __re
     for (int w = 0; w < wave; w++) before += s_w[w];
     s_cls[tid] = before + incl - mine;  // first slot of the class
     __syncthreads();
-    for (int i = tid; i < T; i += 1024) order[atomicAdd(&s_cls[1023u - min(tile_maxc[i] >> shift, 1023u)], 1u)] = (uint32_t)i;
+    for (int i = tid; i < T; i += 1024) {
+        const uint32_t slot = atomicAdd(&s_cls[1023u - min(tile_maxc[i] >> shift, 1023u)], 1u);
+        order[slot] = (uint32_t)i;
+        if (order_copy) order_copy[slot] = (uint32_t)i;  // (sgr_forward_opts.tile_order_out; may alias the forward's tile_order: it is done)
+    }
 }
 
 // walk hint for the next visit of this camera: what the tile walked now, plus a margin, plus one batch
@@ -596,12 +612,24 @@ __global__ void __launch_bounds__(256) k_make_hint(int T, const uint32_t* __rest
 void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
                           uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
-                          uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, uint32_t* tile_need_out, float hint_margin,
-                          uint32_t* header_host_dev, hipStream_t s)
+                          uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, const uint32_t* launch_order, hipStream_t s)
 {
     const int T = gx * gy;  // (tile_maxc and tile_walked were zeroed by the tile scan: the blocks of a tile combine with atomicMax)
     hipLaunchKernelGGL(k_blend_fwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg, final_T,
-                       n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap, tile_need);
+                       n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap, tile_need, launch_order);
+}
+
+// behind the blend: this view's launch order (for its backward: order_scratch; for the camera's next forward: order_out), the walk
+// hint for the camera's next visit and the second header copy
+void sgr_launch_blend_fwd_post(int T, const uint32_t* tile_maxc, const uint32_t* tile_walked, uint32_t* header, uint32_t list_cap,
+                               uint32_t* tile_need_out, float hint_margin, uint32_t* header_host_dev, uint32_t* order_scratch,
+                               uint32_t* order_out, hipStream_t s)
+{
+    if (order_out) {
+        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, T, tile_maxc, header, list_cap, order_scratch, order_out, tile_walked,
+                           hint_margin > 0.f ? hint_margin : 0.25f, tile_need_out, header_host_dev);
+        return;
+    }
     if (tile_need_out || header_host_dev)
         hipLaunchKernelGGL(k_make_hint, dim3(tile_need_out ? (T + 255) / 256 : 1), dim3(256), 0, s, T, tile_walked, header, list_cap,
                            hint_margin > 0.f ? hint_margin : 0.25f, tile_need_out, header_host_dev);
@@ -610,11 +638,14 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
 void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const unsigned long long* blk_mask, const uint32_t* blk_nb, const GeomRec* rec, const float* bg,
                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* acc,
-                          const uint32_t* tile_maxc, const uint32_t* header, uint32_t list_cap, uint32_t* tile_order, hipStream_t s)
+                          const uint32_t* tile_maxc, const uint32_t* header, uint32_t list_cap, uint32_t* tile_order, int order_ready,
+                          hipStream_t s)
 {
     const int T = gx * gy;
-    if (4 * T < 8192) tile_order = nullptr;  // (fewer waves than the chip holds at once: nothing to order)
-    else hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, T, tile_maxc, header, list_cap, tile_order);
+    if (order_ready) {}                           // (the forward sorted: sgr_forward_opts.tile_order_out)
+    else if (4 * T < 8192) tile_order = nullptr;  // (fewer waves than the chip holds at once: nothing to order)
+    else hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, T, tile_maxc, header, list_cap, tile_order, (uint32_t*)nullptr,
+                            (const uint32_t*)nullptr, 0.f, (uint32_t*)nullptr, (uint32_t*)nullptr);
     hipLaunchKernelGGL(k_blend_bwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, blk_mask, blk_nb, rec,
                        bg, final_T, n_contrib, dL_dpix, acc, tile_order, header, list_cap);
 }

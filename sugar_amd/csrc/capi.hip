@@ -289,8 +289,10 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
         StageTimer t(s, SGR_STAGE_BLEND_FWD);
         sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
                              tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, (uint32_t)R, opts->tile_need,
-                             opts->tile_need_out, opts->hint_margin, hh_dev, s);
+                             opts->tile_order, s);
     }
+    sgr_launch_blend_fwd_post(IL.T, tile_maxc, tile_walked, header, (uint32_t)R, opts->tile_need_out, opts->hint_margin, hh_dev,
+                              tile_cursor, opts->tile_order_out, s);
     STAGE_CHECK("blend_fwd");
     // ... and once more behind the blend: word 3 (hint miss) is final only now
     if (opts->header_host && !hh_dev) HIP_TRY(hipMemcpyAsync(opts->header_host + 8, header, 32, hipMemcpyDeviceToHost, s));
@@ -358,7 +360,8 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
             sgr_launch_blend_bwd(width, height, IL.gx, IL.gy, tile_start, point_list, blk_mask, blk_nb, rec, background, final_T,
                                  n_contrib, dL_dpix, acc, reinterpret_cast<const uint32_t*>(img_buffer + IL.tile_maxc),
                                  reinterpret_cast<const uint32_t*>(img_buffer + IL.header), (uint32_t)(R > 0xFFFFFFFFll ? 0xFFFFFFFFll : R),
-                                 reinterpret_cast<uint32_t*>(img_buffer + IL.tile_cursor), s);
+                                 reinterpret_cast<uint32_t*>(img_buffer + IL.tile_cursor),
+                                 (opts && (opts->flags & SGR_BWD_TILE_ORDER_READY)) ? 1 : 0, s);
         }
         STAGE_CHECK("blend_bwd");
         if (phase == 1) {

@@ -175,23 +175,32 @@ __global__ void __launch_bounds__(256, 4) k_l1_ssim_fwd(int W, int H, int tiles_
     }
 }
 
-__global__ void __launch_bounds__(1024) k_l1_ssim_finish(const float2* __restrict__ partial, int n_partial, double n,
-                                                         float lambda, float* __restrict__ loss)
+// the tile partials added in double by ONE workgroup of NT threads: its own small kernel behind the forward, or -- when the
+// backward follows at once, as in the train step -- a spare workgroup of the backward kernel (one launch less on the step's chain)
+template <int NT>
+__device__ __forceinline__ void l1_ssim_finish(const float2* __restrict__ partial, int n_partial, double n, float lambda,
+                                               float* __restrict__ loss)
 {
-    __shared__ double s0[16], s1[16];
+    __shared__ double s0[NT / 64], s1[NT / 64];
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < n_partial; i += 1024) { const float2 v = partial[i]; a += (double)v.x; b += (double)v.y; }
+    for (int i = threadIdx.x; i < n_partial; i += NT) { const float2 v = partial[i]; a += (double)v.x; b += (double)v.y; }
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
     if ((threadIdx.x & 63) == 0) { s0[threadIdx.x >> 6] = a; s1[threadIdx.x >> 6] = b; }
     __syncthreads();
     if (threadIdx.x == 0) {
         double ssim_sum = 0.0, l1_sum = 0.0;
-        for (int w = 0; w < 16; w++) { ssim_sum += s0[w]; l1_sum += s1[w]; }
+        for (int w = 0; w < NT / 64; w++) { ssim_sum += s0[w]; l1_sum += s1[w]; }
         const double ssim_mean = ssim_sum / n, l1_mean = l1_sum / n;
         loss[0] = (float)((1.0 - (double)lambda) * l1_mean + (double)lambda * (1.0 - ssim_mean));
         loss[1] = (float)l1_mean;
         loss[2] = (float)ssim_mean;
     }
+}
+
+__global__ void __launch_bounds__(1024) k_l1_ssim_finish(const float2* __restrict__ partial, int n_partial, double n,
+                                                         float lambda, float* __restrict__ loss)
+{
+    l1_ssim_finish<1024>(partial, n_partial, n, lambda, loss);
 }
 
 // (the backward keeps 32 x 32 tiles: with 28 rows it was 11 % slower)  Three maps are windowed: {dS/dmu1, dS/dE[x^2]} travel
@@ -200,14 +209,19 @@ __global__ void __launch_bounds__(256) k_l1_ssim_bwd(int W, int H, int tiles_x, 
                                                      const float* __restrict__ Y,
                                                      Win win, const float* __restrict__ dm1, const float* __restrict__ ds1,
                                                      const float* __restrict__ ds12, const float* __restrict__ grad_loss,
-                                                     float lambda, float inv_n, float* __restrict__ dX)
+                                                     float lambda, float inv_n, float* __restrict__ dX,
+                                                     const float2* __restrict__ partial, int n_partial, float* __restrict__ loss)
 {
     __shared__ f2 sp[LR][LRP];
     __shared__ float sq[LR][LRP];
     __shared__ f2 hp[LR][LTP];
     __shared__ float hq[LR][LTP];
     int tile, c, tby, tbx;
-    if (!xcd_tile(tiles_x, tiles_y, n_tiles, tile, c, tby, tbx)) return;
+    if (!xcd_tile(tiles_x, tiles_y, n_tiles, tile, c, tby, tbx)) {
+        // (loss != NULL: the grid has eight workgroups more than tiles need; the last one reduces the forward's partials)
+        if (loss && blockIdx.x == gridDim.x - 1) l1_ssim_finish<256>(partial, n_partial, 1.0 / (double)inv_n, lambda, loss);
+        return;
+    }
     const size_t plane = (size_t)c * W * H;
     const int x0 = tbx * LT, y0 = tby * LT;
     const int tid = threadIdx.x;
@@ -309,7 +323,7 @@ size_t sgr_l1_ssim_scratch_bytes(int channels, int width, int height)
 int sgr_l1_ssim_forward(int channels, int width, int height, const float* img, const float* gt, float lambda,
                         char* scratch, float* loss_out, void* stream)
 {
-    if (channels <= 0 || width <= 0 || height <= 0 || !img || !gt || !scratch || !loss_out) return SGR_E_INVALID;
+    if (channels <= 0 || width <= 0 || height <= 0 || !img || !gt || !scratch) return SGR_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const size_t plane = sgr_align((size_t)channels * width * height * 4);
     float* dm1 = reinterpret_cast<float*>(scratch);
@@ -319,13 +333,20 @@ int sgr_l1_ssim_forward(int channels, int width, int height, const float* img, c
     const int tiles_x = (width + LT - 1) / LT, tiles_y = (height + LTY - 1) / LTY, n_tiles = tiles_x * tiles_y * channels;
     hipLaunchKernelGGL(k_l1_ssim_fwd, dim3(8 * ((n_tiles + 7) / 8)), dim3(256), 0, s, width, height, tiles_x, tiles_y, n_tiles, img, gt,
                        make_window(), dm1, ds1, ds12, partial);
-    hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(1024), 0, s, partial, n_tiles, (double)channels * width * height, lambda,
-                       loss_out);
+    if (loss_out)  // (NULL: the caller asks sgr_l1_ssim_backward_ex for the value)
+        hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(1024), 0, s, partial, n_tiles, (double)channels * width * height, lambda,
+                           loss_out);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 
 int sgr_l1_ssim_backward(int channels, int width, int height, const float* img, const float* gt, float lambda,
                          const char* scratch, const float* grad_loss, float* grad_img, void* stream)
+{
+    return sgr_l1_ssim_backward_ex(channels, width, height, img, gt, lambda, scratch, grad_loss, grad_img, nullptr, stream);
+}
+
+int sgr_l1_ssim_backward_ex(int channels, int width, int height, const float* img, const float* gt, float lambda,
+                            const char* scratch, const float* grad_loss, float* grad_img, float* loss_out, void* stream)
 {
     if (channels <= 0 || width <= 0 || height <= 0 || !img || !gt || !scratch || !grad_img) return SGR_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
@@ -335,8 +356,10 @@ int sgr_l1_ssim_backward(int channels, int width, int height, const float* img, 
     const float* ds12 = reinterpret_cast<const float*>(scratch + 2 * plane);
     const int tiles_x = (width + LT - 1) / LT, tiles_y = (height + LT - 1) / LT, n_tiles = tiles_x * tiles_y * channels;
     const float inv_n = (float)(1.0 / ((double)channels * width * height));
-    hipLaunchKernelGGL(k_l1_ssim_bwd, dim3(8 * ((n_tiles + 7) / 8)), dim3(256), 0, s, width, height, tiles_x, tiles_y, n_tiles, img, gt,
-                       make_window(), dm1, ds1, ds12, grad_loss, lambda, inv_n, grad_img);
+    const float2* partial = reinterpret_cast<const float2*>(scratch + 3 * plane);  // (the forward's tiles are 32 x 28)
+    const int n_partial = ((width + LT - 1) / LT) * ((height + LTY - 1) / LTY) * channels;
+    hipLaunchKernelGGL(k_l1_ssim_bwd, dim3(8 * ((n_tiles + 7) / 8) + (loss_out ? 8 : 0)), dim3(256), 0, s, width, height, tiles_x, tiles_y,
+                       n_tiles, img, gt, make_window(), dm1, ds1, ds12, grad_loss, lambda, inv_n, grad_img, partial, n_partial, loss_out);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 

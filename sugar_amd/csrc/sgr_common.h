@@ -173,11 +173,14 @@ void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_star
 void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
                           uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
-                          uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, uint32_t* tile_need_out, float hint_margin,
-                          uint32_t* header_host_dev, hipStream_t s);
+                          uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, const uint32_t* launch_order, hipStream_t s);
+void sgr_launch_blend_fwd_post(int T, const uint32_t* tile_maxc, const uint32_t* tile_walked, uint32_t* header, uint32_t list_cap,
+                               uint32_t* tile_need_out, float hint_margin, uint32_t* header_host_dev, uint32_t* order_scratch,
+                               uint32_t* order_out, hipStream_t s);
 void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const unsigned long long* blk_mask, const uint32_t* blk_nb, const GeomRec* rec, const float* bg,
                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* acc,
-                          const uint32_t* tile_maxc, const uint32_t* header, uint32_t list_cap, uint32_t* tile_order, hipStream_t s);
+                          const uint32_t* tile_maxc, const uint32_t* header, uint32_t list_cap, uint32_t* tile_order, int order_ready,
+                          hipStream_t s);
 // true on the device when the forward that wrote `hdr` must be treated as not having happened
 #define SGR_FORWARD_INVALID(hdr, cap) ((hdr)[SGR_HDR_R] > (cap) || (hdr)[SGR_HDR_HINT_MISS] != 0u || (hdr)[4 + SGR_B2_HDR_OVERFLOW] != 0u)

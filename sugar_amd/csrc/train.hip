@@ -121,20 +121,24 @@ int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* v, int phases, const 
         fo.tile_need_out = v->tile_need_out;
         fo.hint_margin = v->hint_margin;
         fo.chunk_grid = v->chunk_grid;
+        fo.tile_order = v->tile_order;
+        fo.tile_order_out = v->tile_order_out;
         const int64_t R = sgr_forward_ex(fixed_alloc, &g, fixed_alloc, &b, fixed_alloc, &i, P, c.D, c.M, c.background, W, H, means3D, shs,
                                          nullptr, opac, scal, 1.0f, rot, nullptr, v->viewmatrix, v->projmatrix, v->campos,
                                          v->tan_fovx, v->tan_fovy, 0, c.image, c.radii, 0, stream, &fo);
         if (R < 0) return tfail((int)R, std::string("forward: ") + sgr_last_error());
         t->R = R;
         t->have_forward = true;
-        int rc = sgr_l1_ssim_forward(3, W, H, c.image, v->gt_image, c.lambda_dssim, c.loss_scratch, c.loss_out, stream);
+        // (the loss value comes out of a spare workgroup of the backward kernel)
+        int rc = sgr_l1_ssim_forward(3, W, H, c.image, v->gt_image, c.lambda_dssim, c.loss_scratch, nullptr, stream);
         if (rc < 0) return tfail(rc, "l1_ssim_forward failed");
-        rc = sgr_l1_ssim_backward(3, W, H, c.image, v->gt_image, c.lambda_dssim, c.loss_scratch, nullptr, c.grad_image, stream);
+        rc = sgr_l1_ssim_backward_ex(3, W, H, c.image, v->gt_image, c.lambda_dssim, c.loss_scratch, nullptr, c.grad_image, c.loss_out, stream);
         if (rc < 0) return tfail(rc, "l1_ssim_backward failed");
     }
     if (phases & 3) {
         if (!t->have_forward) return tfail(SGR_E_INVALID, "sgr_trainer_step: backward before any forward");
-        sgr_backward_opts bo = {c.max_radii2D, c.grad_accum, c.denom, c.colors + 3 * (size_t)P};  // (camera centre: the row behind the colours)
+        // (camera centre: the row behind the colours; the launch order: sorted by the forward when the view keeps it)
+        sgr_backward_opts bo = {c.max_radii2D, c.grad_accum, c.denom, c.colors + 3 * (size_t)P, v->tile_order_out ? SGR_BWD_TILE_ORDER_READY : 0};
         // compact SH mode (dL_dsh == NULL), raw-parameter gradients straight into the flat gradient buffer.  Both halves asked
         // for at once (no collective to start in between): ONE pass, the preprocess kernel writes the masked colour gradients
         // itself (the split costs a 23 us kernel of its own)

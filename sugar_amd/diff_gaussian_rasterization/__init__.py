@@ -30,7 +30,8 @@ from .. import _lib
 # sugar_amd.train_step rebuilds the SH gradient summed over all views (sgr_sh_grad_from_views).
 # `grad_sink(binning_capacity=n, header_out=pinned int32[16], header_event=torch.cuda.Event)` selects the sync-free forward
 # (sgr_forward_ex): no host round trip for num_rendered; the caller checks the header (a backward on an invalid forward is a
-# no-op on the device).  `tile_need=` / `tile_need_out=` (int32[tiles] device tensors): the walk hint of sgr_forward_opts.
+# no-op on the device).  `tile_need=` / `tile_need_out=` (int32[tiles] device tensors): the walk hint of sgr_forward_opts;
+# `tile_order=` / `tile_order_out=` (int32[tiles]): its launch order (deepest tiles first, written by the previous visit).
 # `single_level_binning=True`: SGR_FLAG_SINGLE_LEVEL_BINNING.  `dens_stats=(max_radii2D, grad_accum, denom)` (float[P]
 # device tensors): the densification statistics of train.py:111-123 fused into the backward (sgr_backward_opts).
 _GRAD_SINK: dict = {}
@@ -150,11 +151,14 @@ class _CModule:
             if hdr_out is not None and not (hdr_out.is_pinned() and hdr_out.numel() >= 16 and hdr_out.dtype == torch.int32):
                 raise RuntimeError("header_out must be a pinned int32 tensor of 16 elements")
             need, need_out = sink.get("tile_need"), sink.get("tile_need_out")
+            order, order_out = sink.get("tile_order"), sink.get("tile_order_out")
             info = _lib.ForwardInfo()
             opts = _lib.ForwardOpts(capacity, flags, hdr_out.data_ptr() if hdr_out is not None else None, None,
                                     need.data_ptr() if need is not None else None,
                                     need_out.data_ptr() if need_out is not None else None, float(sink.get("hint_margin") or 0.0),
-                                    int(sink.get("chunk_grid") or 0), C.pointer(info))
+                                    int(sink.get("chunk_grid") or 0), C.pointer(info),
+                                    order.data_ptr() if order is not None else None,
+                                    order_out.data_ptr() if order_out is not None else None)
             rendered = lib.sgr_forward_ex(
                 scratch.cb("geom"), None, scratch.cb("binning"), None, scratch.cb("img"), None,
                 P, int(degree), int(M), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
@@ -219,11 +223,15 @@ class _CModule:
                 on_colors = grad_out.get("on_colors") if (compact_sh and grad_out) else None
                 stats = grad_out.get("dens_stats") if grad_out else None
                 bopts = None
+                # (the forward of this call sorted the tiles when it was given tile_order_out: no second sort)
+                bflags = _lib.SGR_BWD_TILE_ORDER_READY if (grad_out and grad_out.get("tile_order_out") is not None) else 0
                 if stats is not None:
                     for st in stats:
                         if not (st.is_cuda and st.dtype == torch.float32 and st.numel() == P and st.is_contiguous()):
                             raise RuntimeError("dens_stats: three contiguous float32 device tensors of P elements")
-                    bopts = C.byref(_lib.BackwardOpts(*[st.data_ptr() for st in stats], None))
+                    bopts = C.byref(_lib.BackwardOpts(*[st.data_ptr() for st in stats], None, bflags))
+                elif bflags:
+                    bopts = C.byref(_lib.BackwardOpts(None, None, None, None, bflags))
                 if on_colors is not None:
                     # two halves: the masked colour gradients are final after the blend half, so the caller can start
                     # exchanging them while the preprocess half runs

@@ -549,7 +549,8 @@ class NativeTrainer:
     right behind the forward (the loss and the blend backward are queued by then), before anything is sent."""
 
     def __init__(self, params: GaussianParams, bg, width, height, sh_degree=3, lambda_dssim=0.2, densify_stats=False,
-                 force_collectives=False, walk_hint=True, capacity=None, betas=(0.9, 0.999), eps=1e-15, hint_margin=None):
+                 force_collectives=False, walk_hint=True, capacity=None, betas=(0.9, 0.999), eps=1e-15, hint_margin=None,
+                 launch_order=True):
         import ctypes as C
         from . import _lib
         if not params.flat.is_cuda:
@@ -564,6 +565,7 @@ class NativeTrainer:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.exchange = self.world > 1 or (bool(force_collectives) and dist.is_available() and dist.is_initialized())
         self.walk_hint = bool(walk_hint)
+        self.launch_order = bool(launch_order)  # sgr_forward_opts.tile_order: the blend kernels start with the deepest tiles
         import os as _os
         # measured on the metric scene while Adam's first steps move it (bench.py, 600 steps): margin 0.25 -> 24 forwards
         # repeated, 0.5 -> 13, 1.0 -> 4; list-write pass 57 -> 37 us at 0.5 (a wider margin skips less)
@@ -626,19 +628,25 @@ class NativeTrainer:
         import time as _time
         _t0 = _time.perf_counter()
         C, L = self._C, self._L
-        need = need_out = None
+        need = need_out = order = order_out = None
         if phases & 1:
             ent = self._hints.get(key)
-            if ent is None:  # per camera: [walk hint, hint usable, level-2 chunks of the last validated visit]
-                ent = self._hints[key] = [torch.zeros(self.T, dtype=torch.int32, device=self.dev), False, 0]
+            if ent is None:  # per camera: [walk hint, hint usable, level-2 chunks of the last validated visit, launch order, order usable]
+                ent = self._hints[key] = [torch.zeros(self.T, dtype=torch.int32, device=self.dev), False, 0,
+                                          torch.zeros(self.T, dtype=torch.int32, device=self.dev), False]
             if self.walk_hint:
                 # (usable once a forward that wrote it was validated, and not while the hints are paused)
                 need = ent[0].data_ptr() if (ent[1] and use_hint and self._calls >= self._hint_pause_until) else None
                 need_out = ent[0].data_ptr()
+            if self.launch_order:
+                # deepest tiles first, as the camera's previous validated visit sorted them (an invalid forward leaves the buffer
+                # as it was); the same sort serves this step's backward
+                order = ent[3].data_ptr() if ent[4] else None
+                order_out = ent[3].data_ptr()
             self._last_hinted = need is not None
             self._calls += 1
         view = L.TrainView(cam.viewmatrix.data_ptr(), cam.projmatrix.data_ptr(), cam.campos.data_ptr(), cam.tanfovx, cam.tanfovy,
-                           gt.data_ptr(), need, need_out, self.hint_margin, self._chunk_grid(key))
+                           gt.data_ptr(), need, need_out, self.hint_margin, self._chunk_grid(key), order, order_out)
         with torch.cuda.device(self.dev):
             rc = self._lib.sgr_trainer_step(self._h, C.byref(view), phases, C.byref(ex) if ex is not None else None,
                                             C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream))
@@ -694,6 +702,7 @@ class NativeTrainer:
                 if key in self._hints:
                     self._hints[key][1] = True
                     self._hints[key][2] = self._last_chunks
+                    self._hints[key][4] = True
                 self._hint_feedback(False)
                 self._pending = None
                 return
@@ -724,6 +733,7 @@ class NativeTrainer:
                 if key in self._hints:
                     self._hints[key][1] = True
                     self._hints[key][2] = self._last_chunks
+                    self._hints[key][4] = True
                 self._hint_feedback(False)
                 break
             if not (R or missed):

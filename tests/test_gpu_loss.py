@@ -41,6 +41,32 @@ def test_fused_loss_matches_torch_restatement(shape):
     assert float((ga - gb).abs().max()) < 1e-4 * float(gb.abs().max()) + 1e-12
 
 
+@pytest.mark.parametrize("shape", [(3, 1080, 1920), (3, 37, 61)])
+def test_loss_value_out_of_the_backward_kernel(shape):
+    """sgr_l1_ssim_forward(loss_out = NULL) + sgr_l1_ssim_backward_ex(loss_out): the value a spare workgroup of the backward kernel
+    reduces equals the stand-alone finishing kernel's, and the gradient is the same array (the train step's call sequence)."""
+    import ctypes as C
+    from sugar_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    Cn, H, W = shape
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(*shape, generator=g).to(dev)
+    gt = (img.cpu() + 0.2 * torch.randn(*shape, generator=g)).clamp(0, 1).to(dev)
+    scratch = torch.empty(lib.sgr_l1_ssim_scratch_bytes(Cn, W, H), dtype=torch.uint8, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    la, lb = torch.zeros(3, device=dev), torch.full((3,), -1.0, device=dev)
+    ga, gb = torch.empty_like(img), torch.empty_like(img)
+    assert lib.sgr_l1_ssim_forward(Cn, W, H, p(img), p(gt), 0.2, p(scratch), p(la), stream) == 0
+    assert lib.sgr_l1_ssim_backward(Cn, W, H, p(img), p(gt), 0.2, p(scratch), None, p(ga), stream) == 0
+    assert lib.sgr_l1_ssim_forward(Cn, W, H, p(img), p(gt), 0.2, p(scratch), None, stream) == 0
+    assert lib.sgr_l1_ssim_backward_ex(Cn, W, H, p(img), p(gt), 0.2, p(scratch), None, p(gb), p(lb), stream) == 0
+    torch.cuda.synchronize(dev)
+    assert torch.equal(la, lb) and float(la[0]) > 0
+    assert torch.equal(ga, gb)
+
+
 def test_flat_adam_matches_torch_adam():
     """sugar_amd/csrc/adam.hip vs torch.optim.Adam with the reference's six groups (gaussian_model.py:152-166)."""
     from sugar_amd import synthetic as syn

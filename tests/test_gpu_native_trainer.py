@@ -130,6 +130,49 @@ def test_walk_hint_leaves_ranges_and_the_walked_prefix_bit_identical():
     assert int(hdr[8 + 3]) != 0
 
 
+def test_launch_order_is_a_permutation_deepest_first_and_does_not_change_the_result():
+    """sgr_forward_opts.tile_order / tile_order_out: the order written by a forward is a permutation of the tiles sorted by the
+    depth of their deepest contributor (1024 classes), a forward launched in that order returns the same image bit for bit, and
+    a backward told that the order is ready (SGR_BWD_TILE_ORDER_READY) returns the gradients of one that sorts itself."""
+    from sugar_amd import _lib
+    from sugar_amd.diff_gaussian_rasterization import _C, grad_sink
+    from tests import parity_utils as pu
+    lib = _lib.load()
+    dev = torch.device(DEV)
+    scene = syn.make_scene(150000, 21, 0.004, 0.05)
+    W, H = 1000, 600
+    cam = syn.orbit_cameras(W, H)[3]
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    g = np.random.default_rng(1).standard_normal((3, H, W)).astype(np.float32)
+    order = torch.zeros(T, dtype=torch.int32, device=dev)
+    a = pu.run_hip(scene, cam, bg, grad_out=g)
+    with grad_sink(tile_order_out=order):
+        b = pu.run_hip(scene, cam, bg, grad_out=g)          # sorts in the forward, the backward reuses it
+    off = lib.sgr_img_tile_maxc_offset(W, H)
+    o = order.cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.sort(o), np.arange(T))
+    # (tile_maxc of the forward is gone -- its array holds the backward's order -- so the depth comes from n_contrib)
+    depth = b["n_contrib"].reshape(H, W)
+    per_tile = np.zeros(T, dtype=np.int64)
+    gx = (W + 15) // 16
+    for ty in range((H + 15) // 16):
+        for tx in range(gx):
+            per_tile[ty * gx + tx] = depth[16 * ty: 16 * ty + 16, 16 * tx: 16 * tx + 16].max()
+    mc = int(np.diff(a["tile_start"].astype(np.int64)).max())
+    shift = max(mc.bit_length() - 10, 0) if mc >= 1024 else 0
+    cls = per_tile[o] >> shift
+    assert np.all(np.diff(cls) <= 0), "not sorted by depth class, deepest first"
+    assert np.array_equal(a["color"], b["color"])
+    with grad_sink(tile_order=order, tile_order_out=order):   # in place: launched in the order of the previous visit
+        c = pu.run_hip(scene, cam, bg, grad_out=g)
+    assert np.array_equal(a["color"], c["color"]) and np.array_equal(a["n_contrib"], c["n_contrib"])
+    assert np.array_equal(np.sort(order.cpu().numpy()), np.arange(T))
+    for k in a["grads"]:
+        assert pu.rel_stats(b["grads"][k], a["grads"][k])["norm_rel"] < 2e-5, k   # (atomic summation order differs)
+        assert pu.rel_stats(c["grads"][k], a["grads"][k])["norm_rel"] < 2e-5, k
+
+
 def test_fused_densification_statistics():
     """sgr_backward_opts against the reference's own bookkeeping (gaussian_splatting/train.py:111-123,
     scene/gaussian_model.py:405-407) applied to the gradients the plain API returns"""
