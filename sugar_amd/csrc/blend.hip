@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
 // alpha or of the colour term has to be carried.  Same operations on the same values: bit-identical sums.
 // (Measured, same box: the walk is bound by the latency of this dependent chain at the 3 waves per SIMD the LDS footprint allows,
 // not by instruction issue -- removing 2.5 of 30 instructions that sit beside the chain changed the kernel by < 1 %, zeroing the
-// panel row with a second LDS write instead of the two v_mov cost 1.5 %.)
+// panel row with a second LDS write instead of the two v_mov cost 1.5 % there and 5 % at the 5 waves per SIMD of the 8-row groups.)
 #define SGR_BWD_BODY(X, Y, A, B, CZ, OP, R, G_, BL, POS, XY, OFF)                                 \
     "v_sub_f32 " X ", " X ", %[px]\n"                                                             \
     "v_sub_f32 " Y ", " Y ", %[py]\n"                                                             \
