@@ -160,7 +160,11 @@ __global__ void __launch_bounds__(256) k_rs_prepare(int n, const uint32_t* __res
 // launches and two more trips through HBM per pass: 12 dependent launches for a 1M-key sort that moves 50 MB), and publishes
 // its own inclusive sum.  The pairs are permuted into the chunk's order through LDS, and consecutive threads store
 // consecutive slots of every digit's run: coalesced runs instead of one transaction per key.  Stable by construction.
-__global__ void __launch_bounds__(256) k_rs_pass(int n, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+#ifndef RS_WAVES
+#define RS_WAVES 16  // waves per chunk: a chunk's keys are ranked 64 at a time by each wave, a serial chain per wave
+#endif
+#define RS_THREADS (64 * RS_WAVES)
+__global__ void __launch_bounds__(RS_THREADS) k_rs_pass(int n, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                  uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int shift,
                                                  int n_chunks, uint32_t* __restrict__ status, uint32_t* __restrict__ counters,
                                                  const uint2* __restrict__ aux_by_val, uint2* __restrict__ aux_out,
@@ -176,31 +180,31 @@ __global__ void __launch_bounds__(256) k_rs_pass(int n, const uint32_t* __restri
         else aux_out = nullptr;
     }
     const uint32_t kmin = pr.kmin, kmax1 = pr.kmax1;
-    __shared__ uint32_t s_cnt[4][256];   // per-wave digit counts, then per-wave first slot (chunk-local)
+    __shared__ uint32_t s_cnt[RS_WAVES][256];   // per-wave digit counts, then per-wave first slot (chunk-local)
     __shared__ uint32_t s_loc[256];      // chunk-local first slot of every digit
     __shared__ uint32_t s_base[256];     // global first slot of every digit's run for this chunk
-    __shared__ uint32_t s_scan[256];
+    __shared__ uint32_t s_scan[8];
     __shared__ uint32_t s_k[RS_ITEMS], s_v[RS_ITEMS];
     __shared__ int s_chunk;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid == 0) s_chunk = (int)atomicAdd(&counters[4 * 256 + pass], 1u);
-    s_cnt[0][tid] = 0; s_cnt[1][tid] = 0; s_cnt[2][tid] = 0; s_cnt[3][tid] = 0;
+    for (int i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&s_cnt[0][0])[i] = 0u;
     __syncthreads();
     const int chunk = s_chunk;
     const int base = chunk * RS_ITEMS;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    constexpr int G = RS_ITEMS / 256;  // groups of 64 keys per wave
+    constexpr int G = RS_ITEMS / RS_THREADS;  // groups of 64 keys per wave
     uint32_t rk[G], rv[G];
 #pragma unroll
     for (int i = 0; i < G; i++) {
-        const int k = base + wave * (RS_ITEMS / 4) + i * 64 + lane;
+        const int k = base + wave * (RS_ITEMS / RS_WAVES) + i * 64 + lane;
         rk[i] = (k < n) ? keys_in[k] : 0xFFFFFFFFu;
         rv[i] = (k < n) ? (vals_in ? vals_in[k] : (uint32_t)k) : 0u;
     }
     uint32_t lrank[G];  // rank of the key among the keys of ITS WAVE with the same digit
 #pragma unroll
     for (int i = 0; i < G; i++) {
-        const int k = base + wave * (RS_ITEMS / 4) + i * 64 + lane;
+        const int k = base + wave * (RS_ITEMS / RS_WAVES) + i * 64 + lane;
         const bool live = k < n;
         const uint32_t digit = rs_digit(rk[i], kmin, kmax1, shift);
         unsigned long long same = __ballot(live);
@@ -217,17 +221,22 @@ __global__ void __launch_bounds__(256) k_rs_pass(int n, const uint32_t* __restri
         WAVE_FENCE();
     }
     __syncthreads();
-    {   // thread d: digit d
-        const uint32_t c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid], c3 = s_cnt[3][tid];
-        const uint32_t mine = c0 + c1 + c2 + c3;
-        uint32_t* st = status + (size_t)pass * n_chunks * 256 + tid;  // this pass, digit d: word of chunk k at st[k * 256]
+    // threads 0..255: thread d owns digit d (the first four waves; the others only keep the barriers company)
+    const bool owner = tid < 256;
+    uint32_t mine = 0, tot = 0, i_mine = 0, i_tot = 0;
+    uint32_t* st = status + (size_t)pass * n_chunks * 256 + (owner ? tid : 0);  // this pass, digit d: word of chunk k at st[k * 256]
+    if (owner) {
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; w++) mine += s_cnt[w][tid];
         rs_post(st + (size_t)chunk * 256, mine | (chunk == 0 ? RS_FLAG_P : RS_FLAG_A));
-        const uint32_t tot = counters[pass * 256 + tid];
+        tot = counters[pass * 256 + tid];
         // two exclusive scans over the 256 digits: the chunk's counts (chunk-local starts) and the global totals (run
         // starts): shuffle scans inside the four waves, then the earlier waves' totals (one barrier instead of 32)
-        const uint32_t i_mine = wave_incl_scan(mine), i_tot = wave_incl_scan(tot);
+        i_mine = wave_incl_scan(mine); i_tot = wave_incl_scan(tot);
         if (lane == 63) { s_scan[wave] = i_mine; s_scan[4 + wave] = i_tot; }
-        __syncthreads();
+    }
+    __syncthreads();
+    if (owner) {
         uint32_t loc = i_mine - mine, gbase = i_tot - tot;
 #pragma unroll
         for (int w = 0; w < 3; w++)
@@ -254,12 +263,14 @@ __global__ void __launch_bounds__(256) k_rs_pass(int n, const uint32_t* __restri
         if (chunk != 0) rs_post(st + (size_t)chunk * 256, (prefix + mine) | RS_FLAG_P);
         s_loc[tid] = loc;
         s_base[tid] = gbase + prefix;
-        s_cnt[0][tid] = loc; s_cnt[1][tid] = loc + c0; s_cnt[2][tid] = loc + c0 + c1; s_cnt[3][tid] = loc + c0 + c1 + c2;
+        uint32_t run = loc;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; w++) { const uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < G; i++) {
-        const int k = base + wave * (RS_ITEMS / 4) + i * 64 + lane;
+        const int k = base + wave * (RS_ITEMS / RS_WAVES) + i * 64 + lane;
         if (k < n) {
             const uint32_t digit = rs_digit(rk[i], kmin, kmax1, shift);
             const uint32_t pos = s_cnt[wave][digit] + lrank[i];
@@ -270,7 +281,7 @@ __global__ void __launch_bounds__(256) k_rs_pass(int n, const uint32_t* __restri
     const int live_n = min(RS_ITEMS, n - base);
 #pragma unroll
     for (int i = 0; i < G; i++) {
-        const int j = i * 256 + tid;
+        const int j = i * RS_THREADS + tid;
         if (j < live_n) {
             const uint32_t key = s_k[j], val = s_v[j];
             const uint32_t digit = rs_digit(key, kmin, kmax1, shift);
@@ -563,7 +574,7 @@ void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_
     static const int allow_skip = getenv("SGR_SORT_FOUR_PASSES") ? 0 : 1;  // (development: always run the fourth pass)
     hipLaunchKernelGGL(k_rs_prepare, dim3(chunks), dim3(256), 0, s, P, keys_a, chunks, status, minmax, n_minmax, params, counters, allow_skip);
     for (int pass = 0; pass < 4; pass++)
-        hipLaunchKernelGGL(k_rs_pass, dim3(chunks), dim3(256), 0, s, P, kin[pass], vin[pass], kout[pass], vout[pass], 8 * pass, chunks,
+        hipLaunchKernelGGL(k_rs_pass, dim3(chunks), dim3(RS_THREADS), 0, s, P, kin[pass], vin[pass], kout[pass], vout[pass], 8 * pass, chunks,
                            status, counters, rect_by_id, pass >= 2 ? rects_sorted : (uint2*)nullptr, params, pass, keys_a, vals_a);
     *order_out = vals_a;
 }
