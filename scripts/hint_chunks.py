@@ -26,7 +26,8 @@ n_chunks = int(hdr[5])
 sup_start = img[off[0]: off[0] + 4 * (T1 + 1)].view(np.uint32).astype(np.int64)
 chunk_base = img[off[1]: off[1] + 4 * (T1 + 1)].view(np.uint32).astype(np.int64)
 cnt2 = img[off[2]: off[2] + 4 * 64 * n_chunks].view(np.uint32).reshape(n_chunks, 64).astype(np.int64)
-chunk_sup = img[off[3]: off[3] + 4 * n_chunks].view(np.uint32).astype(np.int64)
+# chunk_info: one uint4 {super-tile, first level-1 entry, entries, -} per chunk (binning2.hip: k_sup_scan)
+chunk_sup = img[off[3]: off[3] + 16 * n_chunks].view(np.uint32).reshape(n_chunks, 4)[:, 0].astype(np.int64)
 need = hint.cpu().numpy().astype(np.int64)
 ts = hp["tile_start"].astype(np.int64)
 print("R1 =", hdr[4], "chunks =", n_chunks, "T1 =", T1)
