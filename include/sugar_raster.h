@@ -141,6 +141,11 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user,
  * overflow).  Both produce bit-identical lists and ranges; the single level needs one LDS counter per tile (at most about
  * 38 000 tiles) and always takes the host round trip. */
 #define SGR_FLAG_SINGLE_LEVEL_BINNING 2
+/* SGR_FLAG_DEFER_POST (used by sgr_trainer_step): the forward stops behind the blend kernel -- launch order, walk hint and the
+ * second header copy are NOT written and header_event is NOT recorded by the call; the caller has them done by the kernel that
+ * follows (the loss forward carries that job in a spare workgroup) and records the event itself.  Needs header_host to be
+ * device-mapped pinned memory; the call fails with SGR_E_INVALID otherwise. */
+#define SGR_FLAG_DEFER_POST 4
 #define SGR_MODE_RAW_PARAMS 4 /* or-ed into the `phase` argument of sgr_backward_phase (phases 0, 1, 2 as before) */
 /* Compact SH mode only (dL_dsh == NULL): the backward skips the SH block altogether -- no read of shs, and dL_dmean3D
  * comes out WITHOUT the term through the view direction; sgr_sh_adam_from_views_ex forms that term. */

@@ -18,6 +18,7 @@
 // 36-byte atomic request into a 64-byte accumulator record instead of the reference's up to 64 x 9 float atomics
 // (backward.cu:523-554).
 #include "sgr_common.h"
+#include "tile_order.h"
 
 namespace {
 
@@ -551,48 +552,9 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
 // Launch order of the backward: tiles by how deep the forward walked them (tile_maxc), deepest first, so that the waves still
 // running when the grid drains are the short ones.  (Workgroups start in index order; with ~2.5 dispatch rounds of waves whose
 // lifetimes spread over an order of magnitude, raster order leaves a quarter of the chip idle at the end.)  One workgroup:
-// a counting sort over 1024 depth classes; ties land in arbitrary order.
-// (behind a forward that keeps the order, the same launch also does k_make_hint's work: tile_walked != NULL)
-__global__ void __launch_bounds__(1024) k_tile_order(int T, const uint32_t* __restrict__ tile_maxc, const uint32_t* __restrict__ header,
-                                                     uint32_t list_cap, uint32_t* __restrict__ order, uint32_t* __restrict__ order_copy,
-                                                     const uint32_t* __restrict__ tile_walked, float margin,
-                                                     uint32_t* __restrict__ need_out, uint32_t* __restrict__ header_host)
-{
-    __shared__ uint32_t s_cls[1024];
-    __shared__ uint32_t s_w[16];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (header_host && tid < 8) header_host[8 + tid] = header[tid];  // (see k_make_hint)
-    if (SGR_FORWARD_INVALID(header, list_cap)) return;
-    if (need_out)
-        for (int i = tid; i < T; i += 1024) {
-            const uint32_t w = tile_walked[i];
-            need_out[i] = w + (uint32_t)((float)w * margin) + 64u;
-        }
-    const uint32_t mc = header[SGR_HDR_MAXCOUNT];
-    const int shift = mc >= 1024u ? (32 - __builtin_clz(mc)) - 10 : 0;  // class = 1023 - (depth >> shift): class 0 = deepest
-    s_cls[tid] = 0u;
-    __syncthreads();
-    for (int i = tid; i < T; i += 1024) atomicAdd(&s_cls[1023u - min(tile_maxc[i] >> shift, 1023u)], 1u);
-    __syncthreads();
-    const uint32_t mine = s_cls[tid];
-    uint32_t incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
-        if (lane >= d) incl += y;
-    }
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    uint32_t before = 0;
-    for (int w = 0; w < wave; w++) before += s_w[w];
-    s_cls[tid] = before + incl - mine;  // first slot of the class
-    __syncthreads();
-    for (int i = tid; i < T; i += 1024) {
-        const uint32_t slot = atomicAdd(&s_cls[1023u - min(tile_maxc[i] >> shift, 1023u)], 1u);
-        order[slot] = (uint32_t)i;
-        if (order_copy) order_copy[slot] = (uint32_t)i;  // (sgr_forward_opts.tile_order_out; may alias the forward's tile_order: it is done)
-    }
-}
+// the job of tile_order.h (behind a forward that keeps the order it also writes the walk hint and the host's header copy;
+// in the train step the same job rides in the loss kernel instead, csrc/loss.hip).
+__global__ void __launch_bounds__(1024) k_tile_order(SgrTileOrderJob job) { sgr_tile_order_block<1024>(job); }
 
 // walk hint for the next visit of this camera: what the tile walked now, plus a margin, plus one batch
 __global__ void __launch_bounds__(256) k_make_hint(int T, const uint32_t* __restrict__ tile_walked, const uint32_t* __restrict__ header,
@@ -626,8 +588,9 @@ void sgr_launch_blend_fwd_post(int T, const uint32_t* tile_maxc, const uint32_t*
                                uint32_t* order_out, hipStream_t s)
 {
     if (order_out) {
-        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, T, tile_maxc, header, list_cap, order_scratch, order_out, tile_walked,
-                           hint_margin > 0.f ? hint_margin : 0.25f, tile_need_out, header_host_dev);
+        SgrTileOrderJob job = {T, list_cap, tile_maxc, tile_need_out ? tile_walked : nullptr, header, order_scratch, order_out, tile_need_out,
+                               header_host_dev, hint_margin > 0.f ? hint_margin : 0.25f};
+        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, job);
         return;
     }
     if (tile_need_out || header_host_dev)
@@ -644,8 +607,10 @@ void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
     const int T = gx * gy;
     if (order_ready) {}                           // (the forward sorted: sgr_forward_opts.tile_order_out)
     else if (4 * T < 8192) tile_order = nullptr;  // (fewer waves than the chip holds at once: nothing to order)
-    else hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, T, tile_maxc, header, list_cap, tile_order, (uint32_t*)nullptr,
-                            (const uint32_t*)nullptr, 0.f, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    else {
+        SgrTileOrderJob job = {T, list_cap, tile_maxc, nullptr, header, tile_order, nullptr, nullptr, nullptr, 0.f};
+        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, job);
+    }
     hipLaunchKernelGGL(k_blend_bwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, blk_mask, blk_nb, rec,
                        bg, final_T, n_contrib, dL_dpix, acc, tile_order, header, list_cap);
 }

@@ -4,6 +4,7 @@
 // (DGR/cuda_rasterizer/rasterizer_impl.cu:141-153, 198-336, 340-434) on a caller-supplied HIP stream.
 #include "../../include/sugar_raster.h"
 #include "sgr_common.h"
+#include "tile_order.h"
 
 #include <mutex>
 #include <string>
@@ -291,6 +292,11 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
                              tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, (uint32_t)R, opts->tile_need,
                              opts->tile_order, s);
     }
+    if (flags & SGR_FLAG_DEFER_POST) {  // (the caller's next kernel carries the post-blend job: sgr_forward_post_job)
+        if (opts->header_host && !hh_dev) return fail(SGR_E_INVALID, "SGR_FLAG_DEFER_POST needs a device-mapped header_host");
+        STAGE_CHECK("blend_fwd");
+        return R;
+    }
     sgr_launch_blend_fwd_post(IL.T, tile_maxc, tile_walked, header, (uint32_t)R, opts->tile_need_out, opts->hint_margin, hh_dev,
                               tile_cursor, opts->tile_order_out, s);
     STAGE_CHECK("blend_fwd");
@@ -315,6 +321,26 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn binni
 
 // phase 0: everything; 1: the blend half (accumulator reset, blend backward, and in compact mode the masked colour
 // gradients into dL_dcolor); 2: the preprocess half (in compact mode dL_dcolor is left alone: phase 1 wrote it)
+// The post-blend bookkeeping of a forward run with SGR_FLAG_DEFER_POST, as a job for another kernel (tile_order.h)
+int sgr_forward_post_job(int width, int height, char* img_buffer, int64_t R, const sgr_forward_opts* opts, SgrTileOrderJob* job)
+{
+    if (!img_buffer || !opts || !job) return SGR_E_INVALID;
+    const ImgLayout IL = sgr_img_layout(width, height);
+    uint32_t* hh_dev = nullptr;
+    if (opts->header_host && hipHostGetDevicePointer(reinterpret_cast<void**>(&hh_dev), opts->header_host, 0) != hipSuccess) return SGR_E_INVALID;
+    job->T = IL.T;
+    job->list_cap = (uint32_t)(R > 0xFFFFFFFFll ? 0xFFFFFFFFll : R);
+    job->tile_maxc = reinterpret_cast<const uint32_t*>(img_buffer + IL.tile_maxc);
+    job->tile_walked = opts->tile_need_out ? reinterpret_cast<const uint32_t*>(img_buffer + IL.tile_walked) : nullptr;
+    job->header = reinterpret_cast<const uint32_t*>(img_buffer + IL.header);
+    job->order = reinterpret_cast<uint32_t*>(img_buffer + IL.tile_cursor);
+    job->order_copy = opts->tile_order_out;
+    job->need_out = opts->tile_need_out;
+    job->header_host = hh_dev;
+    job->margin = opts->hint_margin > 0.f ? opts->hint_margin : 0.25f;
+    return 0;
+}
+
 static int backward_impl(int phase, int P, int D, int M, int64_t R, const float* background, int width, int height,
                          const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
                          float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,

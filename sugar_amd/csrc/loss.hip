@@ -14,6 +14,7 @@
 // HBM traffic: x, y read twice, three partial maps written and read once: ~9 floats per pixel-channel in total.
 #include "../../include/sugar_raster.h"
 #include "sgr_common.h"
+#include "tile_order.h"
 
 namespace {
 
@@ -31,10 +32,13 @@ struct Win { float w[11]; };
 // an L2 and every tile fetches its whole halo from the fabric (rocprofv3 FETCH_SIZE: 2.2x the image bytes in the forward, 1.7x
 // the maps in the backward).  Here XCD k takes the k-th eighth of the (channel, row, column) tile order instead, so that the
 // tiles it works on at about the same time are neighbours.  Returns false for the padding workgroups.
-__device__ __forceinline__ bool xcd_tile(int tiles_x, int tiles_y, int n_tiles, int& tile, int& c, int& ty, int& tx)
+// `lead` = 8 when the grid starts with eight extra workgroups (the first of them carries a side job: dispatched first, it is
+// done long before the tiles are -- as the LAST workgroup of the grid it ran alone after them and its 10 us showed in the step).
+__device__ __forceinline__ bool xcd_tile(int tiles_x, int tiles_y, int n_tiles, int& tile, int& c, int& ty, int& tx, int lead = 0)
 {
     const int per = (n_tiles + 7) >> 3;
-    const int b = blockIdx.x, j = b >> 3;
+    const int b = (int)blockIdx.x - lead, j = b >> 3;
+    if (b < 0) return false;
     tile = (b & 7) * per + j;
     if (j >= per || tile >= n_tiles) return false;
     c = tile / (tiles_x * tiles_y);
@@ -65,7 +69,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(256, 4) k_l1_ssim_fwd(int W, int H, int tiles_x, int tiles_y, int n_tiles, const float* __restrict__ X,
                                                              const float* __restrict__ Y, Win win, float* __restrict__ dm1,
                                                              float* __restrict__ ds1, float* __restrict__ ds12,
-                                                             float2* __restrict__ partial)
+                                                             float2* __restrict__ partial, SgrTileOrderJob job)
 {
     // row strides in 8-byte units are odd and a wave's lanes walk down rows (horizontal pass) or along a row (vertical
     // pass), so the 16 lanes an LDS cycle serves fall into 16 different bank pairs
@@ -74,7 +78,12 @@ __global__ void __launch_bounds__(256, 4) k_l1_ssim_fwd(int W, int H, int tiles_
     __shared__ f2 hs[LRY][LTP];       //                {E[x^2 + y^2], E[xy]}
     __shared__ float red[2][4];
     int tile, c, tby, tbx;
-    if (!xcd_tile(tiles_x, tiles_y, n_tiles, tile, c, tby, tbx)) return;
+    if (!xcd_tile(tiles_x, tiles_y, n_tiles, tile, c, tby, tbx, job.T > 0 ? 8 : 0)) {
+        // train step: the rasterizer's post-blend bookkeeping (launch order, walk hint, header copy: tile_order.h) rides in a spare
+        // workgroup of this kernel -- the grid then starts with eight workgroups more than tiles need
+        if (job.T > 0 && blockIdx.x == 0) sgr_tile_order_block<256>(job);
+        return;
+    }
     const size_t plane = (size_t)c * W * H;
     const int x0 = tbx * LT, y0 = tby * LTY;
     const int tid = threadIdx.x;
@@ -217,9 +226,9 @@ __global__ void __launch_bounds__(256) k_l1_ssim_bwd(int W, int H, int tiles_x, 
     __shared__ f2 hp[LR][LTP];
     __shared__ float hq[LR][LTP];
     int tile, c, tby, tbx;
-    if (!xcd_tile(tiles_x, tiles_y, n_tiles, tile, c, tby, tbx)) {
-        // (loss != NULL: the grid has eight workgroups more than tiles need; the last one reduces the forward's partials)
-        if (loss && blockIdx.x == gridDim.x - 1) l1_ssim_finish<256>(partial, n_partial, 1.0 / (double)inv_n, lambda, loss);
+    if (!xcd_tile(tiles_x, tiles_y, n_tiles, tile, c, tby, tbx, loss ? 8 : 0)) {
+        // (loss != NULL: the grid starts with eight workgroups more than tiles need; the first one reduces the forward's partials)
+        if (loss && blockIdx.x == 0) l1_ssim_finish<256>(partial, n_partial, 1.0 / (double)inv_n, lambda, loss);
         return;
     }
     const size_t plane = (size_t)c * W * H;
@@ -323,6 +332,13 @@ size_t sgr_l1_ssim_scratch_bytes(int channels, int width, int height)
 int sgr_l1_ssim_forward(int channels, int width, int height, const float* img, const float* gt, float lambda,
                         char* scratch, float* loss_out, void* stream)
 {
+    return sgr_l1_ssim_forward_job(channels, width, height, img, gt, lambda, scratch, loss_out, nullptr, stream);
+}
+
+// (internal, sgr_common.h: the forward with the rasterizer's post-blend job on board)
+int sgr_l1_ssim_forward_job(int channels, int width, int height, const float* img, const float* gt, float lambda,
+                            char* scratch, float* loss_out, const SgrTileOrderJob* job, void* stream)
+{
     if (channels <= 0 || width <= 0 || height <= 0 || !img || !gt || !scratch) return SGR_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const size_t plane = sgr_align((size_t)channels * width * height * 4);
@@ -331,8 +347,10 @@ int sgr_l1_ssim_forward(int channels, int width, int height, const float* img, c
     float* ds12 = reinterpret_cast<float*>(scratch + 2 * plane);
     float2* partial = reinterpret_cast<float2*>(scratch + 3 * plane);
     const int tiles_x = (width + LT - 1) / LT, tiles_y = (height + LTY - 1) / LTY, n_tiles = tiles_x * tiles_y * channels;
-    hipLaunchKernelGGL(k_l1_ssim_fwd, dim3(8 * ((n_tiles + 7) / 8)), dim3(256), 0, s, width, height, tiles_x, tiles_y, n_tiles, img, gt,
-                       make_window(), dm1, ds1, ds12, partial);
+    SgrTileOrderJob none = {};
+    const bool ride = job && job->T > 0;
+    hipLaunchKernelGGL(k_l1_ssim_fwd, dim3(8 * ((n_tiles + 7) / 8) + (ride ? 8 : 0)), dim3(256), 0, s, width, height, tiles_x, tiles_y, n_tiles,
+                       img, gt, make_window(), dm1, ds1, ds12, partial, ride ? *job : none);
     if (loss_out)  // (NULL: the caller asks sgr_l1_ssim_backward_ex for the value)
         hipLaunchKernelGGL(k_l1_ssim_finish, dim3(1), dim3(1024), 0, s, partial, n_tiles, (double)channels * width * height, lambda,
                            loss_out);

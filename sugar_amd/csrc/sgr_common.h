@@ -182,5 +182,11 @@ void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* acc,
                           const uint32_t* tile_maxc, const uint32_t* header, uint32_t list_cap, uint32_t* tile_order, int order_ready,
                           hipStream_t s);
+// the post-blend bookkeeping as a job another kernel can carry (tile_order.h); capi.hip fills it for a forward that was run with
+// SGR_FLAG_DEFER_POST, loss.hip's forward kernel executes it in a spare workgroup
+struct SgrTileOrderJob;
+extern "C" int sgr_l1_ssim_forward_job(int channels, int width, int height, const float* img, const float* gt, float lambda, char* scratch,
+                                       float* loss_out, const SgrTileOrderJob* job, void* stream);
+extern "C" int sgr_forward_post_job(int width, int height, char* img_buffer, int64_t R, const sgr_forward_opts* opts, SgrTileOrderJob* job);
 // true on the device when the forward that wrote `hdr` must be treated as not having happened
 #define SGR_FORWARD_INVALID(hdr, cap) ((hdr)[SGR_HDR_R] > (cap) || (hdr)[SGR_HDR_HINT_MISS] != 0u || (hdr)[4 + SGR_B2_HDR_OVERFLOW] != 0u)

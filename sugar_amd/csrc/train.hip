@@ -8,6 +8,7 @@
 // ahead of the GPU at 1.29 ms per step).
 #include "../../include/sugar_raster.h"
 #include "sgr_common.h"
+#include "tile_order.h"
 
 #include <cmath>
 #include <cstring>
@@ -116,7 +117,10 @@ int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* v, int phases, const 
         fo.binning_capacity = c.binning_capacity;
         fo.flags = SGR_FLAG_RAW_PARAMS;
         fo.header_host = c.header_host;
-        fo.header_event = t->hdr_event;
+        // the post-blend bookkeeping (launch order, walk hint, second header copy) rides in the loss forward kernel, which is what
+        // follows the blend here; the event for the host is recorded behind it
+        fo.flags |= SGR_FLAG_DEFER_POST;
+        fo.header_event = nullptr;
         fo.tile_need = v->tile_need;
         fo.tile_need_out = v->tile_need_out;
         fo.hint_margin = v->hint_margin;
@@ -129,16 +133,20 @@ int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* v, int phases, const 
         if (R < 0) return tfail((int)R, std::string("forward: ") + sgr_last_error());
         t->R = R;
         t->have_forward = true;
+        SgrTileOrderJob job;
+        int rc = sgr_forward_post_job(W, H, c.img, R, &fo, &job);
+        if (rc < 0) return tfail(rc, "sgr_forward_post_job failed");
         // (the loss value comes out of a spare workgroup of the backward kernel)
-        int rc = sgr_l1_ssim_forward(3, W, H, c.image, v->gt_image, c.lambda_dssim, c.loss_scratch, nullptr, stream);
+        rc = sgr_l1_ssim_forward_job(3, W, H, c.image, v->gt_image, c.lambda_dssim, c.loss_scratch, nullptr, &job, stream);
         if (rc < 0) return tfail(rc, "l1_ssim_forward failed");
+        if (hipEventRecord(t->hdr_event, s) != hipSuccess) return tfail(SGR_E_HIP, "hipEventRecord failed");
         rc = sgr_l1_ssim_backward_ex(3, W, H, c.image, v->gt_image, c.lambda_dssim, c.loss_scratch, nullptr, c.grad_image, c.loss_out, stream);
         if (rc < 0) return tfail(rc, "l1_ssim_backward failed");
     }
     if (phases & 3) {
         if (!t->have_forward) return tfail(SGR_E_INVALID, "sgr_trainer_step: backward before any forward");
-        // (camera centre: the row behind the colours; the launch order: sorted by the forward when the view keeps it)
-        sgr_backward_opts bo = {c.max_radii2D, c.grad_accum, c.denom, c.colors + 3 * (size_t)P, v->tile_order_out ? SGR_BWD_TILE_ORDER_READY : 0};
+        // (camera centre: the row behind the colours; the launch order: sorted by the job that rode in the loss kernel)
+        sgr_backward_opts bo = {c.max_radii2D, c.grad_accum, c.denom, c.colors + 3 * (size_t)P, SGR_BWD_TILE_ORDER_READY};
         // compact SH mode (dL_dsh == NULL), raw-parameter gradients straight into the flat gradient buffer.  Both halves asked
         // for at once (no collective to start in between): ONE pass, the preprocess kernel writes the masked colour gradients
         // itself (the split costs a 23 us kernel of its own)
