@@ -11,6 +11,7 @@
 #include "tile_order.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -30,6 +31,7 @@ struct sgr_trainer {
     sgr_train_config c;
     hipEvent_t hdr_event = nullptr;
     bool have_forward = false;
+    bool defer_post = false;    // the post-blend bookkeeping rides in the loss forward kernel (needs a device-mapped header_host)
     int64_t R = 0;              // what the last forward returned (= the capacity)
     long long seg_begin[4], seg_end[4];
     float seg_lr[4];
@@ -66,6 +68,13 @@ sgr_trainer* sgr_trainer_create(const sgr_train_config* cfg)
     const float lr[4] = {c.lr_xyz, c.lr_opacity, c.lr_scaling, c.lr_rotation};
     for (int k = 0; k < 4; k++) { t->seg_begin[k] = b[k]; t->seg_end[k] = b[k] + n[k]; t->seg_lr[k] = lr[k]; t->seg_one[k] = 1; }
     std::memset(c.header_host, 0, 64);
+    {
+        // (pinned memory that is not mapped into the device's address space: the forward copies the header with copy commands and
+        // does its own bookkeeping; SGR_TRAINER_NO_DEFER forces that path for a test)
+        void* mapped = nullptr;
+        t->defer_post = hipHostGetDevicePointer(&mapped, c.header_host, 0) == hipSuccess && mapped && !getenv("SGR_TRAINER_NO_DEFER");
+        if (!t->defer_post) (void)hipGetLastError();
+    }
     return t;
 }
 
@@ -119,8 +128,8 @@ int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* v, int phases, const 
         fo.header_host = c.header_host;
         // the post-blend bookkeeping (launch order, walk hint, second header copy) rides in the loss forward kernel, which is what
         // follows the blend here; the event for the host is recorded behind it
-        fo.flags |= SGR_FLAG_DEFER_POST;
-        fo.header_event = nullptr;
+        if (t->defer_post) fo.flags |= SGR_FLAG_DEFER_POST;
+        fo.header_event = t->defer_post ? nullptr : t->hdr_event;
         fo.tile_need = v->tile_need;
         fo.tile_need_out = v->tile_need_out;
         fo.hint_margin = v->hint_margin;
@@ -133,20 +142,22 @@ int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* v, int phases, const 
         if (R < 0) return tfail((int)R, std::string("forward: ") + sgr_last_error());
         t->R = R;
         t->have_forward = true;
-        SgrTileOrderJob job;
-        int rc = sgr_forward_post_job(W, H, c.img, R, &fo, &job);
+        SgrTileOrderJob job = {};
+        int rc = t->defer_post ? sgr_forward_post_job(W, H, c.img, R, &fo, &job) : 0;
         if (rc < 0) return tfail(rc, "sgr_forward_post_job failed");
         // (the loss value comes out of a spare workgroup of the backward kernel)
-        rc = sgr_l1_ssim_forward_job(3, W, H, c.image, v->gt_image, c.lambda_dssim, c.loss_scratch, nullptr, &job, stream);
+        rc = sgr_l1_ssim_forward_job(3, W, H, c.image, v->gt_image, c.lambda_dssim, c.loss_scratch, nullptr, t->defer_post ? &job : nullptr, stream);
         if (rc < 0) return tfail(rc, "l1_ssim_forward failed");
-        if (hipEventRecord(t->hdr_event, s) != hipSuccess) return tfail(SGR_E_HIP, "hipEventRecord failed");
+        if (t->defer_post && hipEventRecord(t->hdr_event, s) != hipSuccess) return tfail(SGR_E_HIP, "hipEventRecord failed");
         rc = sgr_l1_ssim_backward_ex(3, W, H, c.image, v->gt_image, c.lambda_dssim, c.loss_scratch, nullptr, c.grad_image, c.loss_out, stream);
         if (rc < 0) return tfail(rc, "l1_ssim_backward failed");
     }
     if (phases & 3) {
         if (!t->have_forward) return tfail(SGR_E_INVALID, "sgr_trainer_step: backward before any forward");
-        // (camera centre: the row behind the colours; the launch order: sorted by the job that rode in the loss kernel)
-        sgr_backward_opts bo = {c.max_radii2D, c.grad_accum, c.denom, c.colors + 3 * (size_t)P, SGR_BWD_TILE_ORDER_READY};
+        // (camera centre: the row behind the colours; the launch order: sorted by the job that rode in the loss kernel, or by the
+        // forward itself when the view keeps the order)
+        sgr_backward_opts bo = {c.max_radii2D, c.grad_accum, c.denom, c.colors + 3 * (size_t)P,
+                                (t->defer_post || v->tile_order_out) ? SGR_BWD_TILE_ORDER_READY : 0};
         // compact SH mode (dL_dsh == NULL), raw-parameter gradients straight into the flat gradient buffer.  Both halves asked
         // for at once (no collective to start in between): ONE pass, the preprocess kernel writes the masked colour gradients
         // itself (the split costs a 23 us kernel of its own)

@@ -57,6 +57,37 @@ def test_native_step_equals_the_autograd_trainer_and_repairs_itself():
     _close(results["hint"], results["nohint"], start)
 
 
+def test_native_step_without_the_job_in_the_loss_kernel(monkeypatch):
+    """sgr_trainer_step normally lets the loss forward kernel carry the rasterizer's post-blend bookkeeping (launch order, walk hint,
+    second header copy: SGR_FLAG_DEFER_POST).  When the pinned header is not mapped into the device's address space the forward
+    does that itself; SGR_TRAINER_NO_DEFER forces that path: same training, hints and launch orders in use, no repairs."""
+    from sugar_amd.train_step import GaussianParams, NativeTrainer
+    dev = torch.device(DEV)
+    W, H = 400, 240
+    scene = syn.make_scene(30000, 7, 0.01, 0.06)
+    cams = _cams(W, H)
+    gts = [torch.rand(3, H, W, generator=torch.Generator().manual_seed(i)).to(dev) for i in range(8)]
+    flats, losses = [], []
+    for no_defer in (False, True):
+        if no_defer:
+            monkeypatch.setenv("SGR_TRAINER_NO_DEFER", "1")
+        p = GaussianParams(scene, dev)
+        start = p.flat.clone()
+        nt = NativeTrainer(p, torch.zeros(3), W, H)
+        ls = []
+        for i in range(20):
+            loss = nt.step(cams[i % 8], gts[i % 8], cam_key=i % 8)
+            nt.synchronize()
+            ls.append(float(loss))
+        assert nt.redone == 0
+        assert all(ent[1] and ent[4] for ent in nt._hints.values())   # walk hints and launch orders validated and in use
+        for ent in nt._hints.values():
+            assert np.array_equal(np.sort(ent[3].cpu().numpy()), np.arange(nt.T))   # every stored order is a permutation
+        flats.append(p.flat.clone()); losses.append(ls)
+    assert np.allclose(losses[0], losses[1], rtol=2e-4)
+    _close(flats[1], flats[0], start)
+
+
 def test_lagged_validation_skips_and_repeats_an_invalid_step():
     """Without synchronising after every step the validity check lags one step behind; a hint that has become too short
     (forced here) makes that step a no-op on the device and the trainer repeats it before the next one."""
