@@ -87,6 +87,8 @@ void sweep(int n_instr) { for (int w : {1, 2, 3, 4, 6}) rate<MODE>(w, n_instr); 
 int main()
 {
     sweep<DEP1>(48); sweep<DEP2>(48); sweep<DEP4>(48); sweep<DEP8>(48);
-    sweep<EXPDEP1>(48); sweep<EXPDEP2>(48); sweep<RCPDEP1>(48); sweep<CMPMASK>(32); sweep<LDSBCAST>(48);
+    sweep<EXPDEP1>(48); sweep<EXPDEP2>(48); sweep<RCPDEP1>(48);
+    // (the CMPMASK and LDSBCAST modes are kept for reference but not run: the one run of this probe that included them did not
+    // return within two minutes on the GPU box -- profiles/r03_dep_probe.txt ends inside the EXPDEP2 sweep)
     return 0;
 }
