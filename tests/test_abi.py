@@ -44,6 +44,18 @@ def test_ctypes_structs_mirror_the_header():
         assert [f[0] for f in cls._fields_] == _declared_struct(cname), cname
 
 
+def test_python_constants_match_the_header():
+    """every SGR_FLAG_* / SGR_BWD_* constant the Python mirror defines has the header's value"""
+    from sugar_amd import _lib
+    text = open(os.path.join(ROOT, "include", "sugar_raster.h")).read()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+(SGR_[A-Z0-9_]+)\s+\(?(-?\d+)\)?", text)}
+    mirrored = [n for n in dir(_lib) if n.startswith(("SGR_FLAG_", "SGR_BWD_"))]
+    assert len(mirrored) >= 3
+    for n in mirrored:
+        assert n in defs and defs[n] == getattr(_lib, n), n
+    assert defs["SGR_ABI_VERSION"] == _lib.ABI_VERSION
+
+
 def test_library_exports_every_declared_symbol(hip_lib):
     raw = ctypes.CDLL(os.path.join(ROOT, "sugar_amd", "libsugar_raster.so"))
     decl = _declared_functions()
