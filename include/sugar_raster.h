@@ -476,6 +476,31 @@ int sgr_activations_backward(int P, const float* scaling_raw, const float* rotat
                              const float* dL_dscales, const float* dL_drotations, const float* dL_dopacities,
                              float* dL_dscaling_raw, float* dL_drotation_raw, float* dL_dopacity_raw, void* stream);
 
+/* ---- triangle-mesh z-buffer: pytorch3d.renderer.MeshRasterizer's fragments for SuGaR's level-set sampler --------------------
+ * Replaces pytorch3d 0.7.4 `_C.rasterize_meshes` (pytorch3d/csrc/rasterize_meshes/rasterize_meshes.h: RasterizeMeshes(face_verts,
+ * mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size, blur_radius, faces_per_pixel, bin_size,
+ * max_faces_per_bin, perspective_correct, clip_barycentric_coords, cull_backfaces) -> (pix_to_face, zbuf, bary_coords, dists))
+ * for ONE mesh at blur_radius == 0, as reached from sugar_scene/sugar_model.py:1880-1893,1927-1928,1966 (and :1434-1471,
+ * :1661-1698, :2616-2661) and sugar_extractors/coarse_mesh.py:216-225.  pytorch3d is not part of /root/reference (a pinned
+ * dependency, environment.yml:161): the rule is restated from its published sources in oracle/mesh_rasterizer.c.
+ *   face_verts[F,3,3]: per face and vertex (x, y, z): x, y in pytorch3d NDC (+x left, +y up; the SHORTER image side spans
+ *     [-1, 1]), z = view-space depth.  Faces with a vertex at z < 1e-8 do not render (clip them first, as pytorch3d's
+ *     Python-side clip_faces does: sugar_amd/shims/pytorch3d/renderer/mesh/clip.py).
+ *   outputs (row-major [height, width, faces_per_pixel], unfilled slots -1): pix_to_face = index of the face
+ *     (+ face_index_base: pytorch3d numbers faces across the meshes of a batch), zbuf = its interpolated depth; per pixel the
+ *     faces_per_pixel (<= 16) nearest faces whose projection strictly contains the pixel centre, ascending in z, equal z by
+ *     ascending face index.  bary_coords[..,3] and dists (minus the squared NDC distance to the nearest edge) may be NULL.
+ *   blur_radius must be 0 and clip_barycentric_coords false (SGR_E_INVALID otherwise); bin_size / max_faces_per_bin have no
+ *     counterpart: nothing is binned away.
+ *   scratch: sgr_rasterize_meshes_scratch_bytes(F, width, height) bytes of device memory; list_alloc is called once for the
+ *     (tile, face) instance list after ONE host synchronisation (as sgr_forward does for its list).
+ * Returns the number of (16x16 tile, face) instances, or a negative error code. */
+size_t sgr_rasterize_meshes_scratch_bytes(int64_t F, int width, int height);
+int64_t sgr_rasterize_meshes(const float* face_verts, int64_t F, int64_t face_index_base, int width, int height,
+                             float blur_radius, int faces_per_pixel, int perspective_correct, int clip_barycentric_coords,
+                             int cull_backfaces, char* scratch, size_t scratch_bytes, sgr_alloc_fn list_alloc, void* list_user,
+                             int64_t* pix_to_face, float* zbuf, float* bary_coords, float* dists, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

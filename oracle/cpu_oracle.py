@@ -19,8 +19,8 @@ _LIB = None
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "cpu_rasterizer.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, n) for n in ("cpu_rasterizer.c", "mesh_rasterizer.c", "Makefile")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
 

@@ -12,6 +12,21 @@ DGR=/root/reference/gaussian_splatting/submodules/diff-gaussian-rasterization
 KNN=/root/reference/gaussian_splatting/submodules/simple-knn
 OUT="$HERE/../_ref"
 [ -d "$DGR" ] || { echo "[build_ref] $DGR not present (GPU box): using the prebuilt $OUT if any"; exit 0; }
+# The reference's own Python for the path (SuGaR model + vanilla 3DGS model / renderer / losses), staged UNMODIFIED next to the
+# libraries so that the -m gpu tests and `bench.py --reference-loop` can run the reference's classes on the GPU box, where
+# /root/reference does not exist (oracle/_ref/ is git-ignored: nothing of it enters the repository's history).
+stage_py() {
+  local dst="$OUT/pysrc"
+  mkdir -p "$dst/gaussian_splatting"
+  for d in sugar_scene sugar_utils sugar_trainers sugar_extractors; do
+    mkdir -p "$dst/$d"; cp -f /root/reference/$d/*.py "$dst/$d/"
+  done
+  for d in gaussian_renderer scene utils arguments; do
+    mkdir -p "$dst/gaussian_splatting/$d"; cp -f /root/reference/gaussian_splatting/$d/*.py "$dst/gaussian_splatting/$d/"
+  done
+  cp -f /root/reference/gaussian_splatting/train.py "$dst/gaussian_splatting/train.py"
+}
+mkdir -p "$OUT"; stage_py
 STAMP="$OUT/.stamp"
 SIG="$(cat "$DGR"/cuda_rasterizer/*.cu "$DGR"/cuda_rasterizer/*.h "$KNN"/simple_knn.cu "$KNN"/simple_knn.h "$HERE"/ref_capi.cpp "$HERE"/ref_knn_capi.cpp "$HERE"/shim/*.h "$HERE"/build_ref.sh | sha256sum | cut -d' ' -f1)"
 if [ -f "$OUT/libref_rasterizer.so" ] && [ -f "$OUT/libref_simple_knn.so" ] && [ -f "$STAMP" ] && [ "$(cat "$STAMP")" = "$SIG" ]; then exit 0; fi

@@ -26,6 +26,7 @@ SOURCES = {
     "binning2.hip": ["-ffp-contract=off"],
     "blend.hip": ["-fno-slp-vectorize"] + os.environ.get("SGR_BLEND_DEFS", "").split(),  # the auto-formed v_pk_* pairs cost more v_mov shuffles than they save
     "knn.hip": ["-ffp-contract=off"],
+    "mesh_raster.hip": ["-ffp-contract=off"],  # bit-exact with oracle/mesh_rasterizer.c
     "loss.hip": [],
     "adam.hip": [],
     "activations.hip": [],

@@ -86,6 +86,9 @@ struct StageTimer {
 
 }  // namespace
 
+// error reporting for the other translation units (mesh_raster.hip): same thread-local message as sgr_last_error()
+int sgr_fail(int code, const char* msg) { return fail(code, msg ? msg : ""); }
+
 extern "C" {
 
 int sgr_abi_version(void) { return SGR_ABI_VERSION; }

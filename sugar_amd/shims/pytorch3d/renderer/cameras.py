@@ -148,6 +148,16 @@ class FoVPerspectiveCameras:
     def clone(self):
         return self.to(self.device)
 
+    # ---- what MeshRasterizer asks a camera (pytorch3d CamerasBase)
+    def is_perspective(self):
+        return True
+
+    def in_ndc(self):
+        return True
+
+    def get_znear(self):
+        return self.znear
+
     # ---- transforms
     def get_world_to_view_transform(self, **kwargs) -> Transform3d:
         R, T = kwargs.get("R", self.R), kwargs.get("T", self.T)

@@ -104,14 +104,19 @@ def compute_level_surface_points_from_camera_fast(
         n_points_per_pass=2_000_000, density_factor=1., return_pixel_idx=False, return_gaussian_idx=False, return_normals=False,
         compute_flat_normals=False, compute_intersection_for_flat_gaussian=False, use_gaussian_depth=False,
         just_use_depth_as_level=False, _orig=None, _level_set_points=None):
-    """sugar_model.py:1848-2083 on the Gaussian-depth path (`use_gaussian_depth=True`, :1901-1911, :1962-1964): the depth map
-    is a render of the rasterizer with the view-space depth as colour, the pixels are unprojected with the camera, their 16
-    nearest Gaussians come from the k-NN query, and the 21 ray samples x 16 neighbours per pixel, the level crossings and
-    the normals are ONE kernel (the reference materialises [n * 21, 16, 3, 3] tensors in passes of 2M samples).  The
-    mesh-rasterizer path (`use_gaussian_depth=False`) and the flat-Gaussian variants go to the reference's own method."""
+    """sugar_model.py:1848-2083.  The depth map and the front Gaussian of every pixel come from
+      * `use_gaussian_depth=False` (what coarse_mesh.py:26 hard-codes): the splat mesh's nearest-face z-buffer -- the reference's
+        own `splat_mesh` (:695-727) rasterized by `rasterizer` (the stand-in `pytorch3d.renderer.MeshRasterizer` on the HIP
+        z-buffer kernel, sgr_rasterize_meshes), `depth = fragments.zbuf[0, ..., 0]` (:1927-1928), front Gaussian =
+        `pix_to_face // n_triangles_per_gaussian`, neighbours = its row of `knn_idx` (:1966-1968); the view-dependent texture the
+        reference attaches to the mesh first (:1914-1925) is not computed: rasterization does not read it;
+      * `use_gaussian_depth=True` (:1901-1911, :1962-1964): a render of the Gaussian rasterizer with the view-space depth as
+        colour, neighbours from the k-NN query of the unprojected pixel.
+    The pixels are unprojected with the camera, and the 21 ray samples x 16 neighbours per pixel, the level crossings and the
+    normals are ONE kernel (the reference materialises [n * 21, 16, 3, 3] tensors in passes of 2M samples).  The flat-Gaussian
+    variants go to the reference's own method."""
     on_gpu = self.points.is_cuda
-    if _orig is not None and (not use_gaussian_depth or not on_gpu or compute_flat_normals or compute_intersection_for_flat_gaussian
-                              or just_use_depth_as_level):
+    if _orig is not None and (not on_gpu or compute_flat_normals or compute_intersection_for_flat_gaussian or just_use_depth_as_level):
         return _orig(self, nerf_cameras=nerf_cameras, cam_idx=cam_idx, rasterizer=rasterizer, surface_levels=surface_levels,
                      n_surface_points=n_surface_points, primitive_types=primitive_types, triangle_scale=triangle_scale,
                      splat_mesh=splat_mesh, n_points_in_range=n_points_in_range, range_size=range_size,
@@ -120,8 +125,8 @@ def compute_level_surface_points_from_camera_fast(
                      compute_flat_normals=compute_flat_normals,
                      compute_intersection_for_flat_gaussian=compute_intersection_for_flat_gaussian,
                      use_gaussian_depth=use_gaussian_depth, just_use_depth_as_level=just_use_depth_as_level)
-    if not use_gaussian_depth or compute_flat_normals or compute_intersection_for_flat_gaussian or just_use_depth_as_level:
-        raise NotImplementedError("only the Gaussian-depth path is implemented here; the others run the reference's own method")
+    if compute_flat_normals or compute_intersection_for_flat_gaussian or just_use_depth_as_level:
+        raise NotImplementedError("the flat-Gaussian variants run the reference's own method")
     if _level_set_points is None:
         from .field import level_set_points as _level_set_points
     from pytorch3d.transforms import quaternion_apply, quaternion_invert
@@ -134,12 +139,21 @@ def compute_level_surface_points_from_camera_fast(
     p3d_cameras = nerf_cameras.p3d_cameras[cam_idx]
     device = self.points.device
     H, W = self.image_height, self.image_width
-    # splatted depth (:1901-1911)
-    point_depth = p3d_cameras.get_world_to_view_transform().transform_points(self.points)[..., 2:].expand(-1, 3)
-    depth = self.render_image_gaussian_rasterizer(camera_indices=cam_idx, bg_color=torch.Tensor([-1., -1., -1.]).to(device),
-                                                  sh_deg=0, compute_covariance_in_rasterizer=True, return_2d_radii=False,
-                                                  use_same_scale_in_all_directions=False,
-                                                  point_colors=point_depth).contiguous()[..., 0]
+    fragments = None
+    if use_gaussian_depth:  # splatted depth (:1901-1911)
+        point_depth = p3d_cameras.get_world_to_view_transform().transform_points(self.points)[..., 2:].expand(-1, 3)
+        depth = self.render_image_gaussian_rasterizer(camera_indices=cam_idx, bg_color=torch.Tensor([-1., -1., -1.]).to(device),
+                                                      sh_deg=0, compute_covariance_in_rasterizer=True, return_2d_radii=False,
+                                                      use_same_scale_in_all_directions=False,
+                                                      point_colors=point_depth).contiguous()[..., 0]
+    else:                   # nearest face of the splat mesh (:1880-1893, :1912-1928)
+        if rasterizer is None:
+            from pytorch3d.renderer import MeshRasterizer, RasterizationSettings
+            rasterizer = MeshRasterizer(cameras=p3d_cameras, raster_settings=RasterizationSettings(
+                image_size=(H, W), blur_radius=0.0, faces_per_pixel=10, max_faces_per_bin=50_000))
+        mesh = self.splat_mesh(p3d_cameras) if splat_mesh else self.mesh
+        fragments = rasterizer(mesh, cameras=p3d_cameras)
+        depth = fragments.zbuf[0, ..., 0].clone()
     no_depth_mask = depth < 0.
     depth[no_depth_mask] = depth.max() * 1.05
     # back-projection (:1932-1959); the pixel tables of the reference (:1934-1941) as index arithmetic
@@ -156,12 +170,21 @@ def compute_level_surface_points_from_camera_fast(
         ndc_points_idx = torch.arange(n_surface_points, device=device)
     else:
         n_surface_points = min(n_surface_points, ndc_points.shape[1])
-        # (the reference draws this permutation on the CPU, :1955: ~15 ms at 1080p plus the copy; same distribution on the device)
-        ndc_points_idx = torch.randperm(ndc_points.shape[1], device=device)[:n_surface_points]
+        # (drawn on the CPU like the reference, :1955, so that a seeded run picks the same pixels; `device_randperm` of the
+        # class, when set, moves the ~15 ms draw at 1080p to the device)
+        if getattr(self, "_sugar_amd_device_randperm", False):
+            ndc_points_idx = torch.randperm(ndc_points.shape[1], device=device)[:n_surface_points]
+        else:
+            ndc_points_idx = torch.randperm(ndc_points.shape[1])[:n_surface_points].to(device)
         ndc_points = ndc_points[:, ndc_points_idx]
     all_world_points = p3d_cameras.unproject_points(ndc_points, scaled_depth_input=False).view(-1, 3)
-    closest_gaussians_idx = self.get_gaussians_closest_to_samples(all_world_points)                    # :1963 (HIP k-NN)
-    gaussian_idx = closest_gaussians_idx[..., 0]
+    if use_gaussian_depth:
+        closest_gaussians_idx = self.get_gaussians_closest_to_samples(all_world_points)                # :1963 (HIP k-NN)
+        gaussian_idx = closest_gaussians_idx[..., 0]
+    else:                                                                                              # :1966-1968
+        gaussian_idx = fragments.pix_to_face[..., 0].view(-1) // self.n_triangles_per_gaussian
+        gaussian_idx = gaussian_idx[~no_proj_mask][ndc_points_idx.to(device)]
+        closest_gaussians_idx = self.knn_idx[gaussian_idx]
     cam_center = p3d_cameras.get_camera_center()
     gaussian_to_camera = torch.nn.functional.normalize(cam_center - self.points, dim=-1)               # :1971-1972
     gaussian_standard_deviations = (self.scaling * quaternion_apply(quaternion_invert(self.quaternions), gaussian_to_camera)).norm(dim=-1)
