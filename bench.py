@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--no-densify-variant", action="store_true", help="skip the extra timing of the step with dL/dmeans2D + fused densification statistics")
     ap.add_argument("--watchdog-sec", type=int, default=0, help="dump every thread's stack to stderr and exit if the run takes longer than this (0: off at one rank, 900 s with several)")
     ap.add_argument("--host-sync", action="store_true", help="forward with the host round trip for num_rendered (A/B of the sync-free forward)")
+    ap.add_argument("--no-reference-loop", action="store_true", help="skip the untimed legs behind the graded region: the reference's own loop (train.py) on the drop-in rasterizer, the through-API fwd+bwd time, and the same-GPU A/B against the reference's kernels")
+    ap.add_argument("--reference-loop", action="store_true", help="(default behaviour, kept as an explicit switch) run those legs")
+    ap.add_argument("--reference-loop-steps", type=int, default=24)
     args = ap.parse_args()
 
     wd = args.watchdog_sec or (900 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 0)
@@ -321,6 +324,10 @@ def main():
         extras["after_training"] = {"untimed_steps_before": args.drift_steps, "ms_per_step": ms_drift,
                                     "images_per_sec": 1e3 / ms_drift, "num_rendered": trainer.last_num_rendered}
 
+    if world == 1 and not forward_only and not args.no_reference_loop:
+        # release the native trainer's buffers first: the legs below hold a second copy of the model
+        extras.update(unmodified_path_legs(scene, cams, gts, bg_d, dev, args.reference_loop_steps))
+
     if rank == 0:
         K = args.steps
         R_f = float(walked.item()) / n_post
@@ -328,11 +335,26 @@ def main():
         R = rendered / n_post
         alg_bytes = 40.0 * R_f + 20.0 * W * H + 8.0 * T + 12.0  # SURVEY.md section 8d, forward blend
         achieved = alg_bytes / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else 0.0
-        traffic = None
+        # counter-derived figures come from a committed reduction of separate rocprofv3 --pmc passes over THIS command
+        # (scripts/pmc_on_box.sh -> profiles/pmc_blend_fwd.json); they are per workload: another --workload gets null
+        traffic, valu, pmc_src = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_blend_fwd.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                if pj.get("workload_key") == args.workload and args.gaussians is None:
+                    traffic = pj.get("hbm_bytes_per_launch")
+                    pmc_src = pj.get("source")
+                    if pj.get("valu_wave_insts_per_launch") and blend_ms > 0:
+                        n_inst, dt_ns, simds = float(pj["valu_wave_insts_per_launch"]), float(pj["simd_issue_interval_ns"]), 1024
+                        issue_ms = n_inst * dt_ns * 1e-6 / simds
+                        valu = {"kernel": "k_blend_fwd_w", "bound": "valu_issue", "wave_insts_per_launch": n_inst,
+                                "simd_issue_interval_ns": dt_ns, "simds": simds, "issue_ms": issue_ms, "launch_ms": blend_ms,
+                                "frac": issue_ms / blend_ms,
+                                "what": "SQ_INSTS_VALU per launch (committed PMC pass) x the measured interval at which one SIMD "
+                                        "retires wave64 vector instructions (scripts/microbench/valu_rate.hip) / 1024 SIMDs, over "
+                                        "the launch time measured in THIS run: the share of the kernel its vector ALUs are busy",
+                                "source": pj.get("valu_source")}
             except Exception:
                 traffic = None
         out = {
@@ -374,11 +396,15 @@ def main():
             "roofline": {
                 "kernel": "k_blend_fwd_w", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": "profiles/pmc_blend_fwd.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command taken earlier (scripts/r03_on_box.sh -> profiles/r03_pmc_*.txt), NOT measured in this run",
+                "traffic_source": (f"profiles/pmc_blend_fwd.json ({pmc_src}): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
+                                   "command, NOT measured in this run" if traffic is not None else
+                                   "null: no committed PMC reduction for this workload"),
                 "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": blend_ms,
                 "pair_evals_per_s": (256.0 * R_f) / (blend_ms * 1e-3) if blend_ms > 0 else 0.0,
             },
         }
+        if valu is not None:
+            out["roofline_valu"] = valu
         out.update(extras)
         if isinstance(trainer, NativeTrainer):
             out["forwards_repeated"] = {"in_timed_region": marks.get("after_timed", 0) - marks.get("after_warmup", 0),
@@ -438,6 +464,108 @@ class ForwardOnly:
                 self.redone += 1
                 self.capacity = self.last_num_rendered + self.last_num_rendered // 2
         self._forward(cam, self.capacity)
+
+
+def unmodified_path_legs(scene, cams, gts, bg_d, dev, n_steps):
+    """What an UNMODIFIED caller of the reference gets on this GPU, next to the native number (all untimed legs, after the graded
+    region):
+      ms_fwd_bwd_api        SURVEY.md section 8(d): the two `_C` calls only -- `GaussianRasterizer(settings)(...)` and
+                            `color.backward(g)` through the reference-shaped autograd API of this repository -- device events
+                            around each, median over two passes over the cameras;
+      reference_loop        the reference's OWN optimisation loop (gaussian_splatting/train.py:69-128: its render(), l1_loss /
+                            ssim in stock PyTorch, loss.backward(), GaussianModel's torch.optim.Adam) with this repository's
+                            `diff_gaussian_rasterization` underneath (oracle/reference_loop.py; the reference's Python comes from
+                            /root/reference or the staged oracle/_ref/pysrc);
+      vs_reference_same_gpu the reference's own rasterizer kernels (its unmodified .cu sources compiled by hipcc for gfx950 with
+                            the compiler's default contraction, oracle/_ref/libref_rasterizer.so) on the same inputs, forward +
+                            backward, wall clock per call with a synchronise behind each -- against the same wall clock through
+                            this repository's API.  (`vs_baseline` stays null: BASELINE.md holds no published number.)"""
+    from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    out = {}
+    cams_d = [c._replace(viewmatrix=c.viewmatrix.to(dev), projmatrix=c.projmatrix.to(dev), campos=c.campos.to(dev)) for c in cams]
+    H, W = cams[0].image_height, cams[0].image_width
+    leaves = [getattr(scene, k).to(dev).clone().requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")]
+    m2 = torch.zeros_like(leaves[0], requires_grad=True)
+    g = torch.randn(3, H, W, device=dev)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    f_ms, b_ms, f_wall, b_wall = [], [], [], []
+    for it in range(3 * len(cams_d)):
+        cam = cams_d[it % len(cams_d)]
+        st = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, bg_d, 1.0, cam.viewmatrix, cam.projmatrix, 3, cam.campos, False, False)
+        for t in leaves + [m2]:
+            t.grad = None
+        e0, e1, e2 = ev(), ev(), ev()
+        torch.cuda.synchronize(dev); t0 = time.perf_counter()
+        e0.record()
+        color, radii = GaussianRasterizer(st)(leaves[0], m2, leaves[1], shs=leaves[2], scales=leaves[3], rotations=leaves[4])
+        e1.record()
+        torch.cuda.synchronize(dev); t1 = time.perf_counter()
+        color.backward(g)
+        e2.record()
+        torch.cuda.synchronize(dev); t2 = time.perf_counter()
+        if it >= len(cams_d):  # (the first pass warms the allocator)
+            f_ms.append(e0.elapsed_time(e1)); b_ms.append(e1.elapsed_time(e2)); f_wall.append(1e3 * (t1 - t0)); b_wall.append(1e3 * (t2 - t1))
+    med = lambda v: float(np.median(v))
+    out["ms_fwd_bwd_api"] = {"forward": med(f_ms), "backward": med(b_ms), "total": med(f_ms) + med(b_ms),
+                             "wall_clock_forward": med(f_wall), "wall_clock_backward": med(b_wall),
+                             "what": "device events around GaussianRasterizer(settings)(...) and color.backward(g) through the "
+                                     "reference-shaped API (full SH gradient, host round trip for num_rendered, scratch from the "
+                                     "caching allocator); median over 2 passes over the 8 cameras"}
+    del color, radii
+    # ---- the reference's own kernels on the same GPU
+    try:
+        from oracle import ref_gpu
+        if ref_gpu.available():
+            ref_gpu.use("default")
+            rf, rb = [], []
+            with torch.no_grad():
+                for it in range(4):
+                    cam = cams_d[it % len(cams_d)]
+                    torch.cuda.synchronize(dev); t0 = time.perf_counter()
+                    stt = ref_gpu.forward(leaves[0].detach(), leaves[1].detach(), shs=leaves[2].detach(), scales=leaves[3].detach(),
+                                          rotations=leaves[4].detach(), viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix,
+                                          campos=cam.campos, bg=bg_d, W=W, H=H, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy)
+                    t1 = time.perf_counter()
+                    ref_gpu.backward(stt, g)
+                    t2 = time.perf_counter()
+                    if it > 0:
+                        rf.append(1e3 * (t1 - t0)); rb.append(1e3 * (t2 - t1))
+                    del stt
+            mine = med(f_wall) + med(b_wall)
+            out["vs_reference_same_gpu"] = {
+                "ratio": (med(rf) + med(rb)) / mine, "reference_fwd_ms": med(rf), "reference_bwd_ms": med(rb),
+                "this_repo_fwd_ms": med(f_wall), "this_repo_bwd_ms": med(b_wall),
+                "label": "reference sources (DGR/cuda_rasterizer/*.cu, unmodified), hipcc gfx950, same GPU, same inputs, rasterizer "
+                         "forward + backward through each side's API, wall clock with a synchronise behind every call"}
+    except Exception as e:  # the A/B is a side measurement: never take the graded line down with it
+        out["vs_reference_same_gpu"] = {"error": repr(e)}
+    del leaves, m2
+    # ---- the reference's own loop on the drop-in rasterizer
+    try:
+        from oracle import reference_loop as rl
+        if rl.reference_root() is not None:
+            ref = rl.import_reference()
+            opt = rl.optimization_params()
+            gaussians = rl.make_gaussians(ref, scene, dev, opt)
+            loop = rl.Loop(ref, gaussians, [rl.make_viewpoint(c, gt, dev) for c, gt in zip(cams, gts)], bg_d, opt=opt)
+            for _ in range(len(cams)):
+                loop.loop_body()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
+                loss = loop.loop_body()
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / n_steps
+            out["reference_loop"] = {"images_per_sec": 1.0 / dt, "ms_per_step": 1e3 * dt, "steps": n_steps, "final_loss": float(loss),
+                                     "what": "gaussian_splatting/train.py:69-128 with the reference's own render(), l1_loss / ssim "
+                                             "(stock PyTorch convolutions), loss.backward() and GaussianModel's torch.optim.Adam, "
+                                             "`diff_gaussian_rasterization` = this repository's HIP drop-in; same scene, cameras "
+                                             "and target images as the native step", "reference_python": rl.reference_root()}
+            del loop, gaussians
+    except Exception as e:
+        out["reference_loop"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(scene, cam, bg, forward_only=False):

@@ -112,6 +112,18 @@ class _Recorder:
         return image, radii
 
 
+STATE = ("_points", "_scales", "_quaternions", "all_densities", "_sh_coordinates_dc", "_sh_coordinates_rest")
+
+
+def model_state(model):
+    """the model's raw parameters (+ its neighbour table): what a GPU run of the same reference class is loaded with, so that
+    both start from bit-identical parameters (tests/test_gpu_reference_sugar.py)"""
+    st = {"state" + n: getattr(model, n).detach().cpu().numpy().copy() for n in STATE}
+    if getattr(model, "knn_idx", None) is not None:
+        st["state_knn_idx"] = model.knn_idx.cpu().numpy().copy()
+    return st
+
+
 def run():
     """returns {name: np.ndarray}"""
     sm = _import_reference_model()
@@ -137,6 +149,7 @@ def run():
             model._sh_coordinates_rest += 0.15 * torch.randn(P, 15, 3, generator=g)
         wimg = torch.randn(H, W, 3, generator=g)
         out = {"W": np.int32(W), "H": np.int32(H), "dL_dimage_hw3": wimg.numpy()}
+        out.update(model_state(model))
         bgs = [None, torch.tensor([1.0, 1.0, 1.0])]
         for ci, (cam_idx, in_rast) in enumerate(((1, False), (5, True))):
             model.zero_grad(set_to_none=True)
@@ -228,6 +241,7 @@ def run_bound():
             model._sh_coordinates_rest += 0.15 * torch.randn(n, 15, 3, generator=g)
         wimg = torch.randn(H, W, 3, generator=g)
         out = {"W": np.int32(W), "H": np.int32(H), "dL_dimage_hw3": wimg.numpy(), "n_faces": np.int32(len(mesh.triangles))}
+        out.update(model_state(model))
         for ci, (cam_idx, in_rast) in enumerate(((2, False), (6, True))):
             model.zero_grad(set_to_none=True)
             res = model.render_image_gaussian_rasterizer(camera_indices=cam_idx, bg_color=None, sh_deg=3,

@@ -148,3 +148,60 @@ def test_committed_field_fixture_is_what_the_reference_returns(ref):
         else:
             ok = np.isfinite(b)
             np.testing.assert_allclose(a[ok], b[ok], rtol=2e-4, atol=1e-6 * max(1.0, float(np.abs(b[ok]).max())), err_msg=k)
+
+
+def test_level_set_host_logic_on_the_mesh_depth_path_reproduces_the_reference_method(ref):
+    """`use_gaussian_depth=False` (coarse_mesh.py:26): depth and front Gaussian from the splat mesh's z-buffer.  Both sides run the
+    stand-in MeshRasterizer on the CPU oracle backend; the replacement's own host logic (no texture, fragments -> depth ->
+    unprojection -> knn_idx rows) must give the reference method's pixels, Gaussians and points, also for a seeded random subset."""
+    sm, model, _, mf = ref
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_sugar_meshdepth as mm
+    from oracle import sugar_field_torch as restated
+    from sugar_amd import sugar_patch
+    from tests.mesh_backend import oracle_mesh_rasterizer
+
+    def stand_in(world, nbr, cam_center, centers, B, strengths, gstd, surface_levels, n_points_in_range, range_size, density_factor,
+                 return_normals):
+        r = restated.level_set_points(world, nbr, cam_center.reshape(1, 3), centers, B, strengths, gstd, surface_levels,
+                                      n_points_in_range, range_size, density_factor)
+        return {lv: dict(valid=r[lv]["valid"], intersection_points=r[lv]["intersection_points"], normals=r[lv]["normals"]) for lv in r}
+
+    with torch.no_grad(), oracle_mesh_rasterizer():
+        model.primitive_types = 'diamond'
+        model.triangle_scale = 2.
+        model.update_texture_features()
+        rasterizer = mm.make_rasterizer(model)
+        for n in (-1, 500):
+            kw = mm.sampler_kwargs(n)
+            torch.manual_seed(9)
+            a = model.compute_level_surface_points_from_camera_fast(rasterizer=rasterizer, **kw)
+            torch.manual_seed(9)
+            b = sugar_patch.compute_level_surface_points_from_camera_fast(model, rasterizer=rasterizer, _orig=None,
+                                                                          _level_set_points=stand_in, **kw)
+            for lv in mm.LEVELS:
+                assert set(a[lv]) == set(b[lv]) == {"intersection_points", "pixel_idx", "gaussian_idx", "normals"}
+                assert torch.equal(a[lv]["pixel_idx"], b[lv]["pixel_idx"]) and len(a[lv]["pixel_idx"]) > 150
+                assert torch.equal(a[lv]["gaussian_idx"], b[lv]["gaussian_idx"])
+                assert torch.allclose(a[lv]["intersection_points"], b[lv]["intersection_points"], rtol=1e-5, atol=1e-6)
+                assert torch.allclose(a[lv]["normals"], b[lv]["normals"], rtol=1e-4, atol=1e-5)
+        # without a rasterizer argument the replacement builds the one the reference builds (:1880-1893)
+        c = sugar_patch.compute_level_surface_points_from_camera_fast(model, rasterizer=None, _orig=None, _level_set_points=stand_in,
+                                                                      **mm.sampler_kwargs(-1))
+        full = model.compute_level_surface_points_from_camera_fast(rasterizer=None, **mm.sampler_kwargs(-1))
+        assert all(torch.equal(c[lv]["pixel_idx"], full[lv]["pixel_idx"]) for lv in mm.LEVELS)
+
+
+def test_committed_meshdepth_fixture_is_what_the_reference_returns(ref):
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_sugar_meshdepth as mm
+    out = mm.run()
+    gold = np.load(os.path.join(HERE, "golden", "sugar_meshdepth.npz"))
+    assert set(out) == set(gold.files)
+    for k in gold.files:
+        a, b = np.asarray(out[k]), gold[k]
+        assert a.shape == b.shape, k
+        if a.dtype.kind in "iub":
+            assert np.array_equal(a, b), k
+        else:
+            np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-6 * max(1.0, float(np.abs(b).max())), err_msg=k)
