@@ -211,11 +211,17 @@ class _CModule:
             colors = _dev_f32(colors, dev, "colors_precomp"); scales = _dev_f32(scales, dev, "scales")
             rotations = _dev_f32(rotations, dev, "rotations"); sh = _dev_f32(sh, dev, "shs")
             cov3D_precomp = _dev_f32(cov3D_precomp, dev, "cov3D_precomp")
+            # (contiguous copies must stay referenced until the call has been enqueued: SuGaR hands over a TRANSPOSED view matrix,
+            # sugar_model.py:2143-2144 -- a temporary's block would go back to the allocator before its pointer is used)
+            background = _dev_f32(background, dev, "bg")
+            viewmatrix = _dev_f32(viewmatrix, dev, "viewmatrix")
+            projmatrix = _dev_f32(projmatrix, dev, "projmatrix")
+            campos = _dev_f32(campos, dev, "campos")
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream(dev).cuda_stream
                 args = (P, int(degree), int(M), int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
-                        _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix.contiguous()),
-                        _ptr(projmatrix.contiguous()), _ptr(campos.contiguous()), float(tan_fovx), float(tan_fovy), _ptr(radii),
+                        _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
+                        _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii),
                         _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL),
                         _p(dL_dmeans2D), _p(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D),
                         _p(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations), int(bool(debug)),

@@ -115,8 +115,9 @@ class _ScaledRotation(torch.autograd.Function):
         q, s = ctx.saved_tensors
         P, dev = q.shape[0], q.device
         dq, ds = torch.empty_like(q), torch.empty_like(s)
+        g = g.contiguous().float()  # (kept referenced until the call is enqueued: a temporary's block goes back to the allocator at once)
         with torch.cuda.device(dev):
-            rc = lib.sgr_scaled_rotation_backward(P, _p(q), _p(s), ctx.inverse, _p(g.contiguous().float()), _p(dq), _p(ds), _stream(dev))
+            rc = lib.sgr_scaled_rotation_backward(P, _p(q), _p(s), ctx.inverse, _p(g), _p(dq), _p(ds), _stream(dev))
         if rc < 0:
             raise RuntimeError(f"sgr_scaled_rotation_backward failed ({rc})")
         return dq, ds, None

@@ -63,9 +63,10 @@ class _ShToRgb(torch.autograd.Function):
         dsh = torch.empty(P, M, 3, device=dev) if need_sh else None
         dpos = torch.empty(P, 3, device=dev) if (need_pos and pos is not None) else None
         ddir = torch.empty(P, 3, device=dev) if (need_dir and dirs is not None) else None
+        g = g.contiguous().float()  # (kept referenced until the call is enqueued)
         with torch.cuda.device(dev):
             rc = lib.sgr_sh_to_rgb_backward(P, degree, M, _p(sh_rows), _p(pos), _p(cen), 0 if cen is None else cen.shape[0],
-                                            _p(dirs), _p(g.contiguous().float()), _p(dsh), _p(dpos), _p(ddir),
+                                            _p(dirs), _p(g), _p(dsh), _p(dpos), _p(ddir),
                                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         if rc < 0:
             raise RuntimeError(f"sgr_sh_to_rgb_backward failed ({rc})")

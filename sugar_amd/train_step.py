@@ -261,8 +261,9 @@ class FlatAdam:
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             dcol, vstride = _view_rows(dcolor_all)
+            campos_all = campos_all.contiguous()  # (kept referenced until the call is enqueued)
             rc = self._lib.sgr_sh_adam_from_views_ex(
-                p.P, int(dcolor_all.shape[0]), int(sh_degree), p.M, vp(means3D), vp(campos_all.contiguous()),
+                p.P, int(dcolor_all.shape[0]), int(sh_degree), p.M, vp(means3D), vp(campos_all),
                 vp(dcol), int(vstride), C.c_void_p(p.flat.data_ptr() + 4 * off),
                 C.c_void_p(self.exp_avg.data_ptr() + 4 * off), C.c_void_p(self.exp_avg_sq.data_ptr() + 4 * off),
                 p.LRS["features"], p.REST_LR, self.betas[0], self.betas[1], self.eps, self.t, float(grad_scale),
@@ -332,8 +333,9 @@ def sh_grad_from_views(means3D, campos_all, dcolor_all, sh_degree, out):
     dev = means3D.device
     with torch.cuda.device(dev):
         dcol, vstride = _view_rows(dcolor_all)
-        rc = lib.sgr_sh_grad_from_views(P, V, int(sh_degree), M, C.c_void_p(means3D.contiguous().data_ptr()),
-                                        C.c_void_p(campos_all.contiguous().data_ptr()),
+        means3D, campos_all = means3D.contiguous(), campos_all.contiguous()  # (kept referenced until the call is enqueued)
+        rc = lib.sgr_sh_grad_from_views(P, V, int(sh_degree), M, C.c_void_p(means3D.data_ptr()),
+                                        C.c_void_p(campos_all.data_ptr()),
                                         C.c_void_p(dcol.data_ptr()), int(vstride), C.c_void_p(out.data_ptr()),
                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     if rc < 0:

@@ -50,3 +50,34 @@ def test_replay_of_the_sugar_call_site(model, call):
         assert _rel(v.grad.cpu().numpy(), GOLD[key]) < 1e-4, n
         checked += 1
     assert checked >= 5
+
+
+def test_camera_matrices_with_transposed_strides_give_the_same_gradients():
+    """SuGaR hands over `torch.Tensor(...).transpose(0, 1).cuda()` (sugar_model.py:2143-2150): a view matrix whose strides are
+    those of its transpose.  Found in round 4 by running the reference class itself on the GPU: the backward took the pointer of
+    a temporary `.contiguous()` copy whose block had already gone back to the caching allocator -- the covariance gradients
+    (scales, rotations, part of the positions) were wrong by up to 5x while image, colour and opacity gradients were right."""
+    GOLD = GOLDS["free"]
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    pre = "c0_"
+    t = lambda k: torch.tensor(GOLD[pre + k], device=DEV)
+    noncontig = lambda k: torch.tensor(GOLD[pre + k].T.copy()).transpose(0, 1).to(DEV)
+    grads = []
+    for vm, pm in ((t("viewmatrix"), t("projmatrix")), (noncontig("viewmatrix"), noncontig("projmatrix")),
+                   (t("viewmatrix"), noncontig("projmatrix")), (noncontig("viewmatrix"), t("projmatrix"))):
+        settings = GaussianRasterizationSettings(
+            image_height=int(GOLD["H"]), image_width=int(GOLD["W"]), tanfovx=float(GOLD[pre + "tanfov"][0]),
+            tanfovy=float(GOLD[pre + "tanfov"][1]), bg=t("bg"), scale_modifier=1.0, viewmatrix=vm, projmatrix=pm,
+            sh_degree=int(GOLD[pre + "sh_degree"]), campos=t("campos"), prefiltered=False, debug=False)
+        inputs = {n: (t("in_" + n).requires_grad_(True) if pre + "in_" + n in GOLD.files else None)
+                  for n in ("means3D", "means2D", "shs", "colors_precomp", "opacities", "scales", "rotations", "cov3D_precomp")}
+        image, _ = GaussianRasterizer(raster_settings=settings)(**inputs)
+        (image.transpose(0, 1).transpose(1, 2) * torch.tensor(GOLD["dL_dimage_hw3"], device=DEV)).sum().backward()
+        # more work on the same stream right away, as a training loop would do: reuses whatever the call released
+        junk = [torch.randn(16, device=DEV) for _ in range(64)]
+        grads.append({n: v.grad.cpu().numpy() for n, v in inputs.items() if v is not None})
+        del junk
+    for g in grads[1:]:
+        for n in grads[0]:
+            assert _rel(g[n], grads[0][n]) < 2e-5, n
+            assert _rel(g[n], GOLD[pre + "grad_" + n]) < 1e-4, n

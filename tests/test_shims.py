@@ -60,10 +60,16 @@ def test_out_of_scope_classes_import_and_raise(p3d):
         # the camera algebra is functional (sugar_scene/cameras.py:311-324 builds its cameras from it) ...
         K = _get_sfm_calibration_matrix(1, "cpu", torch.tensor([[1.5, 2.0]]), torch.tensor([[0.1, -0.2]]))
         assert K.shape == (1, 4, 4) and float(K[0, 0, 0]) == 1.5 and abs(float(K[0, 1, 2]) + 0.2) < 1e-6 and float(K[0, 3, 2]) == 1.0
-        # ... and the mesh rasterizer can be constructed (SuGaR does so unconditionally, sugar_model.py:1880-1893) but not run
-        r = MeshRasterizer(cameras=None, raster_settings=RasterizationSettings(image_size=(8, 8), faces_per_pixel=10))
-        with pytest.raises(NotImplementedError):
-            r(None)
+        # ... and the mesh rasterizer (SuGaR constructs it unconditionally, sugar_model.py:1880-1893) runs on the HIP z-buffer only:
+        # CPU tensors raise (tests/test_mesh_oracle.py drives its host code on the oracle backend, tests/test_gpu_mesh_raster.py the kernel)
+        from pytorch3d.renderer import FoVPerspectiveCameras
+        from pytorch3d.structures import Meshes
+        r = MeshRasterizer(cameras=FoVPerspectiveCameras(), raster_settings=RasterizationSettings(image_size=(8, 8), faces_per_pixel=10))
+        tri = Meshes(verts=[torch.tensor([[0., 0., 2.], [1., 0., 2.], [0., 1., 2.]])], faces=[torch.tensor([[0, 1, 2]])])
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            r(tri)
+        with pytest.raises(ValueError):
+            MeshRasterizer(cameras=None)(tri)
         from pytorch3d.ops import knn_points
         with pytest.raises(RuntimeError):  # HIP only, no CPU fallback
             knn_points(torch.zeros(1, 10, 3), torch.zeros(1, 10, 3), K=4)
