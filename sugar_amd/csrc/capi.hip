@@ -412,6 +412,8 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
     pb.raw_params = raw_params && !cov3D_precomp;
     pb.sh_dir_elsewhere = sh_dir_elsewhere && use_sh && !dL_dsh;  // (compact SH mode only: see sgr_sh_adam_from_views_ex)
     pb.acc = acc;
+    pb.header = reinterpret_cast<const uint32_t*>(img_buffer + IL.header);
+    pb.list_cap = (uint32_t)(R > 0xFFFFFFFFll ? 0xFFFFFFFFll : R);
     pb.campos_row = (opts && compact && phase == 0) ? opts->campos_row : nullptr;  // (phase 1 wrote it with the colours)
     pb.dens_max_radii = opts ? opts->max_radii2D : nullptr;
     pb.dens_accum = opts ? opts->grad_accum : nullptr;

@@ -203,6 +203,28 @@ __device__ __forceinline__ void sh_dir_channel(const int deg, const float* h, co
     }
 }
 
+// The 16 SH basis values of computeColorFromSH's backward (backward.cu:47-97: dRGBdsh0 ... dRGBdsh15), zero beyond the active
+// degree; the very expressions sh_backward multiplies by dL/dRGB, so basis[k] * dL_dRGB[c] is bit-identical to its DSH(k).
+__device__ __forceinline__ void sh_basis16(const int deg, const float x, const float y, const float z, float* b)
+{
+#pragma unroll
+    for (int k = 0; k < 16; k++) b[k] = 0.0f;
+    b[0] = SH_C0;
+    if (deg > 0) {
+        b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x;
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = SH_C2[0] * xy; b[5] = SH_C2[1] * yz; b[6] = SH_C2[2] * (2.f * zz - xx - yy); b[7] = SH_C2[3] * xz;
+            b[8] = SH_C2[4] * (xx - yy);
+            if (deg > 2) {
+                b[9] = SH_C3[0] * y * (3.f * xx - yy); b[10] = SH_C3[1] * xy * z; b[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+                b[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy); b[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
+                b[14] = SH_C3[5] * z * (xx - yy); b[15] = SH_C3[6] * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
+
 // computeColorFromSH backward for one Gaussian (backward.cu:47-137): dsh[k][c] = basis_k(dir) * masked dL/dRGB[c] and the
 // gradient w.r.t. the (normalised) view direction.  `clamped` bit c set = channel c was clamped to 0 by the forward.
 __device__ __forceinline__ void sh_backward(const int deg, const float* sh, const float* dcol, const uint32_t clamped,
@@ -428,6 +450,11 @@ __global__ void __launch_bounds__(256, SGR_PRE_BWD_BLOCKS) k_preprocess_bwd(Prep
 {
     const int idx0 = blockIdx.x * 256 + threadIdx.x;
     if (a.campos_row && idx0 < 3) a.campos_row[idx0] = a.cam_pos[idx0];  // (see sgr_backward_opts)
+    // a sync-free forward whose list outgrew its capacity (or missed its walk hint) did not happen: like the blend backward and
+    // the Adam kernels, leave every output -- gradients AND the densification statistics (denom would count the repeated step
+    // twice) -- untouched; the caller repeats the step.  (The three header words travel with the batch of loads below.)
+    uint32_t hdr_r = 0u, hdr_miss = 0u, hdr_ovf = 0u;
+    if (a.header) { hdr_r = a.header[SGR_HDR_R]; hdr_miss = a.header[SGR_HDR_HINT_MISS]; hdr_ovf = a.header[4 + SGR_B2_HDR_OVERFLOW]; }
     const bool valid = idx0 < a.P;
     const int idx = valid ? idx0 : a.P - 1;  // lanes past the end re-read the last Gaussian and store nothing
     const size_t i3 = 3 * (size_t)idx;
@@ -453,6 +480,7 @@ __global__ void __launch_bounds__(256, SGR_PRE_BWD_BLOCKS) k_preprocess_bwd(Prep
     Cam cam;
     cam_unpack(cam_raw, cam);
     if (!valid) return;
+    if (hdr_r > a.list_cap || hdr_miss != 0u || hdr_ovf != 0u) return;  // SGR_FORWARD_INVALID
     const float* v = cam.vm;
 
     float dmean[3] = {0, 0, 0}, dcov[6] = {0, 0, 0, 0, 0, 0};
@@ -571,12 +599,47 @@ __global__ void __launch_bounds__(256, SGR_PRE_BWD_BLOCKS) k_preprocess_bwd(Prep
         V3 dir_orig = {mean.x - cam.cp[0], mean.y - cam.cp[1], mean.z - cam.cp[2]};
         float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
         float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
-        float dsh[48];
-#pragma unroll
-        for (int k = 0; k < 48; k++) dsh[k] = 0.0f;
         const int deg = a.D;
+        // masked dL/dRGB (backward.cu:42-45): the clamped channels pass no gradient
+        const float dLm[3] = {dcol[0] * ((clamped & 1u) ? 0.0f : 1.0f), dcol[1] * ((clamped & 2u) ? 0.0f : 1.0f),
+                              dcol[2] * ((clamped & 4u) ? 0.0f : 1.0f)};
+        if (STORE_SH) {
+            // dL/dsh[k][c] = basis_k(dir) * masked dL/dRGB[c] (backward.cu:47-97) does not read the coefficients: it is formed from
+            // the 16 basis values and stored four floats at a time BEFORE the 48 coefficients are consumed below.  (Held as 48
+            // values until the end of the kernel, next to the 48 coefficients in flight, this variant needed 168 VGPRs + 24 spilled
+            // ones -- 100 bytes of scratch per lane in the kernel the unmodified 3DGS / SuGaR callers run every step.)
+            float b[16];
+            sh_basis16(deg, x, y, z, b);
+            const int n_act = (deg + 1) * (deg + 1);
+            float* dst = a.dL_dsh + (size_t)idx * n_sh;
+            if (n_sh == 48 && ((uintptr_t)dst & 15) == 0) {
+                float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int e = 4 * i + j, k = e / 3, c = e % 3;
+                        o[j] = k < n_act ? b[k] * dLm[c] : 0.0f;
+                    }
+                    d4[i] = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 48; e++)
+                    if (e < n_sh) dst[e] = (e / 3) < n_act ? b[e / 3] * dLm[e % 3] : 0.0f;
+            }
+        }
         float dL_ddir[3] = {0, 0, 0};
-        sh_backward(deg, sh, dcol, clamped, x, y, z, dsh, dL_ddir);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {  // the view-direction half (backward.cu:99-131), one colour channel at a time
+            float h[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) h[k] = sh[3 * k + c];
+            float dRGBdx, dRGBdy, dRGBdz;
+            sh_dir_channel(deg, h, x, y, z, dRGBdx, dRGBdy, dRGBdz);
+            dL_ddir[0] += dRGBdx * dLm[c]; dL_ddir[1] += dRGBdy * dLm[c]; dL_ddir[2] += dRGBdz * dLm[c];
+        }
         // dnormvdv, auxiliary.h:107-117
         {
             V3 vv = dir_orig;
@@ -593,16 +656,6 @@ __global__ void __launch_bounds__(256, SGR_PRE_BWD_BLOCKS) k_preprocess_bwd(Prep
             a.dL_dcolor[i3] = ((clamped >> 0) & 1u) ? 0.f : dcol[0];
             a.dL_dcolor[i3 + 1] = ((clamped >> 1) & 1u) ? 0.f : dcol[1];
             a.dL_dcolor[i3 + 2] = ((clamped >> 2) & 1u) ? 0.f : dcol[2];
-        }
-        float* dst = STORE_SH ? a.dL_dsh + (size_t)idx * n_sh : nullptr;
-        if (!dst) {
-        } else if (n_sh == 48 && ((uintptr_t)dst & 15) == 0) {
-            float4* d4 = reinterpret_cast<float4*>(dst);
-#pragma unroll
-            for (int i = 0; i < 12; i++) { float4 o = {dsh[4 * i], dsh[4 * i + 1], dsh[4 * i + 2], dsh[4 * i + 3]}; d4[i] = o; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 48; i++) if (i < n_sh) dst[i] = dsh[i];
         }
     }
     if (a.scales) {  // computeCov3D backward, backward.cu:278-341

@@ -135,6 +135,7 @@ struct PreprocessBwdArgs {
     int sh_dir_elsewhere;  // compact mode only: skip the SH block (dRGB/d(view direction) -> dL_dmean3D is formed by k_sh_adam_from_views)
     float* campos_row;  // compact mode: receives the camera centre (the row behind the colour gradients in a send buffer) or NULL
     float* dens_max_radii; float* dens_accum; float* dens_denom;  // fused densification statistics (sgr_backward_opts) or NULL
+    const uint32_t* header; uint32_t list_cap;  // the forward's device header (or NULL): an INVALID sync-free forward makes the kernel a no-op
     const float* acc;  // [P][SGR_ACC_STRIDE] sums from the blend backward: {dcol r,g,b, S0, Sx, Sy, Sxx, Sxy, Syy, pad x3}
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor;  // written here from acc
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
