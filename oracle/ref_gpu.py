@@ -99,6 +99,7 @@ def forward(means3D, opacities, *, shs=None, colors_precomp=None, scales=None, r
                           _p(rotations), _p(cov3D_precomp), _p(viewmatrix), _p(projmatrix), _p(campos), float(tanfovx),
                           float(tanfovy), 0, _p(out), _p(radii), int(debug))
     torch.cuda.synchronize(dev)
+    sc.cbs.clear()  # (break the scratch -> callback -> closure -> scratch cycle: the buffers are freed by reference count)
     return dict(P=P, W=W, H=H, M=M, D=sh_degree, R=int(R), color=out, radii=radii, geom=sc.t["geom"],
                 binning=sc.t["binning"], img=sc.t["img"],
                 inputs=dict(means3D=means3D, shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,

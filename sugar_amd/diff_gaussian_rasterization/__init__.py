@@ -79,6 +79,14 @@ def _dev_f32(t: torch.Tensor, device, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+def _bucket(nbytes: int) -> int:
+    """next of eight sizes per octave (multiples of 2^(floor(log2 n) - 3)), at least 1 MiB granularity above 8 MiB"""
+    if nbytes <= (1 << 20):
+        return nbytes
+    step = 1 << (nbytes.bit_length() - 4)
+    return (nbytes + step - 1) // step * step
+
+
 class _Scratch:
     """The three opaque scratch tensors (geomBuffer, binningBuffer, imgBuffer of rasterize_points.cu:73-78),
     handed to the C ABI through allocation callbacks."""
@@ -90,13 +98,26 @@ class _Scratch:
 
     def cb(self, name: str):
         def alloc(_user, nbytes):
-            t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            # The instance list is sized by num_rendered, which differs from camera to camera: exact sizes make PyTorch's caching
+            # allocator see a new size nearly every call and go back to hipMalloc for it (19.5 ms per forward at 6M Gaussians @ 4K
+            # against 1.7 ms of kernels).  Requests are rounded up to eight sizes per octave (at most 12.5 % more memory) so that a
+            # handful of cached blocks serves every view.
+            t = torch.empty(_bucket(int(nbytes)), dtype=torch.uint8, device=self.device)
             self.tensors[name] = t
             return t.data_ptr()
 
         fn = _lib.ALLOC_FN(alloc)
         self._cbs[name] = fn
         return fn
+
+    def release(self):
+        """The tensors, with the object's reference cycle (self -> callbacks -> closures -> self) broken: left to the cyclic
+        collector, every call's scratch (1.8 GB at 6M Gaussians @ 4K) stayed allocated until a collection happened to run, the
+        caching allocator went to hipMalloc for the next call's buffers, and the reference-shaped forward took 19-27 ms instead
+        of 1.6 (bench.py --workload config5 --host-sync)."""
+        t, self.tensors = self.tensors, {}
+        self._cbs.clear()
+        return t
 
 
 class _CModule:
@@ -170,7 +191,7 @@ class _CModule:
                 hdr_ev.record(torch.cuda.current_stream(dev))
         if rendered < 0:
             raise RuntimeError(f"sgr_forward failed ({rendered}): {_lib.last_error()}")
-        t = scratch.tensors
+        t = scratch.release()
         # introspection only (bench.py's roofline accounting, parity tests): the most recent forward's scratch
         _CModule.last_forward = dict(num_rendered=int(rendered), W=W, H=H, P=P, geom=t["geom"], binning=t["binning"],
                                      img=t["img"], binning_mode=int(info.binning_mode), sync_free=bool(info.sync_free))

@@ -225,7 +225,7 @@ def test_twenty_iterations_of_the_reference_loop_against_the_native_trainer():
         trainer.synchronize()
         nat_losses.append(float(trainer.loss_out[0]))
     assert np.allclose(ref_losses, nat_losses, rtol=2e-4), (ref_losses, nat_losses)
-    assert ref_losses[-1] < ref_losses[0]
+    assert np.mean(ref_losses[-8:]) < np.mean(ref_losses[:8])  # (the same eight views, two passes later)
     pairs = (("xyz", gaussians._xyz, 0.00016), ("opacity", gaussians._opacity, 0.05), ("scaling", gaussians._scaling, 0.005),
              ("rotation", gaussians._rotation, 0.001))
     for name, theirs, lr in pairs:
