@@ -359,10 +359,39 @@ __global__ void __launch_bounds__(128) k_grid_query(int N, const float* __restri
                     }
                 }
             }
-        // every point outside rings 0..r is at least r*h away (conservatively ignoring the offset inside the own cell)
-        const float reach = (float)r * g.h;
-        if (bd[K - 1] < reach * reach) break;
         if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == G - 1 && y1 == G - 1 && z1 == G - 1) break;  // whole grid searched
+        // Lower bound of the distance to every point NOT yet visited.  Such a point lies beyond one of the faces of the visited box
+        // that are inside the grid (beyond a face on the grid's boundary there are no points), so along that axis it is at least the
+        // query's distance to the face away, and along the two other axes at least the query's distance to the GRID (zero for a
+        // query inside it): bound^2 = min over inner faces of face^2 + sum of the other axes' grid distances^2.  For a query inside
+        // the cloud this is the old r * h (plus its offset in its own cell); for one OUTSIDE -- a pixel of the level-set sampler
+        // unprojected in front of the cloud -- the second term carries the distance to the cloud, and a handful of rings suffice
+        // where r * h alone needed (distance / h) rings: 10 % of the sampler's 124k queries used to fall through to the exhaustive
+        // kernels for 13 of its 14.3 ms.  Planes and cell assignment are float computations: the margin keeps the bound valid.
+        const float qa[3] = {qx, qy, qz}, oa[3] = {g.ox, g.oy, g.oz};
+        const int ca[3] = {cx, cy, cz};
+        float gd2[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float dlo = oa[a] - qa[a], dhi = qa[a] - (oa[a] + (float)G * g.h);
+            const float dd = fmaxf(fmaxf(dlo, dhi), 0.0f) * (1.0f - 1e-5f);
+            gd2[a] = dd * dd;
+        }
+        float reach2 = 3.402823466e+38f;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float others = gd2[(a + 1) % 3] + gd2[(a + 2) % 3];
+            const float margin = 4e-6f * (fabsf(qa[a]) + fabsf(oa[a]) + (float)G * g.h);
+            if (ca[a] - r > 0) {
+                const float fd = fmaxf(qa[a] - (oa[a] + (float)(ca[a] - r) * g.h) - margin, 0.0f);
+                reach2 = fminf(reach2, fd * fd + others);
+            }
+            if (ca[a] + r < G - 1) {
+                const float fd = fmaxf((oa[a] + (float)(ca[a] + r + 1) * g.h) - qa[a] - margin, 0.0f);
+                reach2 = fminf(reach2, fd * fd + others);
+            }
+        }
+        if (bd[K - 1] < reach2) break;
         // A query far from the data (an outlier; a pixel unprojected in front of the cloud) would walk O(G^3) mostly empty
         // cells -- 0.3 ms EACH at 1M points: 1 % of the level-set sampler's 124k pixels cost 370 ms.  After GRID_MAX_RING
         // rings it is handed to the exhaustive kernels instead (same distances, same (distance, index) order: same result).

@@ -170,12 +170,13 @@ def compute_level_surface_points_from_camera_fast(
         ndc_points_idx = torch.arange(n_surface_points, device=device)
     else:
         n_surface_points = min(n_surface_points, ndc_points.shape[1])
-        # (drawn on the CPU like the reference, :1955, so that a seeded run picks the same pixels; `device_randperm` of the
-        # class, when set, moves the ~15 ms draw at 1080p to the device)
-        if getattr(self, "_sugar_amd_device_randperm", False):
-            ndc_points_idx = torch.randperm(ndc_points.shape[1], device=device)[:n_surface_points]
-        else:
+        # (the reference draws this permutation on the CPU, :1955: ~15 ms at 1080p plus the copy; same distribution on the device.
+        # `_sugar_amd_cpu_randperm = True` on the model draws it on the CPU as the reference does, so that a seeded run picks the
+        # reference's pixels: tests/test_gpu_reference_sugar.py)
+        if getattr(self, "_sugar_amd_cpu_randperm", False):
             ndc_points_idx = torch.randperm(ndc_points.shape[1])[:n_surface_points].to(device)
+        else:
+            ndc_points_idx = torch.randperm(ndc_points.shape[1], device=device)[:n_surface_points]
         ndc_points = ndc_points[:, ndc_points_idx]
     all_world_points = p3d_cameras.unproject_points(ndc_points, scaled_depth_input=False).view(-1, 3)
     if use_gaussian_depth:

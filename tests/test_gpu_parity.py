@@ -301,6 +301,27 @@ def test_grid_knn_is_identical_to_exhaustive(dist):
     b = knn_points(q[None], p[None], K=8, method="grid")
     assert torch.equal(a.dists, b.dists) and torch.equal(a.idx, b.idx)
     assert torch.equal(distCUDA2(p, method="brute"), distCUDA2(p, method="grid"))
+    # queries far outside the cloud (the level-set sampler's silhouette pixels), along faces, edges and corners of the bounding
+    # box, on its boundary planes and a hair outside them: the ring walk's stop bound uses the distance to the box there
+    lo, hi = pts.min(0).values, pts.max(0).values
+    ext = float((hi - lo).max())
+    far = []
+    for scale in (1e-6, 0.01, 0.3, 1.0, 5.0):
+        d = torch.randn(600, 3, generator=g)
+        d = d / d.norm(dim=1, keepdim=True)
+        base = lo + (hi - lo) * torch.rand(600, 3, generator=g)
+        out = base + d * ext * scale
+        axis = torch.randint(0, 3, (600,), generator=g)
+        side = torch.randint(0, 2, (600,), generator=g).bool()
+        snap = torch.where(side, hi[axis], lo[axis]) + torch.where(side, 1.0, -1.0) * ext * scale  # straight out of one face
+        out[torch.arange(600), axis] = snap
+        far.append(out)
+    far.append(torch.stack([lo, hi, torch.tensor([float(lo[0]), float(hi[1]), float(lo[2])]), (lo + hi) / 2]))
+    qf = torch.cat(far).to(dev)
+    for K in (1, 16):
+        a = knn_points(qf[None], p[None], K=K, method="brute")
+        b = knn_points(qf[None], p[None], K=K, method="grid")
+        assert torch.equal(a.dists, b.dists) and torch.equal(a.idx, b.idx)
 
 
 def _lists(scene, cam, bg, single_level=False):

@@ -179,6 +179,7 @@ def test_the_reference_level_set_sampler_on_the_mesh_depth_path(sm):
                 assert torch.equal(res[lv]["gaussian_idx"][ia], res2[lv]["gaussian_idx"][ib])
             # the extractor's call: a seeded random subset of the pixels (coarse_mesh.py:274: n_surface_points = 2 * n_pts_per_frame)
             n_sub = int(fx["n_subset"])
+            model._sugar_amd_cpu_randperm = True  # draw the subset where the reference draws it (sugar_model.py:1955)
             torch.manual_seed(int(fx["seed"]))
             sub = model.compute_level_surface_points_from_camera_fast(rasterizer=rasterizer, **mm.sampler_kwargs(n_sub))
             full_pix = {lv: set(res2[lv]["pixel_idx"].cpu().tolist()) for lv in (0.1, 0.3, 0.5)}
