@@ -126,8 +126,14 @@ int sgr_knn(int N, const float* query, int M, const float* ref, int K, float* di
 // =====================================================================================================================
 namespace {
 
-struct GridHdr { unsigned int minb[3], maxb[3], far_count, pad; };  // order-preserving uint encodings of the bbox; fallback count
-#define GRID_MAX_RING 4  // measured (124k queries, 10 % of them far from 1M points): 2: 15.7, 3: 14.3, 4: 14.3, 6: 14.8, 10: 20, 16: 44, 24: 110 ms
+// order-preserving uint encodings of the bbox; far_count: queries handed to the exhaustive kernels, ball_count: to the ball scan
+struct GridHdr { unsigned int minb[3], maxb[3], far_count, ball_count; };
+// Rings a lane walks on its own before it hands its query to k_knn_ball (with K candidates in hand) -- measured, 124k queries
+// against 1M points, 0 / 10 / 30 % of them outside the cloud: cap 1: 1.06 / 1.39 / 2.02 ms, 2: 1.12 / 1.85 / 2.46, 3: 1.13 / 2.57 /
+// 3.15, 4: 1.13 / 3.49 / 4.15 (round 3, exhaustive fallback after 4 rings: 14.3 ms at 10 %).  Self queries (the neighbour rebuild,
+// distCUDA2) do not depend on it: 2.3 / 0.8 ms at 1M.
+#define GRID_MAX_RING 1
+#define GRID_GIVEUP_RING 12  // a lane that has not even MET K points after this many rings goes to the exhaustive kernels
 #define FAR_SINGLE_MAX 16384u  // up to this many far queries: one workgroup each; more: the tiled exhaustive kernel
 
 __device__ __forceinline__ unsigned int f2ord(float f)
@@ -143,7 +149,7 @@ __device__ __forceinline__ float ord2f(unsigned int o)
 __global__ void k_grid_init(GridHdr* h)
 {
     if (threadIdx.x < 3) { h->minb[threadIdx.x] = 0xFFFFFFFFu; h->maxb[threadIdx.x] = 0u; }
-    if (threadIdx.x == 3) h->far_count = 0u;
+    if (threadIdx.x == 3) { h->far_count = 0u; h->ball_count = 0u; }
 }
 
 // Far queries, Q per workgroup (grid-stride over the fallback list): the 256 threads split the reference set -- every point is
@@ -311,7 +317,9 @@ __global__ void __launch_bounds__(128) k_grid_query(int N, const float* __restri
                                                     const unsigned int* __restrict__ cell_start, const float4* __restrict__ sorted,
                                                     float* __restrict__ out_d, int64_t* __restrict__ out_i,
                                                     float* __restrict__ out_mean, unsigned int* __restrict__ far_count,
-                                                    int* __restrict__ far_list, unsigned int far_cap, int max_ring)
+                                                    int* __restrict__ far_list, unsigned int far_cap, int max_ring,
+                                                    unsigned int* __restrict__ ball_count, int* __restrict__ ball_list,
+                                                    float* __restrict__ ball_u2)
 {
     const int t = blockIdx.x * 128 + threadIdx.x;
     if (t >= N) return;
@@ -392,12 +400,21 @@ __global__ void __launch_bounds__(128) k_grid_query(int N, const float* __restri
             }
         }
         if (bd[K - 1] < reach2) break;
-        // A query far from the data (an outlier; a pixel unprojected in front of the cloud) would walk O(G^3) mostly empty
-        // cells -- 0.3 ms EACH at 1M points: 1 % of the level-set sampler's 124k pixels cost 370 ms.  After GRID_MAX_RING
-        // rings it is handed to the exhaustive kernels instead (same distances, same (distance, index) order: same result).
+        // A query far from the data (an outlier; a pixel of the level-set sampler unprojected in front of the cloud) keeps ONE lane
+        // walking hundreds of cells, two dependent loads each, while the other lanes of its wave idle: 10 % such queries cost 13
+        // of the sampler's 14.3 ms (and 6.6 ms still with the tighter bound above).  After `max_ring` rings the lane stops: once
+        // it holds K candidates its K-th best distance U bounds the answer -- the K nearest lie in the ball (q, U) -- and the query
+        // goes to k_knn_ball, where a whole wave scans exactly the cells that ball touches.  A query that has not met K points
+        // after GRID_GIVEUP_RING rings (a far outlier of a tiny set) goes to the exhaustive kernels.  Same distances, same
+        // (distance, index) order everywhere: same result.
         if (r >= max_ring && far_list) {
-            const unsigned int pos = atomicAdd(far_count, 1u);
-            if (pos < far_cap) { far_list[pos] = q; return; }
+            if (bd[K - 1] < 3.0e+38f) {
+                const unsigned int pos = atomicAdd(ball_count, 1u);
+                if (pos < far_cap) { ball_list[pos] = q; ball_u2[pos] = bd[K - 1]; return; }
+            } else if (r >= GRID_GIVEUP_RING) {
+                const unsigned int pos = atomicAdd(far_count, 1u);
+                if (pos < far_cap) { far_list[pos] = q; return; }
+            }
         }
     }
     if (out_mean) {
@@ -408,6 +425,92 @@ __global__ void __launch_bounds__(128) k_grid_query(int N, const float* __restri
             out_d[(size_t)q * K + k] = bd[k];
             out_i[(size_t)q * K + k] = (bi[k] == 0x7FFFFFFF) ? -1 : (int64_t)bi[k];
         }
+    }
+}
+
+// Queries the ring walk handed over with an upper bound U^2 on their K-th nearest distance: ONE WAVE per query.  The K nearest
+// lie in the ball (q, U); a lane takes a row of cells (fixed z, y), intersects it with the ball -- rows farther than U in the
+// (y, z) plane are skipped, the others contribute the x-interval sqrt(U^2 - dy^2 - dz^2) around the query -- and the cells of
+// a row are consecutive in the cell-sorted array, so a row is one contiguous range of points.  Every lane keeps its K best in
+// registers, the wave then draws the K best of the 64 sorted lists with arg-min rounds on (distance, index).  The cover is taken
+// with a margin (float rounding of planes and cell assignment); a larger cover only costs time.
+template <int K, bool EXCLUDE_SELF>
+__global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ query, const GridHdr* __restrict__ hdr, int G,
+                                                  const unsigned int* __restrict__ cell_start, const float4* __restrict__ sorted,
+                                                  float* __restrict__ out_d, int64_t* __restrict__ out_i, float* __restrict__ out_mean,
+                                                  const int* __restrict__ qlist, const float* __restrict__ qu2,
+                                                  const unsigned int* __restrict__ qcount, unsigned int cap)
+{
+    const unsigned int n = min(*qcount, cap);
+    const int lane = threadIdx.x & 63;
+    const GridGeom g = grid_geom(hdr, G);
+    for (unsigned int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
+        const int q = qlist[w];
+        const float qx = query[3 * (size_t)q], qy = query[3 * (size_t)q + 1], qz = query[3 * (size_t)q + 2];
+        const float ext = (float)G * g.h;
+        const float U = sqrtf(qu2[w]) * (1.0f + 1e-5f) + 1e-5f * (ext + fabsf(qx) + fabsf(qy) + fabsf(qz));
+        const float U2 = U * U;
+        // cell rows the ball can touch.  The points live inside the grid, so along y (z) the ball only reaches as far as what the
+        // query's distance to the grid along the two other axes leaves of U: for a query outside the cloud that is a small cap
+        const float gx = fmaxf(fmaxf(g.ox - qx, qx - (g.ox + ext)), 0.0f) * (1.0f - 1e-5f);
+        const float gy = fmaxf(fmaxf(g.oy - qy, qy - (g.oy + ext)), 0.0f) * (1.0f - 1e-5f);
+        const float gz = fmaxf(fmaxf(g.oz - qz, qz - (g.oz + ext)), 0.0f) * (1.0f - 1e-5f);
+        const float Uz = sqrtf(fmaxf(U2 - gx * gx - gy * gy, 0.0f)), Uy = sqrtf(fmaxf(U2 - gx * gx - gz * gz, 0.0f));
+        const int z0 = cell_coord(qz - Uz, g.oz, g), z1 = cell_coord(qz + Uz, g.oz, g);
+        const int y0 = cell_coord(qy - Uy, g.oy, g), y1 = cell_coord(qy + Uy, g.oy, g);
+        const int ny = y1 - y0 + 1, rows = (z1 - z0 + 1) * ny;
+        float bd[K];
+        int bi[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) { bd[k] = 3.402823466e+38f; bi[k] = 0x7FFFFFFF; }
+        for (int row = lane; row < rows; row += 64) {
+            const int z = z0 + row / ny, y = y0 + row % ny;
+            // distance of the query to the slab of cell row (z, y) along each axis (zero inside the slab)
+            const float zl = g.oz + (float)z * g.h, yl = g.oy + (float)y * g.h;
+            const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + g.h)), 0.0f), dy = fmaxf(fmaxf(yl - qy, qy - (yl + g.h)), 0.0f);
+            const float rem = U2 - dz * dz - dy * dy;
+            if (rem < 0.0f) continue;
+            const float xr = sqrtf(rem);
+            if (qx - xr > g.ox + ext || qx + xr < g.ox) continue;  // the row's x-interval misses the grid (the clamp below would scan its end cell)
+            const int x0 = cell_coord(qx - xr, g.ox, g), x1 = cell_coord(qx + xr, g.ox, g);
+            const unsigned int c0 = ((unsigned int)z * G + y) * G + x0;
+            const unsigned int b = cell_start[c0], e = cell_start[c0 + (unsigned int)(x1 - x0) + 1u];
+            for (unsigned int sidx = b; sidx < e; sidx++) {
+                const float4 p = sorted[sidx];
+                int id = __float_as_int(p.w);
+                if (EXCLUDE_SELF && id == q) continue;
+                const float dx = p.x - qx, ddy = p.y - qy, ddz = p.z - qz;
+                float d = dx * dx + ddy * ddy + ddz * ddz;
+                if (!(d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]))) continue;
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    if (d < bd[k] || (d == bd[k] && id < bi[k])) {
+                        const float td = bd[k]; const int ti = bi[k];
+                        bd[k] = d; bi[k] = id; d = td; id = ti;
+                    }
+                }
+            }
+        }
+        // the K best of the 64 sorted lists: K rounds of a wave-wide arg-min of the heads on (distance, index)
+        float sum3 = 0.f;
+        for (int k = 0; k < K; k++) {
+            float d = bd[0]; int id = bi[0]; int who = lane;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float od = __shfl_xor(d, o); const int oi = __shfl_xor(id, o); const int ow = __shfl_xor(who, o);
+                if (od < d || (od == d && oi < id) || (od == d && oi == id && ow < who)) { d = od; id = oi; who = ow; }
+            }
+            if (lane == who) {
+#pragma unroll
+                for (int j = 0; j + 1 < K; j++) { bd[j] = bd[j + 1]; bi[j] = bi[j + 1]; }
+                bd[K - 1] = 3.402823466e+38f; bi[K - 1] = 0x7FFFFFFF;
+            }
+            if (lane == 0) {
+                if (out_mean) { if (k < 3) sum3 += d; }
+                else { out_d[(size_t)q * K + k] = d; out_i[(size_t)q * K + k] = (id == 0x7FFFFFFF) ? -1 : (int64_t)id; }
+            }
+        }
+        if (lane == 0 && out_mean) out_mean[q] = sum3 / 3.0f;
     }
 }
 
@@ -426,7 +529,7 @@ int grid_res(int M)
 }
 
 struct GridScratch { GridHdr* hdr; unsigned int *cell_count, *cursor, *cell_start, *cell_of; float4* sorted; int* far_list;
-                     unsigned int far_cap; size_t total; };
+                     int* ball_list; float* ball_u2; unsigned int far_cap; size_t total; };
 GridScratch carve_grid(char* base, int M)
 {
     const int G = grid_res(M);
@@ -441,6 +544,8 @@ GridScratch carve_grid(char* base, int M)
     s.sorted = reinterpret_cast<float4*>(base + off); off = sgr_align(off + (size_t)M * 16);
     s.far_cap = (unsigned int)(M > 65536 ? M : 65536);  // queries the exhaustive fallback can take (the rest walk on)
     s.far_list = reinterpret_cast<int*>(base + off); off = sgr_align(off + (size_t)s.far_cap * 4);
+    s.ball_list = reinterpret_cast<int*>(base + off); off = sgr_align(off + (size_t)s.far_cap * 4);
+    s.ball_u2 = reinterpret_cast<float*>(base + off); off = sgr_align(off + (size_t)s.far_cap * 4);
     s.total = off;
     return s;
 }
@@ -465,6 +570,9 @@ template <int K, bool EXCLUDE_SELF>
 void launch_far(int N, const float* query, int M, const float* ref, const GridScratch& gs, float* d, int64_t* i, float* mean, hipStream_t s)
 {
     const unsigned int cap = gs.far_cap < (unsigned int)N ? gs.far_cap : (unsigned int)N;
+    const unsigned int ball_groups = (cap + 3) / 4;  // one wave per query, four per workgroup, grid-stride over the (device-side) count
+    hipLaunchKernelGGL((k_knn_ball<K, EXCLUDE_SELF>), dim3(ball_groups < 8192u ? ball_groups : 8192u), dim3(256), 0, s, query, gs.hdr,
+                       grid_res(M), gs.cell_start, gs.sorted, d, i, mean, gs.ball_list, gs.ball_u2, &gs.hdr->ball_count, cap);
     constexpr int Q = K <= 4 ? 8 : (K <= 16 ? 4 : 2);  // queries per workgroup: Q * K (distance, index) pairs per thread in registers
     const unsigned int groups = (cap + Q - 1) / Q;
     hipLaunchKernelGGL((k_knn_far<K, EXCLUDE_SELF, Q>), dim3(groups < 4096u ? groups : 4096u), dim3(256), 0, s, query, M, gs.sorted, d, i,
@@ -479,10 +587,12 @@ void launch_grid_query(bool self, int N, const float* query, int M, const float*
 {
     if (self)
         hipLaunchKernelGGL((k_grid_query<K, false, true>), dim3((N + 127) / 128), dim3(128), 0, s, N, query, gs.hdr, G, gs.cell_start,
-                           gs.sorted, d, i, (float*)nullptr, &gs.hdr->far_count, gs.far_list, gs.far_cap, grid_max_ring());
+                           gs.sorted, d, i, (float*)nullptr, &gs.hdr->far_count, gs.far_list, gs.far_cap, grid_max_ring(), &gs.hdr->ball_count,
+                           gs.ball_list, gs.ball_u2);
     else
         hipLaunchKernelGGL((k_grid_query<K, false, false>), dim3((N + 127) / 128), dim3(128), 0, s, N, query, gs.hdr, G, gs.cell_start,
-                           gs.sorted, d, i, (float*)nullptr, &gs.hdr->far_count, gs.far_list, gs.far_cap, grid_max_ring());
+                           gs.sorted, d, i, (float*)nullptr, &gs.hdr->far_count, gs.far_list, gs.far_cap, grid_max_ring(), &gs.hdr->ball_count,
+                           gs.ball_list, gs.ball_u2);
     launch_far<K, false>(N, query, M, ref, gs, d, i, nullptr, s);
 }
 
@@ -525,7 +635,7 @@ int sgr_dist2_grid(int P, const float* points, float* meanDists, char* scratch, 
     if (rc < 0) return rc;
     hipLaunchKernelGGL((k_grid_query<3, true, true>), dim3((P + 127) / 128), dim3(128), 0, s, P, points, gs.hdr, grid_res(P),
                        gs.cell_start, gs.sorted, (float*)nullptr, (int64_t*)nullptr, meanDists, &gs.hdr->far_count, gs.far_list,
-                       gs.far_cap, grid_max_ring());
+                       gs.far_cap, grid_max_ring(), &gs.hdr->ball_count, gs.ball_list, gs.ball_u2);
     launch_far<3, true>(P, points, P, points, gs, nullptr, nullptr, meanDists, s);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
