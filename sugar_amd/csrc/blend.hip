@@ -177,9 +177,8 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
     // (one spare entry: the walk's look-ahead reads one entry past the last)
     __shared__ __attribute__((aligned(16))) float s_e[65 * (SGR_FWD_ENTRY_BYTES / 4)];
     // workgroup b runs on XCD b % 8: the four blocks of a tile share an XCD (and its L2)
-    const int wg = blockIdx.x;
-    const int sub = (wg >> 3) & 3;
-    const int slot = ((wg >> 5) << 3) + (wg & 7);
+    int slot, sub;
+    sgr_slot_of_workgroup((int)blockIdx.x, slot, sub);
     if (slot >= T_tiles) return;
     // (launch_order: the camera's previous visit, deepest tiles first -- sgr_forward_opts.tile_order; clamped, so a buffer that
     // is not a permutation costs tiles, not memory safety)
@@ -385,8 +384,8 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
     if (SGR_FORWARD_INVALID(header, list_cap)) return;  // the forward was a no-op (blk_nb, masks, lists are not there)
     __shared__ float2 s_zw[BW_SUB * BW_ZW_STRIDE];
     const int wg = blockIdx.x;
-    const int sub = (wg >> 3) & 3;
-    const int slot = ((wg >> 5) << 3) + (wg & 7);
+    int slot, sub;
+    sgr_slot_of_workgroup(wg, slot, sub);
     if (slot >= T_tiles) return;
     const int tile = tile_order ? (int)tile_order[slot] : slot;  // deepest tiles first (k_tile_order)
     const int nb = (int)blk_nb[4 * tile + sub];  // batches the forward walked for this block (0: nothing contributed)
@@ -577,19 +576,20 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
                           uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, const uint32_t* launch_order, hipStream_t s)
 {
     const int T = gx * gy;  // (tile_maxc and tile_walked were zeroed by the tile scan: the blocks of a tile combine with atomicMax)
-    hipLaunchKernelGGL(k_blend_fwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg, final_T,
+    hipLaunchKernelGGL(k_blend_fwd_w, dim3(sgr_blend_grid(T)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg, final_T,
                        n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap, tile_need, launch_order);
 }
 
 // behind the blend: this view's launch order (for its backward: order_scratch; for the camera's next forward: order_out), the walk
 // hint for the camera's next visit and the second header copy
-void sgr_launch_blend_fwd_post(int T, const uint32_t* tile_maxc, const uint32_t* tile_walked, uint32_t* header, uint32_t list_cap,
+void sgr_launch_blend_fwd_post(int gx, int gy, const uint32_t* tile_maxc, const uint32_t* tile_walked, uint32_t* header, uint32_t list_cap,
                                uint32_t* tile_need_out, float hint_margin, uint32_t* header_host_dev, uint32_t* order_scratch,
                                uint32_t* order_out, hipStream_t s)
 {
+    const int T = gx * gy;
     if (order_out) {
         SgrTileOrderJob job = {T, list_cap, tile_maxc, tile_need_out ? tile_walked : nullptr, header, order_scratch, order_out, tile_need_out,
-                               header_host_dev, hint_margin > 0.f ? hint_margin : 0.25f};
+                               header_host_dev, hint_margin > 0.f ? hint_margin : 0.25f, gx, gy};
         hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, job);
         return;
     }
@@ -608,9 +608,9 @@ void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
     if (order_ready) {}                           // (the forward sorted: sgr_forward_opts.tile_order_out)
     else if (4 * T < 8192) tile_order = nullptr;  // (fewer waves than the chip holds at once: nothing to order)
     else {
-        SgrTileOrderJob job = {T, list_cap, tile_maxc, nullptr, header, tile_order, nullptr, nullptr, nullptr, 0.f};
+        SgrTileOrderJob job = {T, list_cap, tile_maxc, nullptr, header, tile_order, nullptr, nullptr, nullptr, 0.f, gx, gy};
         hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, job);
     }
-    hipLaunchKernelGGL(k_blend_bwd_w, dim3(32 * ((T + 7) / 8)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, blk_mask, blk_nb, rec,
+    hipLaunchKernelGGL(k_blend_bwd_w, dim3(sgr_blend_grid(T)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, blk_mask, blk_nb, rec,
                        bg, final_T, n_contrib, dL_dpix, acc, tile_order, header, list_cap);
 }

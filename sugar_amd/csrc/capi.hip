@@ -300,7 +300,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
         STAGE_CHECK("blend_fwd");
         return R;
     }
-    sgr_launch_blend_fwd_post(IL.T, tile_maxc, tile_walked, header, (uint32_t)R, opts->tile_need_out, opts->hint_margin, hh_dev,
+    sgr_launch_blend_fwd_post(IL.gx, IL.gy, tile_maxc, tile_walked, header, (uint32_t)R, opts->tile_need_out, opts->hint_margin, hh_dev,
                               tile_cursor, opts->tile_order_out, s);
     STAGE_CHECK("blend_fwd");
     // ... and once more behind the blend: word 3 (hint miss) is final only now
@@ -341,6 +341,8 @@ int sgr_forward_post_job(int width, int height, char* img_buffer, int64_t R, con
     job->need_out = opts->tile_need_out;
     job->header_host = hh_dev;
     job->margin = opts->hint_margin > 0.f ? opts->hint_margin : 0.25f;
+    job->gx = IL.gx;
+    job->gy = IL.gy;
     return 0;
 }
 

@@ -175,7 +175,7 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
                           uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
                           uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, const uint32_t* launch_order, hipStream_t s);
-void sgr_launch_blend_fwd_post(int T, const uint32_t* tile_maxc, const uint32_t* tile_walked, uint32_t* header, uint32_t list_cap,
+void sgr_launch_blend_fwd_post(int gx, int gy, const uint32_t* tile_maxc, const uint32_t* tile_walked, uint32_t* header, uint32_t list_cap,
                                uint32_t* tile_need_out, float hint_margin, uint32_t* header_host_dev, uint32_t* order_scratch,
                                uint32_t* order_out, hipStream_t s);
 void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
