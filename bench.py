@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--no-densify-variant", action="store_true", help="skip the extra timing of the step with dL/dmeans2D + fused densification statistics")
     ap.add_argument("--watchdog-sec", type=int, default=0, help="dump every thread's stack to stderr and exit if the run takes longer than this (0: off at one rank, 900 s with several)")
     ap.add_argument("--host-sync", action="store_true", help="forward with the host round trip for num_rendered (A/B of the sync-free forward)")
+    ap.add_argument("--cameras", type=int, default=200, help="hint-robustness leg (untimed, behind the graded region, from the drifted state): this many scattered cameras visited in shuffled order, as a real capture's training views are; 0: skip")
     ap.add_argument("--no-reference-loop", action="store_true", help="skip the untimed legs behind the graded region: the reference's own loop (train.py) on the drop-in rasterizer, the through-API fwd+bwd time, and the same-GPU A/B against the reference's kernels")
     ap.add_argument("--reference-loop", action="store_true", help="(default behaviour, kept as an explicit switch) run those legs")
     ap.add_argument("--reference-loop-steps", type=int, default=24)
@@ -323,6 +324,35 @@ def main():
         ms_drift = time_steps(trainer, base + args.drift_steps)
         extras["after_training"] = {"untimed_steps_before": args.drift_steps, "ms_per_step": ms_drift,
                                     "images_per_sec": 1e3 / ms_drift, "num_rendered": trainer.last_num_rendered}
+
+    if world == 1 and native and args.cameras > 0 and args.drift_steps > 0:
+        # The headline revisits 8 cameras every 8 steps: walk hints and launch orders are 8 Adam steps old.  A real capture has
+        # 100-300 views visited in random order (train.py:76-79): a hint is then hundreds of steps old.  Same trainer, drifted state
+        # (no restore), `--cameras` scattered views, shuffled every epoch: one epoch to give every camera its first hint, then one
+        # timed epoch.
+        import random
+        many = [c._replace(viewmatrix=c.viewmatrix.to(dev), projmatrix=c.projmatrix.to(dev), campos=c.campos.to(dev))
+                for c in syn.scattered_cameras(W, H, args.cameras, seed=11)]
+        rnd = random.Random(5)
+
+        def epoch():
+            idx = list(range(len(many)))
+            rnd.shuffle(idx)
+            for i in idx:
+                trainer.step(many[i], gts[i % len(gts)], cam_key=1000 + i)
+        epoch()
+        sync_all()
+        r0, p0 = trainer.redone, trainer.hint_pauses
+        ta = time.perf_counter()
+        epoch()
+        sync_all()
+        ms_many = 1e3 * (time.perf_counter() - ta) / len(many)
+        extras["many_cameras_shuffled"] = {
+            "cameras": len(many), "ms_per_step": ms_many, "images_per_sec": 1e3 / ms_many,
+            "forwards_repeated": trainer.redone - r0, "hint_off_windows": trainer.hint_pauses - p0,
+            "what": "after the drift steps, no restore: scattered cameras visited in shuffled order, one untimed epoch (first visits: no "
+                    "hint yet), one timed epoch; every hint / launch order is one epoch (~" + str(len(many)) + " Adam steps) old"}
+        del many
 
     if world == 1 and not forward_only and not args.no_reference_loop:
         # release the native trainer's buffers first: the legs below hold a second copy of the model

@@ -445,6 +445,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __res
     __shared__ uint32_t s_total;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     uint32_t carry = 0, mx = 0;
+    unsigned long long exact = 0ull;  // this thread's share of the total in 64 bits: the 32-bit scan wraps at 2^32 instances
     for (int base = 0; base < T; base += 8192) {
         uint32_t c[8], incl[8];
 #pragma unroll
@@ -452,6 +453,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __res
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             if (base + j * 1024 + tid >= T) c[j] = 0u;
+            exact += c[j];
             mx = max(mx, c[j]);
             incl[j] = wave_incl_scan(c[j]);
             if (lane == 63) s_seg[j * 16 + wave] = incl[j];
@@ -474,14 +476,20 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __res
         __syncthreads();  // s_seg / s_total are rewritten by the next round
     }
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
-    if (lane == 0) s_max[wave] = mx;
+    for (int o = 32; o > 0; o >>= 1) exact += __shfl_xor(exact, o);
+    __shared__ unsigned long long s_exact[16];
+    if (lane == 0) { s_max[wave] = mx; s_exact[wave] = exact; }
     __syncthreads();
     if (tid == 0) {
         uint32_t m = 0;
-        for (int w = 0; w < 16; w++) m = max(m, s_max[w]);
+        unsigned long long total = 0ull;
+        for (int w = 0; w < 16; w++) { m = max(m, s_max[w]); total += s_exact[w]; }
+        // 2^32 - 1 or more instances: the word SATURATES (the wrapped sum could pass for a small, valid count); no capacity is
+        // ever that large (sgr_forward_ex), so such a forward is invalid for every reader of the header
+        if (total >= 0xFFFFFFFFull) carry = 0xFFFFFFFFu;
         tile_start[T] = carry;
         header[SGR_HDR_R] = carry;
-        header[SGR_HDR_R_HI] = 0;
+        header[SGR_HDR_R_HI] = (uint32_t)(total >> 32);
         header[SGR_HDR_MAXCOUNT] = m;
         header[SGR_HDR_HINT_MISS] = 0;
         if (clear_b2_words) { header[4] = 0; header[5] = 0; header[6] = 0; }  // single-level path: k_sup_scan did not run
@@ -492,7 +500,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __res
         for (int k = 0; k < 2; k++) {
             uint32_t* h = k ? host_b : host_a;
             if (!h) continue;
-            h[0] = carry; h[1] = m; h[2] = 0; h[3] = 0; h[4] = w4; h[5] = w5; h[6] = w6; h[7] = 0;
+            h[0] = carry; h[1] = m; h[2] = (uint32_t)(total >> 32); h[3] = 0; h[4] = w4; h[5] = w5; h[6] = w6; h[7] = 0;
         }
     }
 }

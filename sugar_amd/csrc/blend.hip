@@ -266,23 +266,23 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
 // ---------------------------------------------------------------------------------------------
 // Backward blend.
 //
-// Two lane mappings alternate over groups of 16 Gaussians of the block's list (walked back to front):
+// Two lane mappings alternate over groups of BW_SUB = 8 Gaussians of the block's list (walked back to front; 16 until round 3):
 //   phase A  lane = pixel.  The per-pixel recurrence of backward.cu:486-534 (T /= 1-alpha, accum_rec, dL_dalpha) runs
-//            sequentially over the 16 Gaussians; for each pair the lane stores just Z = G * dL_dalpha and Wt = alpha * T into
+//            sequentially over the group's Gaussians; for each pair the lane stores just Z = G * dL_dalpha and Wt = alpha * T into
 //            a wave-private LDS panel zw[g][pixel].  Hand-scheduled like the forward walk: 27.5 VALU per entry, the
 //            reference's tests as EXEC masks.
-//   phase B  lane = (Gaussian g, pixel rows 2q and 2q+1).  Each lane streams its 16 pixels out of the panel and accumulates,
-//            in registers, the colour sums  sum Wt*dL_dpix  and the raw moments of Z about the block origin; one
-//            4-lane reduction with gfx950 lane swaps per group.
+//   phase B  lane = (Gaussian g, pixel row q).  Each lane streams its 8 pixels out of the panel and accumulates, in registers,
+//            the colour sums  sum Wt*dL_dpix  and the raw moments of Z about the block origin; one 8-lane reduction per group
+//            (a DPP row rotate, then two values per v_permlane16/32_swap).
 // All gradient terms of a pair are linear in {Wt*g_c, Z, Z*dx, Z*dy, Z*dx^2, Z*dx*dy, Z*dy^2} with per-Gaussian
 // coefficients (backward.cu:538-554), so only those nine sums leave the block; the coefficients are applied once per
 // Gaussian by the fused backward-preprocess kernel.  A (block, Gaussian) pair is met exactly once, so the nine sums go
 // straight to global memory: they are handed to nine neighbouring lanes through LDS, and one atomic instruction then
-// carries whole 36-byte records -- ONE request per pair into acc[P][16] (64-byte records).  (Nine separate 16-lane atomic
+// carries whole 36-byte records -- ONE request per pair into acc[P][16] (64-byte records).  (Nine separate atomic
 // instructions per group cost 5x the whole rest of the kernel.)
 // Which list entries to take comes from the forward: it leaves one 64-bit mask per (64-entry batch, block) -- the lanes that
 // survived the block's exact cull -- so the backward neither culls again nor gathers records it will not use; the
-// survivors of several batches are collected in a small LDS queue so that phase B always sees full groups of 16.
+// survivors of several batches are collected in a small LDS queue so that phase B always sees full groups of BW_SUB.
 #define BW_SUB 8            // Gaussians per group (panel rows); phase B's lane roles are written for 8
 #define BW_QCAP (BW_SUB + 64)  // queue entries: at most BW_SUB - 1 left over + 64 new
 #define BW_ZW_STRIDE 65     // float2 units: conflict-free for the phase-A writes and the phase-B reads
@@ -431,7 +431,7 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
     const uint32_t zw_lds = (uint32_t)(uintptr_t)s_zw + 8u * (uint32_t)lane;
 
     int qn = 0;  // entries waiting in the queue (they sit at its front)
-    // the queued entries in groups of 16 (all of them at the end, full groups only before), the rest moves to the front
+    // the queued entries in groups of BW_SUB (all of them at the end, full groups only before), the rest moves to the front
     auto drain = [&](const bool last_batch) {
         int qs = 0;
         while (qn - qs >= BW_SUB || (last_batch && qn > qs)) {

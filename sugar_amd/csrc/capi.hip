@@ -188,6 +188,14 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     const int per_block = legacy_ok ? (((P + IL.n_blocks - 1) / IL.n_blocks + 63) / 64) * 64 : 0;  // Gaussians per slice
     uint2* rects = reinterpret_cast<uint2*>(sort_scratch + sgr_sort_rects_offset(P));
 
+    // host-visible header targets: the caller's pinned memory and this thread's own read-back slot, as device pointers
+    uint32_t* hh_dev = nullptr;
+    if (opts->header_host && hipHostGetDevicePointer(reinterpret_cast<void**>(&hh_dev), opts->header_host, 0) != hipSuccess) {
+        hh_dev = nullptr;
+        (void)hipGetLastError();  // not pinned / not mapped: the copy-command path below
+    }
+    if ((flags & SGR_FLAG_DEFER_POST) && opts->header_host && !hh_dev)  // (checked before anything is enqueued)
+        return fail(SGR_E_INVALID, "SGR_FLAG_DEFER_POST needs a device-mapped header_host");
     PreprocessArgs pa;
     pa.P = P; pa.D = D; pa.M = shs ? M : 0;
     pa.means3D = means3D; pa.scales = scales; pa.scale_modifier = scale_modifier; pa.rotations = rotations;
@@ -209,12 +217,6 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     { StageTimer t(s, SGR_STAGE_SORT); sgr_launch_gaussian_sort(P, sort_scratch, &order, pa.rect_by_id, rects, s); }
     STAGE_CHECK("gaussian_sort");
 
-    // host-visible header targets: the caller's pinned memory and this thread's own read-back slot, as device pointers
-    uint32_t* hh_dev = nullptr;
-    if (opts->header_host && hipHostGetDevicePointer(reinterpret_cast<void**>(&hh_dev), opts->header_host, 0) != hipSuccess) {
-        hh_dev = nullptr;
-        (void)hipGetLastError();  // not pinned / not mapped: the copy-command path below
-    }
     const bool will_sync = !(binning_capacity > 0 && binning_mode == 0);
     uint32_t* pin_dev = nullptr;
     if (will_sync) {
@@ -243,7 +245,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     // instance list gets the caller's capacity, the write pass clamps to it and the blend kernel returns at once when the
     // header says the forward is invalid (R > capacity, or level-1 overflow).  The caller reads the header later.
     const bool nosync = binning_capacity > 0 && two_level;
-    if (binning_capacity > 0xFFFFFFFFll) binning_capacity = 0xFFFFFFFFll;
+    if (binning_capacity > 0xFFFFFFFEll) binning_capacity = 0xFFFFFFFEll;  // (0xFFFFFFFF is the saturated count of k_tile_scan: never valid)
     int64_t R = 0;
     uint32_t n_chunks = 0;
     if (nosync) {
@@ -269,6 +271,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
             HIP_TRY(hipStreamSynchronize(s));
         }
         R = (int64_t)g_pinned.p[SGR_HDR_R];
+        if (R >= 0xFFFFFFFFll) return fail(SGR_E_INVALID, "more than 2^32 - 2 (Gaussian, tile) instances in one view");
         n_chunks = g_pinned.p[4 + SGR_B2_HDR_CHUNKS];
     }
     if (opts->info) { opts->info->binning_mode = two_level ? 0 : 1; opts->info->sync_free = nosync ? 1 : 0; }

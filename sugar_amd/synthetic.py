@@ -122,6 +122,18 @@ def orbit_cameras(W: int, H: int, n: int = 8, radius: float = 3.0, elev_deg: flo
     return cams
 
 
+def scattered_cameras(W: int, H: int, n: int = 200, seed: int = 0) -> list[Camera]:
+    """n look-at cameras on a shell around the scene (azimuth uniform, elevation -10..50 degrees, radius 2.5..3.5): the camera count
+    of a real capture (SuGaR's scenes have 100-300 training views), for bench.py's hint-robustness leg"""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(n, 3, generator=g)
+    cams = []
+    for k in range(n):
+        az = 2 * math.pi * float(u[k, 0]); el = math.radians(-10.0 + 60.0 * float(u[k, 1])); r = 2.5 + float(u[k, 2])
+        cams.append(look_at_camera((r * math.cos(el) * math.cos(az), r * math.cos(el) * math.sin(az), r * math.sin(el)), (0.0, 0.0, 0.0), W, H))
+    return cams
+
+
 def make_config(name: str, P: int | None = None):
     """Returns (scene, cameras, bg[3]) for a BASELINE config name; P may override the Gaussian count."""
     P0, W, H, seed, s_lo, s_hi, max_norm, bg = CONFIGS[name]

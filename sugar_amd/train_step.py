@@ -574,6 +574,7 @@ class NativeTrainer:
         self.hint_margin = float(hint_margin if hint_margin is not None else _os.environ.get("SGR_HINT_MARGIN", 0.5))
         self._recent_misses = []   # step numbers of the latest hint misses
         self._hint_pause_until = 0
+        self.hint_pauses = 0       # times the hints were switched off for 64 forwards (three misses within 32)
         self.host_work_s = 0.0     # time spent preparing and enqueueing steps (the waits for the header are not in it)
         self._calls = 0            # forwards enqueued so far (the clock of the hint policy; `t` is Adam's and may be reset)
         self.exp_avg = torch.zeros_like(params.flat)
@@ -685,6 +686,7 @@ class NativeTrainer:
             if len(self._recent_misses) >= 3:
                 self._hint_pause_until = self._calls + 64
                 self._recent_misses = []
+                self.hint_pauses += 1
 
     def _repair(self, key, R, missed):
         self.redone += 1
@@ -716,7 +718,12 @@ class NativeTrainer:
 
     def step(self, cam, gt_image, cam_key=None):
         """One optimisation step on `cam` (device tensors) against `gt_image` [3,H,W]; returns the loss as a device scalar
-        (a view of `self.loss_out`: read it before the next step, or clone it)."""
+        (a view of `self.loss_out`: read it before the next step, or clone it).
+
+        Without a gradient exchange the step is validated ONE STEP LATE (see the class docstring): until the next `step()` or
+        `synchronize()` has looked at the forward's header, `loss_out` / `image` may belong to a forward that did not happen
+        (list capacity or walk hint exceeded: the blend wrote nothing and the loss kernel saw the previous image).  Call
+        `synchronize()` before reading them -- it repeats such a step -- as bench.py and the tests do."""
         key = id(cam) if cam_key is None else cam_key
         if not self.exchange:
             self._resolve()
