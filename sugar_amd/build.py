@@ -66,12 +66,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
+    # (variant builds for same-box A/B runs: SGR_SRC_OVERRIDE="preprocess.hip=/tmp/old_preprocess.hip,..." compiles another version of
+    # a translation unit against the current headers)
+    override = dict(kv.split("=", 1) for kv in os.environ.get("SGR_SRC_OVERRIDE", "").split(",") if "=" in kv)
     for src, extra in SOURCES.items():
-        path = os.path.join(CSRC, src)
+        path = override.get(src) or os.path.join(CSRC, src)
         if not os.path.exists(path):
             continue
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *COMMON, *extra, "-c", path, "-o", obj]
+        cmd = [hipcc, *COMMON, *extra, f"-I{CSRC}", "-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -450,9 +450,10 @@ __global__ void __launch_bounds__(256, SGR_PRE_BWD_BLOCKS) k_preprocess_bwd(Prep
 {
     const int idx0 = blockIdx.x * 256 + threadIdx.x;
     if (a.campos_row && idx0 < 3) a.campos_row[idx0] = a.cam_pos[idx0];  // (see sgr_backward_opts)
-    // a sync-free forward whose list outgrew its capacity (or missed its walk hint) did not happen: like the blend backward and
-    // the Adam kernels, leave every output -- gradients AND the densification statistics (denom would count the repeated step
-    // twice) -- untouched; the caller repeats the step.  (The three header words travel with the batch of loads below.)
+    // a sync-free forward whose list outgrew its capacity (or missed its walk hint) did not happen: the gradients are written as
+    // zeros (a caller of the autograd API must never see uninitialised memory) and the densification statistics stay untouched
+    // (denom would count the repeated step twice); the caller repeats the step.  (The three header words travel with the batch
+    // of loads below.)
     uint32_t hdr_r = 0u, hdr_miss = 0u, hdr_ovf = 0u;
     if (a.header) { hdr_r = a.header[SGR_HDR_R]; hdr_miss = a.header[SGR_HDR_HINT_MISS]; hdr_ovf = a.header[4 + SGR_B2_HDR_OVERFLOW]; }
     const bool valid = idx0 < a.P;
@@ -480,12 +481,12 @@ __global__ void __launch_bounds__(256, SGR_PRE_BWD_BLOCKS) k_preprocess_bwd(Prep
     Cam cam;
     cam_unpack(cam_raw, cam);
     if (!valid) return;
-    if (hdr_r > a.list_cap || hdr_miss != 0u || hdr_ovf != 0u) return;  // SGR_FORWARD_INVALID
+    const bool fwd_invalid = hdr_r > a.list_cap || hdr_miss != 0u || hdr_ovf != 0u;  // SGR_FORWARD_INVALID: zero gradients, no statistics
     const float* v = cam.vm;
 
     float dmean[3] = {0, 0, 0}, dcov[6] = {0, 0, 0, 0, 0, 0};
     const int n_sh = a.M * 3;
-    if (!(radius > 0)) {
+    if (fwd_invalid || !(radius > 0)) {
         if (a.dL_dmean2D) { a.dL_dmean2D[i3] = 0; a.dL_dmean2D[i3 + 1] = 0; a.dL_dmean2D[i3 + 2] = 0; }
         if (a.dL_dconic) { float4 z4 = {0, 0, 0, 0}; *reinterpret_cast<float4*>(a.dL_dconic + 4 * (size_t)idx) = z4; }
         a.dL_dopacity[idx] = 0;
