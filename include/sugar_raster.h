@@ -501,6 +501,17 @@ int64_t sgr_rasterize_meshes(const float* face_verts, int64_t F, int64_t face_in
                              int cull_backfaces, char* scratch, size_t scratch_bytes, sgr_alloc_fn list_alloc, void* list_user,
                              int64_t* pix_to_face, float* zbuf, float* bary_coords, float* dists, void* stream);
 
+/* The splat mesh of SuGaR's level-set sampler as face_verts for sgr_rasterize_meshes, straight from the Gaussian buffers:
+ * SuGaR.triangle_vertices (sugar_scene/sugar_model.py:481-514) + SuGaR.splat_mesh(mode='perspective') (:695-716) + the vertex
+ * transform of pytorch3d's MeshRasterizer (world -> view -> NDC x, y; view-space z) in one kernel.
+ *   points[P,3], scaling[P,3] (activated), quaternions[P,4] (unit, real part first), primitive_verts[4,3] (the canonical
+ *   corners, sugar_model.py:242-249, device), triangle_scale (:262), world_to_view[16] / projection[16]: the camera's
+ *   get_world_to_view_transform() / get_projection_transform() matrices in pytorch3d's row-vector convention (device).
+ *   face_verts[2P,3,3]: faces 2g and 2g+1 belong to Gaussian g (corner order [0,2,1], [0,3,2], :254-256). */
+int sgr_splat_mesh_face_verts(int P, const float* points, const float* scaling, const float* quaternions,
+                              const float* primitive_verts, float triangle_scale, const float* world_to_view,
+                              const float* projection, float* face_verts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,7 @@ SIGNATURES = {
     "sgr_knn_grid": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "sgr_dist2_grid": (_i, [_i, _vp, _vp, _vp, _vp]),
     "sgr_rasterize_meshes_scratch_bytes": (_sz, [_i64, _i, _i]),
+    "sgr_splat_mesh_face_verts": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "sgr_rasterize_meshes": (_i64, [_vp, _i64, _i64, _i, _i, _f, _i, _i, _i, _i, _vp, _sz, ALLOC_FN, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

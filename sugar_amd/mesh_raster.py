@@ -82,3 +82,29 @@ def rasterize_face_verts(face_verts: torch.Tensor, mesh_to_face_first_idx, num_f
             if rc < 0:
                 raise RuntimeError(f"sgr_rasterize_meshes failed ({rc}): {_lib.last_error()}")
     return p2f, zbuf, bary, dists
+
+
+def splat_face_verts(points: torch.Tensor, scaling: torch.Tensor, quaternions: torch.Tensor, primitive_verts: torch.Tensor,
+                     triangle_scale: float, world_to_view: torch.Tensor, projection: torch.Tensor) -> torch.Tensor:
+    """face_verts[2P,3,3] of SuGaR's splat mesh for one camera, straight from the Gaussian buffers (sgr_splat_mesh_face_verts):
+    `SuGaR.triangle_vertices` + `SuGaR.splat_mesh(mode='perspective')` + `MeshRasterizer.transform` in one kernel.
+    world_to_view / projection: the camera's 4x4 matrices in pytorch3d's row-vector convention ([1,4,4] or [4,4])."""
+    if not points.is_cuda:
+        raise RuntimeError("splat_face_verts needs tensors on a ROCm device; there is no CPU fallback")
+    lib = _lib.load()
+    dev = points.device
+    f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+    pts, sc, q, prim = f32(points), f32(scaling), f32(quaternions), f32(primitive_verts)
+    V, Pm = f32(world_to_view).reshape(-1), f32(projection).reshape(-1)
+    P = pts.shape[0]
+    if sc.shape != (P, 3) or q.shape != (P, 4) or prim.shape != (4, 3) or V.numel() != 16 or Pm.numel() != 16:
+        raise ValueError("splat_face_verts: expected points[P,3], scaling[P,3], quaternions[P,4], primitive_verts[4,3] and two 4x4 matrices")
+    out = torch.empty(2 * P, 3, 3, dtype=torch.float32, device=dev)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    with torch.cuda.device(dev):
+        rc = lib.sgr_splat_mesh_face_verts(P, vp(pts), vp(sc), vp(q), vp(prim), float(triangle_scale), vp(V), vp(Pm), vp(out),
+                                           C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc < 0:
+        raise RuntimeError(f"sgr_splat_mesh_face_verts failed ({rc}): {_lib.last_error()}")
+    return out
+

@@ -54,10 +54,11 @@ class MeshRasterizer(torch.nn.Module):
             out_verts.append(torch.cat([verts_ndc[..., :2], verts_view[..., 2:3]], dim=-1))
         return Meshes(out_verts, meshes_world.faces_list(), textures=meshes_world.textures)
 
-    def forward(self, meshes_world, **kwargs) -> Fragments:
-        meshes_proj = self.transform(meshes_world, **kwargs)
-        rs = kwargs.get("raster_settings", self.raster_settings)
-        cameras = kwargs.get("cameras", self.cameras)
+    @staticmethod
+    def resolved_settings(rs, cameras):
+        """(clip_barycentric_coords, perspective_correct, z_clip_value) as MeshRasterizer.forward derives them from the settings and
+        the camera: hard rasterization keeps unclipped barycentrics, perspective cameras interpolate perspective-correctly and clip
+        at znear / 2"""
         clip_barycentric_coords = rs.clip_barycentric_coords
         if clip_barycentric_coords is None:
             clip_barycentric_coords = rs.blur_radius > 0.0
@@ -70,6 +71,13 @@ class MeshRasterizer(torch.nn.Module):
             if torch.is_tensor(znear):
                 znear = znear.min().item()
             z_clip = None if znear is None else znear / 2
+        return clip_barycentric_coords, perspective_correct, z_clip
+
+    def forward(self, meshes_world, **kwargs) -> Fragments:
+        meshes_proj = self.transform(meshes_world, **kwargs)
+        rs = kwargs.get("raster_settings", self.raster_settings)
+        cameras = kwargs.get("cameras", self.cameras)
+        clip_barycentric_coords, perspective_correct, z_clip = self.resolved_settings(rs, cameras)
         pix_to_face, zbuf, bary_coords, dists = rasterize_meshes(
             meshes_proj, image_size=rs.image_size, blur_radius=rs.blur_radius, faces_per_pixel=rs.faces_per_pixel, bin_size=rs.bin_size,
             max_faces_per_bin=rs.max_faces_per_bin, clip_barycentric_coords=clip_barycentric_coords,

@@ -151,8 +151,10 @@ def compute_level_surface_points_from_camera_fast(
             from pytorch3d.renderer import MeshRasterizer, RasterizationSettings
             rasterizer = MeshRasterizer(cameras=p3d_cameras, raster_settings=RasterizationSettings(
                 image_size=(H, W), blur_radius=0.0, faces_per_pixel=10, max_faces_per_bin=50_000))
-        mesh = self.splat_mesh(p3d_cameras) if splat_mesh else self.mesh
-        fragments = rasterizer(mesh, cameras=p3d_cameras)
+        fragments = _splat_fragments(self, p3d_cameras, rasterizer) if splat_mesh else None
+        if fragments is None:
+            mesh = self.splat_mesh(p3d_cameras) if splat_mesh else self.mesh
+            fragments = rasterizer(mesh, cameras=p3d_cameras)
         depth = fragments.zbuf[0, ..., 0].clone()
     no_depth_mask = depth < 0.
     depth[no_depth_mask] = depth.max() * 1.05
@@ -210,6 +212,38 @@ def compute_level_surface_points_from_camera_fast(
             outputs['normals'] = r['normals']
         all_outputs[surface_level] = outputs
     return all_outputs
+
+
+def _splat_fragments(self, p3d_cameras, rasterizer):
+    """The fragments `rasterizer(self.splat_mesh(camera), cameras=camera)` returns, without the 4 P-vertex tensors in between: the
+    splat mesh's faces come out of ONE kernel that reads the Gaussian buffers (sgr_splat_mesh_face_verts: triangle_vertices :481-514,
+    splat_mesh :695-716 and the rasterizer's vertex transform), then clipping + z-buffer as the stand-in MeshRasterizer does.  Only
+    with the stand-in rasterizer of sugar_amd.shims (a real pytorch3d rasterizer gets the reference's mesh: returns None); the
+    interpolation weights and distances nobody reads here are not produced (None in the tuple)."""
+    import importlib
+    try:
+        fn = getattr(importlib.import_module("pytorch3d.renderer.mesh.rasterize_meshes"), "rasterize_face_verts_ndc", None)
+        from pytorch3d.renderer.mesh.rasterizer import Fragments, MeshRasterizer
+    except ImportError:
+        return None
+    if fn is None or not isinstance(rasterizer, MeshRasterizer) or not hasattr(MeshRasterizer, "resolved_settings"):
+        return None
+    if not self.points.is_cuda:
+        return None  # (CPU tensors: the host-logic tests run the reference's own splat_mesh on the oracle backend)
+    from .mesh_raster import splat_face_verts
+    rs = rasterizer.raster_settings
+    if rs.blur_radius != 0.0 or self.primitive_types not in ("diamond", "square"):
+        return None
+    prim = self._diamond_verts if self.primitive_types == "diamond" else self._square_verts
+    face_verts = splat_face_verts(self.points, self.scaling, self.quaternions, prim, self.triangle_scale,
+                                  p3d_cameras.get_world_to_view_transform().get_matrix(), p3d_cameras.get_projection_transform().get_matrix())
+    clip_bary, persp, z_clip = MeshRasterizer.resolved_settings(rs, p3d_cameras)
+    n = face_verts.shape[0]
+    dev = face_verts.device
+    p2f, zbuf, bary, dists = fn(face_verts, torch.zeros(1, dtype=torch.int64, device=dev), torch.full((1,), n, dtype=torch.int64, device=dev),
+                                rs.image_size, rs.blur_radius, rs.faces_per_pixel, persp, clip_bary, rs.cull_backfaces, z_clip,
+                                rs.cull_to_frustum, want_bary=False, want_dists=False)
+    return Fragments(pix_to_face=p2f, zbuf=zbuf, bary_coords=bary, dists=dists)
 
 
 _IMPL = dict(get_points_rgb=get_points_rgb, get_covariance=get_covariance, get_field_values=get_field_values,

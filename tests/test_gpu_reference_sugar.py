@@ -156,6 +156,18 @@ def test_the_reference_level_set_sampler_on_the_mesh_depth_path(sm):
         # -- the fragments of the splat mesh: nearest face and depth per pixel (HIP z-buffer) against the CPU oracle's
         mesh = model.splat_mesh(cam)
         assert _rel(mesh.verts_list()[0], fx["splat_verts"]) < 1e-5
+        # -- the same faces out of ONE kernel reading the Gaussian buffers (sgr_splat_mesh_face_verts) against the reference's
+        #    triangle_vertices / splat_mesh followed by the rasterizer's vertex transform
+        from sugar_amd.mesh_raster import splat_face_verts
+        proj_mesh = rasterizer.transform(mesh, cameras=cam)
+        ref_fv = proj_mesh.verts_packed()[proj_mesh.faces_packed()]
+        fused = splat_face_verts(model.points, model.scaling, model.quaternions, model._diamond_verts, model.triangle_scale,
+                                 cam.get_world_to_view_transform().get_matrix(), cam.get_projection_transform().get_matrix())
+        assert fused.shape == ref_fv.shape == (2 * model.n_points, 3, 3)
+        finite = torch.isfinite(ref_fv).all(-1).all(-1) & torch.isfinite(fused).all(-1).all(-1)
+        assert float(finite.float().mean()) > 0.999
+        err = (fused[finite] - ref_fv[finite]).abs().amax(dim=(1, 2)) / ref_fv[finite].abs().amax(dim=(1, 2)).clamp_min(1e-3)
+        assert float(err.max()) < 2e-4 and float(err.median()) < 2e-6, (float(err.max()), float(err.median()))
         fr = rasterizer(mesh, cameras=cam)
         assert fr.zbuf.is_cuda and fr.pix_to_face.dtype == torch.int64 and fr.pix_to_face.shape == (1,) + fx["frag_pix_to_face"].shape
         same = (fr.pix_to_face[0].cpu().numpy() == fx["frag_pix_to_face"])
