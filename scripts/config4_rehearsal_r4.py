@@ -51,6 +51,7 @@ model.primitive_types, model.triangle_scale = 'diamond', 2.
 model.point_idx_per_pixel = torch.zeros(2, 2, dtype=torch.int32, device=dev)
 model.verts_uv = torch.zeros(4 * P, 2, device=dev); model.faces_uv = model.triangles
 model._texture_initialized = True
+model.texture_size = 2
 from pytorch3d.renderer import MeshRasterizer, RasterizationSettings
 rasterizer = MeshRasterizer(cameras=nerf.training_cameras.p3d_cameras[0],
                             raster_settings=RasterizationSettings(image_size=(H, W), blur_radius=0.0, faces_per_pixel=10, max_faces_per_bin=50_000))

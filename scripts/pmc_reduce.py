@@ -1,0 +1,35 @@
+"""Reduce the PMC passes of scripts/r04_on_box.sh to profiles/pmc_blend_fwd.json (what bench.py's roofline.traffic and roofline_valu
+read): per launch of k_blend_fwd_w, HBM bytes from FETCH_SIZE / WRITE_SIZE with the gfx950 correction of
+/opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE counts 128-byte requests as 64: doubled; WRITE_SIZE as reported; KiB units) and
+the wave-instruction count from SQ_INSTS_VALU.
+    python scripts/pmc_reduce.py gpurun_out/r04 > profiles/pmc_blend_fwd.json"""
+import json
+import os
+import sys
+
+
+def avg(path, counter, kernel):
+    for line in open(path):
+        f = line.split()
+        if len(f) >= 6 and f[4] == counter and kernel in line:
+            return float(f[1]), float(f[2]), float(f[3])
+    raise SystemExit(f"{counter} of {kernel} not found in {path}")
+
+
+d = sys.argv[1]
+tag = os.path.basename(os.path.normpath(d))
+fetch = avg(os.path.join(d, "pmc_FETCH_SIZE.txt"), "FETCH_SIZE", "k_blend_fwd_w")
+write = avg(os.path.join(d, "pmc_WRITE_SIZE.txt"), "WRITE_SIZE", "k_blend_fwd_w")
+valu = avg(os.path.join(d, "pmc_SQ_INSTS_VALU.txt"), "SQ_INSTS_VALU", "k_blend_fwd_w")
+out = {
+    "kernel": "k_blend_fwd_w", "workload": "metric (1M Gaussians @ 1920x1080)", "workload_key": "metric",
+    "source": [f"profiles/{tag}_pmc_FETCH_SIZE.txt", f"profiles/{tag}_pmc_WRITE_SIZE.txt"],
+    "FETCH_SIZE_KiB_per_launch": fetch[0], "FETCH_SIZE_KiB_min_max": fetch[1:], "WRITE_SIZE_KiB_per_launch": write[0],
+    "correction": "gfx950 rocprofv3 FETCH_SIZE counts 128-B requests as 64 B: doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported",
+    "hbm_bytes_per_launch": (2.0 * fetch[0] + write[0]) * 1024.0,
+    "valu_wave_insts_per_launch": valu[0], "simd_issue_interval_ns": 1.25,
+    "valu_source": [f"profiles/{tag}_pmc_SQ_INSTS_VALU.txt", "profiles/r02_valu_issue_rate.txt"],
+    "note": "launch order: tiles by depth class of the camera's previous visit (default); the first, raster-ordered visit of a camera fetches "
+            "less (the min of FETCH_SIZE_KiB_min_max)",
+}
+print(json.dumps(out, indent=1))
