@@ -60,17 +60,18 @@ counts = {}
 k = [0]
 
 
-def sample(use_gaussian_depth, n=124_000):
+def sample(use_gaussian_depth, n=124_000, n_pass=2_000_000):
     with torch.no_grad():
         r = model.compute_level_surface_points_from_camera_fast(
             cam_idx=k[0] % len(cams), rasterizer=rasterizer, surface_levels=[0.1, 0.3, 0.5], n_surface_points=n, primitive_types='diamond',
-            triangle_scale=2., splat_mesh=True, n_points_in_range=21, range_size=3., n_points_per_pass=2_000_000, density_factor=1.,
+            triangle_scale=2., splat_mesh=True, n_points_in_range=21, range_size=3., n_points_per_pass=n_pass, density_factor=1.,
             return_pixel_idx=True, return_gaussian_idx=True, return_normals=True, compute_flat_normals=False,
             use_gaussian_depth=use_gaussian_depth)
     k[0] += 1
     counts[str(use_gaussian_depth)] = {str(lv): int(r[lv]["intersection_points"].shape[0]) for lv in r}
 
 
+print("leg: splat mesh + rasterizer", file=sys.stderr, flush=True)
 with torch.no_grad():
     cam0 = nerf.training_cameras.p3d_cameras[0]
     out["ms_splat_mesh_reference_method"] = timed(lambda: model.splat_mesh(cam0), 5)
@@ -79,14 +80,21 @@ with torch.no_grad():
     fr = rasterizer(mesh, cameras=cam0)
     out["mesh_pixels_covered"] = float((fr.pix_to_face[0, ..., 0] >= 0).float().mean())
     del fr, mesh
-out["ms_sampling_per_view_mesh_depth"] = timed(lambda: sample(False), 8)
-out["ms_sampling_per_view_gaussian_depth"] = timed(lambda: sample(True), 8)
+if not os.environ.get("ONLY_UNTOUCHED"):
+    print("leg: patched mesh depth", file=sys.stderr, flush=True)
+    out["ms_sampling_per_view_mesh_depth"] = timed(lambda: sample(False), 8)
+    print("leg: patched gaussian depth", file=sys.stderr, flush=True)
+    out["ms_sampling_per_view_gaussian_depth"] = timed(lambda: sample(True), 8)
 out["level_set_points_per_view"] = counts
 # the untouched reference method on the same inputs (its level sets are tensor code in passes of 2M samples)
 from sugar_amd import sugar_patch
 sugar_patch.uninstall(sm)
+print("leg: untouched reference method", file=sys.stderr, flush=True)
 try:
-    out["ms_sampling_per_view_mesh_depth_reference_tensor_code"] = timed(lambda: sample(False), 3, warm=1)
+    # (n_points_per_pass 100k instead of the extractor's 2M: at 2M samples x 16 neighbours the reference's batched 3x3 matmul,
+    # sugar_model.py:2000, takes a GPU memory fault inside the BLAS library of this ROCm stack -- 32M matrices in one batch)
+    out["ms_sampling_per_view_mesh_depth_reference_tensor_code"] = timed(lambda: sample(False, n_pass=100_000), 3, warm=1)
+    out["reference_tensor_code_note"] = "n_points_per_pass=100000 (2000000, the extractor's value, faults in the batched matmul of sugar_model.py:2000 on this ROCm stack)"
 except Exception as e:  # (memory)
     out["ms_sampling_per_view_mesh_depth_reference_tensor_code"] = repr(e)
 print(json.dumps(out))
