@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--preroll", type=int, default=600, help="untimed steps before the warm-up steps (parameters restored afterwards); 0: none")
     ap.add_argument("--sh-dir-in-adam", action="store_true", help="form dRGB/d(view direction) -> dL/dxyz in the SH-Adam kernel instead of the backward preprocess kernel (A/B)")
     ap.add_argument("--force-collectives", action="store_true", help="N = 1: create a one-rank RCCL group and run the gradient exchange anyway (exercises the collective path on one GPU)")
+    ap.add_argument("--native-collectives", action="store_true", help="with a process group: the gradient exchange inside the library (sgr_trainer_step_exchange, RCCL bound at run time, one call per step) instead of torch.distributed collectives between four phase calls")
     ap.add_argument("--python-step", action="store_true", help="the autograd-based ViewShardedTrainer (Python between the kernels) instead of the native step (A/B)")
     ap.add_argument("--no-walk-hint", action="store_true", help="native step without the walk hint of the list-write pass (A/B)")
     ap.add_argument("--no-launch-order", action="store_true", help="native step with the blend kernels' workgroups in raster order instead of the camera's previous depth order (A/B)")
@@ -125,7 +126,7 @@ def main():
         trainer = ForwardOnly(scene, dev, bg_d, GaussianRasterizer, GaussianRasterizationSettings, _C, host_sync=args.host_sync)
     elif native:
         trainer = NativeTrainer(params, bg_d, W, H, force_collectives=args.force_collectives, walk_hint=not args.no_walk_hint,
-                                launch_order=not args.no_launch_order)
+                                launch_order=not args.no_launch_order, native_collectives=True if args.native_collectives else None)
     else:
         trainer = ViewShardedTrainer(params, GaussianRasterizer, GaussianRasterizationSettings, bg_d,
                                      sync_free=False if args.host_sync else None,
@@ -445,7 +446,8 @@ def main():
                                         "pre_roll_and_warmup": marks.get("after_warmup", 0), "whole_run": trainer.redone}
         if comm is not None:
             out.update(comm)
-            out["config"]["collectives"] = "forced on a one-rank RCCL group" if world == 1 else "RCCL"
+            out["config"]["collectives"] = ("forced on a one-rank RCCL group" if world == 1 else "RCCL") + \
+                (", enqueued by the library (sgr_trainer_step_exchange)" if getattr(trainer, "native_collectives", False) else ", torch.distributed between four phase calls")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cams[0], bg, forward_only)
         sys.stdout.flush()

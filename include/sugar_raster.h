@@ -403,6 +403,20 @@ int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* view, int phases, con
  * receives the two header copies (word 0: the real num_rendered, word 3: hint miss, word 6: level-1 overflow). */
 int sgr_trainer_forward_valid(sgr_trainer* t, uint32_t* header_out);
 const char* sgr_trainer_last_error(void);
+/* The gradient exchange of the view-sharded step INSIDE the library (extension; SURVEY.md section 8e: one view per GPU, replicas,
+ * "RCCL all-reduce of parameter grads over xGMI"): RCCL is bound at run time (dlopen of librccl.so -- the copy PyTorch has already
+ * loaded, if any), one communicator per trainer, collectives on a stream of the library's own.
+ *   sgr_rccl_unique_id(out[128])      rank 0: ncclGetUniqueId; the caller distributes the 128 bytes (torch.distributed, MPI, a file)
+ *   sgr_trainer_comm_init(t, id, world, rank, recv, recv_bytes)   ncclCommInitRank; recv: world x (P + 1) x 3 floats (device)
+ *   sgr_trainer_step_exchange(t, view, step, stream)   ONE call per step: phase 1, header check BEFORE anything is sent, all-gather
+ *       of the masked colour gradients + camera centres beside phase 2, all-reduce of flat_grad[0 .. n_small) beside phase 4,
+ *       phase 8 behind it.  Returns 0, or 1 when this rank's forward was invalid (nothing sent, nothing changed: enlarge the
+ *       capacity / drop the hint and call again -- the other ranks wait in the all-gather), or a negative error code. */
+int sgr_rccl_unique_id(char* out128);
+int sgr_trainer_comm_init(sgr_trainer* t, const char* id128, int world, int rank, float* recv, size_t recv_bytes);
+int sgr_trainer_comm_destroy(sgr_trainer* t);
+int sgr_trainer_step_exchange(sgr_trainer* t, const sgr_train_view* view, int step, void* stream);
+double sgr_trainer_last_exchange_wait_ms(sgr_trainer* t); /* host time the last call spent waiting for the forward's header */
 size_t sgr_bin2_bytes(int P, int width, int height); /* scratch of the two-level binning appended to the image scratch */
 
 /* ---- SuGaR density field and level-set surface sampler (share the Gaussian buffers) --------------

@@ -35,6 +35,11 @@ SIGNATURES = {
     "sgr_trainer_step": (_i, [_vp, _vp, _i, _vp, _vp]),
     "sgr_trainer_forward_valid": (_i, [_vp, _vp]),
     "sgr_trainer_last_error": (C.c_char_p, []),
+    "sgr_rccl_unique_id": (_i, [_vp]),
+    "sgr_trainer_comm_init": (_i, [_vp, _vp, _i, _i, _vp, _sz]),
+    "sgr_trainer_comm_destroy": (_i, [_vp]),
+    "sgr_trainer_step_exchange": (_i, [_vp, _vp, _i, _vp]),
+    "sgr_trainer_last_exchange_wait_ms": (C.c_double, [_vp]),
     "sgr_bin2_bytes": (_sz, [_i, _i, _i]),
     "sgr_sh_grad_from_views": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp]),
     "sgr_sh_adam_from_views": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _f, _vp]),

@@ -10,9 +10,11 @@
 #include "sgr_common.h"
 #include "tile_order.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 
 namespace {
@@ -25,10 +27,63 @@ char* fixed_alloc(void* user, size_t bytes)
     return bytes <= b->bytes ? b->p : nullptr;
 }
 
+// ---- RCCL, bound at run time (no link-time dependency: a process that never exchanges gradients never loads it, and a process that
+// already has torch's copy loaded shares it).  Only what the view-sharded step needs: rccl.h:40-43,187,220,260,339,448,466,611,678.
+struct RcclUniqueId { char internal[128]; };
+typedef void* RcclComm;
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(RcclUniqueId*) = nullptr;
+    int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(RcclComm) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok() const { return GetUniqueId && CommInitRank && CommDestroy && AllGather && AllReduce; }
+};
+const int RCCL_FLOAT = 7, RCCL_SUM = 0;
+Rccl& rccl()
+{
+    static Rccl r;
+    if (r.handle) return r;
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+        r.handle = dlopen(name, RTLD_NOW | RTLD_NOLOAD);  // torch's copy, if it is already in the process
+        if (r.handle) break;
+    }
+    if (!r.handle)
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.handle) break;
+        }
+    if (!r.handle) return r;
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.handle, "ncclAllGather"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.handle, "ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
+    return r;
+}
+
+// the camera centres of all views, row P of every rank's block of the gathered buffer, as one [world, 3] array
+__global__ void k_gather_campos(int world, size_t block_floats, size_t row_offset, const float* __restrict__ recv, float* __restrict__ out)
+{
+    const int i = threadIdx.x;
+    if (i < 3 * world) out[i] = recv[(size_t)(i / 3) * block_floats + row_offset + (size_t)(i % 3)];
+}
+
 }  // namespace
 
 struct sgr_trainer {
     sgr_train_config c;
+    // gradient exchange inside the library (sgr_trainer_comm_init)
+    RcclComm comm = nullptr;
+    int world = 1, rank = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_colors = nullptr, ev_gathered = nullptr, ev_small = nullptr, ev_reduced = nullptr;
+    float* recv = nullptr;        // caller's buffer: world x (P + 1) x 3 floats
+    float* campos_all = nullptr;  // world x 3 floats (owned)
+    double last_wait_ms = 0.0;    // what the last sgr_trainer_step_exchange spent waiting for the forward's header
     hipEvent_t hdr_event = nullptr;
     bool have_forward = false;
     bool defer_post = false;    // the post-blend bookkeeping rides in the loss forward kernel (needs a device-mapped header_host)
@@ -81,6 +136,7 @@ sgr_trainer* sgr_trainer_create(const sgr_train_config* cfg)
 void sgr_trainer_destroy(sgr_trainer* t)
 {
     if (!t) return;
+    (void)sgr_trainer_comm_destroy(t);
     if (t->hdr_event) (void)hipEventDestroy(t->hdr_event);
     delete t;
 }
@@ -193,6 +249,110 @@ int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* v, int phases, const 
             if (rc < 0) return tfail(rc, "adam launch failed");
         }
     }
+    return 0;
+}
+
+
+// ---- the gradient exchange of the view-sharded step inside the library: RCCL on a stream of its own, no interpreter between
+// the four phases (include/sugar_raster.h)
+int sgr_rccl_unique_id(char* out128)
+{
+    Rccl& r = rccl();
+    if (!r.ok()) return tfail(SGR_E_INVALID, "RCCL could not be loaded (librccl.so)");
+    RcclUniqueId id;
+    const int rc = r.GetUniqueId(&id);
+    if (rc != 0) return tfail(SGR_E_HIP, std::string("ncclGetUniqueId: ") + (r.GetErrorString ? r.GetErrorString(rc) : "failed"));
+    std::memcpy(out128, id.internal, 128);
+    return 0;
+}
+
+int sgr_trainer_comm_init(sgr_trainer* t, const char* id128, int world, int rank, float* recv, size_t recv_bytes)
+{
+    if (!t || !id128 || world < 1 || rank < 0 || rank >= world || !recv) return tfail(SGR_E_INVALID, "sgr_trainer_comm_init: bad argument");
+    if (recv_bytes < (size_t)world * ((size_t)t->c.P + 1) * 3 * sizeof(float))
+        return tfail(SGR_E_INVALID, "sgr_trainer_comm_init: receive buffer smaller than world x (P + 1) x 3 floats");
+    if (t->comm) return tfail(SGR_E_INVALID, "sgr_trainer_comm_init: already initialised");
+    Rccl& r = rccl();
+    if (!r.ok()) return tfail(SGR_E_INVALID, "RCCL could not be loaded (librccl.so)");
+    RcclUniqueId id;
+    std::memcpy(id.internal, id128, 128);
+    int rc = r.CommInitRank(&t->comm, world, id, rank);
+    if (rc != 0) { t->comm = nullptr; return tfail(SGR_E_HIP, std::string("ncclCommInitRank: ") + (r.GetErrorString ? r.GetErrorString(rc) : "failed")); }
+    t->world = world; t->rank = rank; t->recv = recv;
+    bool ok = hipStreamCreateWithFlags(&t->comm_stream, hipStreamNonBlocking) == hipSuccess;
+    for (hipEvent_t* e : {&t->ev_colors, &t->ev_gathered, &t->ev_small, &t->ev_reduced})
+        ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&t->campos_all), (size_t)world * 3 * sizeof(float)) == hipSuccess;
+    if (!ok) { (void)sgr_trainer_comm_destroy(t); return tfail(SGR_E_HIP, "sgr_trainer_comm_init: stream / event / buffer creation failed"); }
+    return 0;
+}
+
+double sgr_trainer_last_exchange_wait_ms(sgr_trainer* t) { return t ? t->last_wait_ms : 0.0; }
+
+int sgr_trainer_comm_destroy(sgr_trainer* t)
+{
+    if (!t) return 0;
+    if (t->comm_stream) (void)hipStreamSynchronize(t->comm_stream);
+    if (t->comm) { (void)rccl().CommDestroy(t->comm); t->comm = nullptr; }
+    for (hipEvent_t* e : {&t->ev_colors, &t->ev_gathered, &t->ev_small, &t->ev_reduced})
+        if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+    if (t->comm_stream) { (void)hipStreamDestroy(t->comm_stream); t->comm_stream = nullptr; }
+    if (t->campos_all) { (void)hipFree(t->campos_all); t->campos_all = nullptr; }
+    t->world = 1; t->rank = 0; t->recv = nullptr;
+    return 0;
+}
+
+// One view-sharded step with the exchange inside: forward + loss + blend half of the backward; the forward's header is waited for
+// and checked HERE, before anything is sent (a rank whose list outgrew its capacity or missed its walk hint returns 1 with nothing
+// sent and nothing changed: the caller enlarges the capacity / drops the hint and calls again, while the other ranks wait in the
+// all-gather); then all-gather of the masked colour gradients (+ camera centre row) on the communication stream beside the
+// preprocess half, all-reduce of the 11 small floats per Gaussian beside the SH half of Adam, and the two Adam kernels behind their
+// events.  Same kernels and the same places for the collectives as the torch.distributed path of sugar_amd.train_step.NativeTrainer.
+int sgr_trainer_step_exchange(sgr_trainer* t, const sgr_train_view* v, int step, void* stream)
+{
+    if (!t || !v || step < 1) return tfail(SGR_E_INVALID, "sgr_trainer_step_exchange: bad argument");
+    if (!t->comm) return tfail(SGR_E_INVALID, "sgr_trainer_step_exchange: sgr_trainer_comm_init first");
+    Rccl& r = rccl();
+    hipStream_t s = (hipStream_t)stream;
+    const sgr_train_config& c = t->c;
+    const size_t P = (size_t)c.P, block = (P + 1) * 3;
+    int rc = sgr_trainer_step(t, v, 1, nullptr, stream);
+    if (rc < 0) return rc;
+    uint32_t hdr[16];
+    const auto w0 = std::chrono::steady_clock::now();
+    rc = sgr_trainer_forward_valid(t, hdr);
+    t->last_wait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+    if (rc < 0) return rc;
+    if (rc == 0) return 1;  // invalid forward: nothing was sent
+#define EX_TRY(expr, what)                                                                     \
+    do {                                                                                       \
+        if ((expr) != hipSuccess) return tfail(SGR_E_HIP, std::string(what) + ": HIP call failed"); \
+    } while (0)
+    EX_TRY(hipEventRecord(t->ev_colors, s), "record colours");
+    EX_TRY(hipStreamWaitEvent(t->comm_stream, t->ev_colors, 0), "wait colours");
+    int nrc = r.AllGather(c.colors, t->recv, block, RCCL_FLOAT, t->comm, t->comm_stream);
+    if (nrc != 0) return tfail(SGR_E_HIP, std::string("ncclAllGather: ") + (r.GetErrorString ? r.GetErrorString(nrc) : "failed"));
+    EX_TRY(hipEventRecord(t->ev_gathered, t->comm_stream), "record gathered");
+    rc = sgr_trainer_step(t, v, 2, nullptr, stream);
+    if (rc < 0) return rc;
+    EX_TRY(hipEventRecord(t->ev_small, s), "record small gradients");
+    EX_TRY(hipStreamWaitEvent(t->comm_stream, t->ev_small, 0), "wait small gradients");
+    nrc = r.AllReduce(c.flat_grad, c.flat_grad, (size_t)c.n_small, RCCL_FLOAT, RCCL_SUM, t->comm, t->comm_stream);
+    if (nrc != 0) return tfail(SGR_E_HIP, std::string("ncclAllReduce: ") + (r.GetErrorString ? r.GetErrorString(nrc) : "failed"));
+    EX_TRY(hipEventRecord(t->ev_reduced, t->comm_stream), "record reduced");
+    EX_TRY(hipStreamWaitEvent(s, t->ev_gathered, 0), "wait gathered");
+    hipLaunchKernelGGL(k_gather_campos, dim3(1), dim3(256), 0, s, t->world, block, 3 * P, t->recv, t->campos_all);
+    if (t->world > 85) return tfail(SGR_E_INVALID, "more than 85 ranks");
+    sgr_train_exchange ex;
+    std::memset(&ex, 0, sizeof(ex));
+    ex.n_views = t->world; ex.all_colors = t->recv; ex.view_stride = (int64_t)(P + 1); ex.all_campos = t->campos_all;
+    ex.grad_scale = 1.0f / (float)t->world; ex.step = step;
+    rc = sgr_trainer_step(t, v, 4, &ex, stream);
+    if (rc < 0) return rc;
+    EX_TRY(hipStreamWaitEvent(s, t->ev_reduced, 0), "wait reduced");
+    rc = sgr_trainer_step(t, v, 8, &ex, stream);
+    if (rc < 0) return rc;
+#undef EX_TRY
     return 0;
 }
 

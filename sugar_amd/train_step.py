@@ -552,7 +552,7 @@ class NativeTrainer:
 
     def __init__(self, params: GaussianParams, bg, width, height, sh_degree=3, lambda_dssim=0.2, densify_stats=False,
                  force_collectives=False, walk_hint=True, capacity=None, betas=(0.9, 0.999), eps=1e-15, hint_margin=None,
-                 launch_order=True):
+                 launch_order=True, native_collectives=None):
         import ctypes as C
         from . import _lib
         if not params.flat.is_cuda:
@@ -617,6 +617,26 @@ class NativeTrainer:
         self._h = lib.sgr_trainer_create(C.byref(self._cfg))
         if not self._h:
             raise RuntimeError("sgr_trainer_create failed: " + lib.sgr_trainer_last_error().decode(errors="replace"))
+        # The gradient exchange inside the library (sgr_trainer_step_exchange: RCCL bound at run time, collectives on the library's own
+        # stream, ONE call per step, no interpreter between the phases).  Opt-in (`native_collectives=True` or SGR_NATIVE_COLLECTIVES=1)
+        # and only with the RCCL backend: it could be exercised with one rank only on the one-GPU test boxes, so the torch.distributed
+        # path -- tested with two ranks over gloo -- stays the default for the driver's multi-GPU runs.
+        if native_collectives is None:
+            native_collectives = _os.environ.get("SGR_NATIVE_COLLECTIVES", "0") == "1"
+        self.native_collectives = False
+        if native_collectives and self.exchange:
+            if dist.get_backend() != "nccl":
+                raise RuntimeError("native_collectives needs the RCCL (\"nccl\") process group backend")
+            idbuf = C.create_string_buffer(128)
+            if dist.get_rank() == 0 and lib.sgr_rccl_unique_id(idbuf) < 0:
+                raise RuntimeError("sgr_rccl_unique_id failed: " + lib.sgr_trainer_last_error().decode(errors="replace"))
+            box = [idbuf.raw]
+            dist.broadcast_object_list(box, src=0)
+            with torch.cuda.device(dev):
+                rc = lib.sgr_trainer_comm_init(self._h, box[0], self.world, dist.get_rank(), self._recv.data_ptr(), self._recv.numel() * 4)
+            if rc < 0:
+                raise RuntimeError("sgr_trainer_comm_init failed: " + lib.sgr_trainer_last_error().decode(errors="replace"))
+            self.native_collectives = True
 
     def __del__(self):
         try:
@@ -627,7 +647,7 @@ class NativeTrainer:
             pass
 
     # ---- one phase mask, one call
-    def _call(self, cam, gt, key, phases, ex, use_hint=True):
+    def _call(self, cam, gt, key, phases, ex, use_hint=True, exchange_step=None):
         import time as _time
         _t0 = _time.perf_counter()
         C, L = self._C, self._L
@@ -651,11 +671,17 @@ class NativeTrainer:
         view = L.TrainView(cam.viewmatrix.data_ptr(), cam.projmatrix.data_ptr(), cam.campos.data_ptr(), cam.tanfovx, cam.tanfovy,
                            gt.data_ptr(), need, need_out, self.hint_margin, self._chunk_grid(key), order, order_out)
         with torch.cuda.device(self.dev):
-            rc = self._lib.sgr_trainer_step(self._h, C.byref(view), phases, C.byref(ex) if ex is not None else None,
-                                            C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream))
+            stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+            if exchange_step is not None:
+                rc = self._lib.sgr_trainer_step_exchange(self._h, C.byref(view), int(exchange_step), stream)
+            else:
+                rc = self._lib.sgr_trainer_step(self._h, C.byref(view), phases, C.byref(ex) if ex is not None else None, stream)
         self.host_work_s += _time.perf_counter() - _t0
+        if exchange_step is not None:  # (the wait for the forward's header inside the call is not the host's own work)
+            self.host_work_s -= 1e-3 * float(self._lib.sgr_trainer_last_exchange_wait_ms(self._h))
         if rc < 0:
             raise RuntimeError(f"sgr_trainer_step failed ({rc}): " + self._lib.sgr_trainer_last_error().decode(errors="replace"))
+        return rc
 
     def _chunk_grid(self, key):
         """workgroups worth launching for the level-2 tile passes: what this camera's last visit had, plus a quarter"""
@@ -732,9 +758,24 @@ class NativeTrainer:
             self._call(cam, gt_image, key, 15, ex)
             self._pending = (cam, gt_image, key)
             return self.loss_out[0]
-        # ---- with the gradient exchange: phases with the collectives between them
+        # ---- with the gradient exchange
         P, world = self.params.P, self.world
         self.t += 1
+        if self.native_collectives:  # ONE call: the phases, the header check and the RCCL collectives are enqueued by the library
+            while True:
+                rc = self._call(cam, gt_image, key, 1, None, exchange_step=self.t)
+                ok, R, missed = self._valid()  # (the call has already waited for this header: no second wait)
+                if rc == 0:
+                    if key in self._hints:
+                        self._hints[key][1] = True
+                        self._hints[key][2] = self._last_chunks
+                        self._hints[key][4] = True
+                    self._hint_feedback(False)
+                    return self.loss_out[0]
+                if not (R or missed):
+                    raise RuntimeError("level-1 binning overflow: this view needs the single-level binning (use ViewShardedTrainer)")
+                self._repair(key, R, missed)
+        # ... or as four phase calls with torch.distributed collectives between them
         while True:
             self._call(cam, gt_image, key, 1, None)
             ok, R, missed = self._valid()

@@ -141,6 +141,18 @@ def _rccl_worker(rank, world, port, out_dir):
         nt.step(cams[s % len(cams)], gts[s % len(cams)], cam_key=s)
     nt.synchronize()
     np.save(os.path.join(out_dir, "rccl_native.npy"), pn.flat.detach().cpu().numpy())
+    # ... and with the exchange INSIDE the library: one sgr_trainer_step_exchange call per step, RCCL bound at run time (its own
+    # communicator, its own stream); the first step starts with a list capacity that is too small and must come back as "repeat"
+    # BEFORE anything was sent
+    pl = GaussianParams(scene, dev)
+    nl = NativeTrainer(pl, torch.zeros(3), W, H, force_collectives=True, native_collectives=True, capacity=50000)
+    assert nl.exchange and nl.native_collectives
+    for s in range(3):
+        nl.step(cams[s % len(cams)], gts[s % len(cams)], cam_key=s)
+    nl.synchronize()
+    assert nl.redone >= 1
+    np.save(os.path.join(out_dir, "rccl_native_in_library.npy"), pl.flat.detach().cpu().numpy())
+    del nl
     np.save(os.path.join(out_dir, "rccl_forced.npy"), flats[True])
     np.save(os.path.join(out_dir, "rccl_plain.npy"), flats[False])
     np.save(os.path.join(out_dir, "rccl_flat_exchange.npy"), params.flat.detach().cpu().numpy())
@@ -150,12 +162,12 @@ def _rccl_worker(rank, world, port, out_dir):
 def test_single_rank_rccl_group_runs_the_collective_path(tmp_path):
     scene = syn.make_scene(P, 17, 0.01, 0.08)
     mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
-    a, b, c, d = (np.load(tmp_path / f"rccl_{n}.npy") for n in ("forced", "plain", "flat_exchange", "native"))
+    a, b, c, d, e = (np.load(tmp_path / f"rccl_{n}.npy") for n in ("forced", "plain", "flat_exchange", "native", "native_in_library"))
     from sugar_amd.train_step import GaussianParams
     start = GaussianParams(scene, torch.device("cuda:0")).flat.detach().cpu().numpy()
     upd = np.abs(b - start).max()
     assert upd > 1e-4
-    for other in (a, c, d):
+    for other in (a, c, d, e):
         # (float atomics in the blend backward: the sign of a near-zero gradient may flip a +-lr Adam step)
         assert float((np.abs(other - b) > 1e-2 * upd).mean()) < 1e-4
         assert float(np.linalg.norm(other - b) / np.linalg.norm(b - start)) < 1e-3
