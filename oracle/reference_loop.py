@@ -36,13 +36,8 @@ def import_reference():
     for p in (os.path.join(ref, "gaussian_splatting"), ROOT):
         if p not in sys.path:
             sys.path.insert(0, p)
-    if "plyfile" not in sys.modules:
-        try:
-            import plyfile  # noqa: F401
-        except ImportError:
-            m = types.ModuleType("plyfile")
-            m.PlyData = m.PlyElement = object
-            sys.modules["plyfile"] = m
+    from sugar_amd import shims
+    shims.install()  # `plyfile` (gaussian_model.py:18) is absent from the image: stand-in
     import gaussian_renderer
     from scene.gaussian_model import GaussianModel
     from utils.loss_utils import l1_loss, ssim

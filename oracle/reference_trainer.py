@@ -1,0 +1,184 @@
+"""TEST INFRASTRUCTURE / DEMONSTRATION, NOT PRODUCT: the reference's own SuGaR trainer --
+`sugar_trainers/coarse_sdf.py::coarse_training_with_sdf_regularization(args)`, every statement of it, its files untouched -- run
+on this repository's drop-ins: `diff_gaussian_rasterization` and `simple_knn` (HIP), the `pytorch3d` / `plyfile` stand-ins
+(sugar_amd.shims) and, optionally, the HIP routes of SuGaR's field methods (shims.install(patch_sugar=...)).
+
+What it needs and the reference does not ship: a scene on disk.  `write_dataset` makes one in the layout the trainer reads
+(sugar_scene/gs_model.py:69-160, sugar_scene/cameras.py:15-139):
+
+    <root>/scene/images/<name>.png                                  ground-truth views (rendered here from a "true" surface)
+    <root>/gs/cameras.json                                          camera_to_JSON records (camera_utils.py:62-82)
+    <root>/gs/point_cloud/iteration_7000/point_cloud.ply            the "trained 3DGS" the trainer starts from: the true scene
+                                                                    with perturbed colours, opacities and scales
+
+The trainer's schedule is hard-coded in its body (15 000 iterations, starting at 6 999 when initialised from a trained 3DGS:
+coarse_sdf.py:18-226,472-473: entropy regularisation from 7 000, pruning + SDF / normal regularisation with 1M samples from
+9 000).  To stop a run early WITHOUT touching the file, the module-level name `ssim` the loop calls once per iteration
+(coarse_sdf.py:11,459) is wrapped by a counter that raises after `stop_at`; the module-level name `Console` the function builds its rich console from
+(coarse_sdf.py:13,18) is replaced by one that writes to a file so the loss lines it prints every 50 iterations can be read back.
+
+Used by tests/test_gpu_reference_trainer.py and scripts/run_reference_trainer.py (the log committed under profiles/)."""
+from __future__ import annotations
+
+import json
+import math
+import os
+import re
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class _Stop(Exception):
+    pass
+
+
+def surface_scene(P: int, seed: int = 0):
+    """Flat Gaussians on a bumpy closed surface (radius about 0.8), colours a smooth function of position: something an SDF
+    regulariser has a surface to find in.  Returns a sugar_amd.synthetic.Scene (activated values)."""
+    from sugar_amd import synthetic as syn
+    g = torch.Generator().manual_seed(seed)
+    d = torch.randn(P, 3, generator=g)
+    d = d / d.norm(dim=1, keepdim=True)
+    r = 0.8 + 0.12 * torch.sin(3.0 * d[:, :1]) * torch.cos(2.0 * d[:, 1:2]) + 0.08 * torch.sin(5.0 * d[:, 2:3])
+    means = d * r
+    # tangent frame: normal ~ radial direction (good enough for a bumpy sphere); quaternion rotating z onto the normal
+    n = d
+    z = torch.tensor([0.0, 0.0, 1.0]).expand_as(n)
+    axis = torch.linalg.cross(z, n)
+    s = axis.norm(dim=1, keepdim=True).clamp_min(1e-8)
+    ang = torch.atan2(s, (z * n).sum(1, keepdim=True))
+    axis = axis / s
+    quat = torch.cat([torch.cos(ang / 2), axis * torch.sin(ang / 2)], dim=1)
+    quat = quat / quat.norm(dim=1, keepdim=True)
+    spacing = 0.8 * math.sqrt(4 * math.pi / P)
+    tang = spacing * (0.7 + 0.9 * torch.rand(P, 2, generator=g))
+    scales = torch.cat([tang, 0.15 * spacing * torch.ones(P, 1)], dim=1)   # third axis (local z = normal) is the thin one
+    opac = torch.sigmoid(2.0 + torch.randn(P, 1, generator=g))
+    rgb = 0.5 + 0.35 * torch.stack([torch.sin(4 * means[:, 0]), torch.sin(5 * means[:, 1] + 1.0), torch.cos(3 * means[:, 2])], dim=1)
+    shs = torch.zeros(P, 16, 3)
+    shs[:, 0] = (rgb - 0.5) / syn.SH_C0
+    shs[:, 1:4] = 0.03 * torch.randn(P, 3, 3, generator=g)
+    return syn.Scene(means.contiguous(), scales.contiguous(), quat.contiguous(), opac.contiguous(), shs.contiguous())
+
+
+def write_dataset(root: str, P: int = 60_000, n_cams: int = 48, W: int = 480, H: int = 320, seed: int = 0, device: str = "cuda:0"):
+    """the on-disk scene described in the module docstring; GT images come from the HIP rasterizer (GPU needed)"""
+    from PIL import Image
+    from sugar_amd import io as sio, synthetic as syn
+    from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    scene = surface_scene(P, seed)
+    cams = syn.scattered_cameras(W, H, n=n_cams, seed=seed + 1)
+    img_dir = os.path.join(root, "scene", "images")
+    gs_dir = os.path.join(root, "gs")
+    os.makedirs(img_dir, exist_ok=True)
+    os.makedirs(gs_dir, exist_ok=True)
+    dev = torch.device(device)
+    records = []
+    with torch.no_grad():
+        for i, c in enumerate(cams):
+            settings = GaussianRasterizationSettings(
+                image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=torch.zeros(3, device=dev), scale_modifier=1.0,
+                viewmatrix=c.viewmatrix.to(dev), projmatrix=c.projmatrix.to(dev), sh_degree=3, campos=c.campos.to(dev),
+                prefiltered=False, debug=False)
+            img, _ = GaussianRasterizer(settings)(
+                means3D=scene.means3D.to(dev), means2D=torch.zeros(P, 3, device=dev), shs=scene.shs.to(dev), colors_precomp=None,
+                opacities=scene.opacities.to(dev), scales=scene.scales.to(dev), rotations=scene.rotations.to(dev), cov3D_precomp=None)
+            arr = (img.clamp(0, 1).permute(1, 2, 0).cpu().numpy() * 255.0 + 0.5).astype(np.uint8)
+            name = f"view_{i:03d}"
+            Image.fromarray(arr, "RGB").save(os.path.join(img_dir, name + ".png"))
+            w2c = c.viewmatrix.t().double().numpy()
+            records.append(sio.camera_to_json(i, name, w2c[:3, :3].T.copy(), w2c[:3, 3].copy(), 2 * math.atan(c.tanfovx),
+                                              2 * math.atan(c.tanfovy), W, H))
+    with open(os.path.join(gs_dir, "cameras.json"), "w") as f:
+        json.dump(records, f)
+    # the "trained 3DGS" checkpoint: the true scene, perturbed, as raw (pre-activation) parameters
+    g = torch.Generator().manual_seed(seed + 2)
+    shs = scene.shs.clone()
+    shs[:, 0] += 0.25 * torch.randn(P, 3, generator=g)
+    o = scene.opacities.clamp(1e-4, 1 - 1e-4)
+    raw_o = torch.log(o / (1 - o)) + 0.5 * torch.randn(P, 1, generator=g)
+    raw_s = torch.log(scene.scales) + 0.15 * torch.randn(P, 3, generator=g)
+    sio.save_gaussian_ply(os.path.join(gs_dir, "point_cloud", "iteration_7000", "point_cloud.ply"),
+                          scene.means3D, shs, raw_o, raw_s, scene.rotations)
+    return types.SimpleNamespace(scene_path=os.path.join(root, "scene"), checkpoint_path=gs_dir + "/", n_cams=n_cams, P=P, W=W, H=H)
+
+
+def import_trainer(patch_sugar: bool):
+    """the reference's `sugar_trainers.coarse_sdf`, from /root/reference or the staged snapshot oracle/_ref/pysrc"""
+    from tests import ref_env
+    sm = ref_env.import_sugar_model(patch_sugar=patch_sugar)
+    import sugar_trainers.coarse_sdf as tr
+    ref = ref_env.reference_root()
+    assert os.path.abspath(tr.__file__).startswith(os.path.abspath(ref)), tr.__file__
+    import diff_gaussian_rasterization as dgr
+    import simple_knn
+    for m in (dgr, simple_knn):
+        assert os.path.abspath(m.__file__).startswith(ROOT), m.__file__   # the HIP drop-ins, not some other install
+    return tr, sm
+
+
+LOSS_LINE = re.compile(r"loss:\s*([-+0-9.eE]+|nan|inf)\s*\[\s*(\d+)/\s*(\d+)\]")
+
+
+def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: str | None = None):
+    """Runs the unmodified trainer on `data` until its iteration counter reaches `stop_at` (or 15 000).  Returns a dict with the
+    (iteration, loss) pairs the trainer printed, the host time stamps of each iteration and the events it announced."""
+    from rich.console import Console
+    tr, sm = import_trainer(patch_sugar)
+    log_path = log_path or os.path.join(out_dir, "trainer_console.log")
+    os.makedirs(out_dir, exist_ok=True)
+    log_file = open(log_path, "w")
+    saved = (tr.Console, tr.ssim)
+    stamps = []
+    first_iteration = 7000   # coarse_sdf.py:472-473 + the `iteration += 1` at :486
+
+    def counted_ssim(*a, **k):
+        stamps.append(time.time())
+        if first_iteration + len(stamps) - 1 > stop_at:
+            raise _Stop()
+        return saved[1](*a, **k)
+
+    tr.Console = lambda *a, **k: Console(file=log_file, width=200, force_terminal=False)
+    tr.ssim = counted_ssim
+    args = types.SimpleNamespace(gpu=0, scene_path=data.scene_path, checkpoint_path=data.checkpoint_path, iteration_to_load=7000,
+                                 estimation_factor=0.2, normal_factor=0.2, output_dir=os.path.join(out_dir, "coarse"), eval=True,
+                                 white_background=False)
+    finished = False
+    t0 = time.time()
+    try:
+        try:
+            tr.coarse_training_with_sdf_regularization(args)
+            finished = True
+        except _Stop:
+            pass
+        torch.cuda.synchronize()
+    finally:
+        tr.Console, tr.ssim = saved
+        log_file.close()
+        if patch_sugar:
+            from sugar_amd import sugar_patch
+            sugar_patch.uninstall(sm)
+    wall = time.time() - t0
+    text = open(log_path).read()
+    losses = [(int(m.group(2)), float(m.group(1))) for m in LOSS_LINE.finditer(text)]
+    events = [e for e in ("Starting entropy regularization", "Stopping entropy regularization", "Pruning gaussians with low-opacity",
+                          "Starting SDF regularization", "Starting SDF estimation loss", "Starting SDF better normal loss",
+                          "Resetting neighbors", "Training finished") if e in text]
+    left = re.findall(r"Pruning finished: (\d+) gaussians left", text)
+    its = np.asarray(stamps)
+    def rate(lo, hi):
+        a, b = lo - first_iteration, min(hi - first_iteration, len(its) - 1)
+        return float((b - a) / (its[b] - its[a])) if b > a else None
+    return dict(finished=finished, iterations_run=len(stamps) - (0 if finished else 1), last_iteration=first_iteration + len(stamps) - 2
+                if not finished else 15_000, wall_s=wall, losses=losses, events=events,
+                gaussians_after_pruning=int(left[-1]) if left else None,
+                it_per_s_before_9000=rate(7050, 8950), it_per_s_after_9000=rate(9050, 15_000), log=log_path,
+                patch_sugar=patch_sugar)

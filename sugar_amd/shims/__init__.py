@@ -29,11 +29,25 @@ def install(patch_sugar=False) -> str:
     (sugar_amd.sugar_patch), without touching the reference's files.  Pass the imported `sugar_scene.sugar_model` module, or
     True to import it (the reference must then be on sys.path)."""
     mode = _install_pytorch3d()
+    _install_plyfile()
     if patch_sugar:
         from .. import sugar_patch
         module = importlib.import_module("sugar_scene.sugar_model") if patch_sugar is True else patch_sugar
         sugar_patch.install(module)
     return mode
+
+
+def _install_plyfile() -> None:
+    """`plyfile` (gaussian_model.py:18, dataset_readers.py:22) is not in the ROCm image: when it cannot be imported, the
+    stand-in under this directory (vertex elements of binary PLY files only) takes the name"""
+    try:
+        if importlib.util.find_spec("plyfile") is not None:
+            return
+    except (ImportError, ValueError):
+        pass
+    if _HERE not in sys.path:
+        sys.path.insert(0, _HERE)
+    importlib.invalidate_caches()
 
 
 def _install_pytorch3d() -> str:

@@ -4,8 +4,8 @@ In the build container the reference tree is /root/reference.  On the GPU box it
 stages an UNMODIFIED, git-ignored snapshot of the path's Python (sugar_scene/, sugar_utils/, gaussian_splatting/{scene,utils,
 gaussian_renderer,arguments}) next to the compiled reference kernels in oracle/_ref/pysrc, which travels with the snapshot like
 oracle/_ref/*.so.  `import_sugar_model()` / `import_gaussian_splatting()` import from whichever exists, with this repository's
-drop-in packages (`diff_gaussian_rasterization`, `simple_knn`) and the `pytorch3d` stand-in on the path and empty `open3d` /
-`plyfile` modules for the imports the path never calls."""
+drop-in packages (`diff_gaussian_rasterization`, `simple_knn`), the `pytorch3d` / `plyfile` stand-ins on the path and an empty
+`open3d` module for an import the path never calls."""
 import os
 import sys
 import types
@@ -21,14 +21,13 @@ def reference_root():
 
 
 def _stubs():
-    for name in ("open3d", "plyfile"):
-        if name not in sys.modules:
-            try:
-                __import__(name)
-            except ImportError:
-                m = types.ModuleType(name)
-                m.PlyData = m.PlyElement = object
-                sys.modules[name] = m
+    from sugar_amd import shims
+    shims.install()  # pytorch3d and plyfile stand-ins where the real packages are absent
+    if "open3d" not in sys.modules:
+        try:
+            import open3d  # noqa: F401
+        except ImportError:
+            sys.modules["open3d"] = types.ModuleType("open3d")  # imported by the trainers/extractors, never called on this path
 
 
 def import_sugar_model(patch_sugar=False):

@@ -110,3 +110,58 @@ def test_ply_reader_accepts_reordered_properties_and_comments(tmp_path):
     (tmp_path / "ascii.ply").write_text("ply\nformat ascii 1.0\nelement vertex 0\nend_header\n")
     with pytest.raises(ValueError):
         sio.load_gaussian_ply(str(tmp_path / "ascii.ply"))
+
+
+def test_reference_save_ply_is_read_back_by_load_gaussian_ply_and_the_other_way(tmp_path, monkeypatch):
+    """The reference's own GaussianModel.save_ply (gaussian_model.py:191-208) writing through the `plyfile` stand-in, read by
+    sugar_amd.io -- and sugar_amd.io's writer read through the stand-in by the statements of GaussianModel.load_ply
+    (:215-247, its device="cuda" tensor construction aside).  With the real `plyfile` installed the same test pins the layout
+    for real; with the stand-in it pins the column order / reshape rules of the two reference functions against each other."""
+    import pytest
+    from tests import ref_env
+    if ref_env.reference_root() is None:
+        pytest.skip("no reference tree")
+    from sugar_amd import shims
+    for name in ("plyfile",):
+        monkeypatch.delitem(__import__("sys").modules, name, raising=False)
+    shims.install()
+    _, GaussianModel, _, _ = ref_env.import_gaussian_splatting()
+    import plyfile
+    g = GaussianModel(3)
+    P, rng = 37, torch.Generator().manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=rng)
+    g._xyz, g._features_dc, g._features_rest = rnd(P, 3), rnd(P, 1, 3), rnd(P, 15, 3)
+    g._opacity, g._scaling, g._rotation = rnd(P, 1), rnd(P, 3), rnd(P, 4)
+    path = str(tmp_path / "point_cloud" / "iteration_7" / "point_cloud.ply")
+    g.save_ply(path)
+    d = sio.load_gaussian_ply(path)
+    assert torch.equal(d["xyz"], g._xyz) and torch.equal(d["opacity"], g._opacity)
+    assert torch.equal(d["features"], torch.cat([g._features_dc, g._features_rest], dim=1))
+    assert torch.equal(d["scaling"], g._scaling) and torch.equal(d["rotation"], g._rotation)
+    # the other direction: our writer, the reference's reading statements
+    path2 = str(tmp_path / "ours.ply")
+    sio.save_gaussian_ply(path2, d["xyz"], d["features"], d["opacity"], d["scaling"], d["rotation"])
+    assert open(path2, "rb").read() == open(path, "rb").read()  # byte-identical files
+    v = plyfile.PlyData.read(path2).elements[0]
+    rest = sorted([p.name for p in v.properties if p.name.startswith("f_rest_")], key=lambda x: int(x.split("_")[-1]))
+    extra = np.stack([np.asarray(v[n]) for n in rest], axis=1).reshape(P, 3, 15)                  # :229-235
+    assert np.array_equal(extra.transpose(0, 2, 1), g._features_rest.numpy())                        # :251 transpose(1, 2)
+
+
+def test_sfm_point_cloud_round_trip_through_the_plyfile_stand_in(tmp_path):
+    """storePly / fetchPly (gaussian_splatting/scene/dataset_readers.py:107-130): float positions and normals, uchar colours"""
+    import pytest
+    from tests import ref_env
+    if ref_env.reference_root() is None:
+        pytest.skip("no reference tree")
+    from sugar_amd import shims
+    shims.install()
+    ref_env.import_gaussian_splatting()
+    from scene.dataset_readers import fetchPly, storePly
+    rng = np.random.default_rng(2)
+    xyz = rng.standard_normal((50, 3)).astype(np.float32)
+    rgb = rng.integers(0, 256, (50, 3)).astype(np.uint8)
+    p = str(tmp_path / "points3D.ply")
+    storePly(p, xyz, rgb)
+    pcd = fetchPly(p)
+    assert np.array_equal(pcd.points, xyz) and np.allclose(pcd.colors, rgb / 255.0) and np.array_equal(pcd.normals, np.zeros_like(xyz))
