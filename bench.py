@@ -599,8 +599,31 @@ def unmodified_path_legs(scene, cams, gts, bg_d, dev, n_steps):
                                              "`diff_gaussian_rasterization` = this repository's HIP drop-in; same scene, cameras "
                                              "and target images as the native step", "reference_python": rl.reference_root()}
             del loop, gaussians
+            # the same loop once more with the reference's `ssim` bound to the HIP loss kernels (shims.install(patch_losses=True):
+            # still the reference's loop, render(), l1_loss and optimiser; one name rebound, no file touched)
+            from sugar_amd import shims
+            n_rebound = shims.install_losses()
+            try:
+                ref2 = rl.import_reference()
+                gaussians = rl.make_gaussians(ref2, scene, dev, opt)
+                loop = rl.Loop(ref2, gaussians, [rl.make_viewpoint(c, gt, dev) for c, gt in zip(cams, gts)], bg_d, opt=opt)
+                for _ in range(len(cams)):
+                    loop.loop_body()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(n_steps):
+                    loss2 = loop.loop_body()
+                torch.cuda.synchronize(dev)
+                dt2 = (time.perf_counter() - t0) / n_steps
+                out["reference_loop"]["with_patch_losses"] = {
+                    "images_per_sec": 1.0 / dt2, "ms_per_step": 1e3 * dt2, "final_loss": float(loss2), "names_rebound": n_rebound,
+                    "what": "the same loop with `ssim` answered by k_l1_ssim_fwd/bwd (lambda = 1) instead of five grouped "
+                            "convolutions + ~25 elementwise kernels and their autograd twins"}
+                del loop, gaussians
+            finally:
+                shims.uninstall_losses()
     except Exception as e:
-        out["reference_loop"] = {"error": repr(e)}
+        out.setdefault("reference_loop", {})["error"] = repr(e)
     torch.cuda.empty_cache()
     return out
 

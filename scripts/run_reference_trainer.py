@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--width", type=int, default=480)
     ap.add_argument("--height", type=int, default=320)
     ap.add_argument("--no-patch", action="store_true", help="drop-in packages only; SuGaR's own tensor code for the field methods")
+    ap.add_argument("--patch-losses", action="store_true", help="also bind the trainer's `ssim` to the HIP loss kernels")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "reference_trainer"))
     a = ap.parse_args()
     from oracle import reference_trainer as rt
@@ -31,8 +32,8 @@ def main():
     try:
         data = rt.write_dataset(work, P=a.gaussians, n_cams=a.cameras, W=a.width, H=a.height)
         os.makedirs(a.out, exist_ok=True)
-        tag = "dropins_only" if a.no_patch else "patched"
-        res = rt.run(data, os.path.join(work, "out"), stop_at=a.stop_at, patch_sugar=not a.no_patch,
+        tag = ("dropins_only" if a.no_patch else "patched") + ("_losses" if a.patch_losses else "")
+        res = rt.run(data, os.path.join(work, "out"), stop_at=a.stop_at, patch_sugar=not a.no_patch, patch_losses=a.patch_losses,
                      log_path=os.path.join(a.out, f"trainer_console_{tag}.log"))
         res.update(gaussians=a.gaussians, cameras=a.cameras, width=a.width, height=a.height)
         with open(os.path.join(a.out, f"summary_{tag}.json"), "w") as f:

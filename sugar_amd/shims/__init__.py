@@ -21,20 +21,69 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def install(patch_sugar=False) -> str:
+def install(patch_sugar=False, patch_losses=False) -> str:
     """Returns "patched" (real pytorch3d found, knn_points redirected) or "shim" (stand-in package activated).
 
     `patch_sugar`: also route SuGaR's own Gaussian-buffer-sharing tensor code -- `get_points_rgb`, `get_covariance(return_sqrt)`,
     `get_field_values`, `compute_level_surface_points_from_camera_fast(use_gaussian_depth=True)` -- to the HIP kernels
     (sugar_amd.sugar_patch), without touching the reference's files.  Pass the imported `sugar_scene.sugar_model` module, or
-    True to import it (the reference must then be on sys.path)."""
+    True to import it (the reference must then be on sys.path).
+
+    `patch_losses`: also replace the reference's `ssim` by the fused HIP loss kernels (see install_losses)."""
     mode = _install_pytorch3d()
     _install_plyfile()
+    if patch_losses:
+        install_losses()
     if patch_sugar:
         from .. import sugar_patch
         module = importlib.import_module("sugar_scene.sugar_model") if patch_sugar is True else patch_sugar
         sugar_patch.install(module)
     return mode
+
+
+_LOSS_MODULES = ("sugar_utils.loss_utils", "utils.loss_utils")
+
+
+def install_losses() -> int:
+    """`patch_losses`: the reference's `ssim` (sugar_utils/loss_utils.py:39-48, gaussian_splatting/utils/loss_utils.py:39-48) --
+    five grouped 11x11 convolutions and ~25 elementwise kernels per call, plus autograd -- is replaced by the HIP pair of
+    `sugar_amd.fused_loss` for the call shape the training loops use, in the two modules that define it and in every loaded
+    module that had already imported the name (`from sugar_utils.loss_utils import ssim`, coarse_sdf.py:11, train.py:16).
+    Returns the number of names rebound.  `uninstall_losses()` undoes it."""
+    from ..fused_loss import make_ssim
+    originals = {}
+    for name in _LOSS_MODULES:
+        mod = sys.modules.get(name)
+        if mod is None and name.startswith("sugar_utils."):   # (a bare `utils` package could be anybody's: only if already loaded)
+            try:
+                mod = importlib.import_module(name)
+            except ImportError:
+                mod = None
+        if mod is None:
+            continue
+        f = getattr(mod, "ssim", None)
+        if f is not None and not hasattr(f, "_sugar_amd_original"):
+            originals[id(f)] = (f, make_ssim(f))
+    count = 0
+    for mod in list(sys.modules.values()):
+        d = getattr(mod, "__dict__", None)
+        if not isinstance(d, dict):
+            continue
+        f = d.get("ssim")
+        if f is not None and id(f) in originals and originals[id(f)][0] is f:
+            d["ssim"] = originals[id(f)][1]
+            count += 1
+    return count
+
+
+def uninstall_losses() -> int:
+    count = 0
+    for mod in list(sys.modules.values()):
+        d = getattr(mod, "__dict__", None)
+        if isinstance(d, dict) and hasattr(d.get("ssim"), "_sugar_amd_original"):
+            d["ssim"] = d["ssim"]._sugar_amd_original
+            count += 1
+    return count
 
 
 def _install_plyfile() -> None:

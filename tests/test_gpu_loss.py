@@ -87,3 +87,39 @@ def test_flat_adam_matches_torch_adam():
     f0 = GaussianParams(scene, dev).params["features"]
     da = (a.params["features"] - f0).abs()
     assert da[:, 0].mean() > 5 * da[:, 1:].mean()
+
+
+@pytest.mark.parametrize("shape", [(3, 1080, 1920), (1, 3, 208, 320), (3, 37, 61)])
+def test_drop_in_ssim_matches_the_reference_function(shape):
+    """`shims.install(patch_losses=True)`: the reference's own `ssim` (sugar_utils/loss_utils.py:39-63, imported from the staged
+    reference) against the HIP-backed replacement, value and gradient, in the two call shapes the loops use ([3,H,W] at
+    train.py:89, [1,3,H,W] at coarse_sdf.py:446-459) -- combined the way the loops combine it with the reference's l1_loss"""
+    from tests import ref_env
+    if ref_env.reference_root() is None:
+        pytest.skip("the reference's Python is not staged")
+    ref_env.import_sugar_model()
+    import sugar_utils.loss_utils as lu
+    from sugar_amd import shims
+    shims.uninstall_losses()
+    original = lu.ssim
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    img = torch.rand(*shape, generator=g)
+    gt = (img + 0.2 * torch.randn(*shape, generator=g)).clamp(0, 1).to(dev)
+    a = img.to(dev).requires_grad_(True); b = img.to(dev).requires_grad_(True)
+    shims.install_losses()
+    try:
+        assert lu.ssim is not original
+        la = 0.8 * lu.l1_loss(a, gt) + 0.2 * (1.0 - lu.ssim(a, gt)); la.backward()
+    finally:
+        shims.uninstall_losses()
+    lb = 0.8 * lu.l1_loss(b, gt) + 0.2 * (1.0 - original(b, gt)); lb.backward()
+    assert abs(float(la) - float(lb)) < 5e-6
+    ga, gb = a.grad.cpu().double(), b.grad.cpu().double()
+    assert float((ga - gb).norm() / gb.norm()) < 2e-5
+    # ssim alone, scaled: the gradient's sign and the incoming factor
+    c = img.to(dev).requires_grad_(True); d = img.to(dev).requires_grad_(True)
+    patched = __import__("sugar_amd.fused_loss", fromlist=["make_ssim"]).make_ssim(original)
+    (2.5 * patched(c, gt)).backward(); (2.5 * original(d, gt)).backward()
+    gc, gd = c.grad.cpu().double(), d.grad.cpu().double()
+    assert float((gc - gd).norm() / gd.norm()) < 2e-5

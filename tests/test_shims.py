@@ -211,3 +211,35 @@ def test_camera_algebra_round_trips_and_matches_the_gaussian_splatting_camera(p3
     py_p3 = (H / min(W, H) - ndc[:, 1]) * (min(W, H) - 1) / 2
     # the two pixel conventions differ by the (min - 1) / min factor SuGaR's table uses: within a pixel over the image
     assert float((px_p3 - px_gs).abs().max()) < 1.0 and float((py_p3 - py_gs).abs().max()) < 1.0
+
+
+def test_patch_losses_rebinds_ssim_everywhere_and_cpu_calls_reach_the_original():
+    """shims.install(patch_losses=True): the name `ssim` is rebound in the defining module and in modules that imported it
+    earlier; a call the HIP kernels do not cover (here: CPU tensors) is answered by the reference's own function"""
+    import types as _types
+    from tests import ref_env
+    if ref_env.reference_root() is None:
+        pytest.skip("no reference tree")
+    ref_env.import_sugar_model()
+    import sugar_utils.loss_utils as lu
+    from sugar_amd import shims
+    shims.uninstall_losses()
+    original = lu.ssim
+    early = _types.ModuleType("early_importer"); early.ssim = lu.ssim
+    sys.modules["early_importer"] = early
+    try:
+        n = shims.install_losses()
+        assert n >= 2 and lu.ssim is not original and early.ssim is lu.ssim and lu.ssim._sugar_amd_original is original
+        assert shims.install_losses() == 0   # idempotent
+        g = torch.Generator().manual_seed(0)
+        a = torch.rand(3, 40, 52, generator=g, requires_grad=True); b = torch.rand(3, 40, 52, generator=g)
+        v = lu.ssim(a, b)
+        assert torch.equal(v, original(a, b))
+        v.backward()
+        assert a.grad is not None
+        per_image = lu.ssim(a[None].detach(), b[None], size_average=False)      # other call shapes: the original's answer
+        assert per_image.shape == (1,)
+    finally:
+        assert shims.uninstall_losses() >= 2
+        del sys.modules["early_importer"]
+    assert lu.ssim is original
