@@ -47,8 +47,7 @@ def surface_scene(P: int, seed: int = 0):
     g = torch.Generator().manual_seed(seed)
     d = torch.randn(P, 3, generator=g)
     d = d / d.norm(dim=1, keepdim=True)
-    r = 0.8 + 0.12 * torch.sin(3.0 * d[:, :1]) * torch.cos(2.0 * d[:, 1:2]) + 0.08 * torch.sin(5.0 * d[:, 2:3])
-    means = d * r
+    means = d * surface_radius(d)[:, None]
     # tangent frame: normal ~ radial direction (good enough for a bumpy sphere); quaternion rotating z onto the normal
     n = d
     z = torch.tensor([0.0, 0.0, 1.0]).expand_as(n)
@@ -154,11 +153,11 @@ def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: st
     args = types.SimpleNamespace(gpu=0, scene_path=data.scene_path, checkpoint_path=data.checkpoint_path, iteration_to_load=7000,
                                  estimation_factor=0.2, normal_factor=0.2, output_dir=os.path.join(out_dir, "coarse"), eval=True,
                                  white_background=False)
-    finished = False
+    finished, model_path = False, None
     t0 = time.time()
     try:
         try:
-            tr.coarse_training_with_sdf_regularization(args)
+            model_path = tr.coarse_training_with_sdf_regularization(args)
             finished = True
         except _Stop:
             pass
@@ -186,4 +185,102 @@ def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: st
                 if not finished else 15_000, wall_s=wall, losses=losses, events=events,
                 gaussians_after_pruning=int(left[-1]) if left else None,
                 it_per_s_before_9000=rate(7050, 8950), it_per_s_after_9000=rate(9050, 15_000), log=log_path,
-                patch_sugar=patch_sugar, patch_losses=patch_losses)
+                patch_sugar=patch_sugar, patch_losses=patch_losses, model_path=model_path)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The coarse-mesh extractor: sugar_extractors/coarse_mesh.py::extract_mesh_from_coarse_sugar(args), untouched.  Everything up to
+# its first open3d call runs on the drop-ins: loading the 3DGS checkpoint and the coarse SuGaR model, pruning, building the splat
+# mesh and pytorch3d's MeshRasterizer (coarse_mesh.py:203-225), and the loop over ALL training cameras (:243-327): an RGB render and
+# `compute_level_surface_points_from_camera_fast(use_gaussian_depth=False, rasterizer=...)` per view, three level sets each.  The
+# Poisson reconstruction that follows is open3d's (out of scope): the stand-in `open3d.geometry.PointCloud` raises, and the point
+# clouds the loop accumulated are read out of the function's frame.
+class _Open3DReached(Exception):
+    pass
+
+
+def _open3d_that_stops():
+    o3d = types.ModuleType("open3d")
+    o3d.geometry = types.ModuleType("open3d.geometry")
+    o3d.utility = types.ModuleType("open3d.utility")
+    o3d.io = types.ModuleType("open3d.io")
+
+    def stop(*a, **k):
+        raise _Open3DReached("open3d.geometry.PointCloud(): Poisson reconstruction is open3d's, outside this package")
+    o3d.geometry.PointCloud = stop
+    return o3d
+
+
+def run_extractor(data, out_dir: str, coarse_model_path: str | None, patch_sugar: bool = True, log_path: str | None = None):
+    """Runs the unmodified extractor up to the Poisson step.  `coarse_model_path=None`: `--use_vanilla_3dgs True` (the model is
+    built from the 3DGS checkpoint, coarse_mesh.py:141-165), else the `.pt` the coarse trainer saved.  Returns per level the
+    sampled points / normals / Gaussian ids (GPU tensors) and the loop's wall time per camera."""
+    from rich.console import Console
+    from tests import ref_env
+    sm = ref_env.import_sugar_model(patch_sugar=patch_sugar)
+    saved_o3d = sys.modules.get("open3d")
+    sys.modules["open3d"] = _open3d_that_stops()
+    sys.modules.pop("sugar_extractors.coarse_mesh", None)   # (it binds `o3d` at import)
+    import sugar_extractors.coarse_mesh as ex
+    assert os.path.abspath(ex.__file__).startswith(os.path.abspath(ref_env.reference_root())), ex.__file__
+    os.makedirs(out_dir, exist_ok=True)
+    log_path = log_path or os.path.join(out_dir, "extractor_console.log")
+    log_file = open(log_path, "w")
+    saved_console = ex.Console
+    ex.Console = lambda *a, **k: Console(file=log_file, width=200, force_terminal=False)
+    stamps = []
+    orig_fast = sm.SuGaR.compute_level_surface_points_from_camera_fast
+
+    def timed_fast(self, *a, **k):
+        stamps.append(time.time())
+        return orig_fast(self, *a, **k)
+    sm.SuGaR.compute_level_surface_points_from_camera_fast = timed_fast
+    args = types.SimpleNamespace(scene_path=data.scene_path, checkpoint_path=data.checkpoint_path, iteration_to_load=7000, eval=True,
+                                 coarse_model_path=coarse_model_path, surface_level=None, decimation_target=None,
+                                 mesh_output_dir=os.path.join(out_dir, "coarse_mesh"), bboxmin=None, bboxmax=None, center_bbox=True,
+                                 use_centers_to_extract_mesh=False, use_marching_cubes=False, use_vanilla_3dgs=coarse_model_path is None,
+                                 gpu=0)
+    outputs, reached = None, False
+    # The trainer's checkpoint holds numpy scalars next to the state dict (sugar_model.py:2296-2301); the reference pins torch 2.0.1
+    # (environment.yml), whose torch.load unpickled them -- torch >= 2.6 refuses unless told otherwise.  An environment setting of
+    # this harness, not a change to the extractor.
+    saved_env = os.environ.get("TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD")
+    os.environ["TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD"] = "1"
+    t0 = time.time()
+    try:
+        try:
+            ex.extract_mesh_from_coarse_sugar(args)
+        except _Open3DReached as e:
+            reached = True
+            tb = e.__traceback__
+            while tb is not None:
+                if tb.tb_frame.f_code.co_name == "extract_mesh_from_coarse_sugar":
+                    outputs = tb.tb_frame.f_locals.get("surface_levels_outputs")
+                tb = tb.tb_next
+        torch.cuda.synchronize()
+    finally:
+        t1 = time.time()
+        sm.SuGaR.compute_level_surface_points_from_camera_fast = orig_fast
+        if saved_env is None:
+            os.environ.pop("TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD", None)
+        else:
+            os.environ["TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD"] = saved_env
+        ex.Console = saved_console
+        log_file.close()
+        if saved_o3d is not None:
+            sys.modules["open3d"] = saved_o3d
+        else:
+            sys.modules.pop("open3d", None)
+        sys.modules.pop("sugar_extractors.coarse_mesh", None)
+        if patch_sugar:
+            from sugar_amd import sugar_patch
+            sugar_patch.uninstall(sm)
+    n = len(stamps)
+    per_cam = (t1 - stamps[1]) / (n - 1) if n > 2 else None   # (the first camera also resets the neighbours and warms allocations)
+    return dict(reached_poisson=reached, cameras=n, wall_s=t1 - t0, ms_per_camera=None if per_cam is None else 1e3 * per_cam,
+                outputs=outputs, log=log_path, patch_sugar=patch_sugar)
+
+
+def surface_radius(d):
+    """the radius of surface_scene's surface in unit direction d [N,3]"""
+    return 0.8 + 0.12 * torch.sin(3.0 * d[:, 0]) * torch.cos(2.0 * d[:, 1]) + 0.08 * torch.sin(5.0 * d[:, 2])

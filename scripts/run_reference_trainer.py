@@ -25,6 +25,10 @@ def main():
     ap.add_argument("--height", type=int, default=320)
     ap.add_argument("--no-patch", action="store_true", help="drop-in packages only; SuGaR's own tensor code for the field methods")
     ap.add_argument("--patch-losses", action="store_true", help="also bind the trainer's `ssim` to the HIP loss kernels")
+    ap.add_argument("--extract", action="store_true",
+                    help="then run the reference's coarse-mesh extractor (sugar_extractors/coarse_mesh.py, untouched) up to its "
+                         "Poisson step: on the trained model if the training ran to 15000, else on the 3DGS checkpoint")
+    ap.add_argument("--skip-training", action="store_true")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "reference_trainer"))
     a = ap.parse_args()
     from oracle import reference_trainer as rt
@@ -33,9 +37,26 @@ def main():
         data = rt.write_dataset(work, P=a.gaussians, n_cams=a.cameras, W=a.width, H=a.height)
         os.makedirs(a.out, exist_ok=True)
         tag = ("dropins_only" if a.no_patch else "patched") + ("_losses" if a.patch_losses else "")
-        res = rt.run(data, os.path.join(work, "out"), stop_at=a.stop_at, patch_sugar=not a.no_patch, patch_losses=a.patch_losses,
+        res = {"finished": False, "model_path": None}
+        if not a.skip_training:
+          res = rt.run(data, os.path.join(work, "out"), stop_at=a.stop_at, patch_sugar=not a.no_patch, patch_losses=a.patch_losses,
                      log_path=os.path.join(a.out, f"trainer_console_{tag}.log"))
         res.update(gaussians=a.gaussians, cameras=a.cameras, width=a.width, height=a.height)
+        if a.extract:
+            import torch
+            ext = rt.run_extractor(data, os.path.join(work, "extract"), res["model_path"] if res["finished"] else None,
+                                   patch_sugar=not a.no_patch, log_path=os.path.join(a.out, f"extractor_console_{tag}.log"))
+            levels = {}
+            for lvl, o in (ext.pop("outputs") or {}).items():
+                p = o["points"]
+                d = p / p.norm(dim=1, keepdim=True).clamp_min(1e-9)
+                err = (p.norm(dim=1) - rt.surface_radius(d)).abs()
+                levels[str(lvl)] = {"points": int(p.shape[0]), "finite": bool(torch.isfinite(p).all() and torch.isfinite(o["normals"]).all()),
+                                    "distance_to_true_surface_median": float(err.median()) if len(err) else None,
+                                    "distance_to_true_surface_p90": float(err.quantile(0.9)) if len(err) else None,
+                                    "normal_dot_radial_median": float((torch.nn.functional.normalize(o["normals"], dim=1) * d).sum(1).abs().median()) if len(err) else None}
+            ext["levels"] = levels
+            res["extractor"] = ext
         with open(os.path.join(a.out, f"summary_{tag}.json"), "w") as f:
             json.dump(res, f, indent=1)
         print(json.dumps(res))

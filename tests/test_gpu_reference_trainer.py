@@ -34,3 +34,28 @@ def test_the_unmodified_coarse_trainer_runs_through_its_schedule_on_the_drop_ins
         assert e in res["events"], e
     assert 0 < res["gaussians_after_pruning"] <= 30_000
     assert torch.cuda.is_available()
+
+
+def test_the_unmodified_coarse_mesh_extractor_samples_every_camera_up_to_its_poisson_step(tmp_path):
+    """sugar_extractors/coarse_mesh.py::extract_mesh_from_coarse_sugar, untouched, in its `--use_vanilla_3dgs` mode: checkpoint
+    and cameras from disk, pruning, the splat mesh, pytorch3d's MeshRasterizer (here: the HIP z-buffer behind the stand-in), then
+    per training camera an RGB render and compute_level_surface_points_from_camera_fast(use_gaussian_depth=False) for the levels
+    0.1 / 0.3 / 0.5 (coarse_mesh.py:243-327).  The first open3d call (Poisson) ends the run; the accumulated point clouds are read
+    from the function's frame.  The scene is a known surface, so the samples can be judged: they lie on it, normals along it."""
+    from tests import ref_env
+    if ref_env.reference_root() is None:
+        pytest.skip("the reference's Python is not staged (oracle/ref_build/build_ref.sh)")
+    from oracle import reference_trainer as rt
+    data = rt.write_dataset(str(tmp_path / "data"), P=30_000, n_cams=24, W=320, H=208)
+    res = rt.run_extractor(data, str(tmp_path / "extract"), coarse_model_path=None, patch_sugar=True)
+    assert res["reached_poisson"] and res["cameras"] == 21          # 24 views, every 8th held out (coarse_mesh.py:20-21)
+    assert sorted(res["outputs"]) == [0.1, 0.3, 0.5]
+    for level, o in res["outputs"].items():
+        p, n = o["points"], o["normals"]
+        assert p.is_cuda and p.shape[0] > 100_000 and p.shape == n.shape and o["pix_to_gaussians"].shape[0] == p.shape[0]
+        assert bool(torch.isfinite(p).all()) and bool(torch.isfinite(n).all())
+        d = p / p.norm(dim=1, keepdim=True)
+        err = (p.norm(dim=1) - rt.surface_radius(d)).abs()
+        assert float(err.median()) < 0.03 and float(err.quantile(0.9)) < 0.06, (level, float(err.median()))
+        assert float((torch.nn.functional.normalize(n, dim=1) * d).sum(1).abs().median()) > 0.9
+        assert int(o["pix_to_gaussians"].min()) >= 0
