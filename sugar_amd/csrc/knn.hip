@@ -279,26 +279,84 @@ __global__ void __launch_bounds__(256) k_grid_count(int M, const float* __restri
     atomicAdd(&cell_count[c], 1u);
 }
 
-// exclusive scan of the cell counts: one 1024-thread workgroup (G^3 <= 2M cells)
-__global__ void __launch_bounds__(1024) k_grid_scan(int n, const unsigned int* __restrict__ cnt, unsigned int* __restrict__ start)
+// exclusive scan of the cell counts (G^3 <= 2M cells), two launches: sums of 4096-cell blocks, then every block adds up the sums
+// before it (at most 512) and scans its own cells -- 16 consecutive cells per thread, 64 contiguous bytes per lane.  (Until round 4
+// one 1024-thread workgroup walked the whole array with a stride of cells/1024 between neighbouring threads: 0.27 ms at 176k cells.)
+#define GRID_SCAN_BLOCK 4096
+__device__ __forceinline__ unsigned int grid_scan_load16(int n, const unsigned int* __restrict__ cnt, int base, unsigned int v[16])
 {
-    __shared__ unsigned int s_part[1024];
-    const int tid = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int b = tid * per, e = min(n, b + per);
     unsigned int sum = 0;
-    for (int i = b; i < e; i++) sum += cnt[i];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        unsigned int v = (tid >= o) ? s_part[tid - o] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+    if (base + 16 <= n) {
+        const uint4* p = reinterpret_cast<const uint4*>(cnt + base);
+        const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w; v[12] = d.x; v[13] = d.y; v[14] = d.z; v[15] = d.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = (base + i < n) ? cnt[base + i] : 0u;
     }
-    unsigned int run = s_part[tid] - sum;
-    for (int i = b; i < e; i++) { start[i] = run; run += cnt[i]; }
-    if (tid == 1023) start[n] = s_part[1023];
+#pragma unroll
+    for (int i = 0; i < 16; i++) sum += v[i];
+    return sum;
+}
+
+// sum over the 256 threads of a workgroup, returned to every thread; `mine_excl` = sum over the threads before this one
+__device__ __forceinline__ unsigned int grid_block_scan(unsigned int x, unsigned int* s_wave, unsigned int& mine_excl)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int incl = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int y = (unsigned int)__shfl_up((int)incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const unsigned int t = s_wave[w];
+        if (w < wave) before += t;
+        total += t;
+    }
+    mine_excl = before + incl - x;
+    __syncthreads();
+    return total;
+}
+
+__global__ void __launch_bounds__(256) k_grid_blocksum(int n, const unsigned int* __restrict__ cnt, unsigned int* __restrict__ part)
+{
+    __shared__ unsigned int s_wave[4];
+    unsigned int v[16], excl;
+    const unsigned int sum = grid_scan_load16(n, cnt, (int)blockIdx.x * GRID_SCAN_BLOCK + (int)threadIdx.x * 16, v);
+    const unsigned int total = grid_block_scan(sum, s_wave, excl);
+    if (threadIdx.x == 0) part[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(256) k_grid_scan(int n, const unsigned int* __restrict__ cnt, const unsigned int* __restrict__ part,
+                                                   unsigned int* __restrict__ start)
+{
+    __shared__ unsigned int s_wave[4];
+    unsigned int before = 0, excl;
+    for (int j = (int)threadIdx.x; j < (int)blockIdx.x; j += 256) before += part[j];
+    const unsigned int offset = grid_block_scan(before, s_wave, excl);
+    unsigned int v[16];
+    const int base = (int)blockIdx.x * GRID_SCAN_BLOCK + (int)threadIdx.x * 16;
+    const unsigned int sum = grid_scan_load16(n, cnt, base, v);
+    const unsigned int total = grid_block_scan(sum, s_wave, excl);
+    unsigned int run = offset + excl;
+    if (base + 16 <= n) {
+        unsigned int o[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) { o[i] = run; run += v[i]; }
+        uint4* q = reinterpret_cast<uint4*>(start + base);
+        q[0] = make_uint4(o[0], o[1], o[2], o[3]); q[1] = make_uint4(o[4], o[5], o[6], o[7]);
+        q[2] = make_uint4(o[8], o[9], o[10], o[11]); q[3] = make_uint4(o[12], o[13], o[14], o[15]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) { if (base + i < n) start[base + i] = run; run += v[i]; }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) start[n] = offset + total;
 }
 
 __global__ void __launch_bounds__(256) k_grid_scatter(int M, const float* __restrict__ pts, const unsigned int* __restrict__ cell_of,
@@ -528,7 +586,7 @@ int grid_res(int M)
     return G;
 }
 
-struct GridScratch { GridHdr* hdr; unsigned int *cell_count, *cursor, *cell_start, *cell_of; float4* sorted; int* far_list;
+struct GridScratch { GridHdr* hdr; unsigned int *cell_count, *cursor, *cell_start, *cell_of, *scan_part; float4* sorted; int* far_list;
                      int* ball_list; float* ball_u2; unsigned int far_cap; size_t total; };
 GridScratch carve_grid(char* base, int M)
 {
@@ -541,6 +599,7 @@ GridScratch carve_grid(char* base, int M)
     s.cursor = reinterpret_cast<unsigned int*>(base + off); off = sgr_align(off + cells * 4);
     s.cell_start = reinterpret_cast<unsigned int*>(base + off); off = sgr_align(off + (cells + 1) * 4);
     s.cell_of = reinterpret_cast<unsigned int*>(base + off); off = sgr_align(off + (size_t)M * 4);
+    s.scan_part = reinterpret_cast<unsigned int*>(base + off); off = sgr_align(off + ((cells + GRID_SCAN_BLOCK - 1) / GRID_SCAN_BLOCK) * 4);
     s.sorted = reinterpret_cast<float4*>(base + off); off = sgr_align(off + (size_t)M * 16);
     s.far_cap = (unsigned int)(M > 65536 ? M : 65536);  // queries the exhaustive fallback can take (the rest walk on)
     s.far_list = reinterpret_cast<int*>(base + off); off = sgr_align(off + (size_t)s.far_cap * 4);
@@ -560,7 +619,9 @@ int build_grid(int M, const float* ref, const GridScratch& gs, hipStream_t s)
     hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, s, gs.hdr);
     hipLaunchKernelGGL(k_grid_bbox, dim3(min((M + 255) / 256, 1024)), dim3(256), 0, s, M, ref, gs.hdr);
     hipLaunchKernelGGL(k_grid_count, dim3((M + 255) / 256), dim3(256), 0, s, M, ref, gs.hdr, G, gs.cell_count, gs.cell_of);
-    hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, s, (int)cells, gs.cell_count, gs.cell_start);
+    const int scan_blocks = (int)((cells + GRID_SCAN_BLOCK - 1) / GRID_SCAN_BLOCK);
+    hipLaunchKernelGGL(k_grid_blocksum, dim3(scan_blocks), dim3(256), 0, s, (int)cells, gs.cell_count, gs.scan_part);
+    hipLaunchKernelGGL(k_grid_scan, dim3(scan_blocks), dim3(256), 0, s, (int)cells, gs.cell_count, gs.scan_part, gs.cell_start);
     hipLaunchKernelGGL(k_grid_scatter, dim3((M + 255) / 256), dim3(256), 0, s, M, ref, gs.cell_of, gs.cell_start, gs.cursor, gs.sorted);
     return 0;
 }
