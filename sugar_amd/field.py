@@ -138,7 +138,7 @@ def density_field(x, nbr_idx, centers, inv_scaled_rot, strengths, density_factor
 def level_set_points(world_points, nbr_idx, cam_center, centers, inv_scaled_rot, strengths, gaussian_std,
                      surface_levels=(0.1, 0.3, 0.5), n_points_in_range: int = 21, range_size: float = 3.0,
                      density_factor: float = 1.0, return_normals: bool = True):
-    """Per level: dict(valid=bool[N], intersection_points=[n_valid,3], normals=[n_valid,3]) -- the `outputs` of
+    """Per level: dict(valid=bool[N], valid_idx=int64[n_valid], intersection_points=[n_valid,3], normals=[n_valid,3]) -- the `outputs` of
     sugar_model.py:2013-2081 (rows where the reference's empty_pixels is False)."""
     lib = _lib.load()
     wp, nb, ce, Bm, st = _prep(world_points, nbr_idx, centers, inv_scaled_rot, strengths)
@@ -161,5 +161,7 @@ def level_set_points(world_points, nbr_idx, cam_center, centers, inv_scaled_rot,
     out = {}
     for i, level in enumerate(surface_levels):
         m = valid[i].bool()
-        out[level] = dict(valid=m, intersection_points=pts[i][m], normals=(nrm[i][m] if return_normals else None))
+        rows = m.nonzero(as_tuple=True)[0]      # one host round trip per level; every per-level output is gathered with it
+        out[level] = dict(valid=m, valid_idx=rows, intersection_points=pts[i].index_select(0, rows),
+                          normals=(nrm[i].index_select(0, rows) if return_normals else None))
     return out

@@ -155,38 +155,38 @@ def compute_level_surface_points_from_camera_fast(
         if fragments is None:
             mesh = self.splat_mesh(p3d_cameras) if splat_mesh else self.mesh
             fragments = rasterizer(mesh, cameras=p3d_cameras)
-        depth = fragments.zbuf[0, ..., 0].clone()
-    no_depth_mask = depth < 0.
-    depth[no_depth_mask] = depth.max() * 1.05
-    # back-projection (:1932-1959); the pixel tables of the reference (:1934-1941) as index arithmetic
-    m = min(W, H)
-    rows = torch.arange(H, device=device, dtype=torch.float32)[:, None].expand(H, W)
-    cols = torch.arange(W, device=device, dtype=torch.float32)[None, :].expand(H, W)
-    ndc_x = W / m - (cols / (m - 1)) * 2
-    ndc_y = H / m - (rows / (m - 1)) * 2
-    ndc_points = torch.stack((ndc_x.reshape(-1), ndc_y.reshape(-1), depth.reshape(-1)), dim=-1)
-    no_proj_mask = no_depth_mask.view(-1)
-    ndc_points = ndc_points[~no_proj_mask][None]
+        depth = fragments.zbuf[0, ..., 0]
+    # Pixels with a depth, in raster order -- the rows `x[~no_proj_mask]` keeps (:1929-1931, :1942-1946) -- found ONCE; the random
+    # subset (:1948-1957), the back-projection (:1932-1959) and the front Gaussians are then computed for the picked pixels only.
+    # (The reference builds [H*W, 3] NDC tables, masks them three times -- each a host round trip -- and indexes the result; same
+    # values, same order, same permutation.)
+    depth_flat = depth.reshape(-1)
+    valid_pix = torch.logical_not(depth_flat < 0.).nonzero(as_tuple=True)[0]
+    n_valid = valid_pix.shape[0]
     if n_surface_points == -1:
-        n_surface_points = ndc_points.shape[1]
-        ndc_points_idx = torch.arange(n_surface_points, device=device)
+        picked = valid_pix
     else:
-        n_surface_points = min(n_surface_points, ndc_points.shape[1])
+        n_surface_points = min(n_surface_points, n_valid)
         # (the reference draws this permutation on the CPU, :1955: ~15 ms at 1080p plus the copy; same distribution on the device.
         # `_sugar_amd_cpu_randperm = True` on the model draws it on the CPU as the reference does, so that a seeded run picks the
         # reference's pixels: tests/test_gpu_reference_sugar.py)
         if getattr(self, "_sugar_amd_cpu_randperm", False):
-            ndc_points_idx = torch.randperm(ndc_points.shape[1])[:n_surface_points].to(device)
+            ndc_points_idx = torch.randperm(n_valid)[:n_surface_points].to(device)
         else:
-            ndc_points_idx = torch.randperm(ndc_points.shape[1], device=device)[:n_surface_points]
-        ndc_points = ndc_points[:, ndc_points_idx]
+            ndc_points_idx = torch.randperm(n_valid, device=device)[:n_surface_points]
+        picked = valid_pix[ndc_points_idx]
+    m = min(W, H)
+    rows = torch.div(picked, W, rounding_mode="floor")
+    cols = picked - rows * W
+    ndc_x = W / m - (cols.to(torch.float32) / (m - 1)) * 2          # the pixel tables of :1934-1941 as index arithmetic
+    ndc_y = H / m - (rows.to(torch.float32) / (m - 1)) * 2
+    ndc_points = torch.stack((ndc_x, ndc_y, depth_flat[picked]), dim=-1)[None]
     all_world_points = p3d_cameras.unproject_points(ndc_points, scaled_depth_input=False).view(-1, 3)
     if use_gaussian_depth:
         closest_gaussians_idx = self.get_gaussians_closest_to_samples(all_world_points)                # :1963 (HIP k-NN)
         gaussian_idx = closest_gaussians_idx[..., 0]
     else:                                                                                              # :1966-1968
-        gaussian_idx = fragments.pix_to_face[..., 0].view(-1) // self.n_triangles_per_gaussian
-        gaussian_idx = gaussian_idx[~no_proj_mask][ndc_points_idx.to(device)]
+        gaussian_idx = fragments.pix_to_face[0, ..., 0].reshape(-1)[picked] // self.n_triangles_per_gaussian
         closest_gaussians_idx = self.knn_idx[gaussian_idx]
     cam_center = p3d_cameras.get_camera_center()
     gaussian_to_camera = torch.nn.functional.normalize(cam_center - self.points, dim=-1)               # :1971-1972
@@ -198,16 +198,16 @@ def compute_level_surface_points_from_camera_fast(
                                 surface_levels=tuple(surface_levels), n_points_in_range=n_points_in_range, range_size=range_size,
                                 density_factor=density_factor, return_normals=return_normals)
     all_outputs = {}
-    pixel_idx_all = None
-    if return_pixel_idx:
-        pixel_idx_all = torch.arange(H * W, dtype=torch.long, device=device)[~no_proj_mask][ndc_points_idx.to(device)]
     for surface_level in surface_levels:
         r = res[surface_level]
         outputs = {'intersection_points': r['intersection_points']}
+        rows = r.get('valid_idx')
+        if rows is None and (return_pixel_idx or return_gaussian_idx):
+            rows = r['valid'].nonzero(as_tuple=True)[0]
         if return_pixel_idx:
-            outputs['pixel_idx'] = pixel_idx_all[r['valid']]
+            outputs['pixel_idx'] = picked[rows]
         if return_gaussian_idx:
-            outputs['gaussian_idx'] = gaussian_idx[r['valid']]
+            outputs['gaussian_idx'] = gaussian_idx[rows]
         if return_normals:
             outputs['normals'] = r['normals']
         all_outputs[surface_level] = outputs
