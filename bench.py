@@ -620,6 +620,28 @@ def unmodified_path_legs(scene, cams, gts, bg_d, dev, n_steps):
                     "what": "the same loop with `ssim` answered by k_l1_ssim_fwd/bwd (lambda = 1) instead of five grouped "
                             "convolutions + ~25 elementwise kernels and their autograd twins"}
                 del loop, gaussians
+                # ... and with the optimiser the reference builds (GaussianModel.training_setup: torch.optim.Adam over six
+                # tensors) stepping on the one-launch HIP Adam (shims.install(patch_optimizer=True))
+                shims.install_optimizer()
+                try:
+                    gaussians = rl.make_gaussians(ref2, scene, dev, opt)
+                    loop = rl.Loop(ref2, gaussians, [rl.make_viewpoint(c, gt, dev) for c, gt in zip(cams, gts)], bg_d, opt=opt)
+                    for _ in range(len(cams)):
+                        loop.loop_body()
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    for _ in range(n_steps):
+                        loss3 = loop.loop_body()
+                    torch.cuda.synchronize(dev)
+                    dt3 = (time.perf_counter() - t0) / n_steps
+                    out["reference_loop"]["with_patch_losses_and_optimizer"] = {
+                        "images_per_sec": 1.0 / dt3, "ms_per_step": 1e3 * dt3, "final_loss": float(loss3),
+                        "optimizer_class": type(gaussians.optimizer).__name__,
+                        "what": "additionally GaussianModel.optimizer (the torch.optim.Adam the reference constructs) adopted by "
+                                "sugar_amd.fused_adam.FusedAdam: one k_adam launch per parameter tensor instead of ~50 multi-tensor kernels"}
+                    del loop, gaussians
+                finally:
+                    shims.uninstall_optimizer()
             finally:
                 shims.uninstall_losses()
     except Exception as e:

@@ -318,7 +318,7 @@ int sgr_l1_ssim_backward_ex(int channels, int width, int height, const float* im
 
 /* ---- one-launch Adam over a flat parameter buffer -----------------------------------------------
  * torch.optim.Adam semantics (eps inside the bias-corrected denominator, no weight decay / amsgrad) as configured by
- * gaussian_splatting/scene/gaussian_model.py:152-166.  n (multiple of 4) floats in params / grads / exp_avg / exp_avg_sq;
+ * gaussian_splatting/scene/gaussian_model.py:152-166.  n floats in params / grads / exp_avg / exp_avg_sq (16-byte aligned);
  * the learning rate of element i is given by up to 8 segments k (HOST arrays): for seg_begin[k] <= i < seg_end[k] it is
  * seg_lr_a[k] when (i - seg_begin[k]) % seg_period[k] < seg_split[k], else seg_lr_b[k]; elements in no segment keep
  * lr 0 (their moments still update).  `step` is the 1-based step count used for bias correction; gradients are

@@ -127,7 +127,8 @@ def import_trainer(patch_sugar: bool):
 LOSS_LINE = re.compile(r"loss:\s*([-+0-9.eE]+|nan|inf)\s*\[\s*(\d+)/\s*(\d+)\]")
 
 
-def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: str | None = None, patch_losses: bool = False):
+def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: str | None = None, patch_losses: bool = False,
+        patch_optimizer: bool = False):
     """Runs the unmodified trainer on `data` until its iteration counter reaches `stop_at` (or 15 000).  Returns a dict with the
     (iteration, loss) pairs the trainer printed, the host time stamps of each iteration and the events it announced."""
     from rich.console import Console
@@ -135,6 +136,9 @@ def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: st
     if patch_losses:
         from sugar_amd import shims
         shims.install_losses()   # the trainer's module-level `ssim` -> HIP loss kernels (before the counter wraps it)
+    if patch_optimizer:
+        from sugar_amd import shims as _shims
+        _shims.install_optimizer()   # SuGaROptimizer's torch.optim.Adam -> FusedAdam
     log_path = log_path or os.path.join(out_dir, "trainer_console.log")
     os.makedirs(out_dir, exist_ok=True)
     log_file = open(log_path, "w")
@@ -167,6 +171,8 @@ def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: st
         log_file.close()
         if patch_losses:
             shims.uninstall_losses()
+        if patch_optimizer:
+            _shims.uninstall_optimizer()
         if patch_sugar:
             from sugar_amd import sugar_patch
             sugar_patch.uninstall(sm)
@@ -185,7 +191,7 @@ def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: st
                 if not finished else 15_000, wall_s=wall, losses=losses, events=events,
                 gaussians_after_pruning=int(left[-1]) if left else None,
                 it_per_s_before_9000=rate(7050, 8950), it_per_s_after_9000=rate(9050, 15_000), log=log_path,
-                patch_sugar=patch_sugar, patch_losses=patch_losses, model_path=model_path)
+                patch_sugar=patch_sugar, patch_losses=patch_losses, patch_optimizer=patch_optimizer, model_path=model_path)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

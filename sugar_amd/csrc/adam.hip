@@ -65,10 +65,10 @@ __device__ __forceinline__ void lr_of4(const AdamSegs& sg, long long e0, float* 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256) k_adam(long long n4, f4* __restrict__ p, const f4* __restrict__ g,
-                                              f4* __restrict__ m, f4* __restrict__ v, AdamSegs sg, float b1, float b2,
+                                              f4* __restrict__ m, f4* __restrict__ v, AdamSegs sg, float b1, float b2, float omb1, float omb2,
                                               float eps, float bc1, float bc2_sqrt, float grad_scale,
                                               const float* __restrict__ extra, long long extra_n,
-                                              const uint32_t* __restrict__ guard, uint32_t guard_cap)
+                                              const uint32_t* __restrict__ guard, uint32_t guard_cap, int n_tail)
 {
     if (guard && SGR_FORWARD_INVALID(guard, guard_cap)) return;  // the step's forward was a no-op: so is its optimiser step
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -90,14 +90,31 @@ __global__ void __launch_bounds__(256) k_adam(long long n4, f4* __restrict__ p, 
         lr_of4(sg, 4 * i, lr);
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            mf[c] = b1 * mf[c] + (1.f - b1) * gf[c];
-            vf[c] = b2 * vf[c] + (1.f - b2) * gf[c] * gf[c];
+            mf[c] = b1 * mf[c] + omb1 * gf[c];
+            vf[c] = b2 * vf[c] + omb2 * gf[c] * gf[c];
             const float denom = sqrtf(vf[c]) / bc2_sqrt + eps;
             pf[c] -= (lr[c] / bc1) * (mf[c] / denom);
         }
         p[i] = pp;
         __builtin_nontemporal_store(mm, &m[i]);
         __builtin_nontemporal_store(vv, &v[i]);
+    }
+    // the last n % 4 elements of a buffer whose length is no multiple of four (a drop-in optimiser meets [P,3] tensors with odd P)
+    if (n_tail > 0 && blockIdx.x == 0 && (int)threadIdx.x < n_tail) {
+        const long long e = 4 * n4 + threadIdx.x;
+        float* pf = reinterpret_cast<float*>(p); float* mf = reinterpret_cast<float*>(m); float* vf = reinterpret_cast<float*>(v);
+        float gg = reinterpret_cast<const float*>(g)[e];
+        if (e < extra_n) gg += extra[e];
+        gg *= grad_scale;
+        const int k = seg_of(sg, e);
+        float lr = 0.f;
+#pragma unroll
+        for (int j = 0; j < ADAM_MAX_SEG; j++)
+            if (j == k) lr = ((int)((e - sg.begin[j]) % sg.period[j]) < sg.split[j]) ? sg.lr_a[j] : sg.lr_b[j];
+        const float mm = b1 * mf[e] + omb1 * gg, vv = b2 * vf[e] + omb2 * gg * gg;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        pf[e] -= (lr / bc1) * (mm / denom);
+        mf[e] = mm; vf[e] = vv;
     }
 }
 
@@ -110,7 +127,8 @@ int sgr_adam_launch(long long n, float* params, const float* grads, float* exp_a
 {
     if (n <= 0) return 0;
     if (extra_n < 0 || extra_n > n || (extra_n > 0 && !extra)) return SGR_E_INVALID;
-    if (!params || !grads || !exp_avg || !exp_avg_sq || n_seg < 0 || n_seg > ADAM_MAX_SEG || step < 1 || (n & 3)) return SGR_E_INVALID;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n_seg < 0 || n_seg > ADAM_MAX_SEG || step < 1) return SGR_E_INVALID;
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return SGR_E_INVALID;  // float4 accesses
     AdamSegs sg;
     sg.n = n_seg;
     for (int k = 0; k < ADAM_MAX_SEG; k++) {
@@ -119,14 +137,15 @@ int sgr_adam_launch(long long n, float* params, const float* grads, float* exp_a
         sg.lr_a[k] = on ? seg_lr_a[k] : 0.f; sg.lr_b[k] = on ? seg_lr_b[k] : 0.f;
         sg.period[k] = on && seg_period[k] > 0 ? seg_period[k] : 1; sg.split[k] = on ? seg_split[k] : 1;
     }
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    float bc1, bc2_sqrt;
+    sgr_bias_corrections(beta1, beta2, step, &bc1, &bc2_sqrt);
     const long long n4 = n / 4;
-    const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, stream, n4, reinterpret_cast<f4*>(params),
                        reinterpret_cast<const f4*>(grads), reinterpret_cast<f4*>(exp_avg),
-                       reinterpret_cast<f4*>(exp_avg_sq), sg, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale, extra, extra_n, guard,
-                       guard_cap);
+                       reinterpret_cast<f4*>(exp_avg_sq), sg, beta1, beta2, sgr_one_minus(beta1), sgr_one_minus(beta2), eps, bc1, bc2_sqrt, grad_scale, extra, extra_n, guard,
+                       guard_cap, (int)(n & 3));
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 

@@ -515,8 +515,8 @@ int sgr_sh_adam_from_views_ex(int P, int n_views, int D, int M, const float* mea
     if (n_views <= 0 || D < 0 || D > 3 || M < (D + 1) * (D + 1) || M > 16 || step < 1 || !means3D || !campos_all || !dcolor_all ||
         !sh_params || !exp_avg || !exp_avg_sq)
         return fail(SGR_E_INVALID, "sgr_sh_adam_from_views: bad argument");
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    float bc1, bc2_sqrt;
+    sgr_bias_corrections(beta1, beta2, step, &bc1, &bc2_sqrt);
     if (view_stride != 0 && view_stride < P) return fail(SGR_E_INVALID, "sgr_sh_adam_from_views: view_stride < P");
     if (dmean_extra && (M != 16 || ((uintptr_t)sh_params & 15)))
         return fail(SGR_E_INVALID, "sgr_sh_adam_from_views_ex: dmean_extra needs M == 16 and 16-byte aligned sh_params");

@@ -843,7 +843,7 @@ __global__ void __launch_bounds__(256) k_sh_grad_from_views(int P, int V, int D,
 // The same sum, consumed on the spot: Adam on the Gaussian's SH coefficients (adam.hip's update, lr_dc for the three DC
 // values and lr_rest for the others: gaussian_model.py:157-158) without ever writing the 48-float gradient to memory.
 struct ShAdamArgs {
-    float lr_dc, lr_rest, b1, b2, eps, bc1, bc2_sqrt, grad_scale;
+    float lr_dc, lr_rest, b1, b2, omb1, omb2, eps, bc1, bc2_sqrt, grad_scale;
     const uint32_t* guard; uint32_t guard_cap;  // forward header + list capacity: the step is a no-op if that forward was invalid (NULL: no check)
 };
 
@@ -912,8 +912,8 @@ __global__ void __launch_bounds__(64) k_sh_adam_from_views(int P, int V, int D, 
     const int live = min(64, P - g0);
     auto upd = [&](int c, float g, float& p, float& m, float& v) {
         g *= a.grad_scale;
-        m = a.b1 * m + (1.f - a.b1) * g;
-        v = a.b2 * v + (1.f - a.b2) * g * g;
+        m = a.b1 * m + a.omb1 * g;
+        v = a.b2 * v + a.omb2 * g * g;
         const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
         p -= ((c < 3 ? a.lr_dc : a.lr_rest) / a.bc1) * (m / denom);
     };
@@ -1110,7 +1110,7 @@ void sgr_launch_sh_adam_from_views(int P, int V, int D, int M, size_t vstride, c
                                    float eps, float bc1, float bc2_sqrt, float grad_scale, float* dmean_extra, hipStream_t s,
                                    const uint32_t* guard, uint32_t guard_cap)
 {
-    ShAdamArgs a = {lr_dc, lr_rest, b1, b2, eps, bc1, bc2_sqrt, grad_scale, guard, guard_cap};
+    ShAdamArgs a = {lr_dc, lr_rest, b1, b2, sgr_one_minus(b1), sgr_one_minus(b2), eps, bc1, bc2_sqrt, grad_scale, guard, guard_cap};
     if (dmean_extra)
         hipLaunchKernelGGL(k_sh_adam_from_views<true>, dim3((P + 63) / 64), dim3(64), 0, s, P, V, D, M, vstride, means3D, campos, dcolor,
                            sh, exp_avg, exp_avg_sq, a, dmean_extra);

@@ -1,5 +1,8 @@
 // sgr_common.h -- shared declarations of the gfx950 rasterizer (private to sugar_amd/csrc).
 #pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -144,6 +147,31 @@ void sgr_launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
 void sgr_launch_masked_colors(int P, const GeomRec* rec, const float* acc, float* out, const float* cam_pos, float* campos_row, hipStream_t s);
 void sgr_launch_sh_grad_from_views(int P, int V, int D, int M, size_t vstride, const float* means3D, const float* campos,
                                    const float* dcolor, float* dL_dsh, hipStream_t s);
+
+// torch.optim.Adam forms `1 - beta` and `1 - beta ** step` in DOUBLE from the Python float the caller wrote (0.999); this C ABI
+// carries floats (0.999f = 0.99900001287...), and `1.f - 0.999f` is off by 1.3e-5 relative.  The coefficient helpers recover the
+// shortest decimal that rounds to the float -- what repr() would print -- and do the arithmetic in double like torch.
+static inline double sgr_intended_double(float x)
+{
+    static thread_local float memo_x[2] = {0.f, 0.f};
+    static thread_local double memo_d[2] = {0.0, 0.0};
+    for (int k = 0; k < 2; k++) if (memo_x[k] == x && memo_x[k] != 0.f) return memo_d[k];
+    double out = (double)x;
+    char buf[48];
+    for (int p = 1; p <= 9; p++) {
+        snprintf(buf, sizeof buf, "%.*g", p, (double)x);
+        const double d = strtod(buf, nullptr);
+        if ((float)d == x) { out = d; break; }
+    }
+    memo_x[1] = memo_x[0]; memo_d[1] = memo_d[0]; memo_x[0] = x; memo_d[0] = out;
+    return out;
+}
+static inline float sgr_one_minus(float beta) { return (float)(1.0 - sgr_intended_double(beta)); }
+static inline void sgr_bias_corrections(float beta1, float beta2, int step, float* bc1, float* bc2_sqrt)
+{
+    *bc1 = (float)(1.0 - pow(sgr_intended_double(beta1), (double)step));
+    *bc2_sqrt = (float)sqrt(1.0 - pow(sgr_intended_double(beta2), (double)step));
+}
 
 void sgr_launch_sh_adam_from_views(int P, int V, int D, int M, size_t vstride, const float* means3D, const float* campos,
                                    const float* dcolor, float* sh, float* exp_avg, float* exp_avg_sq, float lr_dc, float lr_rest, float b1, float b2,

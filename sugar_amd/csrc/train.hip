@@ -230,8 +230,8 @@ int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* v, int phases, const 
     }
     if (phases & 12) {
         if (!ex || ex->step < 1 || ex->n_views < 1) return tfail(SGR_E_INVALID, "sgr_trainer_step: exchange description missing");
-        const float bc1 = 1.f - powf(c.beta1, (float)ex->step);
-        const float bc2_sqrt = sqrtf(1.f - powf(c.beta2, (float)ex->step));
+        float bc1, bc2_sqrt;
+        sgr_bias_corrections(c.beta1, c.beta2, ex->step, &bc1, &bc2_sqrt);
         if (phases & 4) {
             const float* cols = ex->all_colors ? ex->all_colors : c.colors;
             const float* cams = ex->all_campos ? ex->all_campos : (ex->all_colors ? nullptr : c.colors + 3 * (size_t)P);

@@ -21,7 +21,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def install(patch_sugar=False, patch_losses=False) -> str:
+def install(patch_sugar=False, patch_losses=False, patch_optimizer=False) -> str:
     """Returns "patched" (real pytorch3d found, knn_points redirected) or "shim" (stand-in package activated).
 
     `patch_sugar`: also route SuGaR's own Gaussian-buffer-sharing tensor code -- `get_points_rgb`, `get_covariance(return_sqrt)`,
@@ -29,11 +29,14 @@ def install(patch_sugar=False, patch_losses=False) -> str:
     (sugar_amd.sugar_patch), without touching the reference's files.  Pass the imported `sugar_scene.sugar_model` module, or
     True to import it (the reference must then be on sys.path).
 
-    `patch_losses`: also replace the reference's `ssim` by the fused HIP loss kernels (see install_losses)."""
+    `patch_losses`: also replace the reference's `ssim` by the fused HIP loss kernels (see install_losses).
+    `patch_optimizer`: the `torch.optim.Adam` instances the reference builds step on the one-launch HIP Adam (install_optimizer)."""
     mode = _install_pytorch3d()
     _install_plyfile()
     if patch_losses:
         install_losses()
+    if patch_optimizer:
+        install_optimizer()
     if patch_sugar:
         from .. import sugar_patch
         module = importlib.import_module("sugar_scene.sugar_model") if patch_sugar is True else patch_sugar
@@ -82,6 +85,56 @@ def uninstall_losses() -> int:
         d = getattr(mod, "__dict__", None)
         if isinstance(d, dict) and hasattr(d.get("ssim"), "_sugar_amd_original"):
             d["ssim"] = d["ssim"]._sugar_amd_original
+            count += 1
+    return count
+
+
+_OPTIMIZER_SITES = (("scene.gaussian_model", "GaussianModel", "training_setup"),        # gaussian_model.py:152-166
+                    ("sugar_scene.sugar_optimizer", "SuGaROptimizer", "__init__"))       # sugar_optimizer.py:60-85
+
+
+def install_optimizer() -> int:
+    """`patch_optimizer`: the two places where the reference builds its `torch.optim.Adam(l, lr=0.0, eps=1e-15)` are wrapped so
+    that the instance they leave in `self.optimizer` is adopted by `sugar_amd.fused_adam.FusedAdam` -- the same object, state and
+    param_groups, a `torch.optim.Adam` subclass whose `step()` is one HIP launch per parameter tensor instead of ~50 multi-tensor
+    kernels.  Only modules that are already imported (or `sugar_scene.*`, importable by name) are touched.  Returns the number of
+    sites wrapped; `uninstall_optimizer()` undoes it."""
+    import functools
+    from ..fused_adam import adopt
+    count = 0
+    for modname, clsname, method in _OPTIMIZER_SITES:
+        mod = sys.modules.get(modname)
+        if mod is None and modname.startswith("sugar_scene."):
+            try:
+                mod = importlib.import_module(modname)
+            except ImportError:
+                mod = None
+        cls = getattr(mod, clsname, None) if mod is not None else None
+        if cls is None or hasattr(cls.__dict__.get(method), "_sugar_amd_original"):
+            continue
+        original = getattr(cls, method)
+
+        def make(original):
+            @functools.wraps(original)
+            def wrapped(self, *a, **k):
+                out = original(self, *a, **k)
+                if getattr(self, "optimizer", None) is not None:
+                    adopt(self.optimizer)
+                return out
+            wrapped._sugar_amd_original = original
+            return wrapped
+        setattr(cls, method, make(original))
+        count += 1
+    return count
+
+
+def uninstall_optimizer() -> int:
+    count = 0
+    for modname, clsname, method in _OPTIMIZER_SITES:
+        cls = getattr(sys.modules.get(modname), clsname, None)
+        f = cls.__dict__.get(method) if cls is not None else None
+        if hasattr(f, "_sugar_amd_original"):
+            setattr(cls, method, f._sugar_amd_original)
             count += 1
     return count
 

@@ -243,3 +243,38 @@ def test_patch_losses_rebinds_ssim_everywhere_and_cpu_calls_reach_the_original()
         assert shims.uninstall_losses() >= 2
         del sys.modules["early_importer"]
     assert lu.ssim is original
+
+
+def test_patch_optimizer_adopts_the_reference_optimizers_and_keeps_adam_semantics_on_cpu():
+    """shims.install_optimizer(): `GaussianModel.training_setup` / `SuGaROptimizer.__init__` leave a FusedAdam -- still a
+    torch.optim.Adam with the same groups and state layout; with CPU parameters its step is the parent's step, bit for bit"""
+    from tests import ref_env
+    if ref_env.reference_root() is None:
+        pytest.skip("no reference tree")
+    ref_env.import_sugar_model()
+    import sugar_scene.sugar_optimizer as so
+    from sugar_amd import shims
+    from sugar_amd.fused_adam import FusedAdam, adopt
+    shims.uninstall_optimizer()
+    try:
+        assert shims.install_optimizer() >= 1 and shims.install_optimizer() == 0
+        assert hasattr(so.SuGaROptimizer.__dict__["__init__"], "_sugar_amd_original")
+        g = torch.Generator().manual_seed(3)
+        ps = [torch.nn.Parameter(torch.randn(7, 3, generator=g)), torch.nn.Parameter(torch.randn(5, generator=g))]
+        qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+        a = adopt(torch.optim.Adam([{"params": [ps[0]], "lr": 1e-2, "name": "a"}, {"params": [ps[1]], "lr": 3e-3, "name": "b"}], lr=0.0, eps=1e-15))
+        b = torch.optim.Adam([{"params": [qs[0]], "lr": 1e-2, "name": "a"}, {"params": [qs[1]], "lr": 3e-3, "name": "b"}], lr=0.0, eps=1e-15)
+        assert isinstance(a, FusedAdam) and isinstance(a, torch.optim.Adam)
+        for it in range(3):
+            for p, q in zip(ps, qs):
+                gr = torch.randn(p.shape, generator=g)
+                p.grad = gr.clone(); q.grad = gr.clone()
+            a.step(); b.step()
+        for p, q in zip(ps, qs):
+            assert torch.equal(p, q)
+            assert set(a.state[p]) == set(b.state[q]) == {"step", "exp_avg", "exp_avg_sq"}
+            assert torch.equal(a.state[p]["exp_avg_sq"], b.state[q]["exp_avg_sq"])
+        assert a.state_dict()["param_groups"][0]["name"] == "a"
+    finally:
+        assert shims.uninstall_optimizer() >= 1
+    assert not hasattr(so.SuGaROptimizer.__dict__["__init__"], "_sugar_amd_original")
