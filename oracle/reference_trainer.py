@@ -110,11 +110,16 @@ def write_dataset(root: str, P: int = 60_000, n_cams: int = 48, W: int = 480, H:
     return types.SimpleNamespace(scene_path=os.path.join(root, "scene"), checkpoint_path=gs_dir + "/", n_cams=n_cams, P=P, W=W, H=H)
 
 
-def import_trainer(patch_sugar: bool):
-    """the reference's `sugar_trainers.coarse_sdf`, from /root/reference or the staged snapshot oracle/_ref/pysrc"""
+TRAINERS = {"coarse_sdf": "coarse_training_with_sdf_regularization",            # sugar_trainers/coarse_sdf.py:17
+            "coarse_density": "coarse_training_with_density_regularization"}    # sugar_trainers/coarse_density.py:17
+
+
+def import_trainer(patch_sugar: bool, trainer: str = "coarse_sdf"):
+    """the reference's `sugar_trainers.<trainer>`, from /root/reference or the staged snapshot oracle/_ref/pysrc"""
+    import importlib
     from tests import ref_env
     sm = ref_env.import_sugar_model(patch_sugar=patch_sugar)
-    import sugar_trainers.coarse_sdf as tr
+    tr = importlib.import_module("sugar_trainers." + trainer)
     ref = ref_env.reference_root()
     assert os.path.abspath(tr.__file__).startswith(os.path.abspath(ref)), tr.__file__
     import diff_gaussian_rasterization as dgr
@@ -128,11 +133,11 @@ LOSS_LINE = re.compile(r"loss:\s*([-+0-9.eE]+|nan|inf)\s*\[\s*(\d+)/\s*(\d+)\]")
 
 
 def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: str | None = None, patch_losses: bool = False,
-        patch_optimizer: bool = False):
+        patch_optimizer: bool = False, trainer: str = "coarse_sdf"):
     """Runs the unmodified trainer on `data` until its iteration counter reaches `stop_at` (or 15 000).  Returns a dict with the
     (iteration, loss) pairs the trainer printed, the host time stamps of each iteration and the events it announced."""
     from rich.console import Console
-    tr, sm = import_trainer(patch_sugar)
+    tr, sm = import_trainer(patch_sugar, trainer)
     if patch_losses:
         from sugar_amd import shims
         shims.install_losses()   # the trainer's module-level `ssim` -> HIP loss kernels (before the counter wraps it)
@@ -161,7 +166,7 @@ def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: st
     t0 = time.time()
     try:
         try:
-            model_path = tr.coarse_training_with_sdf_regularization(args)
+            model_path = getattr(tr, TRAINERS[trainer])(args)
             finished = True
         except _Stop:
             pass
@@ -191,7 +196,7 @@ def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: st
                 if not finished else 15_000, wall_s=wall, losses=losses, events=events,
                 gaussians_after_pruning=int(left[-1]) if left else None,
                 it_per_s_before_9000=rate(7050, 8950), it_per_s_after_9000=rate(9050, 15_000), log=log_path,
-                patch_sugar=patch_sugar, patch_losses=patch_losses, patch_optimizer=patch_optimizer, model_path=model_path)
+                patch_sugar=patch_sugar, patch_losses=patch_losses, patch_optimizer=patch_optimizer, model_path=model_path, trainer=trainer)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
