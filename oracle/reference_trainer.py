@@ -295,3 +295,130 @@ def run_extractor(data, out_dir: str, coarse_model_path: str | None, patch_sugar
 def surface_radius(d):
     """the radius of surface_scene's surface in unit direction d [N,3]"""
     return 0.8 + 0.12 * torch.sin(3.0 * d[:, 0]) * torch.cos(2.0 * d[:, 1]) + 0.08 * torch.sin(5.0 * d[:, 2])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The refinement trainer: sugar_trainers/refine.py::refined_training(args), untouched -- the surface-bound model of BASELINE config 4:
+# Gaussians tied to the triangles of a mesh (six per triangle, flat, their positions / scales / rotations functions of the mesh
+# vertices and two in-plane parameters), optimised through the rasterizer with pytorch3d's mesh_normal_consistency on the mesh.  It
+# gets its mesh from `open3d.io.read_triangle_mesh` (open3d is absent: the harness's stand-in reads the arrays this file wrote) and
+# ends by itself after `args.refinement_iterations`; at the end it exports the Gaussians through GaussianModel.save_ply (plyfile
+# stand-in).
+def icosphere(level: int):
+    """unit icosphere: (vertices [V,3] float64, faces [F,3] int64), F = 20 * 4**level, outward orientation"""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1),
+         (-t, 0, -1), (-t, 0, 1)]
+    verts = [np.asarray(p, dtype=np.float64) / np.linalg.norm(p) for p in v]
+    faces = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+             (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    for _ in range(level):
+        cache, out = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = verts[a] + verts[b]
+                verts.append(m / np.linalg.norm(m))
+                cache[key] = len(verts) - 1
+            return cache[key]
+        for a, b, c in faces:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            out += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        faces = out
+    return np.stack(verts), np.asarray(faces, dtype=np.int64)
+
+
+def write_surface_mesh(path: str, level: int = 5):
+    """the surface of `surface_scene` as a triangle mesh with vertex colours (arrays in an .npz: what the open3d stand-in reads)"""
+    d, faces = icosphere(level)
+    dt = torch.from_numpy(d).float()
+    verts = (dt * surface_radius(dt)[:, None]).numpy().astype(np.float64)
+    rgb = 0.5 + 0.35 * np.stack([np.sin(4 * verts[:, 0]), np.sin(5 * verts[:, 1] + 1.0), np.cos(3 * verts[:, 2])], axis=1)
+    np.savez(path, vertices=verts, triangles=faces, vertex_colors=rgb)
+    return faces.shape[0]
+
+
+def _open3d_that_reads_npz():
+    o3d = types.ModuleType("open3d")
+    o3d.io = types.ModuleType("open3d.io")
+
+    def read_triangle_mesh(path, *a, **k):
+        z = np.load(path)
+        return types.SimpleNamespace(vertices=z["vertices"], triangles=z["triangles"], vertex_colors=z["vertex_colors"],
+                                     vertex_normals=z["vertices"] / np.linalg.norm(z["vertices"], axis=1, keepdims=True))
+    o3d.io.read_triangle_mesh = read_triangle_mesh
+    return o3d
+
+
+def run_refine(data, out_dir: str, iterations: int = 400, gaussians_per_triangle: int = 6, mesh_level: int = 5,
+               patch_sugar: bool = True, patch_losses: bool = False, patch_optimizer: bool = False, log_path: str | None = None):
+    import importlib
+    from rich.console import Console
+    from tests import ref_env
+    from sugar_amd import shims
+    sm = ref_env.import_sugar_model(patch_sugar=patch_sugar)
+    saved_o3d = sys.modules.get("open3d")
+    sys.modules["open3d"] = _open3d_that_reads_npz()
+    sys.modules.pop("sugar_trainers.refine", None)   # (it binds `o3d` at import)
+    tr = importlib.import_module("sugar_trainers.refine")
+    assert os.path.abspath(tr.__file__).startswith(os.path.abspath(ref_env.reference_root())), tr.__file__
+    if patch_losses:
+        shims.install_losses()
+    if patch_optimizer:
+        shims.install_optimizer()
+    os.makedirs(out_dir, exist_ok=True)
+    out_dir = os.path.abspath(out_dir)
+    mesh_path = os.path.join(out_dir, "surface_mesh.npz")
+    n_faces = write_surface_mesh(mesh_path, mesh_level)
+    log_path = os.path.abspath(log_path or os.path.join(out_dir, "refine_console.log"))
+    log_file = open(log_path, "w")
+    saved = (tr.Console, tr.ssim)
+    stamps = []
+
+    def counted_ssim(*a, **k):
+        stamps.append(time.time())
+        return saved[1](*a, **k)
+    tr.Console = lambda *a, **k: Console(file=log_file, width=200, force_terminal=False)
+    tr.ssim = counted_ssim
+    args = types.SimpleNamespace(gpu=0, scene_path=data.scene_path, checkpoint_path=data.checkpoint_path, mesh_path=mesh_path,
+                                 iteration_to_load=7000, normal_consistency_factor=0.1, gaussians_per_triangle=gaussians_per_triangle,
+                                 n_vertices_in_fg=1_000_000, refinement_iterations=iterations, bboxmin=None, bboxmax=None,
+                                 output_dir=os.path.join("output", "refined", "scene"), eval=True, white_background=False,
+                                 export_ply=True)
+    # (a RELATIVE output directory, as the reference's command line gives it: the export path at refine.py:880-885 is rebuilt with
+    # os.path.join(*model_path.split(os.sep)), which drops the root of an absolute path)
+    model_path, t0, cwd = None, time.time(), os.getcwd()
+    os.chdir(out_dir)
+    try:
+        model_path = tr.refined_training(args)
+        torch.cuda.synchronize()
+    finally:
+        wall = time.time() - t0
+        os.chdir(cwd)
+        tr.Console, tr.ssim = saved
+        log_file.close()
+        if patch_losses:
+            shims.uninstall_losses()
+        if patch_optimizer:
+            shims.uninstall_optimizer()
+        if saved_o3d is not None:
+            sys.modules["open3d"] = saved_o3d
+        else:
+            sys.modules.pop("open3d", None)
+        sys.modules.pop("sugar_trainers.refine", None)
+        if patch_sugar:
+            from sugar_amd import sugar_patch
+            sugar_patch.uninstall(sm)
+    text = open(log_path).read()
+    losses = [(int(m.group(2)), float(m.group(1))) for m in LOSS_LINE.finditer(text)]
+    its = np.asarray(stamps)
+    rate = float((len(its) - 51) / (its[-1] - its[50])) if len(its) > 60 else None
+    ply = None
+    for root, _, files in os.walk(os.path.join(out_dir, "output")):
+        for f in files:
+            if f.endswith(".ply"):
+                ply = os.path.join(root, f)
+    return dict(model_path=model_path, iterations_run=len(stamps), wall_s=wall, losses=losses, it_per_s=rate, mesh_faces=n_faces,
+                gaussians=n_faces * gaussians_per_triangle, exported_ply=ply, finished="Final model saved" in text, log=log_path,
+                patch_sugar=patch_sugar, patch_losses=patch_losses, patch_optimizer=patch_optimizer)

@@ -31,6 +31,9 @@ def main():
                     help="then run the reference's coarse-mesh extractor (sugar_extractors/coarse_mesh.py, untouched) up to its "
                          "Poisson step: on the trained model if the training ran to 15000, else on the 3DGS checkpoint")
     ap.add_argument("--skip-training", action="store_true")
+    ap.add_argument("--refine", type=int, default=0, metavar="N",
+                    help="then run the reference's refinement trainer (sugar_trainers/refine.py, untouched) for N iterations on a mesh "
+                         "of the scene's surface, six Gaussians per triangle")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "reference_trainer"))
     a = ap.parse_args()
     from oracle import reference_trainer as rt
@@ -59,6 +62,10 @@ def main():
                                     "normal_dot_radial_median": float((torch.nn.functional.normalize(o["normals"], dim=1) * d).sum(1).abs().median()) if len(err) else None}
             ext["levels"] = levels
             res["extractor"] = ext
+        if a.refine:
+            res["refine"] = rt.run_refine(data, os.path.join(work, "refine"), iterations=a.refine, patch_sugar=not a.no_patch,
+                                          patch_losses=a.patch_losses, patch_optimizer=a.patch_optimizer,
+                                          log_path=os.path.join(a.out, f"refine_console_{tag}.log"))
         with open(os.path.join(a.out, f"summary_{tag}.json"), "w") as f:
             json.dump(res, f, indent=1)
         print(json.dumps(res))
