@@ -133,7 +133,7 @@ LOSS_LINE = re.compile(r"loss:\s*([-+0-9.eE]+|nan|inf)\s*\[\s*(\d+)/\s*(\d+)\]")
 
 
 def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: str | None = None, patch_losses: bool = False,
-        patch_optimizer: bool = False, trainer: str = "coarse_sdf"):
+        patch_optimizer: bool = False, trainer: str = "coarse_sdf", profile_window=None):
     """Runs the unmodified trainer on `data` until its iteration counter reaches `stop_at` (or 15 000).  Returns a dict with the
     (iteration, loss) pairs the trainer printed, the host time stamps of each iteration and the events it announced."""
     from rich.console import Console
@@ -151,9 +151,23 @@ def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: st
     stamps = []
     first_iteration = 7000   # coarse_sdf.py:472-473 + the `iteration += 1` at :486
 
+    prof = {"window": profile_window, "p": None, "table": None}
+
     def counted_ssim(*a, **k):
         stamps.append(time.time())
-        if first_iteration + len(stamps) - 1 > stop_at:
+        it = first_iteration + len(stamps) - 1
+        if prof["window"] is not None:      # torch profiler over [a, b): started / stopped at the one call per iteration
+            if it == prof["window"][0]:
+                from torch.profiler import profile, ProfilerActivity
+                torch.cuda.synchronize()
+                prof["p"] = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA])
+                prof["p"].__enter__()
+            elif it == prof["window"][1] and prof["p"] is not None:
+                torch.cuda.synchronize()
+                prof["p"].__exit__(None, None, None)
+                prof["table"] = prof["p"].key_averages().table(sort_by="cuda_time_total", row_limit=60, max_name_column_width=90)
+                prof["p"] = None
+        if it > stop_at:
             raise _Stop()
         return saved[1](*a, **k)
 
@@ -196,7 +210,7 @@ def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: st
                 if not finished else 15_000, wall_s=wall, losses=losses, events=events,
                 gaussians_after_pruning=int(left[-1]) if left else None,
                 it_per_s_before_9000=rate(7050, 8950), it_per_s_after_9000=rate(9050, 15_000), log=log_path,
-                patch_sugar=patch_sugar, patch_losses=patch_losses, patch_optimizer=patch_optimizer, model_path=model_path, trainer=trainer)
+                patch_sugar=patch_sugar, patch_losses=patch_losses, patch_optimizer=patch_optimizer, model_path=model_path, trainer=trainer, profile_table=prof["table"])
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

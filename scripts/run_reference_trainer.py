@@ -31,6 +31,8 @@ def main():
                     help="then run the reference's coarse-mesh extractor (sugar_extractors/coarse_mesh.py, untouched) up to its "
                          "Poisson step: on the trained model if the training ran to 15000, else on the 3DGS checkpoint")
     ap.add_argument("--skip-training", action="store_true")
+    ap.add_argument("--profile-window", type=int, nargs=2, default=None, metavar=("FROM", "TO"),
+                    help="torch profiler over these trainer iterations; the kernel table goes to <out>/profile_<tag>.txt")
     ap.add_argument("--refine", type=int, default=0, metavar="N",
                     help="then run the reference's refinement trainer (sugar_trainers/refine.py, untouched) for N iterations on a mesh "
                          "of the scene's surface, six Gaussians per triangle")
@@ -44,8 +46,12 @@ def main():
         tag = ("" if a.trainer == "coarse_sdf" else a.trainer + "_") + ("dropins_only" if a.no_patch else "patched") + ("_losses" if a.patch_losses else "") + ("_adam" if a.patch_optimizer else "")
         res = {"finished": False, "model_path": None}
         if not a.skip_training:
-          res = rt.run(data, os.path.join(work, "out"), stop_at=a.stop_at, patch_sugar=not a.no_patch, patch_losses=a.patch_losses, patch_optimizer=a.patch_optimizer, trainer=a.trainer,
+          res = rt.run(data, os.path.join(work, "out"), stop_at=a.stop_at, patch_sugar=not a.no_patch, patch_losses=a.patch_losses, patch_optimizer=a.patch_optimizer, trainer=a.trainer, profile_window=a.profile_window,
                      log_path=os.path.join(a.out, f"trainer_console_{tag}.log"))
+        table = res.pop("profile_table", None)
+        if table:
+            with open(os.path.join(a.out, f"profile_{tag}.txt"), "w") as f:
+                f.write(f"torch profiler, trainer iterations {a.profile_window[0]} .. {a.profile_window[1] - 1}\n" + table + "\n")
         res.update(gaussians=a.gaussians, cameras=a.cameras, width=a.width, height=a.height)
         if a.extract:
             import torch

@@ -230,6 +230,19 @@ __global__ void __launch_bounds__(256) k_density_bwd_fill(long long NK, const lo
     pair_list[start[nbr[p]] + rank[p]] = (uint32_t)p;
 }
 
+// sum over the 16 lanes of a DPP row, returned to every lane of the row (row_ror:8 / 4 / 2 / 1 fold into the adds)
+__device__ __forceinline__ float row_sum16(float x)
+{
+    x += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x128, 0xF, 0xF, false));
+    x += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x124, 0xF, 0xF, false));
+    x += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x122, 0xF, 0xF, false));
+    x += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x121, 0xF, 0xF, false));
+    return x;
+}
+
+// SIXTEEN lanes (one DPP row) per Gaussian: they stride over its pairs and fold their 13 partial sums with row rotates.  (One lane
+// per Gaussian, until round 4, walked its list alone -- 280 dependent gathers on average when 1M samples x 16 neighbours meet 57k
+// Gaussians, on 900 waves: 2.0 ms; a trainer's SDF phase has exactly that shape.)
 __global__ void __launch_bounds__(256) k_density_bwd_gather(int P, int K, const float* __restrict__ x,
                                                             const float* __restrict__ centers, const float* __restrict__ B,
                                                             const float* __restrict__ strengths, const float4* __restrict__ packed, float factor,
@@ -238,15 +251,16 @@ __global__ void __launch_bounds__(256) k_density_bwd_gather(int P, int K, const 
                                                             const uint32_t* __restrict__ pair_list, float* __restrict__ dcenters,
                                                             float* __restrict__ dB, float* __restrict__ dstrengths)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= P) return;
+    const int t = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 4);
+    const uint32_t sub = threadIdx.x & 15;
+    if (t >= P) return;   // (whole rows leave together: the row rotates below never cross a row)
     const GaussNbr g = load_nbr(t, centers, B, strengths, packed);
     float dc0 = 0.f, dc1 = 0.f, dc2 = 0.f, ds = 0.f;
     float b[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) b[i] = 0.f;
     const uint32_t e0 = start[t], e1 = start[t + 1];
-    for (uint32_t e = e0; e < e1; e++) {
+    for (uint32_t e = e0 + sub; e < e1; e += 16) {
         const uint32_t p = pair_list[e];
         const uint32_t n = p / (uint32_t)K;
         const float dx = x[3 * (size_t)n] - g.mx, dy = x[3 * (size_t)n + 1] - g.my, dz = x[3 * (size_t)n + 2] - g.mz;
@@ -265,10 +279,19 @@ __global__ void __launch_bounds__(256) k_density_bwd_gather(int P, int K, const 
         b[3] += dy * dw0; b[4] += dy * dw1; b[5] += dy * dw2;
         b[6] += dz * dw0; b[7] += dz * dw1; b[8] += dz * dw2;
     }
-    dcenters[3 * (size_t)t] = dc0; dcenters[3 * (size_t)t + 1] = dc1; dcenters[3 * (size_t)t + 2] = dc2;
+    dc0 = row_sum16(dc0); dc1 = row_sum16(dc1); dc2 = row_sum16(dc2); ds = row_sum16(ds);
 #pragma unroll
-    for (int i = 0; i < 9; i++) dB[9 * (size_t)t + i] = b[i];
-    dstrengths[t] = ds;
+    for (int i = 0; i < 9; i++) b[i] = row_sum16(b[i]);
+    if (sub == 0) {
+        dcenters[3 * (size_t)t] = dc0; dcenters[3 * (size_t)t + 1] = dc1; dcenters[3 * (size_t)t + 2] = dc2;
+        dstrengths[t] = ds;
+    }
+    if (sub < 9) {   // nine lanes store the nine entries of dB (each holds all the sums)
+        float v = b[0];
+#pragma unroll
+        for (int i = 1; i < 9; i++) v = (sub == (uint32_t)i) ? b[i] : v;
+        dB[9 * (size_t)t + sub] = v;
+    }
 }
 
 // ---- SuGaR.get_covariance(return_sqrt=True[, inverse_scales=True]), sugar_scene/sugar_model.py:730-736 ---------------------
@@ -527,7 +550,7 @@ int sgr_density_field_backward_gather(int N, int K, int P, const float* x, const
         hipLaunchKernelGGL(k_density_bwd_fill, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, (long long)nk, nbr, start, rank,
                            pair_list);
     }
-    hipLaunchKernelGGL(k_density_bwd_gather, dim3((P + 255) / 256), dim3(256), 0, s, P, K, x, centers, inv_scaled_rot, strengths,
+    hipLaunchKernelGGL(k_density_bwd_gather, dim3((unsigned)(((size_t)P * 16 + 255) / 256)), dim3(256), 0, s, P, K, x, centers, inv_scaled_rot, strengths,
                        reinterpret_cast<const float4*>(packed), density_factor, dL_dopacities, dL_ddensity, start, pair_list, dL_dcenters, dL_dinv_scaled_rot, dL_dstrengths);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
