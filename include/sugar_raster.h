@@ -462,6 +462,16 @@ int sgr_density_field_backward_gather(int N, int K, int P, const float* x, const
                                       const float* inv_scaled_rot, const float* strengths, float density_factor,
                                       const float* dL_dopacities, const float* dL_ddensity, float* dL_dx, float* dL_dcenters,
                                       float* dL_dinv_scaled_rot, float* dL_dstrengths, char* scratch, const float* packed, void* stream);
+
+/* ---- backward of a row gather -------------------------------------------------------------------------------------------------
+ * out[p, 0..W) = sum over { n : idx[n] == p } of src[n, 0..W): what autograd computes for `x[idx]` (x: [P, W] float32, idx: N int64
+ * entries, src = the incoming gradient [N, W]) -- the scatter-add of SURVEY.md section 8 row a21, met by SuGaR's regulariser at
+ * sugar_model.py:922-925 and coarse_sdf.py:690-692.  W in 1..4; every row of `out` is WRITTEN (rows without entries get zeros);
+ * negative indices wrap once, entries outside [-P, P) are ignored; N < 2^32.  The order of the additions inside a row is not fixed
+ * (ranks come from atomics).  scratch: sgr_scatter_add_rows_scratch_bytes(N, P) bytes of device memory.  No host synchronisation. */
+size_t sgr_scatter_add_rows_scratch_bytes(long long N, int P);
+int sgr_scatter_add_rows(long long N, const int64_t* idx, const float* src, int W, int P, float* out, char* scratch, void* stream);
+
 int sgr_level_set_points(int N, int K, const float* world_points, const int64_t* nbr_idx, const float* cam_center,
                          const float* centers, const float* inv_scaled_rot, const float* strengths,
                          const float* gaussian_std, int n_levels, const float* levels_host, int n_range, float range_size,

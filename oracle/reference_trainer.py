@@ -133,11 +133,14 @@ LOSS_LINE = re.compile(r"loss:\s*([-+0-9.eE]+|nan|inf)\s*\[\s*(\d+)/\s*(\d+)\]")
 
 
 def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: str | None = None, patch_losses: bool = False,
-        patch_optimizer: bool = False, trainer: str = "coarse_sdf", profile_window=None):
+        patch_optimizer: bool = False, trainer: str = "coarse_sdf", profile_window=None, patch_gathers: bool = False):
     """Runs the unmodified trainer on `data` until its iteration counter reaches `stop_at` (or 15 000).  Returns a dict with the
     (iteration, loss) pairs the trainer printed, the host time stamps of each iteration and the events it announced."""
     from rich.console import Console
     tr, sm = import_trainer(patch_sugar, trainer)
+    if patch_gathers:
+        from sugar_amd import sugar_patch as _sp
+        _sp.install_row_gathers(sm)   # SuGaR.points / scaling / quaternions / get_normals(): row gathers with a HIP backward
     if patch_losses:
         from sugar_amd import shims
         shims.install_losses()   # the trainer's module-level `ssim` -> HIP loss kernels (before the counter wraps it)
@@ -192,6 +195,8 @@ def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: st
             shims.uninstall_losses()
         if patch_optimizer:
             _shims.uninstall_optimizer()
+        if patch_gathers:
+            _sp.uninstall_row_gathers(sm)
         if patch_sugar:
             from sugar_amd import sugar_patch
             sugar_patch.uninstall(sm)
@@ -210,7 +215,8 @@ def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: st
                 if not finished else 15_000, wall_s=wall, losses=losses, events=events,
                 gaussians_after_pruning=int(left[-1]) if left else None,
                 it_per_s_before_9000=rate(7050, 8950), it_per_s_after_9000=rate(9050, 15_000), log=log_path,
-                patch_sugar=patch_sugar, patch_losses=patch_losses, patch_optimizer=patch_optimizer, model_path=model_path, trainer=trainer, profile_table=prof["table"])
+                patch_sugar=patch_sugar, patch_losses=patch_losses, patch_optimizer=patch_optimizer, patch_gathers=patch_gathers, model_path=model_path, trainer=trainer,
+                profile_table=prof["table"])
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--height", type=int, default=320)
     ap.add_argument("--no-patch", action="store_true", help="drop-in packages only; SuGaR's own tensor code for the field methods")
     ap.add_argument("--patch-losses", action="store_true", help="also bind the trainer's `ssim` to the HIP loss kernels")
+    ap.add_argument("--patch-gathers", action="store_true", help="also give SuGaR's per-Gaussian tensors a HIP row-gather backward")
     ap.add_argument("--trainer", default="coarse_sdf", choices=["coarse_sdf", "coarse_density"])
     ap.add_argument("--patch-optimizer", action="store_true", help="also let SuGaROptimizer's torch.optim.Adam step on the HIP Adam")
     ap.add_argument("--extract", action="store_true",
@@ -43,10 +44,10 @@ def main():
     try:
         data = rt.write_dataset(work, P=a.gaussians, n_cams=a.cameras, W=a.width, H=a.height)
         os.makedirs(a.out, exist_ok=True)
-        tag = ("" if a.trainer == "coarse_sdf" else a.trainer + "_") + ("dropins_only" if a.no_patch else "patched") + ("_losses" if a.patch_losses else "") + ("_adam" if a.patch_optimizer else "")
+        tag = ("" if a.trainer == "coarse_sdf" else a.trainer + "_") + ("dropins_only" if a.no_patch else "patched") + ("_losses" if a.patch_losses else "") + ("_adam" if a.patch_optimizer else "") + ("_gathers" if a.patch_gathers else "")
         res = {"finished": False, "model_path": None}
         if not a.skip_training:
-          res = rt.run(data, os.path.join(work, "out"), stop_at=a.stop_at, patch_sugar=not a.no_patch, patch_losses=a.patch_losses, patch_optimizer=a.patch_optimizer, trainer=a.trainer, profile_window=a.profile_window,
+          res = rt.run(data, os.path.join(work, "out"), stop_at=a.stop_at, patch_sugar=not a.no_patch, patch_losses=a.patch_losses, patch_optimizer=a.patch_optimizer, trainer=a.trainer, profile_window=a.profile_window, patch_gathers=a.patch_gathers,
                      log_path=os.path.join(a.out, f"trainer_console_{tag}.log"))
         table = res.pop("profile_table", None)
         if table:

@@ -66,6 +66,8 @@ SIGNATURES = {
     "sgr_density_field_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "sgr_density_field_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgr_density_field_backward_scratch_bytes": (_sz, [_i, _i, _i]),
+    "sgr_scatter_add_rows_scratch_bytes": (_sz, [C.c_longlong, _i]),
+    "sgr_scatter_add_rows": (_i, [C.c_longlong, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "sgr_density_field_backward_gather": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgr_scaled_rotation_forward": (_i, [_i, _vp, _vp, _i, _vp, _vp]),
     "sgr_scaled_rotation_backward": (_i, [_i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -294,6 +294,58 @@ __global__ void __launch_bounds__(256) k_density_bwd_gather(int P, int K, const 
     }
 }
 
+// ---- out[p, :] = sum over { n : idx[n] == p } of src[n, :]  -- the backward of a row gather `x[idx]` --------------------------------
+// What autograd runs for every `tensor[index]` of the regulariser (sugar_model.py:922-925: points / quaternions / scaling of 1M sampled
+// Gaussians; coarse_sdf.py:690-692: the normals of 1M x 16 neighbours): stock PyTorch sorts the indices and reduces segments, 1.3 ms per
+// call on average and six calls per iteration.  Same grouping as the density backward above: a returning integer atomic gives every
+// entry its rank among the entries of its row, a scan turns the counts into list offsets, and sixteen lanes per row add its entries up.
+// Negative indices wrap once (Python semantics); entries outside [-P, P) are ignored.
+__device__ __forceinline__ long long rows_wrap(long long i, int P) { return i < 0 ? i + P : i; }
+
+__global__ void __launch_bounds__(256) k_rows_rank(long long N, const long long* __restrict__ idx, int P, uint32_t* __restrict__ cnt,
+                                                   uint32_t* __restrict__ rank)
+{
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const long long g = rows_wrap(idx[n], P);
+    if (g >= 0 && g < P) rank[n] = atomicAdd(&cnt[g], 1u);
+}
+
+__global__ void __launch_bounds__(256) k_rows_fill(long long N, const long long* __restrict__ idx, int P, const uint32_t* __restrict__ start,
+                                                   const uint32_t* __restrict__ rank, uint32_t* __restrict__ list)
+{
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const long long g = rows_wrap(idx[n], P);
+    if (g >= 0 && g < P) list[start[g] + rank[n]] = (uint32_t)n;
+}
+
+template <int W>
+__global__ void __launch_bounds__(256) k_rows_gather(int P, const float* __restrict__ src, const uint32_t* __restrict__ start,
+                                                     const uint32_t* __restrict__ list, float* __restrict__ out)
+{
+    const int t = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 4);
+    const uint32_t sub = threadIdx.x & 15;
+    if (t >= P) return;
+    float acc[W];
+#pragma unroll
+    for (int c = 0; c < W; c++) acc[c] = 0.f;
+    const uint32_t e0 = start[t], e1 = start[t + 1];
+    for (uint32_t e = e0 + sub; e < e1; e += 16) {
+        const float* r = src + (size_t)list[e] * W;
+#pragma unroll
+        for (int c = 0; c < W; c++) acc[c] += r[c];
+    }
+#pragma unroll
+    for (int c = 0; c < W; c++) acc[c] = row_sum16(acc[c]);
+    if (sub < (uint32_t)W) {
+        float v = acc[0];
+#pragma unroll
+        for (int c = 1; c < W; c++) v = (sub == (uint32_t)c) ? acc[c] : v;
+        out[(size_t)t * W + sub] = v;
+    }
+}
+
 // ---- SuGaR.get_covariance(return_sqrt=True[, inverse_scales=True]), sugar_scene/sugar_model.py:730-736 ---------------------
 // out[a][b] = R(q)[a][b] * s[b],  R = pytorch3d's quaternion_to_matrix (real part first, two_s = 2 / |q|^2: any non-zero q),
 // s = scaling or 1 / clamp(scaling, 1e-8).  The reference builds it with ~25 elementwise launches (plus autograd twins) every
@@ -552,6 +604,45 @@ int sgr_density_field_backward_gather(int N, int K, int P, const float* x, const
     }
     hipLaunchKernelGGL(k_density_bwd_gather, dim3((unsigned)(((size_t)P * 16 + 255) / 256)), dim3(256), 0, s, P, K, x, centers, inv_scaled_rot, strengths,
                        reinterpret_cast<const float4*>(packed), density_factor, dL_dopacities, dL_ddensity, start, pair_list, dL_dcenters, dL_dinv_scaled_rot, dL_dstrengths);
+    return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
+}
+
+size_t sgr_scatter_add_rows_scratch_bytes(long long N, int P)
+{
+    const size_t n = (size_t)(N > 0 ? N : 0), p = (size_t)(P > 0 ? P : 0);
+    const size_t blocks = (p + FSCAN_BLOCK - 1) / FSCAN_BLOCK + 1;
+    return sgr_align((p + 1) * 4) * 2 + sgr_align(blocks * 4) + 2 * sgr_align(n * 4);  // cnt | start | block sums | rank | list
+}
+
+int sgr_scatter_add_rows(long long N, const int64_t* idx, const float* src, int W, int P, float* out, char* scratch, void* stream)
+{
+    if (P <= 0) return 0;
+    if (N < 0 || W < 1 || W > 4 || (N > 0 && (!idx || !src)) || !out || !scratch || (unsigned long long)N > 0xFFFFFFFFull)
+        return SGR_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t pa = sgr_align(((size_t)P + 1) * 4);
+    const int n_blocks = (P + FSCAN_BLOCK - 1) / FSCAN_BLOCK;
+    const size_t ba = sgr_align(((size_t)n_blocks + 1) * 4);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(scratch);
+    uint32_t* start = reinterpret_cast<uint32_t*>(scratch + pa);
+    uint32_t* block_sums = reinterpret_cast<uint32_t*>(scratch + 2 * pa);
+    uint32_t* rank = reinterpret_cast<uint32_t*>(scratch + 2 * pa + ba);
+    uint32_t* list = reinterpret_cast<uint32_t*>(scratch + 2 * pa + ba + sgr_align((size_t)N * 4));
+    const long long* ix = reinterpret_cast<const long long*>(idx);
+    if (hipMemsetAsync(cnt, 0, ((size_t)P + 1) * 4, s) != hipSuccess) return SGR_E_HIP;
+    const unsigned nb = (unsigned)(((size_t)N + 255) / 256);
+    if (N > 0) hipLaunchKernelGGL(k_rows_rank, dim3(nb), dim3(256), 0, s, N, ix, P, cnt, rank);
+    hipLaunchKernelGGL(k_fscan_sums, dim3(n_blocks), dim3(256), 0, s, P, cnt, block_sums);
+    hipLaunchKernelGGL(k_fscan_top, dim3(1), dim3(1024), 0, s, n_blocks, block_sums, start + P);
+    hipLaunchKernelGGL(k_fscan_apply, dim3(n_blocks), dim3(256), 0, s, P, cnt, block_sums, start);
+    if (N > 0) hipLaunchKernelGGL(k_rows_fill, dim3(nb), dim3(256), 0, s, N, ix, P, start, rank, list);
+    const unsigned gb = (unsigned)(((size_t)P * 16 + 255) / 256);
+    switch (W) {
+        case 1: hipLaunchKernelGGL(k_rows_gather<1>, dim3(gb), dim3(256), 0, s, P, src, start, list, out); break;
+        case 2: hipLaunchKernelGGL(k_rows_gather<2>, dim3(gb), dim3(256), 0, s, P, src, start, list, out); break;
+        case 3: hipLaunchKernelGGL(k_rows_gather<3>, dim3(gb), dim3(256), 0, s, P, src, start, list, out); break;
+        default: hipLaunchKernelGGL(k_rows_gather<4>, dim3(gb), dim3(256), 0, s, P, src, start, list, out); break;
+    }
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 

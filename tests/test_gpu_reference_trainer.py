@@ -20,10 +20,10 @@ def test_the_unmodified_coarse_trainer_runs_through_its_schedule_on_the_drop_ins
         pytest.skip("the reference's Python is not staged (oracle/ref_build/build_ref.sh)")
     from oracle import reference_trainer as rt
     data = rt.write_dataset(str(tmp_path / "data"), P=30_000, n_cams=24, W=320, H=208)
-    # (`patches`: also the reference's `ssim` and the optimiser it builds on the HIP kernels -- shims.install(patch_losses=True,
-    # patch_optimizer=True); the second trainer of the reference, coarse_density.py, has the same loop with a density regulariser)
+    # (`patches`: also the reference's `ssim`, the optimiser it builds and the row gathers of SuGaR's per-Gaussian tensors on the HIP
+    # kernels -- shims.install(patch_losses=True, patch_optimizer=True, patch_gathers=True); the second trainer of the reference, coarse_density.py, has the same loop with a density regulariser)
     res = rt.run(data, str(tmp_path / "out"), stop_at=9060, patch_sugar=True, patch_losses=patches, patch_optimizer=patches,
-                 trainer=trainer)
+                 patch_gathers=patches, trainer=trainer)
     assert not res["finished"] and res["last_iteration"] == 9060
     its = [i for i, _ in res["losses"]]
     assert its[0] == 7000 and its[-1] == 9050 and len(its) == 42          # one line per 50 iterations (coarse_sdf.py:221,761)

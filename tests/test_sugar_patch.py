@@ -12,6 +12,7 @@
 import inspect
 import os
 import sys
+import types
 
 import numpy as np
 import pytest
@@ -206,3 +207,31 @@ def test_committed_meshdepth_fixture_is_what_the_reference_returns(ref):
             assert np.array_equal(a, b), k
         else:
             np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-6 * max(1.0, float(np.abs(b).max())), err_msg=k)
+
+
+def test_row_gather_wrappers_leave_cpu_models_alone_and_come_off_again():
+    """sugar_patch.install_row_gathers on the reference class: properties and get_normals keep returning what they returned for a CPU
+    model (plain tensors, same values, gradients flow), and uninstall restores the original descriptors"""
+    from tests import ref_env
+    if ref_env.reference_root() is None:
+        pytest.skip("no reference tree")
+    sm = ref_env.import_sugar_model()
+    from sugar_amd import sugar_patch
+    cls = sm.SuGaR
+    before = {n: cls.__dict__[n] for n in sugar_patch.ROW_GATHER_PROPERTIES + sugar_patch.ROW_GATHER_METHODS}
+    names = sugar_patch.install_row_gathers(sm)
+    try:
+        assert set(names) == set(before) and sugar_patch.install_row_gathers(sm) == names      # idempotent
+        assert all(cls.__dict__[n] is not before[n] for n in before)
+        fake = types.SimpleNamespace(binded_to_surface_mesh=False, learnable_positions=True, learnable_shifts=False,
+                                     _points=torch.nn.Parameter(torch.randn(6, 3)),
+                                     _quaternions=torch.nn.Parameter(torch.randn(6, 4)))
+        pts = cls.points.fget(fake)
+        q = cls.quaternions.fget(fake)
+        assert type(q) is torch.Tensor and pts is fake._points
+        assert torch.allclose(q, torch.nn.functional.normalize(fake._quaternions, dim=-1))
+        q[torch.tensor([0, 0, 5])].sum().backward()
+        assert fake._quaternions.grad is not None
+    finally:
+        sugar_patch.uninstall_row_gathers(sm)
+    assert all(cls.__dict__[n] is before[n] for n in before)
