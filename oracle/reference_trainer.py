@@ -129,6 +129,11 @@ def import_trainer(patch_sugar: bool, trainer: str = "coarse_sdf"):
     return tr, sm
 
 
+def _adam_stats():
+    from sugar_amd import fused_adam
+    return dict(fused_adam.STATS)
+
+
 LOSS_LINE = re.compile(r"loss:\s*([-+0-9.eE]+|nan|inf)\s*\[\s*(\d+)/\s*(\d+)\]")
 
 
@@ -216,7 +221,7 @@ def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: st
                 gaussians_after_pruning=int(left[-1]) if left else None,
                 it_per_s_before_9000=rate(7050, 8950), it_per_s_after_9000=rate(9050, 15_000), log=log_path,
                 patch_sugar=patch_sugar, patch_losses=patch_losses, patch_optimizer=patch_optimizer, patch_gathers=patch_gathers, model_path=model_path, trainer=trainer,
-                profile_table=prof["table"])
+                profile_table=prof["table"], adam_stats=_adam_stats())
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

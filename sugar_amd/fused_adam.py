@@ -5,8 +5,9 @@ runs that step as ~50 multi-tensor kernels (1.5 ms at 1M Gaussians on an MI355X)
 
 `FusedAdam` IS a `torch.optim.Adam`: same constructor, same `param_groups`, same per-parameter state (`step`, `exp_avg`,
 `exp_avg_sq` -- what the reference's densifier cuts, concatenates and resets: gaussian_model.py:258-316, sugar_densifier.py), same
-`state_dict()`.  Only `step()` differs, and only when every parameter is what the kernel covers (float32, contiguous, on a ROCm
-device, dense gradient, no weight decay / amsgrad / maximize / capturable / differentiable); anything else is the parent's step.
+`state_dict()`.  Only `step()` differs, and only when every parameter is what the kernel covers (float32, on a ROCm
+device, dense gradient, no weight decay / amsgrad / maximize / capturable / differentiable; strided parameters are updated in a
+dense copy); anything else is the parent's step.
 `adopt(optimizer)` turns an existing `torch.optim.Adam` instance into one in place."""
 from __future__ import annotations
 
@@ -17,19 +18,35 @@ import torch
 from . import _lib
 
 
-def _supported(group, p) -> bool:
-    return (not group.get("amsgrad", False) and group.get("weight_decay", 0) == 0 and not group.get("maximize", False)
-            and not group.get("capturable", False) and not group.get("differentiable", False)
-            and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad is not None and not p.grad.is_sparse
-            and p.grad.dtype == torch.float32 and p.data_ptr() % 16 == 0)
+STATS = {"fused_steps": 0, "fallback_steps": 0, "last_fallback_reason": None}   # (diagnostics: which path the steps took)
+
+
+def _unsupported_reason(group, p):
+    """None when the kernel covers this parameter, else a short reason (the step then is the parent's)"""
+    for flag in ("amsgrad", "maximize", "capturable", "differentiable"):
+        if group.get(flag, False):
+            return flag
+    if group.get("weight_decay", 0) != 0:
+        return "weight_decay"
+    if not p.is_cuda:
+        return "parameter not on a ROCm device"
+    if p.dtype != torch.float32 or p.grad.dtype != torch.float32:
+        return "dtype"
+    if p.grad.is_sparse:
+        return "sparse gradient"
+    return None
 
 
 class FusedAdam(torch.optim.Adam):
     @torch.no_grad()
     def step(self, closure=None):
         todo = [(g, p) for g in self.param_groups for p in g["params"] if p.grad is not None]
-        if not todo or not all(_supported(g, p) for g, p in todo):
+        reason = "no gradients" if not todo else next((r for r in (_unsupported_reason(g, p) for g, p in todo) if r), None)
+        if reason is not None:
+            STATS["fallback_steps"] += 1
+            STATS["last_fallback_reason"] = reason
             return super().step(closure)
+        STATS["fused_steps"] += 1
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -44,20 +61,26 @@ class FusedAdam(torch.optim.Adam):
                 state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             state["step"] += 1
             m, v = state["exp_avg"], state["exp_avg_sq"]
-            grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-            if not (m.is_contiguous() and v.is_contiguous() and m.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0
-                    and grad.data_ptr() % 16 == 0):
-                raise RuntimeError("FusedAdam: optimiser state is not contiguous / 16-byte aligned")
+            # A strided parameter -- SuGaR's `_scales` / `_quaternions` are column slices of one [1, P, 7] tensor until the first
+            # pruning (sugar_model.py:313-318) -- is updated in a dense copy and written back; its moments are dense already
+            # (zeros_like of a tensor with gaps is contiguous).
+            dense = p if (p.is_contiguous() and p.data_ptr() % 16 == 0) else p.detach().contiguous()
+            grad = p.grad if (p.grad.is_contiguous() and p.grad.data_ptr() % 16 == 0) else p.grad.contiguous()
+            if not (m.is_contiguous() and v.is_contiguous()):
+                m = state["exp_avg"] = m.contiguous()
+                v = state["exp_avg_sq"] = v.contiguous()
             lr = float(group["lr"])
             b1, b2 = group["betas"]
             n = p.numel()
             with torch.cuda.device(p.device):
-                rc = lib.sgr_adam_step(n, C.c_void_p(p.data_ptr()), C.c_void_p(grad.data_ptr()), C.c_void_p(m.data_ptr()),
+                rc = lib.sgr_adam_step(n, C.c_void_p(dense.data_ptr()), C.c_void_p(grad.data_ptr()), C.c_void_p(m.data_ptr()),
                                        C.c_void_p(v.data_ptr()), 1, one(0), one(n), (C.c_float * 1)(lr), (C.c_float * 1)(lr),
                                        (C.c_int * 1)(1), (C.c_int * 1)(1), float(b1), float(b2), float(group["eps"]),
                                        int(state["step"]), 1.0, C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream))
             if rc < 0:
                 raise RuntimeError(f"sgr_adam_step failed ({rc})")
+            if dense is not p:
+                p.copy_(dense)
         return loss
 
 

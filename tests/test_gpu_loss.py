@@ -139,7 +139,13 @@ def test_fused_adam_drop_in_matches_torch_adam_on_the_reference_parameter_shapes
     init = {k: torch.randn(*s, generator=g) for k, s in shapes.items()}
     def build(cls):
         ps = {k: torch.nn.Parameter(v.clone().to(dev)) for k, v in init.items()}
+        # SuGaR's free model keeps quaternions and scales as column slices of one [1, P, 7] tensor (sugar_model.py:313-318): strided
+        radiuses = torch.cat([init["rotation"], init["scaling"]], dim=1).to(dev)[None].clone()
+        ps["rotation"] = torch.nn.Parameter(radiuses[0, ..., :4]); ps["scaling"] = torch.nn.Parameter(radiuses[0, ..., 4:])
+        assert not ps["scaling"].is_contiguous()
         return ps, cls([{"params": [ps[k]], "lr": lrs[k], "name": k} for k in shapes], lr=0.0, eps=1e-15)
+    from sugar_amd import fused_adam
+    before = dict(fused_adam.STATS)
     pa, oa = build(FusedAdam)
     pb, ob = build(torch.optim.Adam)
     for it in range(6):
@@ -177,3 +183,4 @@ def test_fused_adam_drop_in_matches_torch_adam_on_the_reference_parameter_shapes
     assert moved > 1e-2
     sd = oa.state_dict()
     assert [grp["name"] for grp in sd["param_groups"]] == list(shapes) and len(sd["state"]) == 6
+    assert fused_adam.STATS["fused_steps"] == before["fused_steps"] + 6 and fused_adam.STATS["fallback_steps"] == before["fallback_steps"]

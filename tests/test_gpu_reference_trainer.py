@@ -25,6 +25,8 @@ def test_the_unmodified_coarse_trainer_runs_through_its_schedule_on_the_drop_ins
     res = rt.run(data, str(tmp_path / "out"), stop_at=9060, patch_sugar=True, patch_losses=patches, patch_optimizer=patches,
                  patch_gathers=patches, trainer=trainer)
     assert not res["finished"] and res["last_iteration"] == 9060
+    if patches:   # every optimiser step of the run went through the HIP Adam (SuGaR's strided `_scales` / `_quaternions` included)
+        assert res["adam_stats"]["fused_steps"] >= 2061 and res["adam_stats"]["fallback_steps"] == 0, res["adam_stats"]
     its = [i for i, _ in res["losses"]]
     assert its[0] == 7000 and its[-1] == 9050 and len(its) == 42          # one line per 50 iterations (coarse_sdf.py:221,761)
     assert all(math.isfinite(v) for _, v in res["losses"])
