@@ -247,13 +247,17 @@ def _open3d_that_stops():
     return o3d
 
 
-def run_extractor(data, out_dir: str, coarse_model_path: str | None, patch_sugar: bool = True, log_path: str | None = None):
+def run_extractor(data, out_dir: str, coarse_model_path: str | None, patch_sugar: bool = True, log_path: str | None = None,
+                  patch_gathers: bool = False):
     """Runs the unmodified extractor up to the Poisson step.  `coarse_model_path=None`: `--use_vanilla_3dgs True` (the model is
     built from the 3DGS checkpoint, coarse_mesh.py:141-165), else the `.pt` the coarse trainer saved.  Returns per level the
     sampled points / normals / Gaussian ids (GPU tensors) and the loop's wall time per camera."""
     from rich.console import Console
     from tests import ref_env
     sm = ref_env.import_sugar_model(patch_sugar=patch_sugar)
+    if patch_gathers:
+        from sugar_amd import sugar_patch as _sp
+        _sp.install_row_gathers(sm)
     saved_o3d = sys.modules.get("open3d")
     sys.modules["open3d"] = _open3d_that_stops()
     sys.modules.pop("sugar_extractors.coarse_mesh", None)   # (it binds `o3d` at import)
@@ -308,6 +312,8 @@ def run_extractor(data, out_dir: str, coarse_model_path: str | None, patch_sugar
         else:
             sys.modules.pop("open3d", None)
         sys.modules.pop("sugar_extractors.coarse_mesh", None)
+        if patch_gathers:
+            _sp.uninstall_row_gathers(sm)
         if patch_sugar:
             from sugar_amd import sugar_patch
             sugar_patch.uninstall(sm)
@@ -377,7 +383,8 @@ def _open3d_that_reads_npz():
 
 
 def run_refine(data, out_dir: str, iterations: int = 400, gaussians_per_triangle: int = 6, mesh_level: int = 5,
-               patch_sugar: bool = True, patch_losses: bool = False, patch_optimizer: bool = False, log_path: str | None = None):
+               patch_sugar: bool = True, patch_losses: bool = False, patch_optimizer: bool = False, log_path: str | None = None,
+               patch_gathers: bool = False):
     import importlib
     from rich.console import Console
     from tests import ref_env
@@ -392,6 +399,9 @@ def run_refine(data, out_dir: str, iterations: int = 400, gaussians_per_triangle
         shims.install_losses()
     if patch_optimizer:
         shims.install_optimizer()
+    if patch_gathers:
+        from sugar_amd import sugar_patch as _sp
+        _sp.install_row_gathers(sm)
     os.makedirs(out_dir, exist_ok=True)
     out_dir = os.path.abspath(out_dir)
     mesh_path = os.path.join(out_dir, "surface_mesh.npz")
@@ -427,6 +437,8 @@ def run_refine(data, out_dir: str, iterations: int = 400, gaussians_per_triangle
             shims.uninstall_losses()
         if patch_optimizer:
             shims.uninstall_optimizer()
+        if patch_gathers:
+            _sp.uninstall_row_gathers(sm)
         if saved_o3d is not None:
             sys.modules["open3d"] = saved_o3d
         else:

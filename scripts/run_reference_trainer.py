@@ -57,7 +57,8 @@ def main():
         if a.extract:
             import torch
             ext = rt.run_extractor(data, os.path.join(work, "extract"), res["model_path"] if res["finished"] else None,
-                                   patch_sugar=not a.no_patch, log_path=os.path.join(a.out, f"extractor_console_{tag}.log"))
+                                   patch_sugar=not a.no_patch, patch_gathers=a.patch_gathers,
+                                   log_path=os.path.join(a.out, f"extractor_console_{tag}.log"))
             levels = {}
             for lvl, o in (ext.pop("outputs") or {}).items():
                 p = o["points"]
@@ -71,7 +72,7 @@ def main():
             res["extractor"] = ext
         if a.refine:
             res["refine"] = rt.run_refine(data, os.path.join(work, "refine"), iterations=a.refine, patch_sugar=not a.no_patch,
-                                          patch_losses=a.patch_losses, patch_optimizer=a.patch_optimizer,
+                                          patch_losses=a.patch_losses, patch_optimizer=a.patch_optimizer, patch_gathers=a.patch_gathers,
                                           log_path=os.path.join(a.out, f"refine_console_{tag}.log"))
         with open(os.path.join(a.out, f"summary_{tag}.json"), "w") as f:
             json.dump(res, f, indent=1)

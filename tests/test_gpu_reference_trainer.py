@@ -53,7 +53,7 @@ def test_the_unmodified_coarse_mesh_extractor_samples_every_camera_up_to_its_poi
         pytest.skip("the reference's Python is not staged (oracle/ref_build/build_ref.sh)")
     from oracle import reference_trainer as rt
     data = rt.write_dataset(str(tmp_path / "data"), P=30_000, n_cams=24, W=320, H=208)
-    res = rt.run_extractor(data, str(tmp_path / "extract"), coarse_model_path=None, patch_sugar=True)
+    res = rt.run_extractor(data, str(tmp_path / "extract"), coarse_model_path=None, patch_sugar=True, patch_gathers=True)
     assert res["reached_poisson"] and res["cameras"] == 21          # 24 views, every 8th held out (coarse_mesh.py:20-21)
     assert sorted(res["outputs"]) == [0.1, 0.3, 0.5]
     for level, o in res["outputs"].items():
@@ -79,7 +79,7 @@ def test_the_unmodified_refinement_trainer_optimises_gaussians_bound_to_a_mesh(t
     from sugar_amd import io as sio
     data = rt.write_dataset(str(tmp_path / "data"), P=30_000, n_cams=24, W=320, H=208)
     res = rt.run_refine(data, str(tmp_path / "refine"), iterations=200, mesh_level=4, patch_sugar=True, patch_losses=True,
-                        patch_optimizer=True)
+                        patch_optimizer=True, patch_gathers=True)
     assert res["finished"] and res["iterations_run"] == 200 and res["mesh_faces"] == 5120
     its = [i for i, _ in res["losses"]]
     assert its == [1, 50, 100, 150, 200]
