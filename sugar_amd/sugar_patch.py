@@ -97,6 +97,27 @@ def get_field_values(self, x, gaussian_idx=None, closest_gaussians_idx=None, gau
     return fields
 
 
+def random_prefix_of_permutation(n: int, k: int, device) -> torch.Tensor:
+    """`torch.randperm(n, device=device)[:k]` in distribution -- k distinct indices of range(n), every ordered k-tuple equally likely --
+    without permuting all n when k is a small part of it (the extractor keeps 124k of ~2M pixels per view, coarse_mesh.py:243,276:
+    a device randperm of 2M is a 0.5 ms sort).  Uniform draws WITH replacement, repeated values dropped after their first occurrence,
+    first k kept: sequential sampling without replacement."""
+    if k * 8 > n:
+        return torch.randperm(n, device=device)[:k]
+    m = k + k // 4 + 64
+    while True:
+        draws = torch.randint(n, (m,), device=device)
+        vals, order = torch.sort(draws, stable=True)
+        first = torch.ones(m, dtype=torch.bool, device=device)
+        first[1:] = vals[1:] != vals[:-1]               # in a STABLE sort the first of a run of equal values is the earliest draw
+        keep = torch.empty(m, dtype=torch.bool, device=device)
+        keep[order] = first
+        kept = draws[keep]                               # first occurrences, in draw order
+        if kept.shape[0] >= k:
+            return kept[:k]
+        m *= 2
+
+
 # ------------------------------------------------------------------------- compute_level_surface_points_from_camera_fast
 def compute_level_surface_points_from_camera_fast(
         self, nerf_cameras=None, cam_idx=0, rasterizer=None, surface_levels=[0.1, 0.3, 0.5], n_surface_points=-1,
@@ -173,7 +194,7 @@ def compute_level_surface_points_from_camera_fast(
         if getattr(self, "_sugar_amd_cpu_randperm", False):
             ndc_points_idx = torch.randperm(n_valid)[:n_surface_points].to(device)
         else:
-            ndc_points_idx = torch.randperm(n_valid, device=device)[:n_surface_points]
+            ndc_points_idx = random_prefix_of_permutation(n_valid, n_surface_points, device)
         picked = valid_pix[ndc_points_idx]
     m = min(W, H)
     rows = torch.div(picked, W, rounding_mode="floor")

@@ -235,3 +235,26 @@ def test_row_gather_wrappers_leave_cpu_models_alone_and_come_off_again():
     finally:
         sugar_patch.uninstall_row_gathers(sm)
     assert all(cls.__dict__[n] is before[n] for n in before)
+
+
+def test_random_prefix_of_permutation_is_a_sample_without_replacement():
+    """distinct, in range, right length; every index equally likely in every slot (chi-square over many draws, fixed seed); the
+    large-k branch is torch.randperm itself"""
+    from sugar_amd.sugar_patch import random_prefix_of_permutation as rp
+    torch.manual_seed(1234)
+    n, k = 400, 40            # k * 8 <= n: the rejection branch
+    counts = torch.zeros(n)
+    first = torch.zeros(n)
+    trials = 4000
+    for _ in range(trials):
+        s = rp(n, k, "cpu")
+        assert s.shape == (k,) and s.dtype == torch.int64 and int(s.min()) >= 0 and int(s.max()) < n and len(set(s.tolist())) == k
+        counts[s] += 1
+        first[s[0]] += 1
+    exp = trials * k / n
+    chi2 = float(((counts - exp) ** 2 / exp).sum())
+    assert chi2 < 400 + 5 * (2 * 400) ** 0.5, chi2            # chi-square with 399 degrees of freedom: mean 399, sd 28
+    chi2_first = float(((first - trials / n) ** 2 / (trials / n)).sum())
+    assert chi2_first < 400 + 5 * (2 * 400) ** 0.5, chi2_first
+    s = rp(100, 60, "cpu")
+    assert len(set(s.tolist())) == 60
