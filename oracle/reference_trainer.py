@@ -81,6 +81,7 @@ def write_dataset(root: str, P: int = 60_000, n_cams: int = 48, W: int = 480, H:
     os.makedirs(gs_dir, exist_ok=True)
     dev = torch.device(device)
     records = []
+    on_dev = {k: getattr(scene, k).to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
     with torch.no_grad():
         for i, c in enumerate(cams):
             settings = GaussianRasterizationSettings(
@@ -88,8 +89,8 @@ def write_dataset(root: str, P: int = 60_000, n_cams: int = 48, W: int = 480, H:
                 viewmatrix=c.viewmatrix.to(dev), projmatrix=c.projmatrix.to(dev), sh_degree=3, campos=c.campos.to(dev),
                 prefiltered=False, debug=False)
             img, _ = GaussianRasterizer(settings)(
-                means3D=scene.means3D.to(dev), means2D=torch.zeros(P, 3, device=dev), shs=scene.shs.to(dev), colors_precomp=None,
-                opacities=scene.opacities.to(dev), scales=scene.scales.to(dev), rotations=scene.rotations.to(dev), cov3D_precomp=None)
+                means3D=on_dev["means3D"], means2D=torch.zeros(P, 3, device=dev), shs=on_dev["shs"], colors_precomp=None,
+                opacities=on_dev["opacities"], scales=on_dev["scales"], rotations=on_dev["rotations"], cov3D_precomp=None)
             arr = (img.clamp(0, 1).permute(1, 2, 0).cpu().numpy() * 255.0 + 0.5).astype(np.uint8)
             name = f"view_{i:03d}"
             Image.fromarray(arr, "RGB").save(os.path.join(img_dir, name + ".png"))
