@@ -467,8 +467,8 @@ int sgr_density_field_backward_gather(int N, int K, int P, const float* x, const
  * out[p, 0..W) = sum over { n : idx[n] == p } of src[n, 0..W): what autograd computes for `x[idx]` (x: [P, W] float32, idx: N int64
  * entries, src = the incoming gradient [N, W]) -- the scatter-add of SURVEY.md section 8 row a21, met by SuGaR's regulariser at
  * sugar_model.py:922-925 and coarse_sdf.py:690-692.  W in 1..4; every row of `out` is WRITTEN (rows without entries get zeros);
- * negative indices wrap once, entries outside [-P, P) are ignored; N < 2^32.  The order of the additions inside a row is not fixed
- * (ranks come from atomics).  scratch: sgr_scatter_add_rows_scratch_bytes(N, P) bytes of device memory.  No host synchronisation. */
+ * negative indices wrap once, entries outside [-P, P) are ignored; N < 2^32.  The entries of a row are added in the order of the
+ * entries (stable radix grouping): the result is reproducible bit for bit.  scratch: sgr_scatter_add_rows_scratch_bytes(N, P) bytes of device memory.  No host synchronisation. */
 size_t sgr_scatter_add_rows_scratch_bytes(long long N, int P);
 int sgr_scatter_add_rows(long long N, const int64_t* idx, const float* src, int W, int P, float* out, char* scratch, void* stream);
 

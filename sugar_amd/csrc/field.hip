@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256) k_density_bwd_rank(int N, int K, const fl
     for (int k = 0; k < K; k++) {
         const size_t p = (size_t)n * K + k;
         const long long gi = nbr[p];
-        rank[p] = atomicAdd(&cnt[gi], 1u);
+        if (cnt) rank[p] = atomicAdd(&cnt[gi], 1u);   // (cnt == NULL: the pairs are grouped by launch_group_by_key instead)
         if (dx_out) {
             const GaussNbr g = load_nbr(gi, centers, B, strengths, packed);
             float w0, w1, w2;
@@ -219,6 +219,160 @@ __global__ void __launch_bounds__(256) k_fscan_apply(int n, const uint32_t* __re
     for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += s_w[w];
 #pragma unroll
     for (int i = 0; i < 8; i++) { if (base + i < n) start[base + i] = run; run += v[i]; }
+}
+
+// ---- stable grouping of M entries by a small integer key: LSD radix sort, 8 bits per pass, ranks formed in LDS -----------------------
+// Replaces "one returning integer atomic per entry for its rank" (16M of them per call in a trainer's SDF phase: ~20 G atomics/s whatever
+// the contention, 0.85 ms) and makes the order of the entries inside a group -- hence of the float additions that follow -- the
+// order of the entries themselves: the backward is reproducible run to run.
+//   per pass: k_grp_hist (digit counts per chunk of 2048 entries, LDS atomics) -> exclusive scan over [digit][chunk] (k_fscan_*) ->
+//             k_grp_scatter (each wave ranks its 64 entries per digit with eight ballots; one leader lane per (unit, digit) publishes
+//             the unit's count, thread d scans digit d over the chunk's 32 units (8 rounds x 4 waves), entries go to offset + rank)
+//   then    : k_grp_bounds  start[g] = first sorted position whose key is >= g   (binary search; keys past P-1 are the ignored entries)
+#define GRP_CHUNK 2048
+#define GRP_ROUNDS 8
+#define GRP_UNITS (GRP_ROUNDS * 4)
+
+__device__ __forceinline__ uint32_t grp_key64(long long k, int P)  // Python-style wrap once; anything else -> the sentinel P
+{
+    if (k < 0) k += P;
+    return (k >= 0 && k < P) ? (uint32_t)k : (uint32_t)P;
+}
+
+template <bool FIRST>
+__global__ void __launch_bounds__(256) k_grp_hist(long long M, const long long* __restrict__ keys64, const uint32_t* __restrict__ key_in,
+                                                  int P, int shift, uint32_t n_chunks, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t s_h[256];
+    const int tid = threadIdx.x;
+    s_h[tid] = 0;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * GRP_CHUNK;
+#pragma unroll
+    for (int r = 0; r < GRP_ROUNDS; r++) {
+        const long long i = base + r * 256 + tid;
+        if (i < M) {
+            const uint32_t key = FIRST ? grp_key64(keys64[i], P) : key_in[i];
+            atomicAdd(&s_h[(key >> shift) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    hist[(size_t)tid * n_chunks + blockIdx.x] = s_h[tid];
+}
+
+template <bool FIRST>
+__global__ void __launch_bounds__(256) k_grp_scatter(long long M, const long long* __restrict__ keys64, const uint32_t* __restrict__ key_in,
+                                                     const uint32_t* __restrict__ val_in, int P, int shift, uint32_t n_chunks,
+                                                     const uint32_t* __restrict__ offs, uint32_t* __restrict__ key_out,
+                                                     uint32_t* __restrict__ val_out)
+{
+    __shared__ uint32_t s_u[GRP_UNITS * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < GRP_UNITS * 256; i += 256) s_u[i] = 0;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * GRP_CHUNK;
+    uint32_t key[GRP_ROUNDS], val[GRP_ROUNDS], rk[GRP_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < GRP_ROUNDS; r++) {
+        const long long i = base + r * 256 + tid;
+        const bool valid = i < M;
+        key[r] = valid ? (FIRST ? grp_key64(keys64[i], P) : key_in[i]) : 0u;
+        val[r] = valid ? (FIRST ? (uint32_t)i : val_in[i]) : 0u;
+        const uint32_t d = (key[r] >> shift) & 255u;
+        unsigned long long mask = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bb = __ballot(bit);
+            mask &= bit ? bb : ~bb;
+        }
+        const unsigned long long below = mask & ((1ull << lane) - 1ull);
+        rk[r] = (uint32_t)__popcll(below);
+        if (valid && below == 0ull) s_u[(r * 4 + wave) * 256 + d] = (uint32_t)__popcll(mask);  // the group's first lane publishes its size
+    }
+    __syncthreads();
+    {
+        uint32_t run = offs[(size_t)tid * n_chunks + blockIdx.x];
+#pragma unroll 8
+        for (int u = 0; u < GRP_UNITS; u++) {
+            const uint32_t t = s_u[u * 256 + tid];
+            s_u[u * 256 + tid] = run;
+            run += t;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < GRP_ROUNDS; r++) {
+        const long long i = base + r * 256 + tid;
+        if (i < M) {
+            const uint32_t d = (key[r] >> shift) & 255u;
+            const uint32_t pos = s_u[(r * 4 + wave) * 256 + d] + rk[r];
+            key_out[pos] = key[r];
+            val_out[pos] = val[r];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_grp_bounds(int P, long long M, const uint32_t* __restrict__ sorted_keys, uint32_t* __restrict__ start)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g > P) return;
+    long long lo = 0, hi = M;   // first position with key >= g
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (sorted_keys[mid] < (uint32_t)g) lo = mid + 1; else hi = mid;
+    }
+    start[g] = (uint32_t)lo;
+}
+
+struct GroupScratch { uint32_t *key_a, *val_a, *key_b, *val_b, *hist, *offs, *block_sums; size_t total; };
+GroupScratch carve_group(char* base, size_t M)
+{
+    GroupScratch g;
+    const size_t n_chunks = (M + GRP_CHUNK - 1) / GRP_CHUNK, H = 256 * (n_chunks ? n_chunks : 1);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { uint32_t* p = reinterpret_cast<uint32_t*>(base + off); off = sgr_align(off + bytes); return p; };
+    g.key_a = take(M * 4); g.val_a = take(M * 4); g.key_b = take(M * 4); g.val_b = take(M * 4);
+    g.hist = take((H + 1) * 4); g.offs = take((H + 1) * 4); g.block_sums = take(((H + FSCAN_BLOCK - 1) / FSCAN_BLOCK + 2) * 4);
+    g.total = off;
+    return g;
+}
+
+// groups the M entries of keys64 (values in [-P, P); others are left out) by key: *list_out = entry numbers, key-major, ascending
+// inside a key; start[0..P] = offsets into it.  Enqueued on s; no host synchronisation.
+int launch_group_by_key(long long M, const long long* keys64, int P, char* scratch, uint32_t* start, const uint32_t** list_out, hipStream_t s)
+{
+    const GroupScratch g = carve_group(scratch, (size_t)M);
+    const uint32_t n_chunks = (uint32_t)(((size_t)M + GRP_CHUNK - 1) / GRP_CHUNK);
+    const size_t H = 256 * (size_t)n_chunks;
+    const int n_blocks = (int)((H + FSCAN_BLOCK - 1) / FSCAN_BLOCK);
+    int bits = 0;
+    while (bits < 32 && ((unsigned long long)P >> bits) != 0ull) bits++;   // P itself (the sentinel) must fit
+    const int passes = (bits + 7) / 8 > 0 ? (bits + 7) / 8 : 1;
+    uint32_t *kin = nullptr, *vin = nullptr, *kout = g.key_a, *vout = g.val_a;
+    for (int pass = 0; pass < passes; pass++) {
+        const int shift = 8 * pass;
+        if (pass == 0) hipLaunchKernelGGL(k_grp_hist<true>, dim3(n_chunks), dim3(256), 0, s, M, keys64, kin, P, shift, n_chunks, g.hist);
+        else hipLaunchKernelGGL(k_grp_hist<false>, dim3(n_chunks), dim3(256), 0, s, M, keys64, kin, P, shift, n_chunks, g.hist);
+        hipLaunchKernelGGL(k_fscan_sums, dim3(n_blocks), dim3(256), 0, s, (int)H, g.hist, g.block_sums);
+        hipLaunchKernelGGL(k_fscan_top, dim3(1), dim3(1024), 0, s, n_blocks, g.block_sums, g.offs + H);
+        hipLaunchKernelGGL(k_fscan_apply, dim3(n_blocks), dim3(256), 0, s, (int)H, g.hist, g.block_sums, g.offs);
+        if (pass == 0) hipLaunchKernelGGL(k_grp_scatter<true>, dim3(n_chunks), dim3(256), 0, s, M, keys64, kin, vin, P, shift, n_chunks, g.offs, kout, vout);
+        else hipLaunchKernelGGL(k_grp_scatter<false>, dim3(n_chunks), dim3(256), 0, s, M, keys64, kin, vin, P, shift, n_chunks, g.offs, kout, vout);
+        kin = kout; vin = vout;
+        kout = (kin == g.key_a) ? g.key_b : g.key_a;
+        vout = (vin == g.val_a) ? g.val_b : g.val_a;
+    }
+    hipLaunchKernelGGL(k_grp_bounds, dim3((unsigned)((P + 1 + 255) / 256)), dim3(256), 0, s, P, M, kin, start);
+    *list_out = vin;
+    return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
+}
+
+// SGR_GROUP_ATOMICS=1: the round-4 grouping by returning atomics (same-box A/B)
+bool group_by_atomics()
+{
+    static const bool v = [] { const char* e = getenv("SGR_GROUP_ATOMICS"); return e && e[0] == '1'; }();
+    return v;
 }
 
 __global__ void __launch_bounds__(256) k_density_bwd_fill(long long NK, const long long* __restrict__ nbr,
@@ -568,7 +722,8 @@ size_t sgr_density_field_backward_scratch_bytes(int N, int K, int P)
 {
     const size_t nk = (size_t)(N > 0 ? N : 0) * (size_t)(K > 0 ? K : 0), p = (size_t)(P > 0 ? P : 0);
     const size_t blocks = (p + FSCAN_BLOCK - 1) / FSCAN_BLOCK + 1;
-    return sgr_align((p + 1) * 4) * 2 + sgr_align(blocks * 4) + 2 * sgr_align(nk * 4);  // cnt | start | block sums | rank | pair_list
+    return sgr_align((p + 1) * 4) * 2 + sgr_align(blocks * 4) + 2 * sgr_align(nk * 4)   // cnt | start | block sums | rank | pair_list
+           + carve_group(nullptr, nk).total;                                            // | the radix grouping's buffers
 }
 
 int sgr_density_field_backward_gather(int N, int K, int P, const float* x, const int64_t* nbr_idx, const float* centers,
@@ -590,20 +745,32 @@ int sgr_density_field_backward_gather(int N, int K, int P, const float* x, const
     uint32_t* rank = reinterpret_cast<uint32_t*>(scratch + 2 * pa + ba);
     uint32_t* pair_list = reinterpret_cast<uint32_t*>(scratch + 2 * pa + ba + sgr_align(nk * 4));
     const long long* nbr = reinterpret_cast<const long long*>(nbr_idx);
-    if (hipMemsetAsync(cnt, 0, ((size_t)P + 1) * 4, s) != hipSuccess) return SGR_E_HIP;
-    if (N > 0) {
-        hipLaunchKernelGGL(k_density_bwd_rank, dim3((N + 255) / 256), dim3(256), 0, s, N, K, x, nbr, centers, inv_scaled_rot,
-                           strengths, reinterpret_cast<const float4*>(packed), density_factor, dL_dopacities, dL_ddensity, dL_dx, cnt, rank);
-    }
-    hipLaunchKernelGGL(k_fscan_sums, dim3(n_blocks), dim3(256), 0, s, P, cnt, block_sums);
-    hipLaunchKernelGGL(k_fscan_top, dim3(1), dim3(1024), 0, s, n_blocks, block_sums, start + P);
-    hipLaunchKernelGGL(k_fscan_apply, dim3(n_blocks), dim3(256), 0, s, P, cnt, block_sums, start);
-    if (N > 0) {
-        hipLaunchKernelGGL(k_density_bwd_fill, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, (long long)nk, nbr, start, rank,
-                           pair_list);
+    const uint32_t* pairs = pair_list;
+    if (group_by_atomics() || N == 0) {
+        if (hipMemsetAsync(cnt, 0, ((size_t)P + 1) * 4, s) != hipSuccess) return SGR_E_HIP;
+        if (N > 0) {
+            hipLaunchKernelGGL(k_density_bwd_rank, dim3((N + 255) / 256), dim3(256), 0, s, N, K, x, nbr, centers, inv_scaled_rot,
+                               strengths, reinterpret_cast<const float4*>(packed), density_factor, dL_dopacities, dL_ddensity, dL_dx, cnt, rank);
+        }
+        hipLaunchKernelGGL(k_fscan_sums, dim3(n_blocks), dim3(256), 0, s, P, cnt, block_sums);
+        hipLaunchKernelGGL(k_fscan_top, dim3(1), dim3(1024), 0, s, n_blocks, block_sums, start + P);
+        hipLaunchKernelGGL(k_fscan_apply, dim3(n_blocks), dim3(256), 0, s, P, cnt, block_sums, start);
+        if (N > 0) {
+            hipLaunchKernelGGL(k_density_bwd_fill, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, (long long)nk, nbr, start, rank,
+                               pair_list);
+        }
+    } else {
+        if (dL_dx) {   // the gradient of the sample positions (a lane per sample; no atomics in this mode)
+            hipLaunchKernelGGL(k_density_bwd_rank, dim3((N + 255) / 256), dim3(256), 0, s, N, K, x, nbr, centers, inv_scaled_rot,
+                               strengths, reinterpret_cast<const float4*>(packed), density_factor, dL_dopacities, dL_ddensity, dL_dx,
+                               (uint32_t*)nullptr, rank);
+        }
+        char* gscratch = scratch + 2 * pa + ba + 2 * sgr_align(nk * 4);
+        const int rc = launch_group_by_key((long long)nk, nbr, P, gscratch, start, &pairs, s);
+        if (rc < 0) return rc;
     }
     hipLaunchKernelGGL(k_density_bwd_gather, dim3((unsigned)(((size_t)P * 16 + 255) / 256)), dim3(256), 0, s, P, K, x, centers, inv_scaled_rot, strengths,
-                       reinterpret_cast<const float4*>(packed), density_factor, dL_dopacities, dL_ddensity, start, pair_list, dL_dcenters, dL_dinv_scaled_rot, dL_dstrengths);
+                       reinterpret_cast<const float4*>(packed), density_factor, dL_dopacities, dL_ddensity, start, pairs, dL_dcenters, dL_dinv_scaled_rot, dL_dstrengths);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 
@@ -611,7 +778,8 @@ size_t sgr_scatter_add_rows_scratch_bytes(long long N, int P)
 {
     const size_t n = (size_t)(N > 0 ? N : 0), p = (size_t)(P > 0 ? P : 0);
     const size_t blocks = (p + FSCAN_BLOCK - 1) / FSCAN_BLOCK + 1;
-    return sgr_align((p + 1) * 4) * 2 + sgr_align(blocks * 4) + 2 * sgr_align(n * 4);  // cnt | start | block sums | rank | list
+    return sgr_align((p + 1) * 4) * 2 + sgr_align(blocks * 4) + 2 * sgr_align(n * 4)   // cnt | start | block sums | rank | list
+           + carve_group(nullptr, n).total;                                           // | the radix grouping's buffers
 }
 
 int sgr_scatter_add_rows(long long N, const int64_t* idx, const float* src, int W, int P, float* out, char* scratch, void* stream)
@@ -629,19 +797,26 @@ int sgr_scatter_add_rows(long long N, const int64_t* idx, const float* src, int 
     uint32_t* rank = reinterpret_cast<uint32_t*>(scratch + 2 * pa + ba);
     uint32_t* list = reinterpret_cast<uint32_t*>(scratch + 2 * pa + ba + sgr_align((size_t)N * 4));
     const long long* ix = reinterpret_cast<const long long*>(idx);
-    if (hipMemsetAsync(cnt, 0, ((size_t)P + 1) * 4, s) != hipSuccess) return SGR_E_HIP;
-    const unsigned nb = (unsigned)(((size_t)N + 255) / 256);
-    if (N > 0) hipLaunchKernelGGL(k_rows_rank, dim3(nb), dim3(256), 0, s, N, ix, P, cnt, rank);
-    hipLaunchKernelGGL(k_fscan_sums, dim3(n_blocks), dim3(256), 0, s, P, cnt, block_sums);
-    hipLaunchKernelGGL(k_fscan_top, dim3(1), dim3(1024), 0, s, n_blocks, block_sums, start + P);
-    hipLaunchKernelGGL(k_fscan_apply, dim3(n_blocks), dim3(256), 0, s, P, cnt, block_sums, start);
-    if (N > 0) hipLaunchKernelGGL(k_rows_fill, dim3(nb), dim3(256), 0, s, N, ix, P, start, rank, list);
+    const uint32_t* entries = list;
+    if (group_by_atomics() || N == 0) {
+        if (hipMemsetAsync(cnt, 0, ((size_t)P + 1) * 4, s) != hipSuccess) return SGR_E_HIP;
+        const unsigned nb = (unsigned)(((size_t)N + 255) / 256);
+        if (N > 0) hipLaunchKernelGGL(k_rows_rank, dim3(nb), dim3(256), 0, s, N, ix, P, cnt, rank);
+        hipLaunchKernelGGL(k_fscan_sums, dim3(n_blocks), dim3(256), 0, s, P, cnt, block_sums);
+        hipLaunchKernelGGL(k_fscan_top, dim3(1), dim3(1024), 0, s, n_blocks, block_sums, start + P);
+        hipLaunchKernelGGL(k_fscan_apply, dim3(n_blocks), dim3(256), 0, s, P, cnt, block_sums, start);
+        if (N > 0) hipLaunchKernelGGL(k_rows_fill, dim3(nb), dim3(256), 0, s, N, ix, P, start, rank, list);
+    } else {
+        char* gscratch = scratch + 2 * pa + ba + 2 * sgr_align((size_t)N * 4);
+        const int rc = launch_group_by_key(N, ix, P, gscratch, start, &entries, s);
+        if (rc < 0) return rc;
+    }
     const unsigned gb = (unsigned)(((size_t)P * 16 + 255) / 256);
     switch (W) {
-        case 1: hipLaunchKernelGGL(k_rows_gather<1>, dim3(gb), dim3(256), 0, s, P, src, start, list, out); break;
-        case 2: hipLaunchKernelGGL(k_rows_gather<2>, dim3(gb), dim3(256), 0, s, P, src, start, list, out); break;
-        case 3: hipLaunchKernelGGL(k_rows_gather<3>, dim3(gb), dim3(256), 0, s, P, src, start, list, out); break;
-        default: hipLaunchKernelGGL(k_rows_gather<4>, dim3(gb), dim3(256), 0, s, P, src, start, list, out); break;
+        case 1: hipLaunchKernelGGL(k_rows_gather<1>, dim3(gb), dim3(256), 0, s, P, src, start, entries, out); break;
+        case 2: hipLaunchKernelGGL(k_rows_gather<2>, dim3(gb), dim3(256), 0, s, P, src, start, entries, out); break;
+        case 3: hipLaunchKernelGGL(k_rows_gather<3>, dim3(gb), dim3(256), 0, s, P, src, start, entries, out); break;
+        default: hipLaunchKernelGGL(k_rows_gather<4>, dim3(gb), dim3(256), 0, s, P, src, start, entries, out); break;
     }
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }

@@ -4,10 +4,10 @@ The regulariser of the coarse trainers gathers per-Gaussian rows by the million 
 `self.quaternions[...]`, `self.scaling[...]` (sugar_model.py:922-925), `sugar.get_normals()[closest_gaussians_idx]` with 1M x 16
 indices (coarse_sdf.py:690-692) -- and autograd's backward of each is a scatter-add that stock PyTorch runs as sort + segmented
 reduction: 46 % of the GPU time of an SDF iteration on an MI355X once the rasterizer, the density field, `ssim` and Adam are HIP.
-`sgr_scatter_add_rows` (csrc/field.hip) does it by counting ranks, a scan and sixteen lanes per row.
+`sgr_scatter_add_rows` (csrc/field.hip) does it with a stable radix grouping of the entries by row and sixteen lanes per row.
 
 Nothing in the reference is edited: `RowGatherTensor` is a `torch.Tensor` subclass whose only behaviour is that indexing it with an
-int64 CUDA tensor goes through `row_gather` (same values, same gradient up to the order of the float additions); every other
+int64 CUDA tensor goes through `row_gather` (same values; the gradient's additions run in entry order, reproducibly); every other
 operation on it is the plain operation and returns plain tensors.  `sugar_amd.sugar_patch.install_row_gathers` makes the SuGaR
 properties `points`, `scaling`, `quaternions` and the method `get_normals` return their usual tensor viewed as this subclass."""
 from __future__ import annotations

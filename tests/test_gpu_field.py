@@ -139,6 +139,10 @@ def test_row_gather_backward_is_the_scatter_add_of_autograd(shape, idx_shape, P)
         assert err <= 2e-5 * ref.abs().max().item() + 1e-6, err
     if P > 10:
         assert float(a.grad[3].abs().max()) == 0.0
+    # the entries of a row are added in the order of the entries (stable radix grouping): the same bits on every run
+    a2 = x0.clone().to(dev).requires_grad_(True)
+    (row_gather(a2, idx_d) * w).sum().backward()
+    assert torch.equal(a2.grad, a.grad)
     # small index sets and other index kinds take the stock path and stay plain tensors
     t = as_row_gather(x0.clone().to(dev).requires_grad_(True) * 1.0)
     assert isinstance(t, RowGatherTensor) or t.dim() == 1 and len(shape) == 0 or True
