@@ -129,9 +129,11 @@ __global__ void __launch_bounds__(256) k_density_bwd(int N, int K, const float* 
 }
 
 // ---- gather formulation of the backward ---------------------------------------------------------------------------
-// The kernel above spends 13 float atomics per (sample, neighbour) pair (208 M at 1M x 16: ~10 ms, L2 atomic rate).  Here a
-// pair costs ONE returning integer atomic (its rank in the list of pairs that reference the same Gaussian); after a scan the
-// pairs are laid out per Gaussian and a lane per Gaussian sums its pairs in registers and writes its 13 outputs once.
+// The kernel above spends 13 float atomics per (sample, neighbour) pair (208 M at 1M x 16: ~10 ms, L2 atomic rate).  Here the
+// pairs are first laid out per Gaussian -- by launch_group_by_key below (stable radix grouping; until the end of round 4, and with
+// SGR_GROUP_ATOMICS=1, by ONE returning integer atomic per pair for its rank, a scan and a fill) -- and sixteen lanes per Gaussian
+// then sum its pairs in registers and write its 13 outputs once.  This kernel: the gradient of the sample positions (a lane per
+// sample), plus the ranks in the atomics mode (cnt != NULL).
 __global__ void __launch_bounds__(256) k_density_bwd_rank(int N, int K, const float* __restrict__ x, const long long* __restrict__ nbr,
                                                           const float* __restrict__ centers, const float* __restrict__ B,
                                                           const float* __restrict__ strengths, const float4* __restrict__ packed, float factor,
@@ -451,8 +453,8 @@ __global__ void __launch_bounds__(256) k_density_bwd_gather(int P, int K, const 
 // ---- out[p, :] = sum over { n : idx[n] == p } of src[n, :]  -- the backward of a row gather `x[idx]` --------------------------------
 // What autograd runs for every `tensor[index]` of the regulariser (sugar_model.py:922-925: points / quaternions / scaling of 1M sampled
 // Gaussians; coarse_sdf.py:690-692: the normals of 1M x 16 neighbours): stock PyTorch sorts the indices and reduces segments, 1.3 ms per
-// call on average and six calls per iteration.  Same grouping as the density backward above: a returning integer atomic gives every
-// entry its rank among the entries of its row, a scan turns the counts into list offsets, and sixteen lanes per row add its entries up.
+// call on average and six calls per iteration.  Same scheme as the density backward above: the entries are grouped by row
+// (launch_group_by_key; k_rows_rank / k_rows_fill are the SGR_GROUP_ATOMICS=1 variant), sixteen lanes per row add its entries up.
 // Negative indices wrap once (Python semantics); entries outside [-P, P) are ignored.
 __device__ __forceinline__ long long rows_wrap(long long i, int P) { return i < 0 ? i + P : i; }
 
