@@ -460,3 +460,105 @@ def run_refine(data, out_dir: str, iterations: int = 400, gaussians_per_triangle
     return dict(model_path=model_path, iterations_run=len(stamps), wall_s=wall, losses=losses, it_per_s=rate, mesh_faces=n_faces,
                 gaussians=n_faces * gaussians_per_triangle, exported_ply=ply, finished="Final model saved" in text, log=log_path,
                 patch_sugar=patch_sugar, patch_losses=patch_losses, patch_optimizer=patch_optimizer)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The vanilla 3DGS trainer as a command line: gaussian_splatting/train.py, untouched, started the way a user would start it on this
+# stack -- `python -m sugar_amd.launch <reference>/gaussian_splatting/train.py -s <scene> -m <out> --iterations N ...` -- on a scene
+# in the COLMAP text layout its `Scene` class reads: cameras.txt / images.txt / points3D.txt + PNG views; the reader converts the
+# points to sparse/0/points3D.ply through `storePly` and reads them back with `fetchPly` (plyfile stand-in).  (The reader of the
+# NeRF-synthetic layout hands an int8 array to PIL with an explicit mode, dataset_readers.py:210, which the Pillow of this image
+# rejects -- a version matter of the reference, not of this stack.)
+# Everything the script does runs: `Scene` / camera loading, `create_from_pcd` (distCUDA2), the loop of train.py:69-128 with its
+# densification and pruning (`densify_and_prune`: optimiser state cut and concatenated -- on the FusedAdam instance when
+# patch_optimizer is on), opacity reset, the evaluation passes, `scene.save` (GaussianModel.save_ply).
+def _rotmat_to_qvec(R):
+    """unit quaternion (w, x, y, z) of a rotation matrix (the inverse of scene/colmap_loader.py:43-53 qvec2rotmat)"""
+    t = np.trace(R)
+    if t > 0:
+        s = math.sqrt(t + 1.0) * 2
+        q = np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = math.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = np.zeros(4)
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    return q / np.linalg.norm(q)
+
+
+def write_colmap_dataset(root: str, P: int = 60_000, n_cams: int = 48, W: int = 480, H: int = 320, n_sfm_points: int = 20_000, seed: int = 0,
+                         device: str = "cuda:0"):
+    """a scene in the COLMAP text layout `readColmapSceneInfo` reads (scene/dataset_readers.py:132-177, scene/colmap_loader.py:83-130,
+    156-178,244-270): images/<name>.png, sparse/0/cameras.txt (one PINHOLE camera), images.txt (world-to-camera quaternion and
+    translation per view), points3D.txt (a sparse, slightly noisy sample of the true surface: what SfM would leave)"""
+    from PIL import Image
+    from sugar_amd import synthetic as syn
+    from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    scene = surface_scene(P, seed)
+    cams = syn.scattered_cameras(W, H, n=n_cams, seed=seed + 1)
+    dev = torch.device(device)
+    on_dev = {k: getattr(scene, k).to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    os.makedirs(os.path.join(root, "images"), exist_ok=True)
+    os.makedirs(os.path.join(root, "sparse", "0"), exist_ok=True)
+    fx, fy = W / (2 * cams[0].tanfovx), H / (2 * cams[0].tanfovy)
+    with open(os.path.join(root, "sparse", "0", "cameras.txt"), "w") as f:
+        f.write("# Camera list with one line of data per camera:\n#   CAMERA_ID, MODEL, WIDTH, HEIGHT, PARAMS[]\n")
+        f.write(f"1 PINHOLE {W} {H} {float(fx)!r} {float(fy)!r} {W / 2} {H / 2}\n")
+    lines = ["# Image list with two lines of data per image:\n#   IMAGE_ID, QW, QX, QY, QZ, TX, TY, TZ, CAMERA_ID, NAME\n#   POINTS2D[] as (X, Y, POINT3D_ID)\n"]
+    with torch.no_grad():
+        for i, c in enumerate(cams):
+            settings = GaussianRasterizationSettings(
+                image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=torch.zeros(3, device=dev), scale_modifier=1.0,
+                viewmatrix=c.viewmatrix.to(dev), projmatrix=c.projmatrix.to(dev), sh_degree=3, campos=c.campos.to(dev),
+                prefiltered=False, debug=False)
+            img, _ = GaussianRasterizer(settings)(
+                means3D=on_dev["means3D"], means2D=torch.zeros(P, 3, device=dev), shs=on_dev["shs"], colors_precomp=None,
+                opacities=on_dev["opacities"], scales=on_dev["scales"], rotations=on_dev["rotations"], cov3D_precomp=None)
+            arr = (img.clamp(0, 1).permute(1, 2, 0).cpu().numpy() * 255.0 + 0.5).astype(np.uint8)
+            name = f"view_{i:03d}.png"
+            Image.fromarray(arr, "RGB").save(os.path.join(root, "images", name))
+            w2c = c.viewmatrix.t().double().numpy()
+            q, t = _rotmat_to_qvec(w2c[:3, :3]), w2c[:3, 3]
+            nums = " ".join(repr(float(v)) for v in (*q, *t))
+            lines.append(f"{i + 1} {nums} 1 {name}\n\n")
+    with open(os.path.join(root, "sparse", "0", "images.txt"), "w") as f:
+        f.writelines(lines)
+    g = torch.Generator().manual_seed(seed + 3)
+    pick = torch.randperm(P, generator=g)[:n_sfm_points]
+    xyz = (scene.means3D[pick] + 0.004 * torch.randn(len(pick), 3, generator=g)).numpy()
+    rgb = (scene.shs[pick, 0] * syn.SH_C0 + 0.5).clamp(0, 1).numpy()
+    with open(os.path.join(root, "sparse", "0", "points3D.txt"), "w") as f:
+        f.write("# 3D point list with one line of data per point:\n#   POINT3D_ID, X, Y, Z, R, G, B, ERROR, TRACK[] as (IMAGE_ID, POINT2D_IDX)\n")
+        for k in range(len(pick)):
+            f.write(f"{k + 1} {float(xyz[k, 0])!r} {float(xyz[k, 1])!r} {float(xyz[k, 2])!r} {int(rgb[k, 0] * 255)} {int(rgb[k, 1] * 255)} "
+                    f"{int(rgb[k, 2] * 255)} 0.5\n")
+    return root
+
+
+def run_vanilla_cli(dataset_dir: str, out_dir: str, iterations: int = 1000, launcher_flags=(), extra_args=(), timeout: int = 900):
+    """`python -m sugar_amd.launch [launcher_flags] <reference>/gaussian_splatting/train.py -s dataset -m out --iterations N --eval ...`
+    in a subprocess.  Returns the exit code, the text it printed, the evaluation lines and the saved point cloud's path."""
+    import socket
+    import subprocess
+    from tests import ref_env
+    ref = ref_env.reference_root()
+    script = os.path.join(ref, "gaussian_splatting", "train.py")
+    with socket.socket() as sock:                  # a free port for the script's network GUI listener (train.py:214)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "sugar_amd.launch", *launcher_flags, script, "-s", dataset_dir, "-m", out_dir, "--iterations", str(iterations),
+           "--eval", "--test_iterations", str(iterations // 2), str(iterations), "--save_iterations", str(iterations), "--port", str(port),
+           *extra_args]
+    t0 = time.time()
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, PYTHONPATH=""))
+    wall = time.time() - t0
+    text = p.stdout + "\n" + p.stderr
+    evals = [(int(m.group(1)), m.group(2), float(m.group(3)), float(m.group(4)))
+             for m in re.finditer(r"\[ITER (\d+)\] Evaluating (\w+): L1 ([-+0-9.eE]+) PSNR ([-+0-9.eE]+)", text)]
+    ply = os.path.join(out_dir, "point_cloud", f"iteration_{iterations}", "point_cloud.ply")
+    return dict(returncode=p.returncode, wall_s=wall, evals=evals, complete="Training complete." in text, ply=ply if os.path.exists(ply) else None,
+                launch_line=next((l for l in text.splitlines() if l.startswith("[sugar_amd.launch]")), None), text=text, cmd=cmd)

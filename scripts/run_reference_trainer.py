@@ -32,6 +32,9 @@ def main():
                     help="then run the reference's coarse-mesh extractor (sugar_extractors/coarse_mesh.py, untouched) up to its "
                          "Poisson step: on the trained model if the training ran to 15000, else on the 3DGS checkpoint")
     ap.add_argument("--skip-training", action="store_true")
+    ap.add_argument("--vanilla-cli", type=int, default=0, metavar="N",
+                    help="also run `python -m sugar_amd.launch <reference>/gaussian_splatting/train.py ... --iterations N` on a COLMAP-layout "
+                         "copy of the scene (the vanilla 3DGS trainer as a command line, densification included)")
     ap.add_argument("--profile-window", type=int, nargs=2, default=None, metavar=("FROM", "TO"),
                     help="torch profiler over these trainer iterations; the kernel table goes to <out>/profile_<tag>.txt")
     ap.add_argument("--refine", type=int, default=0, metavar="N",
@@ -74,6 +77,16 @@ def main():
             res["refine"] = rt.run_refine(data, os.path.join(work, "refine"), iterations=a.refine, patch_sugar=not a.no_patch,
                                           patch_losses=a.patch_losses, patch_optimizer=a.patch_optimizer, patch_gathers=a.patch_gathers,
                                           log_path=os.path.join(a.out, f"refine_console_{tag}.log"))
+        if a.vanilla_cli:
+            cdir = rt.write_colmap_dataset(os.path.join(work, "colmap"), P=a.gaussians, n_cams=a.cameras, W=a.width, H=a.height)
+            flags = [f for f, off in (("--no-patch-losses", not a.patch_losses), ("--no-patch-optimizer", not a.patch_optimizer)) if off]
+            v = rt.run_vanilla_cli(cdir, os.path.join(work, "vanilla_out"), iterations=a.vanilla_cli, launcher_flags=flags)
+            with open(os.path.join(a.out, f"vanilla_cli_{tag}.log"), "w") as f:
+                f.write(" ".join(v["cmd"]) + "\n\n" + v.pop("text"))
+            if v["ply"]:
+                from sugar_amd import io as sio
+                v["gaussians_saved"] = int(sio.load_gaussian_ply(v["ply"])["xyz"].shape[0])
+            res["vanilla_cli"] = v
         with open(os.path.join(a.out, f"summary_{tag}.json"), "w") as f:
             json.dump(res, f, indent=1)
         print(json.dumps(res))

@@ -92,3 +92,24 @@ def test_the_unmodified_refinement_trainer_optimises_gaussians_bound_to_a_mesh(t
     p = ply["xyz"]
     d = p / p.norm(dim=1, keepdim=True)
     assert float((p.norm(dim=1) - rt.surface_radius(d)).abs().median()) < 0.02
+
+
+def test_the_vanilla_3dgs_trainer_command_line_runs_through_the_launcher(tmp_path):
+    """`python -m sugar_amd.launch <reference>/gaussian_splatting/train.py -s ... --iterations 800 --eval ...`: the reference's script
+    and everything under it, untouched -- Scene / COLMAP text reader / points3D -> PLY / create_from_pcd from 10k SfM-like points / the loop of
+    train.py:69-128 with densification from iteration 500 / evaluation / save -- with all opt-in bindings of the launcher on.  From
+    a sparse point cloud to renders of the training views above 22 dB in 800 iterations, and a point cloud on disk that grew."""
+    from tests import ref_env
+    if ref_env.reference_root() is None:
+        pytest.skip("the reference's Python is not staged (oracle/ref_build/build_ref.sh)")
+    from oracle import reference_trainer as rt
+    from sugar_amd import io as sio
+    data = rt.write_colmap_dataset(str(tmp_path / "colmap"), P=30_000, n_cams=32, W=320, H=208, n_sfm_points=10_000)
+    res = rt.run_vanilla_cli(data, str(tmp_path / "out"), iterations=800)
+    assert res["returncode"] == 0 and res["complete"], res["text"][-3000:]
+    assert "'patch_losses': 1" in res["launch_line"] and "'patch_optimizer': 1" in res["launch_line"], res["launch_line"]
+    by = {(it, name): psnr for it, name, _, psnr in res["evals"]}
+    assert by[(800, "train")] > 22.0 and by[(800, "test")] > 20.0 and by[(800, "train")] > by[(400, "train")], res["evals"]
+    ply = sio.load_gaussian_ply(res["ply"])
+    assert ply["xyz"].shape[0] > 10_000 and ply["features"].shape[1:] == (16, 3)      # densified beyond the 10k initial points
+    assert bool(torch.isfinite(ply["xyz"]).all())
