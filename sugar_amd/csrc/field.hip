@@ -65,6 +65,61 @@ __device__ __forceinline__ void bt_mul(const float* Bm, float dx, float dy, floa
     w2 = Bm[2] * dx + Bm[5] * dy + Bm[8] * dz;
 }
 
+// sum over the 16 lanes of a DPP row, returned to every lane of the row (row_ror:8 / 4 / 2 / 1 fold into the adds)
+__device__ __forceinline__ float row_sum16(float x)
+{
+    x += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x128, 0xF, 0xF, false));
+    x += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x124, 0xF, 0xF, false));
+    x += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x122, 0xF, 0xF, false));
+    x += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x121, 0xF, 0xF, false));
+    return x;
+}
+
+// K == 16 (SuGaR's neighbour count): a lane per (sample, neighbour) PAIR, the sixteen pairs of a sample in one DPP row.  The
+// lane-per-sample loops below issue their sixteen record gathers one after the other (each waits for its index): 0.54 ms for 16M pairs
+// against records that fit the L2; with a lane per pair all gathers of a wave are in flight at once.
+__global__ void __launch_bounds__(256) k_density_fwd16(long long NK, const float* __restrict__ x, const long long* __restrict__ nbr,
+                                                       const float* __restrict__ centers, const float* __restrict__ B,
+                                                       const float* __restrict__ strengths, const float4* __restrict__ packed, float factor,
+                                                       float* __restrict__ opac, float* __restrict__ density)
+{
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= NK) return;   // (NK is a multiple of 16: rows leave whole)
+    const size_t n = (size_t)(p >> 4);
+    const GaussNbr g = load_nbr(nbr[p], centers, B, strengths, packed);
+    float w0, w1, w2;
+    bt_mul(g.B, x[3 * n] - g.mx, x[3 * n + 1] - g.my, x[3 * n + 2] - g.mz, w0, w1, w2);
+    const float q = fminf(fmaxf(w0 * w0 + w1 * w1 + w2 * w2, 0.f), 1e8f);
+    const float o = factor * g.s * __expf(-0.5f * q);
+    if (opac) opac[p] = o;
+    const float sum = row_sum16(o);
+    if ((threadIdx.x & 15) == 0) density[n] = sum;
+}
+
+// the gradient of the sample positions, same mapping (the per-Gaussian gradients are the gather kernel's)
+__global__ void __launch_bounds__(256) k_density_dx16(long long NK, const float* __restrict__ x, const long long* __restrict__ nbr,
+                                                      const float* __restrict__ centers, const float* __restrict__ B,
+                                                      const float* __restrict__ strengths, const float4* __restrict__ packed, float factor,
+                                                      const float* __restrict__ g_opac, const float* __restrict__ g_den,
+                                                      float* __restrict__ dx_out)
+{
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= NK) return;
+    const size_t n = (size_t)(p >> 4);
+    const GaussNbr g = load_nbr(nbr[p], centers, B, strengths, packed);
+    float w0, w1, w2;
+    bt_mul(g.B, x[3 * n] - g.mx, x[3 * n + 1] - g.my, x[3 * n + 2] - g.mz, w0, w1, w2);
+    const float q_raw = w0 * w0 + w1 * w1 + w2 * w2;
+    const float e = __expf(-0.5f * fminf(fmaxf(q_raw, 0.f), 1e8f));
+    const float go = (g_opac ? g_opac[p] : 0.f) + (g_den ? g_den[n] : 0.f);
+    const float dq = (q_raw > 0.f && q_raw < 1e8f) ? -0.5f * factor * g.s * e * go : 0.f;
+    const float dw0 = 2.f * w0 * dq, dw1 = 2.f * w1 * dq, dw2 = 2.f * w2 * dq;
+    const float ax = row_sum16(g.B[0] * dw0 + g.B[1] * dw1 + g.B[2] * dw2);
+    const float ay = row_sum16(g.B[3] * dw0 + g.B[4] * dw1 + g.B[5] * dw2);
+    const float az = row_sum16(g.B[6] * dw0 + g.B[7] * dw1 + g.B[8] * dw2);
+    if ((threadIdx.x & 15) == 0) { dx_out[3 * n] = ax; dx_out[3 * n + 1] = ay; dx_out[3 * n + 2] = az; }
+}
+
 __global__ void __launch_bounds__(256) k_density_fwd(int N, int K, const float* __restrict__ x, const long long* __restrict__ nbr,
                                                      const float* __restrict__ centers, const float* __restrict__ B,
                                                      const float* __restrict__ strengths, const float4* __restrict__ packed, float factor,
@@ -386,16 +441,6 @@ __global__ void __launch_bounds__(256) k_density_bwd_fill(long long NK, const lo
     pair_list[start[nbr[p]] + rank[p]] = (uint32_t)p;
 }
 
-// sum over the 16 lanes of a DPP row, returned to every lane of the row (row_ror:8 / 4 / 2 / 1 fold into the adds)
-__device__ __forceinline__ float row_sum16(float x)
-{
-    x += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x128, 0xF, 0xF, false));
-    x += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x124, 0xF, 0xF, false));
-    x += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x122, 0xF, 0xF, false));
-    x += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x121, 0xF, 0xF, false));
-    return x;
-}
-
 // SIXTEEN lanes (one DPP row) per Gaussian: they stride over its pairs and fold their 13 partial sums with row rotates.  (One lane
 // per Gaussian, until round 4, walked its list alone -- 280 dependent gathers on average when 1M samples x 16 neighbours meet 57k
 // Gaussians, on 900 waves: 2.0 ms; a trainer's SDF phase has exactly that shape.)
@@ -669,9 +714,16 @@ int sgr_density_field_forward(int N, int K, const float* x, const int64_t* nbr_i
 {
     if (N <= 0) return 0;
     if (K <= 0 || !x || !nbr_idx || !centers || !inv_scaled_rot || !strengths || !density) return SGR_E_INVALID;
-    hipLaunchKernelGGL(k_density_fwd, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, K, x,
-                       reinterpret_cast<const long long*>(nbr_idx), centers, inv_scaled_rot, strengths, reinterpret_cast<const float4*>(packed),
-                       density_factor, neighbor_opacities, density);
+    if (K == 16) {
+        const long long nk = (long long)N * 16;
+        hipLaunchKernelGGL(k_density_fwd16, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nk, x,
+                           reinterpret_cast<const long long*>(nbr_idx), centers, inv_scaled_rot, strengths, reinterpret_cast<const float4*>(packed),
+                           density_factor, neighbor_opacities, density);
+    } else {
+        hipLaunchKernelGGL(k_density_fwd, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, K, x,
+                           reinterpret_cast<const long long*>(nbr_idx), centers, inv_scaled_rot, strengths, reinterpret_cast<const float4*>(packed),
+                           density_factor, neighbor_opacities, density);
+    }
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 
@@ -762,7 +814,11 @@ int sgr_density_field_backward_gather(int N, int K, int P, const float* x, const
                                pair_list);
         }
     } else {
-        if (dL_dx) {   // the gradient of the sample positions (a lane per sample; no atomics in this mode)
+        if (dL_dx && K == 16) {   // the gradient of the sample positions: a lane per pair
+            hipLaunchKernelGGL(k_density_dx16, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, (long long)nk, x, nbr, centers,
+                               inv_scaled_rot, strengths, reinterpret_cast<const float4*>(packed), density_factor, dL_dopacities,
+                               dL_ddensity, dL_dx);
+        } else if (dL_dx) {       // ... a lane per sample (no atomics in this mode)
             hipLaunchKernelGGL(k_density_bwd_rank, dim3((N + 255) / 256), dim3(256), 0, s, N, K, x, nbr, centers, inv_scaled_rot,
                                strengths, reinterpret_cast<const float4*>(packed), density_factor, dL_dopacities, dL_ddensity, dL_dx,
                                (uint32_t*)nullptr, rank);
