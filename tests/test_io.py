@@ -165,3 +165,25 @@ def test_sfm_point_cloud_round_trip_through_the_plyfile_stand_in(tmp_path):
     storePly(p, xyz, rgb)
     pcd = fetchPly(p)
     assert np.array_equal(pcd.points, xyz) and np.allclose(pcd.colors, rgb / 255.0) and np.array_equal(pcd.normals, np.zeros_like(xyz))
+
+
+def test_colmap_pose_quaternions_of_the_dataset_writer_invert_the_reference_conversion():
+    """oracle/reference_trainer.py::_rotmat_to_qvec (used to write images.txt for the trainer harness) against the reference's
+    qvec2rotmat (gaussian_splatting/scene/colmap_loader.py:43-53), all trace branches"""
+    import pytest
+    from tests import ref_env
+    if ref_env.reference_root() is None:
+        pytest.skip("no reference tree")
+    from sugar_amd import shims
+    shims.install()
+    ref_env.import_gaussian_splatting()
+    from scene.colmap_loader import qvec2rotmat
+    from oracle.reference_trainer import _rotmat_to_qvec
+    rng = np.random.default_rng(0)
+    mats = [np.diag([1.0, -1.0, -1.0]), np.diag([-1.0, 1.0, -1.0]), np.diag([-1.0, -1.0, 1.0]), np.eye(3)]
+    for _ in range(300):
+        q, _r = np.linalg.qr(rng.standard_normal((3, 3)))
+        mats.append(q * np.sign(np.linalg.det(q)))
+    for R in mats:
+        qv = _rotmat_to_qvec(R)
+        assert abs(np.linalg.norm(qv) - 1.0) < 1e-12 and np.allclose(qvec2rotmat(qv), R, atol=1e-12)
