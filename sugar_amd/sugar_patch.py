@@ -261,8 +261,10 @@ def _splat_fragments(self, p3d_cameras, rasterizer):
     clip_bary, persp, z_clip = MeshRasterizer.resolved_settings(rs, p3d_cameras)
     n = face_verts.shape[0]
     dev = face_verts.device
+    # (faces_per_pixel = 1 whatever the caller's settings say -- the extractor asks for 10, coarse_mesh.py:216-221: the sampler reads slot
+    # 0 only (:1928, :1966) and slot 0 of the K nearest faces is the nearest face; these fragments never leave this module)
     p2f, zbuf, bary, dists = fn(face_verts, torch.zeros(1, dtype=torch.int64, device=dev), torch.full((1,), n, dtype=torch.int64, device=dev),
-                                rs.image_size, rs.blur_radius, rs.faces_per_pixel, persp, clip_bary, rs.cull_backfaces, z_clip,
+                                rs.image_size, rs.blur_radius, 1, persp, clip_bary, rs.cull_backfaces, z_clip,
                                 rs.cull_to_frustum, want_bary=False, want_dists=False)
     return Fragments(pix_to_face=p2f, zbuf=zbuf, bary_coords=bary, dists=dists)
 
