@@ -32,6 +32,7 @@ def main():
                     help="then run the reference's coarse-mesh extractor (sugar_extractors/coarse_mesh.py, untouched) up to its "
                          "Poisson step: on the trained model if the training ran to 15000, else on the 3DGS checkpoint")
     ap.add_argument("--skip-training", action="store_true")
+    ap.add_argument("--sfm-points", type=int, default=20_000, help="points3D.txt entries of the COLMAP-layout scene (= initial Gaussians)")
     ap.add_argument("--vanilla-cli", type=int, default=0, metavar="N",
                     help="also run `python -m sugar_amd.launch <reference>/gaussian_splatting/train.py ... --iterations N` on a COLMAP-layout "
                          "copy of the scene (the vanilla 3DGS trainer as a command line, densification included)")
@@ -78,7 +79,8 @@ def main():
                                           patch_losses=a.patch_losses, patch_optimizer=a.patch_optimizer, patch_gathers=a.patch_gathers,
                                           log_path=os.path.join(a.out, f"refine_console_{tag}.log"))
         if a.vanilla_cli:
-            cdir = rt.write_colmap_dataset(os.path.join(work, "colmap"), P=a.gaussians, n_cams=a.cameras, W=a.width, H=a.height)
+            cdir = rt.write_colmap_dataset(os.path.join(work, "colmap"), P=a.gaussians, n_cams=a.cameras, W=a.width, H=a.height,
+                                           n_sfm_points=a.sfm_points)
             flags = [f for f, off in (("--no-patch-losses", not a.patch_losses), ("--no-patch-optimizer", not a.patch_optimizer)) if off]
             v = rt.run_vanilla_cli(cdir, os.path.join(work, "vanilla_out"), iterations=a.vanilla_cli, launcher_flags=flags)
             with open(os.path.join(a.out, f"vanilla_cli_{tag}.log"), "w") as f:
