@@ -5,6 +5,14 @@ hipcc for gfx950 with -ffp-contract=off, oracle/ref_build/build_ref.sh), on the 
     metric     1M Gaussians @ 1920x1080 (the headline workload)        forward + backward
     config 3   2M Gaussians @ 1920x1080                                forward + backward
     config 5   6M Gaussians @ 3840x2160                                forward
+and, since round 5, the two BASELINE configs AS THE TRAINERS THAT DEFINE THEM call the rasterizer:
+    config 3 / precomp   the coarse-SDF step's first call: `colors_precomp` = SuGaR.get_points_rgb (eval_sh + 0.5 clamped,
+                         sugar_model.py:839-883, 2187-2200; coarse_sdf.py:51), sh_degree 0 at the boundary
+    config 3 / depth     its second call: view-space depth as the colour, background = the largest depth
+                         (coarse_sdf.py:575-590) -- colours and a background far outside [0,1]
+    config 4             1M FLAT Gaussians bound to a triangle mesh (sugar_model.py:149-228, 384-475: first scale =
+                         thickness = extent / 1e6): where the 0.3-pixel low-pass and the conic inversion of
+                         forward.cu:74-113 dominate
 
 Bar (BASELINE.json north_star; the reference lines are DGR/cuda_rasterizer/forward.cu:336-351, backward.cu:486-554,
 rasterizer_impl.cu:70-138):
@@ -29,7 +37,7 @@ from sugar_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 GRADS = dict(means3D="dL_dmeans3D", means2D="dL_dmeans2D", opacities="dL_dopacity", shs="dL_dsh", scales="dL_dscales",
-             rotations="dL_drotations")
+             rotations="dL_drotations", colors_precomp="dL_dcolors")
 REPORT = {}
 
 
@@ -52,13 +60,29 @@ def stats(a: torch.Tensor, b: torch.Tensor, floor_frac=1e-3):
                 max_abs=float(d.max()), scale=scale)
 
 
-def _ref(scene, cam, bg, g):
+def _inputs(scene, cam, bg, mode, dev):
+    """the tensors that cross the boundary: (kwargs shared by both sides, bg, sh_degree)"""
+    t = dict(means3D=scene.means3D.to(dev), opacities=scene.opacities.to(dev), scales=scene.scales.to(dev),
+             rotations=scene.rotations.to(dev))
+    if mode == "sh":
+        t["shs"] = scene.shs.to(dev)
+        return t, bg.to(dev), 3
+    if mode == "precomp":
+        t["colors_precomp"] = syn.sh_to_rgb(scene.shs.to(dev), t["means3D"], cam.campos.to(dev))
+        return t, bg.to(dev), 0
+    assert mode == "depth"
+    t["colors_precomp"], bg_d = syn.depth_as_colour(t["means3D"], cam.viewmatrix.to(dev))
+    return t, bg_d, 0
+
+
+def _ref(scene, cam, bg, g, mode="sh"):
     ref_gpu.use("nocontract")
     dev = torch.device(DEV)
-    st = ref_gpu.forward(scene.means3D.to(dev), scene.opacities.to(dev), shs=scene.shs.to(dev), scales=scene.scales.to(dev),
-                         rotations=scene.rotations.to(dev), viewmatrix=cam.viewmatrix.to(dev), projmatrix=cam.projmatrix.to(dev),
-                         campos=cam.campos.to(dev), bg=bg.to(dev), W=cam.image_width, H=cam.image_height, tanfovx=cam.tanfovx,
-                         tanfovy=cam.tanfovy)
+    t, bg_d, deg = _inputs(scene, cam, bg, mode, dev)
+    st = ref_gpu.forward(t["means3D"], t["opacities"], shs=t.get("shs"), colors_precomp=t.get("colors_precomp"),
+                         scales=t["scales"], rotations=t["rotations"], viewmatrix=cam.viewmatrix.to(dev),
+                         projmatrix=cam.projmatrix.to(dev), campos=cam.campos.to(dev), bg=bg_d, W=cam.image_width,
+                         H=cam.image_height, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, sh_degree=deg)
     grads = ref_gpu.backward(st, g) if g is not None else None
     return st, grads
 
@@ -77,19 +101,20 @@ def _ref_views(st):
     return out
 
 
-def _product(scene, cam, bg, g):
+def _product(scene, cam, bg, g, mode="sh"):
     from sugar_amd import _lib
     from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     dev = torch.device(DEV)
     lib = _lib.load()
     H, W = cam.image_height, cam.image_width
-    settings = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, bg.to(dev), 1.0, cam.viewmatrix.to(dev),
-                                             cam.projmatrix.to(dev), 3, cam.campos.to(dev), False, False)
-    leaves = dict(means3D=scene.means3D, opacities=scene.opacities, shs=scene.shs, scales=scene.scales, rotations=scene.rotations)
-    leaves = {k: v.to(dev).requires_grad_(g is not None) for k, v in leaves.items()}
+    t, bg_d, deg = _inputs(scene, cam, bg, mode, dev)
+    settings = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, bg_d, 1.0, cam.viewmatrix.to(dev),
+                                             cam.projmatrix.to(dev), deg, cam.campos.to(dev), False, False)
+    leaves = {k: v.requires_grad_(g is not None) for k, v in t.items()}
     leaves["means2D"] = torch.zeros(scene.means3D.shape[0], 3, device=dev, requires_grad=g is not None)
-    color, radii = GaussianRasterizer(settings)(leaves["means3D"], leaves["means2D"], leaves["opacities"], shs=leaves["shs"],
-                                                scales=leaves["scales"], rotations=leaves["rotations"])
+    color, radii = GaussianRasterizer(settings)(leaves["means3D"], leaves["means2D"], leaves["opacities"], shs=leaves.get("shs"),
+                                                colors_precomp=leaves.get("colors_precomp"), scales=leaves["scales"],
+                                                rotations=leaves["rotations"])
     from sugar_amd.diff_gaussian_rasterization import _C
     lf = _C.last_forward
     R, T = lf["num_rendered"], ((W + 15) // 16) * ((H + 15) // 16)
@@ -106,17 +131,20 @@ def _product(scene, cam, bg, g):
     return out
 
 
-@pytest.mark.parametrize("config,cam_id,backward", [("config2", 0, True), ("metric", 0, True), ("metric", 5, True),
-                                                    ("config3", 2, True), ("config5", 1, False)])
-def test_full_size_parity_with_the_reference(config, cam_id, backward):
+@pytest.mark.parametrize("config,cam_id,backward,mode", [
+    ("config2", 0, True, "sh"), ("metric", 0, True, "sh"), ("metric", 5, True, "sh"), ("config3", 2, True, "sh"),
+    ("config5", 1, False, "sh"),
+    ("config4", 1, True, "sh"), ("config4", 6, True, "precomp"), ("config3", 4, True, "precomp"), ("config3", 6, True, "depth")])
+def test_full_size_parity_with_the_reference(config, cam_id, backward, mode):
     scene, cams, bg = syn.make_config(config)
     cam = cams[cam_id]
     H, W = cam.image_height, cam.image_width
     g = torch.randn(3, H, W, generator=torch.Generator().manual_seed(0)).to(DEV) if backward else None
-    st, rg = _ref(scene, cam, bg, g)
+    st, rg = _ref(scene, cam, bg, g, mode)
     rv = _ref_views(st)
-    hp = _product(scene, cam, bg, g)
-    rep = REPORT.setdefault(f"{config}/cam{cam_id}", dict(P=st["P"], W=W, H=H, num_rendered=st["R"]))
+    hp = _product(scene, cam, bg, g, mode)
+    rep = REPORT.setdefault(f"{config}/cam{cam_id}" + ("" if mode == "sh" else "/" + mode),
+                            dict(P=st["P"], W=W, H=H, num_rendered=st["R"], mode=mode))
     # ---- bit-exact part: tile assignment and depth order
     assert hp["R"] == st["R"]
     assert torch.equal(hp["radii"], st["radii"])
@@ -140,10 +168,86 @@ def test_full_size_parity_with_the_reference(config, cam_id, backward):
     rg2 = ref_gpu.backward(st, g)
     rep["grads"], bad = {}, []
     for k, n in GRADS.items():
+        if k not in hp["grads"]:
+            continue  # (no SH tensor in the precomputed-colour modes, no colour tensor in the SH mode)
         ref = rg[n]
         e = stats(hp["grads"][k].reshape(ref.shape), ref)
         own = stats(rg2[n], ref)
         rep["grads"][k] = dict(product_vs_reference=e, reference_vs_itself=own)
         if not (e["norm_rel"] <= 1e-4 and e["frac_gt_1e4"] <= 1e-3):
             bad.append((k, e, own))
+    assert not bad, bad
+
+
+def test_the_headline_path_itself_matches_the_reference_at_the_metric_size():
+    """The path bench.py's headline number is measured on -- NativeTrainer: raw-parameter mode, sync-free forward with a list
+    capacity, walk hint, blend workgroups launched in the camera's previous depth order, compact SH gradient -- pinned to the
+    reference at 1M Gaussians @ 1920x1080.  Sixteen steps over the eight cameras (every camera's second visit is hinted and
+    ordered); the LAST step's image, its instance count and radii, and its parameter gradients are compared with the
+    reference's kernels run on the parameters that step started from, with the loss gradient that step produced:
+        image                   forward.cu:261-374        bars of this file
+        dL/dxyz, raw opacity / scale / rotation gradients  backward.cu:144-557 chained through exp / sigmoid / normalize
+                                (gaussian_model.py:92-117) as autograd does for the reference
+        clamp-masked dL/dRGB    backward.cu:47-63 (the SH backward's input); and the SH gradient the step's Adam kernel
+                                consumes, rebuilt from it by sgr_sh_grad_from_views, against the reference's dL/dsh."""
+    from sugar_amd.train_step import GaussianParams, NativeTrainer, sh_grad_from_views
+    dev = torch.device(DEV)
+    scene, cams, bg = syn.make_config("metric")
+    W, H = cams[0].image_width, cams[0].image_height
+    cams_d = [c._replace(viewmatrix=c.viewmatrix.to(dev), projmatrix=c.projmatrix.to(dev), campos=c.campos.to(dev)) for c in cams]
+    gen = torch.Generator().manual_seed(1234)
+    gts = [torch.rand(3, H, W, generator=gen).to(dev) for _ in range(8)]
+    params = GaussianParams(scene, dev)
+    P, o, n = params.P, params.offsets, params.sizes
+    nt = NativeTrainer(params, bg.to(dev), W, H)
+    for s in range(15):
+        nt.step(cams_d[s % 8], gts[s % 8], cam_key=s % 8)
+    nt.synchronize()
+    before = params.flat.detach().clone()
+    redone0 = nt.redone
+    cam = cams_d[7]
+    nt.step(cam, gts[7], cam_key=7)
+    nt.synchronize()
+    assert nt.redone == redone0, "the graded step was repaired: it did not run hinted"
+    assert nt._last_hinted and nt._hints[7][1] and nt._hints[7][4]  # walk hint and launch order were in use
+    seg = lambda k, shape: before[o[k]: o[k] + n[k]].view(shape)
+    xyz, raw_op, raw_sc, raw_q, shs = seg("xyz", (P, 3)), seg("opacity", (P, 1)), seg("scaling", (P, 3)), seg("rotation", (P, 4)), \
+        seg("features", (P, params.M, 3))
+    # the activated values the preprocess kernel forms on the fly, bit for bit: the stand-alone activation kernels carry the same
+    # arithmetic operation for operation (csrc/preprocess.hip:274-281), so both sides start from identical inputs
+    from sugar_amd.train_step import _Activations
+    with torch.no_grad():
+        scales, rots, opac = _Activations.apply(raw_sc.contiguous(), raw_q.contiguous(), raw_op.contiguous(), None)
+    qn = raw_q.norm(dim=-1, keepdim=True)
+    ref_gpu.use("nocontract")
+    st = ref_gpu.forward(xyz.contiguous(), opac.contiguous(), shs=shs.contiguous(), scales=scales.contiguous(),
+                         rotations=rots.contiguous(), viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix, campos=cam.campos,
+                         bg=bg.to(dev), W=W, H=H, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy)
+    rep = REPORT.setdefault("metric/native_trainer_step16", dict(P=P, W=W, H=H, num_rendered=st["R"]))
+    assert nt.last_num_rendered == st["R"]
+    assert torch.equal(nt.radii, st["radii"])
+    e = stats(nt.image, st["color"])
+    rep["image"] = e
+    assert e["norm_rel"] <= 1e-5 and e["frac_gt_1e4"] <= 1e-3, e
+    rg = ref_gpu.backward(st, nt._grad_image)
+    fg = params.flat_grad
+    got = dict(xyz=fg[o["xyz"]: o["xyz"] + 3 * P].view(P, 3), opacity=fg[o["opacity"]: o["opacity"] + P].view(P, 1),
+               scaling=fg[o["scaling"]: o["scaling"] + 3 * P].view(P, 3), rotation=fg[o["rotation"]: o["rotation"] + 4 * P].view(P, 4))
+    gq = rg["dL_drotations"]
+    want = dict(xyz=rg["dL_dmeans3D"], opacity=rg["dL_dopacity"] * opac * (1 - opac), scaling=rg["dL_dscales"] * scales,
+                rotation=(gq - rots * (rots * gq).sum(-1, keepdim=True)) / qn)
+    # clamp-masked colour gradient: the reference's `clamped` flags live in its geometry scratch (rasterizer_impl.h:32-44)
+    og = ref_gpu._carve(st["geom"].data_ptr(), [("depths", P, 4), ("clamped", 3 * P, 1)])
+    clamped = st["geom"][og["clamped"]: og["clamped"] + 3 * P].view(P, 3) != 0
+    got["masked_colours"] = nt._send[:P]
+    want["masked_colours"] = rg["dL_dcolors"] * (~clamped)
+    sh = torch.empty(P, params.M, 3, device=dev)
+    sh_grad_from_views(xyz.contiguous(), cam.campos.reshape(1, 3).contiguous(), nt._send[:P][None], 3, sh)
+    got["features"], want["features"] = sh, rg["dL_dsh"]
+    rep["grads"], bad = {}, []
+    for k in got:
+        e = stats(got[k], want[k])
+        rep["grads"][k] = e
+        if not (e["norm_rel"] <= 1e-4 and e["frac_gt_1e4"] <= 1e-3):
+            bad.append((k, e))
     assert not bad, bad
