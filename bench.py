@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--no-reference-loop", action="store_true", help="skip the untimed legs behind the graded region: the reference's own loop (train.py) on the drop-in rasterizer, the through-API fwd+bwd time, and the same-GPU A/B against the reference's kernels")
     ap.add_argument("--reference-loop", action="store_true", help="(default behaviour, kept as an explicit switch) run those legs")
     ap.add_argument("--reference-loop-steps", type=int, default=24)
+    ap.add_argument("--plain-3dgs-step", action="store_true", help="config3 / config4: time the vanilla 3DGS step on the config's scene (what rounds 1-4 printed) instead of the step the config defines")
+    ap.add_argument("--no-eight-thread-baseline", action="store_true", help="skip the extra 8-thread run of the CPU baseline (BASELINE.md section 2's planned core count)")
     args = ap.parse_args()
 
     wd = args.watchdog_sec or (900 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 0)
@@ -121,8 +123,21 @@ def main():
     gtor = torch.Generator().manual_seed(1234)
     gts = [torch.rand(3, H, W, generator=gtor).to(dev) for _ in range(len(cams))]
     params = GaussianParams(scene, dev)
-    native = not (args.python_step or forward_only)
-    if forward_only:
+    coarse_sdf = args.workload == "config3" and not (args.plain_3dgs_step or forward_only)
+    refine_cfg = args.workload == "config4" and not (args.plain_3dgs_step or forward_only)
+    if coarse_sdf or refine_cfg:
+        # (the legs behind the graded region belong to the metric workload: the drifted scene, the 200-camera epoch, the reference's
+        # vanilla loop)
+        args.drift_steps, args.cameras, args.no_reference_loop, args.no_densify_variant = 0, 0, True, True
+    native = not (args.python_step or forward_only or coarse_sdf)
+    if coarse_sdf:
+        gd = torch.Generator().manual_seed(4321)
+        gt_depths = [(2.0 + 2.0 * torch.rand(H, W, generator=gd)).to(dev) for _ in range(len(cams))]
+        trainer = CoarseSdfStep(params, bg_d, GaussianRasterizer, GaussianRasterizationSettings, _C, gt_depths, host_sync=args.host_sync)
+    elif refine_cfg:
+        trainer = RefineViewStep(params, bg_d, W, H, force_collectives=args.force_collectives, walk_hint=not args.no_walk_hint,
+                                 launch_order=not args.no_launch_order, native_collectives=True if args.native_collectives else None)
+    elif forward_only:
         trainer = ForwardOnly(scene, dev, bg_d, GaussianRasterizer, GaussianRasterizationSettings, _C, host_sync=args.host_sync)
     elif native:
         trainer = NativeTrainer(params, bg_d, W, H, force_collectives=args.force_collectives, walk_hint=not args.no_walk_hint,
@@ -140,6 +155,8 @@ def main():
         k = cam_index(s)
         if isinstance(tr, NativeTrainer):
             tr.step(cams_d[k], gts[k], cam_key=k)
+        elif isinstance(tr, CoarseSdfStep):
+            tr.step(cams_d[k], gts[k], k)
         else:
             tr.step(cams_d[k], gts[k])
 
@@ -248,12 +265,16 @@ def main():
     walked_b = torch.zeros((), dtype=torch.int64, device=dev)
     rendered = 0
     n_post = len(cams)
+    n_launch = 0
     lib.sgr_profile_enable((1 << len(STAGES)) - 1)
     for s in range(args.warmup + args.steps, args.warmup + args.steps + n_post):
         do_step(trainer, s)
-        img = trainer._img if isinstance(trainer, NativeTrainer) else _C.last_forward["img"]
-        walked += img[off_walk: off_walk + 4 * T].view(torch.int32).sum()
-        walked_b += img[off_maxc: off_maxc + 4 * T].view(torch.int32).sum()
+        imgs = ([trainer._img] if isinstance(trainer, NativeTrainer) else trainer.last_imgs if isinstance(trainer, CoarseSdfStep)
+                else [_C.last_forward["img"]])
+        for img in imgs:  # (the coarse-SDF step launches the blend kernels twice: RGB pass and depth pass)
+            walked += img[off_walk: off_walk + 4 * T].view(torch.int32).sum()
+            walked_b += img[off_maxc: off_maxc + 4 * T].view(torch.int32).sum()
+        n_launch += len(imgs)
         if isinstance(trainer, NativeTrainer):
             trainer.synchronize()
         rendered += trainer.last_num_rendered
@@ -361,8 +382,8 @@ def main():
 
     if rank == 0:
         K = args.steps
-        R_f = float(walked.item()) / n_post
-        R_b = float(walked_b.item()) / n_post
+        R_f = float(walked.item()) / max(n_launch, 1)
+        R_b = float(walked_b.item()) / max(n_launch, 1)
         R = rendered / n_post
         alg_bytes = 40.0 * R_f + 20.0 * W * H + 8.0 * T + 12.0  # SURVEY.md section 8d, forward blend
         achieved = alg_bytes / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else 0.0
@@ -404,9 +425,21 @@ def main():
             "config": {
                 "workload": (f"{args.workload}: {P} Gaussians @ {W}x{H}, SH degree 3, rasterizer FORWARD only through the "
                              "reference-shaped API, 8 orbit cameras cycled" if forward_only else
+                             f"{args.workload}: {P} Gaussians @ {W}x{H}, SuGaR coarse-SDF-shaped step (coarse_sdf.py:51,575-597; "
+                             "SURVEY 8d config 3): SH->RGB (sh_levels 4) -> raster fwd with colors_precomp -> 0.8 L1 + 0.2 DSSIM; "
+                             "view depth as colour, bg = max depth -> raster fwd -> L1 on the depth map; ONE backward through both "
+                             "(2 raster fwd + 2 raster bwd) -> Adam over 59 floats/Gaussian, 8 orbit cameras cycled" if coarse_sdf else
+                             f"{args.workload}: {P} FLAT Gaussians bound to a {P}-triangle surface mesh (sugar_model.py:149-228, 438-442: "
+                             "first scale = extent / 1e6) @ " + f"{W}x{H}, SH degree 3: 3DGS train step (raster fwd -> 0.8 L1 + 0.2 DSSIM -> bwd "
+                             "-> Adam) + ONE level-set sampling pass of the coarse-mesh extractor for the same view (depth render -> 124k "
+                             "pixels -> k-NN(16) -> 21 samples x 16 neighbours x 3 levels, sugar_model.py:1848-2083), 8 orbit cameras cycled"
+                             if refine_cfg else
                              f"{args.workload}: {P} Gaussians @ {W}x{H}, SH degree 3, 3DGS train step "
                              "(raster fwd -> 0.8 L1 + 0.2 DSSIM -> bwd -> Adam, 59 floats/Gaussian), 8 orbit cameras cycled"),
                 "step_driver": ("reference-shaped Python API" if forward_only else
+                                "reference-shaped Python API + autograd (sugar_amd.shcolor, diff_gaussian_rasterization, fused_loss, FlatAdam)"
+                                + (", host round trip for num_rendered in every forward" if trainer.host_sync else
+                                   ", speculative sync-free forwards (header checked at the end of the call)") if coarse_sdf else
                                 "native (sgr_trainer_step: one call per step, sync-free forward, walk hint "
                                 + ("on" if getattr(trainer, "walk_hint", False) else "off") + ", blend launch order "
                                 + ("by depth" if getattr(trainer, "launch_order", False) else "raster") + ")" if native
@@ -436,6 +469,14 @@ def main():
         }
         if valu is not None:
             out["roofline_valu"] = valu
+        out["parity_bar"] = ("tests/test_gpu_fullsize.py vs the reference's kernels on the same GPU: tile lists / ranges / radii / num_rendered "
+                             "bit-exact; image <= 1e-5 norm-wise; every gradient tensor <= 1e-4 norm-wise AND >= 99.9 % of its elements "
+                             "within 1e-4 relative (floor 1e-3 of the tensor's largest magnitude) -- the element-wise reading of north_star's "
+                             "'within 1e-4 rel', next to the reference's own run-to-run spread from float atomics")
+        if coarse_sdf:
+            out["coarse_sdf_step"] = trainer.report(args.steps)
+        if refine_cfg:
+            out["refine_step"] = trainer.report()
         out.update(extras)
         if forward_only:
             # (a sync-free forward that outgrew its capacity returns at once and would be timed as an abnormally fast step)
@@ -449,12 +490,146 @@ def main():
             out["config"]["collectives"] = ("forced on a one-rank RCCL group" if world == 1 else "RCCL") + \
                 (", enqueued by the library (sgr_trainer_step_exchange)" if getattr(trainer, "native_collectives", False) else ", torch.distributed between four phase calls")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, cams[0], bg, forward_only)
+            out["cpu_baseline"] = cpu_baseline(scene, cams[0], bg, forward_only, mode="coarse_sdf" if coarse_sdf else "sh",
+                                               eight_threads=not args.no_eight_thread_baseline)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_group:
         dist.barrier()
         dist.destroy_process_group()
+
+
+
+class CoarseSdfStep:
+    """BASELINE config 3's step: what sugar_trainers/coarse_sdf.py asks of the rasterizer per iteration
+    after iteration 9000 -- TWO forwards and TWO backwards:
+      1. colours = SuGaR.get_points_rgb (eval_sh + 0.5 clamped, sugar_model.py:839-883; HIP: k_sh_to_rgb_fwd/bwd), handed over as
+         `colors_precomp` (coarse_sdf.py:51, sugar_model.py:2187-2200), photometric loss 0.8 L1 + 0.2 D-SSIM;
+      2. the view-space depth of every centre as its colour, background = the largest depth (coarse_sdf.py:575-590), and a loss on
+         the depth map (an L1 against a target map stands in for the sdf-estimation terms that consume it, :627-716);
+    one autograd backward through both, Adam over all 59 floats per Gaussian.  Parameters, activations and optimiser are the
+    train step's (GaussianParams, fused activation kernels, one-launch FlatAdam); everything between them is the
+    reference-shaped Python API of this repository, as an unmodified trainer would drive it."""
+
+    def __init__(self, params, bg, rasterizer_cls, settings_cls, cmod, gt_depths, host_sync=False, depth_weight=0.1):
+        from sugar_amd.train_step import FlatAdam
+        self.params, self.bg, self.R, self.S, self.cmod = params, bg, rasterizer_cls, settings_cls, cmod
+        self.opt = FlatAdam(params)
+        self.exp_avg, self.exp_avg_sq = self.opt.exp_avg, self.opt.exp_avg_sq
+        self.gt_depths, self.depth_weight = gt_depths, depth_weight
+        self.host_sync = bool(host_sync)
+        self.m2 = torch.zeros(params.P, 3, device=params.flat.device, requires_grad=True)
+        self.last_num_rendered, self.redone, self.last_imgs = 0, 0, []
+        self.knn_ms = None
+
+    @property
+    def t(self):
+        return self.opt.t
+
+    @t.setter
+    def t(self, v):
+        self.opt.t = v
+
+    def _raster(self, cam, bg, a, colors):
+        import contextlib
+        from sugar_amd.diff_gaussian_rasterization import grad_sink
+        st = self.S(image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg,
+                    scale_modifier=1.0, viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix, sh_degree=0, campos=cam.campos,
+                    prefiltered=False, debug=False)
+        with (grad_sink(speculative=False) if self.host_sync else contextlib.nullcontext()):
+            img, _ = self.R(st)(a["means3D"], self.m2, a["opacities"], colors_precomp=colors, scales=a["scales"], rotations=a["rotations"])
+        lf = self.cmod.last_forward
+        self.last_imgs.append(lf["img"])
+        self.last_num_rendered = lf["num_rendered"]
+        self.redone += int(lf.get("speculation_missed", False))
+        return img
+
+    def step(self, cam, gt, k):
+        from sugar_amd import shcolor
+        from sugar_amd.fused_loss import l1_ssim_loss
+        from sugar_amd.sampler import view_depth
+        p = self.params
+        self.last_imgs = []
+        names = list(p.NAMES)
+        leaves = [p.params[n] for n in names]
+        a = p.activated()
+        rgb = shcolor.sh_to_rgb(a["shs"], 4, positions=a["means3D"], camera_centers=cam.campos.reshape(1, 3))
+        image = self._raster(cam, self.bg, a, rgb)
+        loss = l1_ssim_loss(image, gt, 0.2)
+        pd = view_depth(a["means3D"], cam.viewmatrix).expand(-1, 3)
+        bg_depth = pd.detach().max() + torch.zeros(3, dtype=torch.float32, device=pd.device)
+        depth = self._raster(cam, bg_depth, a, pd.contiguous())[0]
+        loss = loss + self.depth_weight * (depth - self.gt_depths[k]).abs().mean()
+        grads = torch.autograd.grad(loss, leaves)
+        with torch.no_grad():
+            for leaf, g in zip(leaves, grads):
+                if g.data_ptr() != leaf.grad.data_ptr():
+                    leaf.grad.copy_(g)
+        self.opt.step()
+        return loss.detach()
+
+    def knn_rebuild(self):
+        """`SuGaR.reset_neighbors` (sugar_model.py:1027-1030: knn_points(points, points, K=16)), every 500 iterations in the coarse
+        trainers (coarse_sdf.py:183,559-561); timed on its own with device events"""
+        from sugar_amd.knn import knn_points
+        xyz = self.params.params["xyz"].detach()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ms = []
+        for _ in range(3):
+            e0.record()
+            idx = knn_points(xyz[None], xyz[None], K=16).idx
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        del idx
+        self.knn_ms = sorted(ms)[1]
+        return self.knn_ms
+
+    def report(self, steps):
+        ms = self.knn_rebuild()
+        return {"rasterizer_calls_per_step": "2 forward + 2 backward", "knn16_rebuild_ms": ms,
+                "knn16_rebuild_ms_amortised_per_step": ms / 500.0,
+                "knn_what": f"knn_points(points, points, K=16) over {self.params.P} Gaussians (HIP grid k-NN), median of 3; the coarse "
+                            "trainers rebuild it every 500 iterations (coarse_sdf.py:183,559-561)",
+                "forwards_repeated_after_a_speculation_miss": self.redone}
+
+
+def RefineViewStep(*args, **kw):
+    """BASELINE config 4 at one view per rank: the train step on 1M flat, mesh-bound Gaussians plus one
+    level-set sampling pass of the coarse-mesh extractor for that view.  (A NativeTrainer subclass, built on first use: bench.py
+    imports sugar_amd behind its argument parser.)"""
+    from sugar_amd.train_step import NativeTrainer
+
+    class _RefineViewStep(NativeTrainer):
+        def __init__(self, params, bg, W, H, n_surface_points=124_000, **kw):
+            super().__init__(params, bg, W, H, **kw)
+            self.n_surface_points = n_surface_points
+            self.sampler_s, self.sampler_calls, self.level_points = 0.0, 0, {}
+
+        def step(self, cam, gt_image, cam_key=None):
+            from sugar_amd import sampler
+            from sugar_amd.train_step import _Activations
+            loss = super().step(cam, gt_image, cam_key=cam_key)
+            p = self.params.params
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                scales, rots, opac = _Activations.apply(p["scaling"].detach(), p["rotation"].detach(), p["opacity"].detach(), None)
+                res = sampler.sample_level_sets(p["xyz"].detach(), scales, rots, opac, cam, n_surface_points=self.n_surface_points)
+            self.sampler_s += time.perf_counter() - t0  # (host wall clock: the pass ends with host round trips of its own)
+            self.sampler_calls += 1
+            self.level_points = {str(lv): int(r["intersection_points"].shape[0]) for lv, r in res.items()}
+            return loss
+
+        def report(self):
+            return {"sampler_pass_ms_host_wall_clock": 1e3 * self.sampler_s / max(self.sampler_calls, 1),
+                    "sampler_passes": self.sampler_calls, "level_set_points_last_view": self.level_points,
+                    "n_surface_points": self.n_surface_points,
+                    "what": "per step: sgr_trainer_step on the flat scene, then sugar_amd.sampler.sample_level_sets for the same view on "
+                            "the updated parameters (activations kernel -> depth render through the rasterizer API -> pixel subset -> "
+                            "back-projection -> HIP k-NN(16) against all Gaussians -> k_level_set); the pass waits for the train step it "
+                            "follows, so its wall clock includes the tail of that step"}
+
+    return _RefineViewStep(*args, **kw)
 
 
 class ForwardOnly:

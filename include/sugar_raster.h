@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 2 /* 2: sgr_forward_ex takes an options struct, binning mode per call, trainer API */
+#define SGR_ABI_VERSION 3 /* 2: sgr_forward_ex takes an options struct, binning mode per call, trainer API; 3: sgr_forward_info.speculation, SGR_FLAG_SPECULATIVE */
 
 #define SGR_E_INVALID (-1) /* bad argument (e.g. NUM_CHANNELS != 3 path, rasterizer_impl.cu:242-245) */
 #define SGR_E_HIP (-2)     /* a HIP runtime call or kernel failed (CHECK_CUDA, auxiliary.h:166-173) */
@@ -101,6 +101,7 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user,
 typedef struct sgr_forward_info {
     int binning_mode;        /* 0: two-level binning, 1: single-level */
     int sync_free;           /* 1: the call did not wait for the device */
+    int speculation;         /* SGR_FLAG_SPECULATIVE: 0 not asked for, 1 hit (the capacity held), 2 miss (list pass and blend ran twice) */
 } sgr_forward_info;
 typedef struct sgr_forward_opts {
     int64_t binning_capacity;
@@ -146,6 +147,15 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user,
  * follows (the loss forward carries that job in a spare workgroup) and records the event itself.  Needs header_host to be
  * device-mapped pinned memory; the call fails with SGR_E_INVALID otherwise. */
 #define SGR_FLAG_DEFER_POST 4
+/* SGR_FLAG_SPECULATIVE (with binning_capacity > 0, two-level binning): the reference's forward semantics -- the call returns the
+ * TRUE instance count, as Rasterizer::forward does (rasterizer_impl.cu:280-281,335) -- without its idle GPU: every kernel of the
+ * forward is enqueued sync-free with `binning_capacity` as the list capacity, and the ONE host wait (for the header the tile scan
+ * writes) happens at the END of the call, while the list-write pass and the blend kernel are still queued or running.  When the
+ * true count exceeds the capacity (or the level-1 list overflowed) the queued kernels were no-ops and the call runs them once more
+ * with the true count (binning_alloc is then called a second time).  The instance list is laid out for the capacity; sgr_backward
+ * finds that layout through the binning buffer's address, so the caller passes the returned count as usual.  Ignored with
+ * SGR_FLAG_DEFER_POST.  sgr_forward_info.speculation reports hit / miss. */
+#define SGR_FLAG_SPECULATIVE 8
 #define SGR_MODE_RAW_PARAMS 4 /* or-ed into the `phase` argument of sgr_backward_phase (phases 0, 1, 2 as before) */
 /* Compact SH mode only (dL_dsh == NULL): the backward skips the SH block altogether -- no read of shs, and dL_dmean3D
  * comes out WITHOUT the term through the view direction; sgr_sh_adam_from_views_ex forms that term. */

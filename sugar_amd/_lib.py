@@ -87,12 +87,12 @@ SIGNATURES = {
     "sgr_rasterize_meshes": (_i64, [_vp, _i64, _i64, _i, _i, _f, _i, _i, _i, _i, _vp, _sz, ALLOC_FN, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
-ABI_VERSION = 2  # SGR_ABI_VERSION of include/sugar_raster.h these bindings were written for
+ABI_VERSION = 3  # SGR_ABI_VERSION of include/sugar_raster.h these bindings were written for
 
 
 # ---- structs of include/sugar_raster.h
 class ForwardInfo(C.Structure):
-    _fields_ = [("binning_mode", _i), ("sync_free", _i)]
+    _fields_ = [("binning_mode", _i), ("sync_free", _i), ("speculation", _i)]
 
 
 class ForwardOpts(C.Structure):
@@ -128,7 +128,7 @@ class TrainExchange(C.Structure):
     _fields_ = [("n_views", _i), ("all_colors", _vp), ("view_stride", _i64), ("all_campos", _vp), ("grad_scale", _f), ("step", _i)]
 
 
-SGR_FLAG_RAW_PARAMS, SGR_FLAG_SINGLE_LEVEL_BINNING = 1, 2
+SGR_FLAG_RAW_PARAMS, SGR_FLAG_SINGLE_LEVEL_BINNING, SGR_FLAG_SPECULATIVE = 1, 2, 8
 SGR_BWD_TILE_ORDER_READY = 1
 HDR_R, HDR_HINT_MISS, HDR_L1_OVERFLOW = 0, 3, 6
 

@@ -7,6 +7,7 @@
 #include "tile_order.h"
 
 #include <mutex>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,29 @@ struct Pinned {
     ~Pinned() { /* leaked on purpose: the HIP runtime may already be gone at thread exit */ }
 };
 thread_local Pinned g_pinned;
+
+// Speculative forward (SGR_FLAG_SPECULATIVE): the instance list is laid out for the caller's guess of the capacity, while the call
+// returns the true instance count.  The backward is handed that count (rasterizer.h:57-84: "R = the value forward returned") and
+// must find the forward's layout: the library remembers, per binning buffer, the capacity it was laid out for.  Every forward sets or
+// clears the entry of the buffer it was given, so a recycled address can never carry a stale layout.
+std::mutex g_layout_mu;
+std::unordered_map<const void*, int64_t> g_layout_R;
+void layout_set(const void* binning, int64_t cap)
+{
+    std::lock_guard<std::mutex> lk(g_layout_mu);
+    if (cap > 0) g_layout_R[binning] = cap; else g_layout_R.erase(binning);
+}
+int64_t layout_get(const void* binning, int64_t R)
+{
+    std::lock_guard<std::mutex> lk(g_layout_mu);
+    auto it = g_layout_R.find(binning);
+    return it == g_layout_R.end() ? R : it->second;
+}
+struct ScanEvent {
+    hipEvent_t e = nullptr;
+    ~ScanEvent() { /* leaked on purpose, like the pinned slot */ }
+};
+thread_local ScanEvent g_scan_ev;
 
 // ---- optional per-stage timing with HIP events on the caller's stream (bench.py's roofline leg) ----------
 struct Prof {
@@ -217,7 +241,11 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     { StageTimer t(s, SGR_STAGE_SORT); sgr_launch_gaussian_sort(P, sort_scratch, &order, pa.rect_by_id, rects, s); }
     STAGE_CHECK("gaussian_sort");
 
-    const bool will_sync = !(binning_capacity > 0 && binning_mode == 0);
+    // speculative: sync-free launches with the caller's capacity, then ONE wait for the tile scan's header at the END of the call,
+    // when the list-write pass and the blend kernel are already queued behind it: the host round trip of rasterizer_impl.cu:280-281
+    // without the idle GPU, and the true instance count as the return value
+    const bool speculative = (flags & SGR_FLAG_SPECULATIVE) && binning_capacity > 0 && binning_mode == 0 && !(flags & SGR_FLAG_DEFER_POST);
+    const bool will_sync = !(binning_capacity > 0 && binning_mode == 0) || speculative;
     uint32_t* pin_dev = nullptr;
     if (will_sync) {
         if (!g_pinned.p) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_pinned.p), 64, hipHostMallocDefault));
@@ -246,18 +274,55 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     // header says the forward is invalid (R > capacity, or level-1 overflow).  The caller reads the header later.
     const bool nosync = binning_capacity > 0 && two_level;
     if (binning_capacity > 0xFFFFFFFEll) binning_capacity = 0xFFFFFFFEll;  // (0xFFFFFFFF is the saturated count of k_tile_scan: never valid)
+    if (speculative) {
+        if (!pin_dev) HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 32, hipMemcpyDeviceToHost, s));
+        if (!g_scan_ev.e) HIP_TRY(hipEventCreateWithFlags(&g_scan_ev.e, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(g_scan_ev.e, s));
+    }
     int64_t R = 0;
     uint32_t n_chunks = 0;
-    if (nosync) {
-        R = binning_capacity;
-        // the chunk count lives on the device: the passes are grid-stride loops over it; the caller may know better than the
-        // capacity bound how many workgroups are worth launching (idle 512-thread workgroups are not free to dispatch)
-        n_chunks = B2.chunk_cap < 8192u ? B2.chunk_cap : 8192u;
-        if (opts->chunk_grid && opts->chunk_grid < n_chunks) n_chunks = opts->chunk_grid;
-    } else {
-        // words 0-3: the tile scan's header (R, ...); words 4-6: the two-level binning's (R1, chunks, overflow)
-        if (!pin_dev) HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 32, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));  // the one host round trip of the forward (rasterizer_impl.cu:280-281)
+    // everything behind the tile scan: list allocation, list-write pass, blend, post-blend bookkeeping
+    char* binning = nullptr;
+    auto tail = [&](int64_t R_, bool nosync_, uint32_t n_chunks_) -> int {
+        const BinLayout BL = sgr_bin_layout(R_, IL.T);
+        binning = binning_alloc(binning_user, BL.total);
+        if (!binning) return fail(SGR_E_ALLOC, "binning scratch allocation failed");
+        uint32_t* point_list = reinterpret_cast<uint32_t*>(binning + BL.point_list);
+        unsigned long long* blk_mask = reinterpret_cast<unsigned long long*>(binning + BL.blk_mask);
+        if (R_ > 0) {
+            StageTimer t(s, SGR_STAGE_SCATTER);
+            if (two_level)
+                sgr_launch_bin2_write(IL.gx, IL.gy, B2, bin2, header + 4, n_chunks_, rects, order, tile_start, point_list,
+                                      nosync_ ? (uint32_t)R_ : 0xFFFFFFFFu, opts->tile_need, s);
+            else
+                sgr_launch_bin_scatter(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, tile_start, blk_hist, point_list, s);
+        }
+        STAGE_CHECK("bin_scatter");
+        {
+            StageTimer t(s, SGR_STAGE_BLEND_FWD);
+            sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
+                                 tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, (uint32_t)R_, opts->tile_need,
+                                 opts->tile_order, s);
+        }
+        if (flags & SGR_FLAG_DEFER_POST) {  // (the caller's next kernel carries the post-blend job: sgr_forward_post_job)
+            STAGE_CHECK("blend_fwd");
+            return 0;
+        }
+        sgr_launch_blend_fwd_post(IL.gx, IL.gy, tile_maxc, tile_walked, header, (uint32_t)R_, opts->tile_need_out, opts->hint_margin, hh_dev,
+                                  tile_cursor, opts->tile_order_out, s);
+        STAGE_CHECK("blend_fwd");
+        // ... and once more behind the blend: word 3 (hint miss) is final only now
+        if (opts->header_host && !hh_dev) HIP_TRY(hipMemcpyAsync(opts->header_host + 8, header, 32, hipMemcpyDeviceToHost, s));
+        if (opts->header_event) HIP_TRY(hipEventRecord((hipEvent_t)opts->header_event, s));
+        return 0;
+    };
+    // the host round trip of the forward (rasterizer_impl.cu:280-281) and what hangs on it: the single-level fallback on a level-1
+    // overflow, the instance count, the chunk count
+    auto read_header = [&](bool already_waited) -> int {
+        if (!already_waited) {
+            if (!pin_dev) HIP_TRY(hipMemcpyAsync(g_pinned.p, header, 32, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
         if (two_level && g_pinned.p[4 + SGR_B2_HDR_OVERFLOW]) {
             // more (Gaussian, super-tile) pairs than the level-1 list holds (huge splats): the single-level path has no such limit
             if (!legacy_ok)
@@ -273,42 +338,48 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
         R = (int64_t)g_pinned.p[SGR_HDR_R];
         if (R >= 0xFFFFFFFFll) return fail(SGR_E_INVALID, "more than 2^32 - 2 (Gaussian, tile) instances in one view");
         n_chunks = g_pinned.p[4 + SGR_B2_HDR_CHUNKS];
+        return 0;
+    };
+    if (opts->info) { opts->info->speculation = 0; }
+    if (nosync) {
+        R = binning_capacity;
+        // the chunk count lives on the device: the passes are grid-stride loops over it; the caller may know better than the
+        // capacity bound how many workgroups are worth launching (idle 512-thread workgroups are not free to dispatch)
+        n_chunks = B2.chunk_cap < 8192u ? B2.chunk_cap : 8192u;
+        if (opts->chunk_grid && opts->chunk_grid < n_chunks) n_chunks = opts->chunk_grid;
+    } else {
+        const int rc = read_header(false);
+        if (rc < 0) return rc;
     }
     if (opts->info) { opts->info->binning_mode = two_level ? 0 : 1; opts->info->sync_free = nosync ? 1 : 0; }
     if (opts->tile_need && !two_level) return fail(SGR_E_INVALID, "the walk hint needs the two-level binning (level-1 overflow on this view)");
-
-    const BinLayout BL = sgr_bin_layout(R, IL.T);
-    char* binning = binning_alloc(binning_user, BL.total);
-    if (!binning) return fail(SGR_E_ALLOC, "binning scratch allocation failed");
-    uint32_t* point_list = reinterpret_cast<uint32_t*>(binning + BL.point_list);
-    unsigned long long* blk_mask = reinterpret_cast<unsigned long long*>(binning + BL.blk_mask);
-
-    if (R > 0) {
-        StageTimer t(s, SGR_STAGE_SCATTER);
-        if (two_level)
-            sgr_launch_bin2_write(IL.gx, IL.gy, B2, bin2, header + 4, n_chunks, rects, order, tile_start, point_list,
-                                  nosync ? (uint32_t)R : 0xFFFFFFFFu, opts->tile_need, s);
-        else
-            sgr_launch_bin_scatter(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, tile_start, blk_hist, point_list, s);
-    }
-    STAGE_CHECK("bin_scatter");
     {
-        StageTimer t(s, SGR_STAGE_BLEND_FWD);
-        sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
-                             tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, (uint32_t)R, opts->tile_need,
-                             opts->tile_order, s);
+        const int rc = tail(R, nosync, n_chunks);
+        if (rc < 0) return rc;
     }
-    if (flags & SGR_FLAG_DEFER_POST) {  // (the caller's next kernel carries the post-blend job: sgr_forward_post_job)
-        if (opts->header_host && !hh_dev) return fail(SGR_E_INVALID, "SGR_FLAG_DEFER_POST needs a device-mapped header_host");
-        STAGE_CHECK("blend_fwd");
+    if (!speculative) {
+        layout_set(binning, 0);
         return R;
     }
-    sgr_launch_blend_fwd_post(IL.gx, IL.gy, tile_maxc, tile_walked, header, (uint32_t)R, opts->tile_need_out, opts->hint_margin, hh_dev,
-                              tile_cursor, opts->tile_order_out, s);
-    STAGE_CHECK("blend_fwd");
-    // ... and once more behind the blend: word 3 (hint miss) is final only now
-    if (opts->header_host && !hh_dev) HIP_TRY(hipMemcpyAsync(opts->header_host + 8, header, 32, hipMemcpyDeviceToHost, s));
-    if (opts->header_event) HIP_TRY(hipEventRecord((hipEvent_t)opts->header_event, s));
+    // ---- speculative: the tile scan's header has long arrived (list-write pass and blend are queued behind it)
+    HIP_TRY(hipEventSynchronize(g_scan_ev.e));
+    const bool overflow = g_pinned.p[4 + SGR_B2_HDR_OVERFLOW] != 0u;
+    const int64_t R_true = (int64_t)g_pinned.p[SGR_HDR_R];
+    if (!overflow && R_true <= binning_capacity) {
+        layout_set(binning, binning_capacity);
+        if (opts->info) opts->info->speculation = 1;
+        return R_true;
+    }
+    // a miss: the kernels queued above were no-ops (SGR_FORWARD_INVALID); the same tail once more with the true count
+    {
+        int rc = read_header(true);
+        if (rc < 0) return rc;
+        if (opts->info) { opts->info->binning_mode = two_level ? 0 : 1; opts->info->sync_free = 0; opts->info->speculation = 2; }
+        if (opts->tile_need && !two_level) return fail(SGR_E_INVALID, "the walk hint needs the two-level binning (level-1 overflow on this view)");
+        rc = tail(R, false, n_chunks);
+        if (rc < 0) return rc;
+    }
+    layout_set(binning, 0);
     return R;
 }
 
@@ -375,7 +446,7 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
     if (phase != 0 && !compact) return fail(SGR_E_INVALID, "the two-phase backward is for the compact SH mode");
 
     const ImgLayout IL = sgr_img_layout(width, height);
-    const BinLayout BL = sgr_bin_layout(R, IL.T);
+    const BinLayout BL = sgr_bin_layout(layout_get(binning_buffer, R), IL.T);  // (a speculative forward laid the list out for its capacity)
     const GeomRec* rec = reinterpret_cast<const GeomRec*>(geom_buffer);
     const float* final_T = reinterpret_cast<const float*>(img_buffer + IL.final_T);
     const uint32_t* n_contrib = reinterpret_cast<const uint32_t*>(img_buffer + IL.n_contrib);

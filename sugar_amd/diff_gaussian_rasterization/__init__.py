@@ -32,9 +32,25 @@ from .. import _lib
 # (sgr_forward_ex): no host round trip for num_rendered; the caller checks the header (a backward on an invalid forward is a
 # no-op on the device).  `tile_need=` / `tile_need_out=` (int32[tiles] device tensors): the walk hint of sgr_forward_opts;
 # `tile_order=` / `tile_order_out=` (int32[tiles]): its launch order (deepest tiles first, written by the previous visit).
+# `speculative=False`: this call takes the plain host round trip for num_rendered instead of the speculative forward (below).
 # `single_level_binning=True`: SGR_FLAG_SINGLE_LEVEL_BINNING.  `dens_stats=(max_radii2D, grad_accum, denom)` (float[P]
 # device tensors): the densification statistics of train.py:111-123 fused into the backward (sgr_backward_opts).
 _GRAD_SINK: dict = {}
+
+# Speculative forward (SGR_FLAG_SPECULATIVE, the default for callers that ask for nothing else): the reference's forward waits for
+# num_rendered in the middle of the pipeline (rasterizer_impl.cu:280-281) with the GPU idle.  From the second call with the same
+# (device, P, W, H) on, the forward is enqueued whole with a list capacity of 1.5 x the largest count seen so far, and the one wait --
+# for the header the tile scan writes -- happens at the END of the call, with the list pass and the blend kernel queued behind it.
+# The call still returns the true num_rendered; a count beyond the capacity costs a repeat of the two tail kernels, never a wrong
+# image.  SGR_SPECULATIVE_FORWARD=0 switches it off process-wide.
+import os as _os
+_SPECULATE = _os.environ.get("SGR_SPECULATIVE_FORWARD", "1") != "0"
+_SPEC_CAP: dict = {}  # (device index, P, W, H) -> largest num_rendered seen
+
+
+def _spec_capacity(key):
+    r = _SPEC_CAP.get(key)
+    return 0 if not r else r + r // 2 + 65536
 
 
 @contextlib.contextmanager
@@ -163,11 +179,18 @@ class _CModule:
             # num_rendered <= n and word 6 == 0) before running the backward, and repeat the forward otherwise
             sink = _GRAD_SINK or {}
             capacity = int(sink.get("binning_capacity") or 0)
+            spec_key = (dev.index, P, W, H)
+            speculate = (_SPECULATE and capacity == 0 and sink.get("speculative", True) and not sink.get("single_level_binning")
+                         and sink.get("tile_need") is None)
+            if speculate:
+                capacity = _spec_capacity(spec_key)
+                speculate = capacity > 0
             # `raw_params=True`: scales / rotations / opacities are the raw 3DGS parameters, activated inside the kernels
             flags = (_lib.SGR_FLAG_RAW_PARAMS if sink.get("raw_params") else 0) | \
-                    (_lib.SGR_FLAG_SINGLE_LEVEL_BINNING if sink.get("single_level_binning") else 0)
+                    (_lib.SGR_FLAG_SINGLE_LEVEL_BINNING if sink.get("single_level_binning") else 0) | \
+                    (_lib.SGR_FLAG_SPECULATIVE if speculate else 0)
             hdr_out, hdr_ev = sink.get("header_out"), sink.get("header_event")
-            if capacity > 0 and (hdr_out is None or hdr_ev is None):
+            if capacity > 0 and not speculate and (hdr_out is None or hdr_ev is None):
                 raise RuntimeError("binning_capacity needs header_out (pinned int32[16]) and header_event (torch.cuda.Event)")
             if hdr_out is not None and not (hdr_out.is_pinned() and hdr_out.numel() >= 16 and hdr_out.dtype == torch.int32):
                 raise RuntimeError("header_out must be a pinned int32 tensor of 16 elements")
@@ -191,10 +214,15 @@ class _CModule:
                 hdr_ev.record(torch.cuda.current_stream(dev))
         if rendered < 0:
             raise RuntimeError(f"sgr_forward failed ({rendered}): {_lib.last_error()}")
+        if _SPECULATE and (speculate or not info.sync_free):  # (the count is the true one in both cases)
+            if int(rendered) > _SPEC_CAP.get(spec_key, 0):
+                _SPEC_CAP[spec_key] = int(rendered)
         t = scratch.release()
         # introspection only (bench.py's roofline accounting, parity tests): the most recent forward's scratch
         _CModule.last_forward = dict(num_rendered=int(rendered), W=W, H=H, P=P, geom=t["geom"], binning=t["binning"],
-                                     img=t["img"], binning_mode=int(info.binning_mode), sync_free=bool(info.sync_free))
+                                     img=t["img"], binning_mode=int(info.binning_mode), sync_free=bool(info.sync_free),
+                                     speculative=bool(speculate), speculation_missed=int(info.speculation) == 2,
+                                     list_capacity=capacity if (speculate and int(info.speculation) == 1) else int(rendered))
         return int(rendered), out_color, radii, t["geom"], t["binning"], t["img"]
 
     @staticmethod

@@ -252,3 +252,42 @@ def test_twenty_iterations_of_the_reference_loop_against_the_native_trainer():
     assert float((d[:, :1] > 2 * 0.0025).float().mean()) < 0.02 and float(d[:, :1].median()) < 0.05 * 0.0025
     # densification statistics of the loop (train.py:111-114) exist and saw the views
     assert float(gaussians.denom.sum()) > 0 and float(gaussians.max_radii2D.max()) > 0
+
+
+def test_the_standalone_sampler_equals_the_reference_class_on_the_gaussian_depth_path(sm):
+    """sugar_amd.sampler.sample_level_sets (raw Gaussian buffers + a plain camera tuple: what bench.py's config-4 line runs) against
+    `SuGaR.compute_level_surface_points_from_camera_fast(use_gaussian_depth=True)` of the reference's own class with its own camera
+    objects (routed to the same kernels by shims.install(patch_sugar=True), which the round-3 fixtures pin to the reference's
+    tensor code): same pixels picked (CPU permutation, same seed), same front Gaussians, same crossing points and normals."""
+    from sugar_amd import sampler, shims, sugar_patch
+    state = np.load(os.path.join(GOLD, "sugar_field.npz"))
+    W, H = int(state["W"]), int(state["H"])
+    model, cams = _free_model(sm, state, W, H)
+    scale = float(np.exp(state["state_scales"]).mean())
+    cam_idx = 3
+    c = cams[cam_idx]
+    cam = syn.Camera(c.image_height, c.image_width, c.tanfovx, c.tanfovy, c.viewmatrix.to(DEV), c.projmatrix.to(DEV), c.campos.to(DEV))
+    n_sub = 1500
+    shims.install(patch_sugar=sm)
+    try:
+        model._sugar_amd_cpu_randperm = True
+        with torch.no_grad():
+            torch.manual_seed(11)
+            ref = model.compute_level_surface_points_from_camera_fast(
+                cam_idx=cam_idx, surface_levels=[0.1, 0.3, 0.5], n_surface_points=n_sub, n_points_in_range=21, range_size=3.,
+                density_factor=1., return_pixel_idx=True, return_gaussian_idx=True, return_normals=True, use_gaussian_depth=True)
+            torch.manual_seed(11)
+            got = sampler.sample_level_sets(model.points, model.scaling, model.quaternions, model.strengths, cam,
+                                            n_surface_points=n_sub, cpu_randperm=True)
+    finally:
+        sugar_patch.uninstall(sm)
+    for lv in (0.1, 0.3, 0.5):
+        a, b = got[lv], ref[lv]
+        pa, pb = a["pixel_idx"].cpu().numpy(), b["pixel_idx"].cpu().numpy()
+        common, ia, ib = np.intersect1d(pa, pb, return_indices=True)
+        assert len(pb) > 100 and len(common) >= 0.99 * max(len(pa), len(pb)), (lv, len(pa), len(pb), len(common))
+        assert (a["gaussian_idx"].cpu().numpy()[ia] == b["gaussian_idx"].cpu().numpy()[ib]).mean() > 0.995
+        d = np.linalg.norm(a["intersection_points"].cpu().numpy()[ia] - b["intersection_points"].cpu().numpy()[ib], axis=1)
+        assert np.quantile(d, 0.99) < 2e-3 * scale, (lv, np.quantile(d, 0.99), scale)
+        dots = (a["normals"].cpu().numpy()[ia] * b["normals"].cpu().numpy()[ib]).sum(axis=1)
+        assert np.quantile(dots, 0.01) > 0.9999
