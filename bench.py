@@ -116,6 +116,7 @@ def main():
     forward_only = args.forward_only or args.workload == "config5"
 
     scene, cams, bg = syn.make_config(args.workload, P=args.gaussians)
+    _CHILD.update(workload=args.workload, gaussians=args.gaussians)
     P = scene.means3D.shape[0]
     W, H = cams[0].image_width, cams[0].image_height
     cams_d = [c._replace(viewmatrix=c.viewmatrix.to(dev), projmatrix=c.projmatrix.to(dev), campos=c.campos.to(dev)) for c in cams]
@@ -657,7 +658,8 @@ class ForwardOnly:
                     scale_modifier=1.0, viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix, sh_degree=3, campos=cam.campos,
                     prefiltered=False, debug=False)
         t = self.t
-        cm = grad_sink(binning_capacity=capacity, header_out=self.hdr, header_event=self.ev) if capacity else contextlib.nullcontext()
+        cm = (grad_sink(binning_capacity=capacity, header_out=self.hdr, header_event=self.ev) if capacity else
+              grad_sink(speculative=False) if self.host_sync else contextlib.nullcontext())
         with torch.no_grad(), cm:
             self.R(st)(t["means3D"], self.m2, t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
 
@@ -825,36 +827,100 @@ def unmodified_path_legs(scene, cams, gts, bg_d, dev, n_steps):
     return out
 
 
-def cpu_baseline(scene, cam, bg, forward_only=False):
+def cpu_baseline(scene, cam, bg, forward_only=False, mode="sh", eight_threads=True):
     """The CPU oracle (a port of the reference rasterizer, oracle/cpu_rasterizer.c) on the host cores: rasterizer
-    forward + backward of ONE view of the same workload; one warm-up run, then the median of three."""
+    forward + backward of ONE view of the same workload; one warm-up run, then the median of three.  `mode="coarse_sdf"`: the two
+    rasterizer calls of the config-3 step (colors_precomp RGB, then depth as colour with bg = max depth), forward + backward each.
+    `eight_threads`: the same sample once more on 8 threads (the core count BASELINE.md section 2 planned for: comparable across
+    boxes), in a child process with a time limit."""
     from oracle import cpu_oracle as orc
+    from sugar_amd import synthetic as syn
     cores = os.cpu_count() or 1
-    orc.set_threads(cores)
     H, W = cam.image_height, cam.image_width
     g = np.random.default_rng(0).standard_normal((3, H, W)).astype(np.float32)
-    kw = dict(shs=scene.shs.numpy(), scales=scene.scales.numpy(), rotations=scene.rotations.numpy(),
-              viewmatrix=cam.viewmatrix.numpy(), projmatrix=cam.projmatrix.numpy(), campos=cam.campos.numpy(),
-              bg=bg.numpy(), W=W, H=H, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy)
+    base = dict(scales=scene.scales.numpy(), rotations=scene.rotations.numpy(), viewmatrix=cam.viewmatrix.numpy(),
+                projmatrix=cam.projmatrix.numpy(), campos=cam.campos.numpy(), W=W, H=H, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy)
+    if mode == "coarse_sdf":
+        pd, bg_depth = syn.depth_as_colour(scene.means3D, cam.viewmatrix)
+        passes = [dict(colors_precomp=syn.sh_to_rgb(scene.shs, scene.means3D, cam.campos).numpy(), bg=bg.numpy(), sh_degree=0),
+                  dict(colors_precomp=pd.numpy(), bg=bg_depth.numpy(), sh_degree=0)]
+    else:
+        passes = [dict(shs=scene.shs.numpy(), bg=bg.numpy())]
+
+    def one_run():
+        tf = tb = 0.0
+        for kw in passes:
+            t0 = time.perf_counter()
+            st = orc.forward(scene.means3D.numpy(), scene.opacities.numpy(), **base, **kw)
+            t1 = time.perf_counter()
+            if not forward_only:
+                orc.backward(st, g)
+            t2 = time.perf_counter()
+            tf += t1 - t0; tb += t2 - t1
+        return tf + tb, tf, tb
+
+    if os.environ.get("SGR_CPU_BASELINE_CHILD"):  # the 8-thread child: one run, no warm-up
+        orc.set_threads(8)
+        return one_run()
+    orc.set_threads(cores)
     runs = []
     for it in range(4):
-        t0 = time.perf_counter()
-        st = orc.forward(scene.means3D.numpy(), scene.opacities.numpy(), **kw)
-        t1 = time.perf_counter()
-        if not forward_only:
-            orc.backward(st, g)
-        t2 = time.perf_counter()
+        r = one_run()
         if it > 0:  # (the first run is the warm-up)
-            runs.append((t2 - t0, t1 - t0, t2 - t1))
+            runs.append(r)
         if it == 1 and runs[0][0] > 12.0:
             break   # bounded sample: a workload this slow on the host gets one timed run
     runs.sort()
     tot, tf, tb = runs[len(runs) // 2]
-    return {"value": 1.0 / tot, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 view, rasterizer forward ({tf:.2f} s)" + ("" if forward_only else f" + backward ({tb:.2f} s)") +
-                      f" only (no loss/Adam), {scene.means3D.shape[0]} Gaussians @ {W}x{H}, OpenMP over {cores} threads "
-                      f"(binning sort is single-threaded); 1 warm-up run, median of {len(runs)}"}
+    what = ("2 rasterizer calls (colors_precomp RGB; depth as colour, bg = max depth)" if mode == "coarse_sdf" else "rasterizer")
+    out = {"value": 1.0 / tot, "unit": "images/s", "cores": cores, "kind": "port",
+           "sample": f"1 view, {what} forward ({tf:.2f} s)" + ("" if forward_only else f" + backward ({tb:.2f} s)") +
+                     f" only (no loss/Adam), {scene.means3D.shape[0]} Gaussians @ {W}x{H}, OpenMP over {cores} threads "
+                     f"(binning sort is single-threaded); 1 warm-up run, median of {len(runs)}"}
+    if eight_threads:
+        out["eight_threads"] = _cpu_baseline_child(forward_only, mode)
+    return out
+
+
+def _cpu_baseline_child(forward_only, mode, limit_s=150):
+    """the same sample on 8 threads, in a child process (a run that would take minutes is cut off and reported as such)"""
+    import subprocess
+    args = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--workload", _CHILD["workload"]]
+    if _CHILD["gaussians"]:
+        args += ["--gaussians", str(_CHILD["gaussians"])]
+    if forward_only:
+        args.append("--forward-only")
+    env = dict(os.environ, SGR_CPU_BASELINE_CHILD=mode, OMP_NUM_THREADS="8")
+    try:
+        r = subprocess.run(args, env=env, capture_output=True, text=True, timeout=limit_s)
+        tot, tf, tb = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"value": 1.0 / tot, "unit": "images/s", "cores": 8, "forward_s": tf, "backward_s": tb,
+                "sample": "the same sample, one run without warm-up, OMP_NUM_THREADS=8 (the core count BASELINE.md section 2 planned)"}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "cores": 8, "sample": f"cut off after {limit_s} s (bounded sample)"}
+    except Exception as e:  # a side figure: never take the graded line down with it
+        return {"value": None, "cores": 8, "error": repr(e)[:200]}
+
+
+_CHILD = {"workload": "metric", "gaussians": None}
+
+
+def _child_main():
+    """`bench.py --cpu-baseline-child`: the 8-thread leg of cpu_baseline (no GPU, no torch.cuda)"""
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cpu-baseline-child", action="store_true")
+    ap.add_argument("--workload", default="metric")
+    ap.add_argument("--gaussians", type=int, default=None)
+    ap.add_argument("--forward-only", action="store_true")
+    a = ap.parse_args()
+    from sugar_amd import synthetic as syn
+    scene, cams, bg = syn.make_config(a.workload, P=a.gaussians)
+    mode = os.environ.get("SGR_CPU_BASELINE_CHILD", "sh")
+    print(json.dumps(cpu_baseline(scene, cams[0], bg, a.forward_only or a.workload == "config5", mode=mode, eight_threads=False)))
 
 
 if __name__ == "__main__":
-    main()
+    if "--cpu-baseline-child" in sys.argv:
+        _child_main()
+    else:
+        main()

@@ -425,6 +425,9 @@ const char* sgr_trainer_last_error(void);
 int sgr_rccl_unique_id(char* out128);
 int sgr_trainer_comm_init(sgr_trainer* t, const char* id128, int world, int rank, float* recv, size_t recv_bytes);
 int sgr_trainer_comm_destroy(sgr_trainer* t);
+/* A rank that hit an error no repeat of the step repairs calls this before it gives up: the communicator is ABORTED (ncclCommAbort),
+ * so that the other ranks' pending collectives fail instead of waiting for ever for a peer that will not join. */
+int sgr_trainer_comm_abort(sgr_trainer* t);
 int sgr_trainer_step_exchange(sgr_trainer* t, const sgr_train_view* view, int step, void* stream);
 double sgr_trainer_last_exchange_wait_ms(sgr_trainer* t); /* host time the last call spent waiting for the forward's header */
 size_t sgr_bin2_bytes(int P, int width, int height); /* scratch of the two-level binning appended to the image scratch */
@@ -477,8 +480,10 @@ int sgr_density_field_backward_gather(int N, int K, int P, const float* x, const
  * out[p, 0..W) = sum over { n : idx[n] == p } of src[n, 0..W): what autograd computes for `x[idx]` (x: [P, W] float32, idx: N int64
  * entries, src = the incoming gradient [N, W]) -- the scatter-add of SURVEY.md section 8 row a21, met by SuGaR's regulariser at
  * sugar_model.py:922-925 and coarse_sdf.py:690-692.  W in 1..4; every row of `out` is WRITTEN (rows without entries get zeros);
- * negative indices wrap once, entries outside [-P, P) are ignored; N < 2^32.  The entries of a row are added in the order of the
- * entries (stable radix grouping): the result is reproducible bit for bit.  scratch: sgr_scatter_add_rows_scratch_bytes(N, P) bytes of device memory.  No host synchronisation. */
+ * negative indices wrap once, entries outside [-P, P) are ignored; N < 2^32.  The sum of a row is deterministic -- the entries are
+ * grouped stably by row, sixteen lanes take every sixteenth entry of the group and their partial sums are folded in a fixed order --
+ * so the result is reproducible bit for bit from run to run; it is NOT the sequential left-to-right sum of the entries (a CPU
+ * `index_add` differs in the last bits).  scratch: sgr_scatter_add_rows_scratch_bytes(N, P) bytes of device memory.  No host synchronisation. */
 size_t sgr_scatter_add_rows_scratch_bytes(long long N, int P);
 int sgr_scatter_add_rows(long long N, const int64_t* idx, const float* src, int W, int P, float* out, char* scratch, void* stream);
 

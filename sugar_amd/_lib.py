@@ -38,6 +38,7 @@ SIGNATURES = {
     "sgr_rccl_unique_id": (_i, [_vp]),
     "sgr_trainer_comm_init": (_i, [_vp, _vp, _i, _i, _vp, _sz]),
     "sgr_trainer_comm_destroy": (_i, [_vp]),
+    "sgr_trainer_comm_abort": (_i, [_vp]),
     "sgr_trainer_step_exchange": (_i, [_vp, _vp, _i, _vp]),
     "sgr_trainer_last_exchange_wait_ms": (C.c_double, [_vp]),
     "sgr_bin2_bytes": (_sz, [_i, _i, _i]),

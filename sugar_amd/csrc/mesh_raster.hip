@@ -495,6 +495,8 @@ int64_t sgr_rasterize_meshes(const float* face_verts, int64_t F, int64_t face_in
         MR_HIP(hipStreamSynchronize(s));
     }
     const int64_t R = (int64_t)g_hdr.p[SGR_HDR_R];
+    // (k_tile_scan saturates the count at 2^32 - 1: the offsets of such a list have wrapped, as in sgr_forward_ex)
+    if (R >= 0xFFFFFFFFll) return sgr_fail(SGR_E_INVALID, "rasterize_meshes: more than 2^32 - 2 (tile, face) instances in one view");
     const uint32_t n_chunks = g_hdr.p[4 + SGR_B2_HDR_CHUNKS];
     char* list = list_alloc(list_user, (size_t)(R > 0 ? R : 1) * 4 + 256);
     if (!list) return sgr_fail(SGR_E_ALLOC, "rasterize_meshes: instance list allocation failed");

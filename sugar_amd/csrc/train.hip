@@ -36,6 +36,7 @@ struct Rccl {
     int (*GetUniqueId)(RcclUniqueId*) = nullptr;
     int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
     int (*CommDestroy)(RcclComm) = nullptr;
+    int (*CommAbort)(RcclComm) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -59,6 +60,7 @@ Rccl& rccl()
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.handle, "ncclCommAbort"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.handle, "ncclAllGather"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.handle, "ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
@@ -272,6 +274,7 @@ int sgr_trainer_comm_init(sgr_trainer* t, const char* id128, int world, int rank
     if (recv_bytes < (size_t)world * ((size_t)t->c.P + 1) * 3 * sizeof(float))
         return tfail(SGR_E_INVALID, "sgr_trainer_comm_init: receive buffer smaller than world x (P + 1) x 3 floats");
     if (t->comm) return tfail(SGR_E_INVALID, "sgr_trainer_comm_init: already initialised");
+    if (world > 85) return tfail(SGR_E_INVALID, "sgr_trainer_comm_init: at most 85 ranks (k_gather_campos gathers 3 x world floats in one workgroup)");
     Rccl& r = rccl();
     if (!r.ok()) return tfail(SGR_E_INVALID, "RCCL could not be loaded (librccl.so)");
     RcclUniqueId id;
@@ -285,6 +288,17 @@ int sgr_trainer_comm_init(sgr_trainer* t, const char* id128, int world, int rank
     ok = ok && hipMalloc(reinterpret_cast<void**>(&t->campos_all), (size_t)world * 3 * sizeof(float)) == hipSuccess;
     if (!ok) { (void)sgr_trainer_comm_destroy(t); return tfail(SGR_E_HIP, "sgr_trainer_comm_init: stream / event / buffer creation failed"); }
     return 0;
+}
+
+// A rank that cannot go on (an error no repeat of the step repairs) tears its communicator down instead of leaving the others
+// blocked in the collective it will never join: their pending RCCL calls then fail with an error instead of waiting for ever.
+int sgr_trainer_comm_abort(sgr_trainer* t)
+{
+    if (!t || !t->comm) return 0;
+    Rccl& r = rccl();
+    if (r.CommAbort) (void)r.CommAbort(t->comm); else (void)r.CommDestroy(t->comm);
+    t->comm = nullptr;
+    return sgr_trainer_comm_destroy(t);
 }
 
 double sgr_trainer_last_exchange_wait_ms(sgr_trainer* t) { return t ? t->last_wait_ms : 0.0; }
@@ -342,7 +356,6 @@ int sgr_trainer_step_exchange(sgr_trainer* t, const sgr_train_view* v, int step,
     EX_TRY(hipEventRecord(t->ev_reduced, t->comm_stream), "record reduced");
     EX_TRY(hipStreamWaitEvent(s, t->ev_gathered, 0), "wait gathered");
     hipLaunchKernelGGL(k_gather_campos, dim3(1), dim3(256), 0, s, t->world, block, 3 * P, t->recv, t->campos_all);
-    if (t->world > 85) return tfail(SGR_E_INVALID, "more than 85 ranks");
     sgr_train_exchange ex;
     std::memset(&ex, 0, sizeof(ex));
     ex.n_views = t->world; ex.all_colors = t->recv; ex.view_stride = (int64_t)(P + 1); ex.all_campos = t->campos_all;

@@ -53,22 +53,32 @@ class FusedAdam(torch.optim.Adam):
                 loss = closure()
         lib = _lib.load()
         one = (C.c_longlong * 1)
+        # Everything a launch can reject is prepared BEFORE any state changes (a step that failed half way would leave some
+        # parameters updated and some step counters advanced): dense, 16-byte aligned storage for parameter, gradient and moments.
+        # `.contiguous()` returns the SAME storage for a contiguous tensor at an odd offset (a `[1:]` slice): those get a real copy.
+        def dense16(t):
+            return t if (t.is_contiguous() and t.data_ptr() % 16 == 0) else t.detach().clone(memory_format=torch.contiguous_format)
+        plan = []
         for group, p in todo:
             state = self.state[p]
             if len(state) == 0:       # (torch.optim.Adam._init_group)
                 state["step"] = torch.tensor(0.0, dtype=torch.float32)
-                state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            state["step"] += 1
-            m, v = state["exp_avg"], state["exp_avg_sq"]
+                state["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
             # A strided parameter -- SuGaR's `_scales` / `_quaternions` are column slices of one [1, P, 7] tensor until the first
-            # pruning (sugar_model.py:313-318) -- is updated in a dense copy and written back; its moments are dense already
-            # (zeros_like of a tensor with gaps is contiguous).
-            dense = p if (p.is_contiguous() and p.data_ptr() % 16 == 0) else p.detach().contiguous()
-            grad = p.grad if (p.grad.is_contiguous() and p.grad.data_ptr() % 16 == 0) else p.grad.contiguous()
-            if not (m.is_contiguous() and v.is_contiguous()):
-                m = state["exp_avg"] = m.contiguous()
-                v = state["exp_avg_sq"] = v.contiguous()
+            # pruning (sugar_model.py:313-318) -- is updated in a dense copy and written back.
+            dense, grad = dense16(p), dense16(p.grad)
+            m, v = dense16(state["exp_avg"]), dense16(state["exp_avg_sq"])
+            if any(t.data_ptr() % 16 != 0 for t in (dense, grad, m, v)):
+                STATS["fallback_steps"] += 1
+                STATS["last_fallback_reason"] = "allocator returned storage that is not 16-byte aligned"
+                STATS["fused_steps"] -= 1
+                super().step(None)
+                return loss
+            plan.append((group, p, state, dense, grad, m, v))
+        for group, p, state, dense, grad, m, v in plan:
+            state["step"] += 1
+            state["exp_avg"], state["exp_avg_sq"] = m, v
             lr = float(group["lr"])
             b1, b2 = group["betas"]
             n = p.numel()

@@ -7,7 +7,7 @@ reduction: 46 % of the GPU time of an SDF iteration on an MI355X once the raster
 `sgr_scatter_add_rows` (csrc/field.hip) does it with a stable radix grouping of the entries by row and sixteen lanes per row.
 
 Nothing in the reference is edited: `RowGatherTensor` is a `torch.Tensor` subclass whose only behaviour is that indexing it with an
-int64 CUDA tensor goes through `row_gather` (same values; the gradient's additions run in entry order, reproducibly); every other
+int64 CUDA tensor goes through `row_gather` (same values; the gradient is a deterministic fixed-order sum -- sixteen strided partial sums per row over the stably grouped entries -- reproducible bit for bit, though not the sequential entry-order sum); every other
 operation on it is the plain operation and returns plain tensors.  `sugar_amd.sugar_patch.install_row_gathers` makes the SuGaR
 properties `points`, `scaling`, `quaternions` and the method `get_normals` return their usual tensor viewed as this subclass."""
 from __future__ import annotations

@@ -33,8 +33,9 @@ def install(patch_sugar=False, patch_losses=False, patch_optimizer=False, patch_
     `patch_optimizer`: the `torch.optim.Adam` instances the reference builds step on the one-launch HIP Adam (install_optimizer).
     `patch_gathers`: `SuGaR.points / scaling / quaternions / get_normals()` return tensors whose row gathers `x[idx]` have a HIP
     backward (sugar_amd.sugar_patch.install_row_gathers); pass the module like `patch_sugar`, or True."""
+    real_plyfile = _real_package("plyfile")  # (probed BEFORE the stand-in directory can shadow it on sys.path)
     mode = _install_pytorch3d()
-    _install_plyfile()
+    _install_plyfile(real_plyfile)
     if patch_losses:
         install_losses()
     if patch_optimizer:
@@ -145,14 +146,31 @@ def uninstall_optimizer() -> int:
     return count
 
 
-def _install_plyfile() -> None:
-    """`plyfile` (gaussian_model.py:18, dataset_readers.py:22) is not in the ROCm image: when it cannot be imported, the
-    stand-in under this directory (vertex elements of binary PLY files only) takes the name"""
+def _real_package(name: str):
+    """the module spec of an installed `name` that is NOT the stand-in under this directory, or None"""
     try:
-        if importlib.util.find_spec("plyfile") is not None:
-            return
+        spec = importlib.util.find_spec(name)
     except (ImportError, ValueError):
-        pass
+        return None
+    if spec is None or spec.origin is None or os.path.abspath(spec.origin).startswith(_HERE):
+        return None
+    return spec
+
+
+def _install_plyfile(real_spec=None) -> None:
+    """`plyfile` (gaussian_model.py:18, dataset_readers.py:22) is not in the ROCm image: when no real package exists, the stand-in
+    under this directory (vertex elements of binary little-endian PLY files only) takes the name.  A real `plyfile` always wins:
+    this directory also holds the `pytorch3d` stand-in and may sit at the front of sys.path on a box that has plyfile but no
+    pytorch3d, so the real module is imported from its own location and pinned in sys.modules."""
+    if real_spec is not None:
+        mod = sys.modules.get("plyfile")
+        if mod is None or os.path.abspath(getattr(mod, "__file__", "") or "").startswith(_HERE):
+            mod = importlib.util.module_from_spec(real_spec)
+            sys.modules["plyfile"] = mod
+            real_spec.loader.exec_module(mod)
+        return
+    if "plyfile" in sys.modules:
+        return
     if _HERE not in sys.path:
         sys.path.insert(0, _HERE)
     importlib.invalidate_caches()

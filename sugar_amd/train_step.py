@@ -133,8 +133,35 @@ class GaussianParams:
     REST_LR = 0.0025 / 20.0
 
     def __init__(self, scene, device):
-        P = scene.means3D.shape[0]
-        M = scene.shs.shape[1]
+        self._layout(scene.means3D.shape[0], scene.shs.shape[1], device)
+        with torch.no_grad():
+            self.params["xyz"].copy_(scene.means3D)
+            self.params["features"].copy_(scene.shs)
+            o = scene.opacities.clamp(1e-6, 1 - 1e-6)
+            self.params["opacity"].copy_(torch.log(o / (1 - o)))  # inverse sigmoid
+            self.params["scaling"].copy_(torch.log(scene.scales))
+            self.params["rotation"].copy_(scene.rotations)
+
+    @classmethod
+    def from_raw(cls, tensors, device):
+        """from the RAW parameter tensors by name (xyz [P,3], opacity [P,1], scaling [P,3], rotation [P,4], features [P,M,3]),
+        copied bit for bit: what a topology change (sugar_amd.densify) hands back"""
+        self = cls.__new__(cls)
+        self._layout(tensors["xyz"].shape[0], tensors["features"].shape[1], device)
+        with torch.no_grad():
+            for k in self.NAMES:
+                self.params[k].copy_(tensors[k].reshape(self.params[k].shape))
+        return self
+
+    def raw(self):
+        """{name: detached view} of the raw parameters"""
+        return {k: v.detach() for k, v in self.params.items()}
+
+    def split_flat(self, flat):
+        """{name: view} of a tensor laid out like `flat` (an Adam moment buffer, the gradient buffer)"""
+        return {k: flat[self.offsets[k]: self.offsets[k] + self.sizes[k]].view(self.params[k].shape) for k in self.NAMES}
+
+    def _layout(self, P, M, device):
         self.P, self.M = P, M
         shapes = dict(xyz=(P, 3), features=(P, M, 3), opacity=(P, 1), scaling=(P, 3), rotation=(P, 4))
         sizes = {k: int(torch.tensor(v).prod()) for k, v in shapes.items()}
@@ -153,13 +180,6 @@ class GaussianParams:
             v.requires_grad_(True)
             v.grad = self.flat_grad[offs[k]: offs[k] + sizes[k]].view(shapes[k])
             self.params[k] = v
-        with torch.no_grad():
-            self.params["xyz"].copy_(scene.means3D)
-            self.params["features"].copy_(scene.shs)
-            o = scene.opacities.clamp(1e-6, 1 - 1e-6)
-            self.params["opacity"].copy_(torch.log(o / (1 - o)))  # inverse sigmoid
-            self.params["scaling"].copy_(torch.log(scene.scales))
-            self.params["rotation"].copy_(scene.rotations)
 
     def activated(self, fused=None, raw=False):
         """gaussian_model.py:92-117: exp / normalize / sigmoid -- one HIP kernel each way on a ROCm device (the gradients
@@ -580,43 +600,17 @@ class NativeTrainer:
         self.exp_avg = torch.zeros_like(params.flat)
         self.exp_avg_sq = torch.zeros_like(params.flat)
         self.t = 0
-        u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
-        self.T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
-        self._geom = u8(lib.sgr_geom_bytes(P))
-        self._img = u8(lib.sgr_img_bytes(self.W, self.H) + lib.sgr_bin2_bytes(P, self.W, self.H))
         self.capacity = int(capacity) if capacity else 24 * P + (1 << 20)
-        self._binning = u8(lib.sgr_binning_bytes(self.capacity, self.W, self.H))
-        self._loss_scratch = u8(lib.sgr_l1_ssim_scratch_bytes(3, self.W, self.H))
-        self.image = torch.empty(3, self.H, self.W, device=dev)
-        self._grad_image = torch.empty(3, self.H, self.W, device=dev)
-        self.loss_out = torch.zeros(3, device=dev)
-        self._send = torch.zeros(P + 1, 3, device=dev)
-        self._recv = torch.empty(self.world * (P + 1), 3, device=dev) if self.exchange else None
-        self._hdr = torch.zeros(16, dtype=torch.int32).pin_memory()
-        self.radii = torch.zeros(P, dtype=torch.int32, device=dev)
         self.densify_stats = bool(densify_stats)
-        if self.densify_stats:  # gaussian_model.py:125-127 / sugar_densifier.py:152-154
-            self.viewspace_grad = torch.zeros(P, 3, device=dev)
-            self.max_radii2D = torch.zeros(P, device=dev)
-            self.xyz_gradient_accum = torch.zeros(P, device=dev)
-            self.denom = torch.zeros(P, device=dev)
+        self._betas, self._eps, self._lambda_dssim = betas, eps, lambda_dssim
+        self._hdr = torch.zeros(16, dtype=torch.int32).pin_memory()
         self._hints = {}       # camera key -> int32[T] walk hint
         self._pending = None   # (cam, gt, key) of the step whose forward has not been validated yet
         self.redone = 0
         self.last_num_rendered = 0
-        o, vp = params.offsets, (lambda t: t.data_ptr() if t is not None else None)
-        st = (lambda name: vp(getattr(self, name))) if self.densify_stats else (lambda name: None)
-        self._cfg = _lib.TrainConfig(
-            P, self.sh_degree, M, self.W, self.H, vp(params.flat), vp(params.flat_grad), vp(self.exp_avg), vp(self.exp_avg_sq),
-            o["xyz"], o["opacity"], o["scaling"], o["rotation"], o["features"], params.n_small,
-            params.LRS["xyz"], params.LRS["opacity"], params.LRS["scaling"], params.LRS["rotation"], params.LRS["features"],
-            params.REST_LR, betas[0], betas[1], eps, lambda_dssim, vp(self.bg), vp(self._geom), self._geom.numel(), vp(self._img),
-            self._img.numel(), vp(self._binning), self._binning.numel(), self.capacity, vp(self._loss_scratch), vp(self.image),
-            vp(self._grad_image), vp(self.loss_out), vp(self._send), vp(self.radii), vp(self._hdr), st("viewspace_grad"),
-            st("max_radii2D"), st("xyz_gradient_accum"), st("denom"))
-        self._h = lib.sgr_trainer_create(C.byref(self._cfg))
-        if not self._h:
-            raise RuntimeError("sgr_trainer_create failed: " + lib.sgr_trainer_last_error().decode(errors="replace"))
+        self.T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+        self._h = None
+        self._allocate()
         # The gradient exchange inside the library (sgr_trainer_step_exchange: RCCL bound at run time, collectives on the library's own
         # stream, ONE call per step, no interpreter between the phases).  Opt-in (`native_collectives=True` or SGR_NATIVE_COLLECTIVES=1)
         # and only with the RCCL backend: it could be exercised with one rank only on the one-GPU test boxes, so the torch.distributed
@@ -637,6 +631,95 @@ class NativeTrainer:
             if rc < 0:
                 raise RuntimeError("sgr_trainer_comm_init failed: " + lib.sgr_trainer_last_error().decode(errors="replace"))
             self.native_collectives = True
+
+    def _allocate(self):
+        """everything sized by the Gaussian count, and the library handle over it (construction, and again after `resize`)"""
+        C, lib, _lib, params, dev = self._C, self._lib, self._L, self.params, self.dev
+        P, M = params.P, params.M
+        u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
+        self._geom = u8(lib.sgr_geom_bytes(P))
+        self._img = u8(lib.sgr_img_bytes(self.W, self.H) + lib.sgr_bin2_bytes(P, self.W, self.H))
+        self._binning = u8(lib.sgr_binning_bytes(self.capacity, self.W, self.H))
+        self._loss_scratch = u8(lib.sgr_l1_ssim_scratch_bytes(3, self.W, self.H))
+        self.image = torch.empty(3, self.H, self.W, device=dev)
+        self._grad_image = torch.empty(3, self.H, self.W, device=dev)
+        self.loss_out = torch.zeros(3, device=dev)
+        self._send = torch.zeros(P + 1, 3, device=dev)
+        self._recv = torch.empty(self.world * (P + 1), 3, device=dev) if self.exchange else None
+        self.radii = torch.zeros(P, dtype=torch.int32, device=dev)
+        if self.densify_stats:  # gaussian_model.py:125-127 / sugar_densifier.py:152-154
+            self.viewspace_grad = torch.zeros(P, 3, device=dev)
+            self.max_radii2D = torch.zeros(P, device=dev)
+            self.xyz_gradient_accum = torch.zeros(P, device=dev)
+            self.denom = torch.zeros(P, device=dev)
+        o, vp = params.offsets, (lambda t: t.data_ptr() if t is not None else None)
+        st = (lambda name: vp(getattr(self, name))) if self.densify_stats else (lambda name: None)
+        betas = self._betas
+        self._cfg = _lib.TrainConfig(
+            P, self.sh_degree, M, self.W, self.H, vp(params.flat), vp(params.flat_grad), vp(self.exp_avg), vp(self.exp_avg_sq),
+            o["xyz"], o["opacity"], o["scaling"], o["rotation"], o["features"], params.n_small,
+            params.LRS["xyz"], params.LRS["opacity"], params.LRS["scaling"], params.LRS["rotation"], params.LRS["features"],
+            params.REST_LR, betas[0], betas[1], self._eps, self._lambda_dssim, vp(self.bg), vp(self._geom), self._geom.numel(),
+            vp(self._img), self._img.numel(), vp(self._binning), self._binning.numel(), self.capacity, vp(self._loss_scratch),
+            vp(self.image), vp(self._grad_image), vp(self.loss_out), vp(self._send), vp(self.radii), vp(self._hdr),
+            st("viewspace_grad"), st("max_radii2D"), st("xyz_gradient_accum"), st("denom"))
+        self._h = lib.sgr_trainer_create(C.byref(self._cfg))
+        if not self._h:
+            raise RuntimeError("sgr_trainer_create failed: " + lib.sgr_trainer_last_error().decode(errors="replace"))
+
+    # ---- topology changes (SURVEY.md section 8e): statistics over all ranks, identical densification, new buffers
+    def all_reduce_densification_stats(self, group=None):
+        """before a densification event: `xyz_gradient_accum` / `denom` summed, `max_radii2D` maximised over the ranks
+        (sugar_densifier.py:156-164); the step in flight is validated first"""
+        if not self.densify_stats:
+            raise RuntimeError("all_reduce_densification_stats: the trainer was built without densify_stats=True")
+        self.synchronize()
+        from .view_parallel import all_reduce_densification_stats
+        all_reduce_densification_stats(self, group=group)
+
+    def densify_and_prune(self, max_grad=0.0002, min_opacity=0.005, extent=1.0, max_screen_size=None, seed=0, group=None):
+        """gaussian_model.py:390-403 on the trainer's own buffers: statistics exchanged over the ranks, clone / split / prune with a
+        generator every rank seeds identically, then `resize`.  Returns (cloned, split, pruned)."""
+        from . import densify
+        if self.world > 1 or (dist.is_available() and dist.is_initialized()):
+            self.all_reduce_densification_stats(group)
+        else:
+            self.synchronize()
+        g = torch.Generator(device=self.dev).manual_seed(int(seed))
+        p = self.params
+        stats = dict(xyz_gradient_accum=self.xyz_gradient_accum, denom=self.denom, max_radii2D=self.max_radii2D)
+        t, m1, m2, nc, ns, npr = densify.densify_and_prune(p.raw(), p.split_flat(self.exp_avg), p.split_flat(self.exp_avg_sq), stats,
+                                                           max_grad=max_grad, min_opacity=min_opacity, extent=extent,
+                                                           max_screen_size=max_screen_size, generator=g)
+        self.resize(t, m1, m2)
+        return nc, ns, npr
+
+    def resize(self, tensors, exp_avg=None, exp_avg_sq=None):
+        """new topology: the raw parameter tensors by name (and optionally their Adam moments; zeros otherwise).  Parameters move
+        into a fresh flat buffer (`self.params` is a NEW GaussianParams), every per-Gaussian buffer is reallocated, the
+        densification statistics start from zero (gaussian_model.py:343-345), the step counter, the per-camera walk hints and launch
+        orders (per tile, not per Gaussian) are kept; the list capacity scales with the Gaussian count."""
+        self.synchronize()
+        old_P = self.params.P
+        if getattr(self, "native_collectives", False):
+            raise RuntimeError("resize: not with the in-library exchange (its receive buffer is registered with the communicator)")
+        if self._h:
+            self._lib.sgr_trainer_destroy(self._h)
+            self._h = None
+        params = GaussianParams.from_raw(tensors, self.dev)
+        self.params = params
+        self.exp_avg = torch.zeros_like(params.flat)
+        self.exp_avg_sq = torch.zeros_like(params.flat)
+        with torch.no_grad():
+            for buf, src in ((self.exp_avg, exp_avg), (self.exp_avg_sq, exp_avg_sq)):
+                if src is not None:
+                    for k, v in params.split_flat(buf).items():
+                        v.copy_(src[k].reshape(v.shape))
+        self.capacity = max(int(self.capacity * (params.P / max(old_P, 1)) * 1.1), 1 << 20)
+        self._pending = None
+        self._allocate()
+        return params
+
 
     def __del__(self):
         try:
@@ -773,6 +856,9 @@ class NativeTrainer:
                     self._hint_feedback(False)
                     return self.loss_out[0]
                 if not (R or missed):
+                    # (the other ranks are already waiting in the all-gather this rank will never join: abort the communicator so
+                    # that they fail instead of hanging)
+                    self._lib.sgr_trainer_comm_abort(self._h)
                     raise RuntimeError("level-1 binning overflow: this view needs the single-level binning (use ViewShardedTrainer)")
                 self._repair(key, R, missed)
         # ... or as four phase calls with torch.distributed collectives between them

@@ -30,6 +30,43 @@ def _setup(dev):
     return scene, cams, gts
 
 
+def _densify_worker(rank, world, port, out_dir):
+    """view-sharded NativeTrainer with densification statistics: 3 steps, one densification event (statistics all-reduced inside
+    `densify_and_prune`), 2 more steps on the new topology"""
+    from sugar_amd.train_step import GaussianParams, NativeTrainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    scene, cams, gts = _setup(dev)
+    tr = NativeTrainer(GaussianParams(scene, dev), torch.zeros(3), W, H, densify_stats=True)
+    for s in range(3):
+        k = (s * world + rank) % len(cams)
+        tr.step(cams[k], gts[k], cam_key=k)
+    tr.synchronize()
+    own = tr.denom.clone()
+    counts = tr.densify_and_prune(max_grad=2e-6, min_opacity=0.05, extent=3.0, max_screen_size=20, seed=5)
+    for s in range(3, 5):
+        k = (s * world + rank) % len(cams)
+        tr.step(cams[k], gts[k], cam_key=k)
+    tr.synchronize()
+    np.savez(os.path.join(out_dir, f"dens_{rank}.npz"), flat=tr.params.flat.detach().cpu().numpy(), counts=np.array(counts + (tr.params.P,)),
+             own_denom_max=float(own.max()), m1=tr.exp_avg.cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_two_ranks_densify_identically(tmp_path):
+    """statistics summed / maximised over the ranks, then the identical clone / split / prune on every rank:
+    the replicas are bit-identical right through the event and the steps after it"""
+    world = 2
+    mp.spawn(_densify_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"dens_{k}.npz") for k in range(world)]
+    assert float(r[0]["own_denom_max"]) == 3.0       # each rank counted its OWN three views before the exchange
+    nc, ns, npr, newP = (int(v) for v in r[0]["counts"])
+    assert nc > 0 and ns > 0 and npr > 0 and newP == P + nc + ns - npr
+    assert np.array_equal(r[0]["counts"], r[1]["counts"])
+    assert np.array_equal(r[0]["flat"], r[1]["flat"]) and np.array_equal(r[0]["m1"], r[1]["m1"]), "replicas diverged across the densification"
+
+
 def _worker(rank, world, port, out_dir, native=False):
     from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     from sugar_amd.train_step import GaussianParams, NativeTrainer, ViewShardedTrainer

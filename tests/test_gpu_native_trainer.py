@@ -272,3 +272,69 @@ def test_densification_statistics_count_a_repaired_step_once():
     assert torch.equal(m0, m1)
     assert float((a0 - a1).norm() / a0.norm()) < 1e-4  # (atomic order of the blend backward)
     assert float((f0 - f1).abs().max()) < 1e-3
+
+
+def test_densify_and_resize_keep_training_and_follow_the_reference_model():
+    """NativeTrainer.densify_and_prune (sugar_amd/densify.py on the trainer's own buffers, then `resize`) against the reference's
+    GaussianModel.densify_and_prune (gaussian_model.py:350-403) started from the same parameters, moments and statistics under the
+    same seed: same clone / split / prune decisions, same new parameters and moments; and the trainer keeps stepping on the new
+    topology with its hints and launch orders (per tile) kept."""
+    from tests import ref_env
+    from sugar_amd.train_step import GaussianParams, NativeTrainer
+    dev = torch.device(DEV)
+    W, H = 320, 200
+    scene = syn.make_scene(20000, 9, 0.004, 0.08)
+    cams = _cams(W, H)
+    gts = [torch.rand(3, H, W, generator=torch.Generator().manual_seed(i)).to(dev) for i in range(8)]
+    p = GaussianParams(scene, dev)
+    nt = NativeTrainer(p, torch.zeros(3), W, H, densify_stats=True)
+    for i in range(10):
+        nt.step(cams[i % 8], gts[i % 8], cam_key=i % 8)
+    nt.synchronize()
+    P0 = p.P
+    kw = dict(max_grad=float(torch.quantile((nt.xyz_gradient_accum / nt.denom.clamp_min(1))[nt.denom > 0], 0.9)),
+              min_opacity=0.05, extent=3.0, max_screen_size=20)
+    snap = dict(raw={k: v.clone() for k, v in p.raw().items()}, m1={k: v.clone() for k, v in p.split_flat(nt.exp_avg).items()},
+                m2={k: v.clone() for k, v in p.split_flat(nt.exp_avg_sq).items()},
+                stats=dict(xyz_gradient_accum=nt.xyz_gradient_accum.clone(), denom=nt.denom.clone(), max_radii2D=nt.max_radii2D.clone()))
+    hints_before = {k: v[0].clone() for k, v in nt._hints.items()}
+    nc, ns, npr = nt.densify_and_prune(seed=77, **kw)
+    newp = nt.params
+    assert nc > 0 and ns > 0 and npr > 0 and newp.P == P0 + nc + ns - npr and newp is not p
+    assert float(nt.denom.sum()) == 0.0 and nt.radii.shape[0] == newp.P
+    assert all(torch.equal(nt._hints[k][0], v) for k, v in hints_before.items())
+    # ---- the reference's own GaussianModel from the same state (when its Python is on this box)
+    if ref_env.reference_root() is not None:
+        _, GaussianModel, _, _ = ref_env.import_gaussian_splatting()
+        gm = GaussianModel(3)
+        raw = snap["raw"]
+        mk = lambda t: torch.nn.Parameter(t.clone().requires_grad_(True))
+        gm._xyz, gm._opacity, gm._scaling, gm._rotation = mk(raw["xyz"]), mk(raw["opacity"]), mk(raw["scaling"]), mk(raw["rotation"])
+        gm._features_dc, gm._features_rest = mk(raw["features"][:, :1]), mk(raw["features"][:, 1:])
+        gm.percent_dense = 0.01
+        groups = [("xyz", gm._xyz), ("f_dc", gm._features_dc), ("f_rest", gm._features_rest), ("opacity", gm._opacity),
+                  ("scaling", gm._scaling), ("rotation", gm._rotation)]
+        gm.optimizer = torch.optim.Adam([{"params": [t], "lr": 1e-3, "name": n} for n, t in groups], lr=0.0, eps=1e-15)
+        mom = lambda d, n: (d["features"][:, :1] if n == "f_dc" else d["features"][:, 1:] if n == "f_rest" else d[n]).clone()
+        for n, t in groups:
+            gm.optimizer.state[t] = dict(step=torch.tensor(10.0), exp_avg=mom(snap["m1"], n), exp_avg_sq=mom(snap["m2"], n))
+        gm.xyz_gradient_accum = snap["stats"]["xyz_gradient_accum"].clone().reshape(-1, 1)
+        gm.denom = snap["stats"]["denom"].clone().reshape(-1, 1)
+        gm.max_radii2D = snap["stats"]["max_radii2D"].clone()
+        torch.manual_seed(77)   # (densify_and_split draws from the global generator, :360)
+        gm.densify_and_prune(kw["max_grad"], kw["min_opacity"], kw["extent"], kw["max_screen_size"])
+        assert gm._xyz.shape[0] == newp.P
+        got = newp.raw()
+        assert torch.equal(got["xyz"], gm._xyz.detach()) and torch.equal(got["scaling"], gm._scaling.detach())
+        assert torch.equal(got["rotation"], gm._rotation.detach()) and torch.equal(got["opacity"], gm._opacity.detach())
+        assert torch.equal(got["features"], torch.cat((gm._features_dc, gm._features_rest), dim=1).detach())
+        m1 = newp.split_flat(nt.exp_avg)
+        assert torch.equal(m1["xyz"], gm.optimizer.state[gm._xyz]["exp_avg"])
+        assert torch.equal(newp.split_flat(nt.exp_avg_sq)["opacity"], gm.optimizer.state[gm._opacity]["exp_avg_sq"])
+    # ---- the trainer goes on: losses keep falling over two more passes, statistics count again
+    losses = []
+    for i in range(16):
+        loss = nt.step(cams[i % 8], gts[i % 8], cam_key=i % 8)
+        nt.synchronize()
+        losses.append(float(loss))
+    assert np.mean(losses[8:]) < np.mean(losses[:8]) and float(nt.denom.max()) == 2.0
