@@ -442,24 +442,32 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
             if (bg_ < rows) {
                 const float* e = s_q + (qs + bg_) * BW_ENTRY_DW;
                 const float2* row = s_zw + bg_ * BW_ZW_STRIDE + BPIX * bq;
+                // Moments of Z about the PIXEL NEAREST THE GAUSSIAN'S CENTRE (xc, yc), not about the block origin: with the origin up
+                // to eight pixels from the centre, the second moments of a splat a pixel wide were differences of numbers a hundred
+                // times their size (x^2 S0 - 2 x Sx + Sxx with x ~ 8 against dx^2 ~ 0.3) and lost two digits -- what BASELINE config 4's
+                // flat, sub-pixel Gaussians exposed (scale gradients 6e-5 off the reference, whose own float-atomic spread there is
+                // 5e-8).  xb - xc is exact, and every product below is of the size of the moment it contributes to.
+                const float xb = e[0] - (float)bx0, yb = e[1] - (float)by0;
+                const float xc = rintf(xb), yc = rintf(yb);
                 float s0 = 0.f, sx = 0.f, sxx = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const float2 v = row[i];
-                    const float xi = (float)i;
-                    s0 += v.x; sx += v.x * xi; sxx += v.x * (xi * xi);
+                    const float t = (float)i - xc;
+                    const float u = v.x * t;
+                    s0 += v.x; sx += u; sxx += u * t;
                     k0 += v.y * rg0[i]; k1 += v.y * rg1[i]; k2 += v.y * rg2[i];
                 }
-                // this lane's share of the raw moments about the block origin (its pixels all have y = bq), shifted to the
-                // Gaussian's centre, d = centre - pixel = (xb - x, yb - y) -- the shift is linear in the moments, so it is applied
-                // to the shares and the shifted shares are summed over the eight lanes of the Gaussian
-                const float y0 = (float)bq;
+                // this lane's share of the moments (its pixels all have y = bq), shifted from (xc, yc) to the Gaussian's centre,
+                // d = centre - pixel = (xb - x, yb - y) -- the shift is linear in the moments, so it is applied to the shares and the
+                // shifted shares are summed over the eight lanes of the Gaussian
+                const float y0 = (float)bq - yc;
                 const float sy = y0 * s0, sxy = y0 * sx, syy = y0 * sy;
-                const float xb = e[0] - (float)bx0, yb = e[1] - (float)by0;
-                const float dxs = xb * s0 - sx, dys = yb * s0 - sy;
-                const float dxx = xb * (xb * s0 - 2.f * sx) + sxx;
-                const float dyy = yb * (yb * s0 - 2.f * sy) + syy;
-                const float dxy = xb * dys - yb * sx + sxy;  // xb yb S0 - xb Sy - yb Sx + Sxy
+                const float xr = xb - xc, yr = yb - yc;
+                const float dxs = xr * s0 - sx, dys = yr * s0 - sy;
+                const float dxx = xr * (xr * s0 - 2.f * sx) + sxx;
+                const float dyy = yr * (yr * s0 - 2.f * sy) + syy;
+                const float dxy = xr * dys - yr * sx + sxy;  // xr yr S0 - xr Sy - yr Sx + Sxy
                 float o[9] = {k0, k1, k2, s0, dxs, dys, dxx, dxy, dyy};
 #pragma unroll
                 for (int v = 0; v < 9; v++) o[v] += pair_in_row(o[v]);  // lanes bq and bq ^ 1
