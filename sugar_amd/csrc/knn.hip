@@ -133,7 +133,7 @@ struct GridHdr { unsigned int minb[3], maxb[3], far_count, ball_count; };
 // 3.15, 4: 1.13 / 3.49 / 4.15 (round 3, exhaustive fallback after 4 rings: 14.3 ms at 10 %).  Self queries (the neighbour rebuild,
 // distCUDA2) do not depend on it: 2.3 / 0.8 ms at 1M.
 #define GRID_MAX_RING 1
-#define GRID_GIVEUP_RING 12  // a lane that has not even MET K points after this many rings goes to the exhaustive kernels
+#define BALL_SAMPLES 4096u     // reference points a query without a bound is compared with in k_knn_ball (64 per lane)
 #define FAR_SINGLE_MAX 16384u  // up to this many far queries: one workgroup each; more: the tiled exhaustive kernel
 
 __device__ __forceinline__ unsigned int f2ord(float f)
@@ -466,13 +466,13 @@ __global__ void __launch_bounds__(128) k_grid_query(int N, const float* __restri
         // after GRID_GIVEUP_RING rings (a far outlier of a tiny set) goes to the exhaustive kernels.  Same distances, same
         // (distance, index) order everywhere: same result.
         if (r >= max_ring && far_list) {
-            if (bd[K - 1] < 3.0e+38f) {
-                const unsigned int pos = atomicAdd(ball_count, 1u);
-                if (pos < far_cap) { ball_list[pos] = q; ball_u2[pos] = bd[K - 1]; return; }
-            } else if (r >= GRID_GIVEUP_RING) {
-                const unsigned int pos = atomicAdd(far_count, 1u);
-                if (pos < far_cap) { far_list[pos] = q; return; }
-            }
+            // (round 5) a lane WITHOUT K candidates hands its query over too, with "no bound yet": k_knn_ball then takes the bound
+            // from a spread sample of the reference set.  It used to walk on, alone, for up to 12 rings (~15 000 cells, two dependent
+            // loads each) and then went to the exhaustive kernels: the level-set sampler's pixels over a SURFACE-bound cloud
+            // (BASELINE config 4: flat Gaussians on a mesh, most grid cells empty, queries 3 - 30 cells off the surface) cost 55 ms
+            // per 124k queries that way.
+            const unsigned int pos = atomicAdd(ball_count, 1u);
+            if (pos < far_cap) { ball_list[pos] = q; ball_u2[pos] = bd[K - 1]; return; }
         }
     }
     if (out_mean) {
@@ -506,7 +506,39 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
         const int q = qlist[w];
         const float qx = query[3 * (size_t)q], qy = query[3 * (size_t)q + 1], qz = query[3 * (size_t)q + 2];
         const float ext = (float)G * g.h;
-        const float U = sqrtf(qu2[w]) * (1.0f + 1e-5f) + 1e-5f * (ext + fabsf(qx) + fabsf(qy) + fabsf(qz));
+        float u2 = qu2[w];
+        if (!(u2 < 3.0e+38f)) {
+            // No bound from the ring walk: take one from BALL_SAMPLES points spread evenly over the cell-sorted array (i.e. over the
+            // cloud).  Every lane keeps the nearest of its share; the K-th smallest of the 64 lane minima is the distance of K
+            // DISTINCT reference points, hence an upper bound of the K-th nearest distance.  With fewer than K finite minima (a set
+            // smaller than K) the bound stays infinite and the cover below is the whole grid: still exact.
+            const unsigned int Mtot = cell_start[(unsigned int)G * G * G];
+            const unsigned int per_lane = BALL_SAMPLES / 64;
+            const float stride = (float)Mtot / (float)BALL_SAMPLES;
+            float best = 3.402823466e+38f;
+            for (unsigned int j = 0; j < per_lane; j++) {
+                unsigned int sidx = (unsigned int)(((float)(j * 64u + (unsigned int)lane) + 0.5f) * stride);
+                if (Mtot <= BALL_SAMPLES) sidx = j * 64u + (unsigned int)lane;  // (a small set: every point once)
+                if (sidx >= Mtot) continue;
+                const float4 p = sorted[sidx];
+                if (EXCLUDE_SELF && __float_as_int(p.w) == q) continue;
+                const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+                best = fminf(best, dx * dx + dy * dy + dz * dz);
+            }
+            float kth = 3.402823466e+38f;
+            for (int k = 0; k < K; k++) {   // K rounds: the smallest remaining lane minimum
+                float m = best;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+                kth = m;
+                const unsigned long long eq = __ballot(best == m);
+                if (lane == (int)__builtin_ctzll(eq | (1ull << 63))) best = 3.402823466e+38f;  // retire ONE holder of the minimum
+            }
+            u2 = K <= 64 ? kth : 3.402823466e+38f;
+        }
+        const bool unbounded = !(u2 < 3.0e+38f);
+        const float U = unbounded ? 4.0f * (ext + fabsf(qx - g.ox) + fabsf(qy - g.oy) + fabsf(qz - g.oz))
+                                  : sqrtf(u2) * (1.0f + 1e-5f) + 1e-5f * (ext + fabsf(qx) + fabsf(qy) + fabsf(qz));
         const float U2 = U * U;
         // cell rows the ball can touch.  The points live inside the grid, so along y (z) the ball only reaches as far as what the
         // query's distance to the grid along the two other axes leaves of U: for a query outside the cloud that is a small cap

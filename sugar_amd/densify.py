@@ -22,7 +22,8 @@ NAMES = ("xyz", "opacity", "scaling", "rotation", "features")
 
 def _build_rotation(r: torch.Tensor) -> torch.Tensor:
     """gaussian_splatting/utils/general_utils.py:78-101 (normalises the quaternion, real part first)"""
-    q = r / r.norm(dim=1, keepdim=True)
+    norm = torch.sqrt(r[:, 0] * r[:, 0] + r[:, 1] * r[:, 1] + r[:, 2] * r[:, 2] + r[:, 3] * r[:, 3])  # (the reference's own sum order)
+    q = r / norm[:, None]
     w, x, y, z = q.unbind(-1)
     R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
                      2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),

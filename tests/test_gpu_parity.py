@@ -405,3 +405,28 @@ def test_backward_is_linear_in_the_pixel_gradient_at_full_size():
         ref = a + 2.0 * b
         assert torch.isfinite(c).all()
         assert float((c - ref).norm() / ref.norm()) < 2e-5
+
+
+def test_grid_knn_on_a_surface_cloud_with_queries_off_the_surface():
+    """BASELINE config 4's geometry: the reference set lies on a 2-D surface (most grid cells are empty) and the queries -- pixels
+    of the level-set sampler unprojected from a blended depth -- sit anywhere from on the surface to a scene diameter away from it,
+    INSIDE the bounding box.  Such queries meet fewer than K points in their first ring: k_knn_ball takes their bound from a spread
+    sample of the set.  Identical values and indices to the exhaustive kernel; also for sets smaller than K and than the sample."""
+    from sugar_amd.knn import knn_points
+    dev = torch.device("cuda:0")
+    b = syn.make_bound_scene(200_000, seed=4)
+    p = b.scene.means3D.to(dev)
+    g = torch.Generator().manual_seed(3)
+    n = 6000
+    base = b.scene.means3D[torch.randint(0, p.shape[0], (n,), generator=g)]
+    off = torch.cat([torch.zeros(1000), 10 ** (torch.rand(n - 1000, generator=g) * 4 - 4) * 2.0])     # 0 ... 2 scene units
+    q = (base * (1.0 - off[:, None] / base.norm(dim=1, keepdim=True))).to(dev)                        # towards the centre of the shape
+    for K in (1, 16, 32):
+        a = knn_points(q[None], p[None], K=K, method="brute")
+        c = knn_points(q[None], p[None], K=K, method="grid")
+        assert torch.equal(a.dists, c.dists) and torch.equal(a.idx, c.idx), K
+    for M in (5, 40, 3000):   # fewer points than K; fewer than the sample; a sample of every point
+        small = p[:M].contiguous()
+        a = knn_points(q[None], small[None], K=16, method="brute")
+        c = knn_points(q[None], small[None], K=16, method="grid")
+        assert torch.equal(a.dists, c.dists) and torch.equal(a.idx, c.idx), M
