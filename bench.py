@@ -285,6 +285,20 @@ def main():
     stages = {n: (ms[i] / cnt[i] if cnt[i] else 0.0) for i, n in enumerate(STAGES)}
     if blend_ms == 0.0:
         blend_ms = stages["blend_fwd"]
+    # the list-write pass with and without the walk hint (the hint is why it is short; same cameras, same moment)
+    list_write = None
+    if isinstance(trainer, NativeTrainer) and trainer.walk_hint:
+        SC = STAGES.index("bin_scatter")
+        trainer.walk_hint = False
+        lib.sgr_profile_enable(1 << SC)
+        for s in range(args.warmup + args.steps + n_post, args.warmup + args.steps + 2 * n_post):
+            do_step(trainer, s)
+        trainer.synchronize()
+        torch.cuda.synchronize(dev)
+        lib.sgr_profile_enable(0)
+        lib.sgr_profile_read(ms, cnt, len(STAGES))
+        trainer.walk_hint = True
+        list_write = {"hinted_ms": stages["bin_scatter"], "unhinted_ms": (ms[SC] / cnt[SC] if cnt[SC] else None)}
 
     # ---- what the collectives cost the step: the same K steps once more with and once without the gradient exchange (after the
     # graded region; without the exchange the replicas drift apart, which is irrelevant for a timing)
@@ -365,7 +379,7 @@ def main():
                 trainer.step(many[i], gts[i % len(gts)], cam_key=1000 + i)
         epoch()
         sync_all()
-        r0, p0 = trainer.redone, trainer.hint_pauses
+        r0, p0, t0r = trainer.redone, trainer.hint_pauses, trainer.repaired_tiles
         ta = time.perf_counter()
         epoch()
         sync_all()
@@ -373,6 +387,7 @@ def main():
         extras["many_cameras_shuffled"] = {
             "cameras": len(many), "ms_per_step": ms_many, "images_per_sec": 1e3 / ms_many,
             "forwards_repeated": trainer.redone - r0, "hint_off_windows": trainer.hint_pauses - p0,
+            "tiles_repaired_in_place": trainer.repaired_tiles - t0r, "tiles_per_view": trainer.T,
             "what": "after the drift steps, no restore: scattered cameras visited in shuffled order, one untimed epoch (first visits: no "
                     "hint yet), one timed epoch; every hint / launch order is one epoch (~" + str(len(many)) + " Adam steps) old"}
         del many
@@ -485,7 +500,10 @@ def main():
             out["config"]["step_driver"] += " (host round trip for num_rendered every call, no extension)" if trainer.host_sync else " (sync-free after one pass over the cameras)"
         if isinstance(trainer, NativeTrainer):
             out["forwards_repeated"] = {"in_timed_region": marks.get("after_timed", 0) - marks.get("after_warmup", 0),
-                                        "pre_roll_and_warmup": marks.get("after_warmup", 0), "whole_run": trainer.redone}
+                                        "pre_roll_and_warmup": marks.get("after_warmup", 0), "whole_run": trainer.redone,
+                                        "tiles_repaired_in_place_whole_run": trainer.repaired_tiles}
+            if list_write is not None:
+                out["list_write_pass"] = list_write
         if comm is not None:
             out.update(comm)
             out["config"]["collectives"] = ("forced on a one-rank RCCL group" if world == 1 else "RCCL") + \

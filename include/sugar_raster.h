@@ -98,6 +98,9 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user,
 #define SGR_HDR_HINT_MISS 3  /* != 0: a tile needed more entries than its walk hint allowed */
 #define SGR_HDR_CHUNKS 5      /* 512-entry chunks of the super-tile lists (two-level binning) */
 #define SGR_HDR_L1_OVERFLOW 6 /* != 0: the level-1 (super-tile) list overflowed its capacity */
+#define SGR_HDR_REPAIR 7      /* tiles that outran their walk hint and were rendered again inside the same forward (round 5): a hint
+                                 that is too short costs those tiles a second pass, not the forward; SGR_HDR_HINT_MISS is only raised
+                                 when more than 1024 tiles did */
 typedef struct sgr_forward_info {
     int binning_mode;        /* 0: two-level binning, 1: single-level */
     int sync_free;           /* 1: the call did not wait for the device */

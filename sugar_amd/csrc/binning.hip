@@ -438,7 +438,8 @@ __global__ void __launch_bounds__(64) k_hist_scan(int T, int n_blocks, uint32_t*
 __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __restrict__ tile_count,
                                                     uint32_t* __restrict__ tile_start, uint32_t* __restrict__ header,
                                                     uint32_t* __restrict__ tile_maxc, uint32_t* __restrict__ tile_walked,
-                                                    int clear_b2_words, uint32_t* __restrict__ host_a, uint32_t* __restrict__ host_b)
+                                                    int clear_b2_words, uint32_t* __restrict__ host_a, uint32_t* __restrict__ host_b,
+                                                    uint32_t* __restrict__ repair_flag)
 {
     __shared__ uint32_t s_seg[128];
     __shared__ uint32_t s_max[16];
@@ -470,7 +471,10 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __res
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int i = base + j * 1024 + tid;
-            if (i < T) { tile_start[i] = carry + s_seg[j * 16 + wave] + incl[j] - c[j]; tile_maxc[i] = 0u; tile_walked[i] = 0u; }
+            if (i < T) {
+                tile_start[i] = carry + s_seg[j * 16 + wave] + incl[j] - c[j]; tile_maxc[i] = 0u; tile_walked[i] = 0u;
+                if (repair_flag) repair_flag[i] = 0u;
+            }
         }
         carry += s_total;
         __syncthreads();  // s_seg / s_total are rewritten by the next round
@@ -621,8 +625,8 @@ void sgr_launch_hist_scan(int T, int n_blocks, uint32_t* blk_hist, uint32_t* til
 }
 
 void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* header, uint32_t* tile_maxc,
-                          uint32_t* tile_walked, int clear_b2_words, uint32_t* host_a, uint32_t* host_b, hipStream_t s)
+                          uint32_t* tile_walked, int clear_b2_words, uint32_t* host_a, uint32_t* host_b, hipStream_t s, uint32_t* repair_flag)
 {
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, tile_count, tile_start, header, tile_maxc, tile_walked,
-                       clear_b2_words, host_a, host_b);
+                       clear_b2_words, host_a, host_b, repair_flag);
 }

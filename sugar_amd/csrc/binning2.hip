@@ -257,11 +257,12 @@ __global__ void __launch_bounds__(64 * SGR_B2_WAVES) k_tile_pass(int gx, int gy,
                                                                  uint32_t* __restrict__ cnt2,
                                                                  const uint32_t* __restrict__ tile_start,
                                                                  uint32_t* __restrict__ point_list, uint32_t list_cap,
-                                                                 const uint32_t* __restrict__ tile_need)
+                                                                 const uint32_t* __restrict__ tile_need, const uint32_t* __restrict__ gate)
 {
     constexpr int SGR_B2_TILES_PER_WAVE = 64 / SGR_B2_WAVES;
     __shared__ uint32_t s_rows[WRITE ? SGR_B2_WAVES * SGR_B2_CHUNK : 1];
     if (hdr[SGR_B2_HDR_OVERFLOW]) return;
+    if (gate && *gate == 0u) return;  // (the repair pass of the walk hint: no tile outran its hint)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t* s_row = s_rows + (WRITE ? wave * SGR_B2_CHUNK : 0);
@@ -459,18 +460,19 @@ void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scr
     uint32_t grid = L.chunk_cap < 8192u ? L.chunk_cap : 8192u;  // the chunk count lives on the device: grid-stride
     if (chunk_grid && chunk_grid < grid) grid = chunk_grid;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_pass<false, SGR_B2_COUNT_WAVES>), dim3(grid), dim3(64 * SGR_B2_COUNT_WAVES), 0, s, gx, gy, L.sgx, L.T1, chunk_info, hdr, L1,
-                       cnt2, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (const uint32_t*)nullptr);
+                       cnt2, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_tile_scan2, dim3(L.T1), dim3(64), 0, s, gx, gy, L.sgx, chunk_base, hdr, cnt2, tile_count);
 }
 
 void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, const uint32_t* hdr, uint32_t n_chunks, const uint2* rects,
                            const uint32_t* order, const uint32_t* tile_start, uint32_t* point_list, uint32_t list_cap,
-                           const uint32_t* tile_need, hipStream_t s)
+                           const uint32_t* tile_need, hipStream_t s, const uint32_t* gate, uint32_t max_grid)
 {
     if (n_chunks == 0) return;
+    if (max_grid && n_chunks > max_grid) n_chunks = max_grid;  // (grid-stride over the device-side chunk count)
     const uint4* L1 = reinterpret_cast<const uint4*>(scratch + L.L1);
     uint32_t* cnt2 = reinterpret_cast<uint32_t*>(scratch + L.cnt2);
     const uint4* chunk_info = reinterpret_cast<const uint4*>(scratch + L.chunk_sup);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_pass<true, SGR_B2_WRITE_WAVES>), dim3(n_chunks), dim3(64 * SGR_B2_WRITE_WAVES), 0, s, gx, gy, L.sgx, L.T1, chunk_info, hdr, L1,
-                       cnt2, tile_start, point_list, list_cap, tile_need);
+                       cnt2, tile_start, point_list, list_cap, tile_need, gate);
 }

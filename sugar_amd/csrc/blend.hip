@@ -168,7 +168,9 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
                                                     uint32_t* __restrict__ tile_walked, float* __restrict__ out_color,
                                                     unsigned long long* __restrict__ blk_mask, uint32_t* __restrict__ blk_nb,
                                                     uint32_t* __restrict__ header, uint32_t list_cap,
-                                                    const uint32_t* __restrict__ tile_need, const uint32_t* __restrict__ launch_order)
+                                                    const uint32_t* __restrict__ tile_need, const uint32_t* __restrict__ launch_order,
+                                                    uint32_t* __restrict__ repair_flag, uint32_t* __restrict__ repair_list,
+                                                    int repair_pass)
 {
     // sync-free forward: the list did not fit the caller's capacity (or the level-1 binning overflowed) -> leave everything
     // untouched; the caller repeats the forward and every later kernel of the step reads the same header
@@ -180,6 +182,15 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
     int slot, sub;
     sgr_slot_of_workgroup((int)blockIdx.x, slot, sub);
     if (slot >= T_tiles) return;
+    if (repair_pass) {
+        // the repair pass of the walk hint: launch_order = the tiles the first pass listed, header word SGR_HDR_REPAIR their count
+        const uint32_t n_rep = header[SGR_HDR_REPAIR];
+        if (n_rep > (uint32_t)SGR_REPAIR_TILES) {  // more than this launch covers: the forward is invalid after all
+            if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&header[SGR_HDR_HINT_MISS], 1u);
+            return;
+        }
+        if ((uint32_t)slot >= n_rep) return;
+    }
     // (launch_order: the camera's previous visit, deepest tiles first -- sgr_forward_opts.tile_order; clamped, so a buffer that
     // is not a permutation costs tiles, not memory safety)
     const int tile = launch_order ? (int)min(launch_order[slot], (uint32_t)(T_tiles - 1)) : slot;
@@ -243,7 +254,15 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
         __builtin_amdgcn_wave_barrier();
     }
     // the hint was too short: pixels of this block are still accumulating where the written prefix ends
-    if (total < total_all && live != 0ull && lane == 0) atomicOr(&header[SGR_HDR_HINT_MISS], 1u);
+    if (total < total_all && live != 0ull && lane == 0) {
+        if (repair_flag) {
+            // (round 5) ... which costs THIS TILE a second pass, not the whole forward: the first of its four blocks to notice puts
+            // the tile on the repair list; the list-write pass and the blend run once more for the listed tiles (capi.hip)
+            if (atomicExch(&repair_flag[tile], 0xFFFFFFFFu) == 0u) repair_list[atomicAdd(&header[SGR_HDR_REPAIR], 1u)] = (uint32_t)tile;
+        } else {
+            atomicOr(&header[SGR_HDR_HINT_MISS], 1u);
+        }
+    }
     if (inside) {
         const size_t pix_id = (size_t)W * py + px;
         const size_t HW = (size_t)H * W;
@@ -581,11 +600,26 @@ __global__ void __launch_bounds__(256) k_make_hint(int T, const uint32_t* __rest
 void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
                           uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
-                          uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, const uint32_t* launch_order, hipStream_t s)
+                          uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, const uint32_t* launch_order, hipStream_t s,
+                          uint32_t* repair_flag, uint32_t* repair_list)
 {
     const int T = gx * gy;  // (tile_maxc and tile_walked were zeroed by the tile scan: the blocks of a tile combine with atomicMax)
     hipLaunchKernelGGL(k_blend_fwd_w, dim3(sgr_blend_grid(T)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg, final_T,
-                       n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap, tile_need, launch_order);
+                       n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap, tile_need, launch_order,
+                       tile_need ? repair_flag : nullptr, repair_list, 0);
+}
+
+void sgr_launch_blend_fwd_repair(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
+                                 const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
+                                 uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
+                                 uint32_t* header, uint32_t list_cap, const uint32_t* repair_list, hipStream_t s)
+{
+    const int T = gx * gy;
+    const int cover = T < SGR_REPAIR_TILES ? T : SGR_REPAIR_TILES;
+    // (T_tiles stays the tile count: it clamps the list's entries; the slots beyond the listed tiles leave at once)
+    hipLaunchKernelGGL(k_blend_fwd_w, dim3(sgr_blend_grid(cover)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg, final_T,
+                       n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap, (const uint32_t*)nullptr,
+                       repair_list, (uint32_t*)nullptr, (uint32_t*)nullptr, 1);
 }
 
 // behind the blend: this view's launch order (for its backward: order_scratch; for the camera's next forward: order_out), the walk

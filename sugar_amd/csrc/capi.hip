@@ -206,6 +206,8 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     uint32_t* tile_walked = reinterpret_cast<uint32_t*>(img + IL.tile_walked);
     uint32_t* blk_nb = reinterpret_cast<uint32_t*>(img + IL.blk_nb);
     uint32_t* header = reinterpret_cast<uint32_t*>(img + IL.header);
+    uint32_t* repair_flag = reinterpret_cast<uint32_t*>(img + IL.repair_flag);
+    uint32_t* repair_list = reinterpret_cast<uint32_t*>(img + IL.repair_list);
 
     uint32_t* blk_hist = reinterpret_cast<uint32_t*>(img + IL.blk_hist);
     char* sort_scratch = geom + sgr_geom_sort_offset(P);
@@ -262,7 +264,8 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
             sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, blk_hist, s);
             sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
         }
-        sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, tile_maxc, tile_walked, two_level ? 0 : 1, hh_dev, pin_dev, s);
+        sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, tile_maxc, tile_walked, two_level ? 0 : 1, hh_dev, pin_dev, s,
+                             opts->tile_need ? repair_flag : nullptr);
     }
     STAGE_CHECK("bin_count");
     // the header for a caller that checks late: right behind the tile scan (words 0 and 6 are final) -- written by the scan
@@ -302,7 +305,17 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
             StageTimer t(s, SGR_STAGE_BLEND_FWD);
             sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
                                  tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, (uint32_t)R_, opts->tile_need,
-                                 opts->tile_order, s);
+                                 opts->tile_order, s, repair_flag, repair_list);
+            if (opts->tile_need && two_level && R_ > 0) {
+                // Walk-hint repair: tiles that outran their hint are on the device's repair list now.  The list-write pass once more
+                // with the repair flags as ITS hint (0: nothing needed; 0xFFFFFFFF: the whole list) and the blend once more over the
+                // listed tiles' full lists -- both gated on the list's count, i.e. two empty launches when every hint held.  A hint
+                // that is too short used to invalidate the forward and with it the whole train step.
+                sgr_launch_bin2_write(IL.gx, IL.gy, B2, bin2, header + 4, n_chunks_, rects, order, tile_start, point_list,
+                                      nosync_ ? (uint32_t)R_ : 0xFFFFFFFFu, repair_flag, s, header + SGR_HDR_REPAIR, 512u);
+                sgr_launch_blend_fwd_repair(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
+                                            tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, (uint32_t)R_, repair_list, s);
+            }
         }
         if (flags & SGR_FLAG_DEFER_POST) {  // (the caller's next kernel carries the post-blend job: sgr_forward_post_job)
             STAGE_CHECK("blend_fwd");

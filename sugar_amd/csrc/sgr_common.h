@@ -41,7 +41,7 @@ size_t sgr_sort_rects_offset(int P);    // binning.hip: offset of the packed rec
 static inline size_t sgr_geom_total(int P) { return sgr_geom_sort_offset(P) + sgr_sort_scratch_bytes(P); }
 
 struct ImgLayout {
-    size_t final_T, n_contrib, tile_start, tile_cursor, tile_maxc, tile_walked, blk_nb, header, blk_hist, total;
+    size_t final_T, n_contrib, tile_start, tile_cursor, tile_maxc, tile_walked, blk_nb, header, repair_flag, repair_list, blk_hist, total;
     int n_blocks;      // slices of the depth order in the ordered binning
     int gx, gy, T;
 };
@@ -60,6 +60,10 @@ static inline ImgLayout sgr_img_layout(int W, int H)
     L.tile_walked = off; off = sgr_align(off + (size_t)L.T * 4);
     L.blk_nb = off;      off = sgr_align(off + (size_t)L.T * 16);  // batches the forward walked, per block
     L.header = off;      off = sgr_align(off + 64);
+    // walk-hint repair (round 5): per tile 0 / 0xFFFFFFFF "this tile outran its hint" (read by the second list-write pass as ITS
+    // walk hint) and the list of those tiles (the second blend pass's launch order); their count is header word SGR_HDR_REPAIR
+    L.repair_flag = off; off = sgr_align(off + (size_t)L.T * 4);
+    L.repair_list = off; off = sgr_align(off + (size_t)L.T * 4);
     // the single-level fallback keeps one LDS counter per tile: beyond ~38 000 tiles (8K images) only the two-level path exists
     L.n_blocks = ((size_t)L.T * 4 <= SGR_LEGACY_LDS_BYTES) ? SGR_BIN_SLICES : 0;
     L.blk_hist = off;    off = sgr_align(off + (size_t)L.n_blocks * L.T * 4);
@@ -87,7 +91,8 @@ void sgr_launch_bin2_count(int P, int gx, int gy, const Bin2Layout& L, char* scr
                            const uint32_t* order, uint32_t* tile_count, uint32_t chunk_grid, hipStream_t s);
 void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, const uint32_t* hdr, uint32_t n_chunks, const uint2* rects,
                            const uint32_t* order, const uint32_t* tile_start, uint32_t* point_list, uint32_t list_cap,
-                           const uint32_t* tile_need, hipStream_t s);
+                           const uint32_t* tile_need, hipStream_t s, const uint32_t* gate = nullptr, uint32_t max_grid = 0u);
+// (gate: a device word; the pass is a no-op when it is zero -- the repair pass of the walk hint, see capi.hip)
 
 // binning: [ point_list u32[R] | blk_mask u64[(R/64 + T + 1) * 4] ]   blk_mask: per 64-entry batch of every tile's list and per
 //           8x8 block of the tile, the lanes (entries) that survive the block's exact cull -- written by the forward blend
@@ -195,14 +200,23 @@ void sgr_launch_bin_scatter(int P, int gx, int gy, int n_slices, int per_slice, 
                             const uint32_t* tile_start, uint32_t* blk_hist, uint32_t* point_list, hipStream_t s);
 void sgr_launch_hist_scan(int T, int n_blocks, uint32_t* blk_hist, uint32_t* tile_count, hipStream_t s);
 void sgr_launch_tile_scan(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* header, uint32_t* tile_maxc,
-                          uint32_t* tile_walked, int clear_b2_words, uint32_t* host_a, uint32_t* host_b, hipStream_t s);  // host_*: device-mapped pinned memory or NULL
+                          uint32_t* tile_walked, int clear_b2_words, uint32_t* host_a, uint32_t* host_b, hipStream_t s,
+                          uint32_t* repair_flag = nullptr);  // host_*: device-mapped pinned memory or NULL; repair_flag[T] is zeroed
 
 // header: the forward's device header; list_cap: instances the list was allocated for (the forward is a no-op when the header
 // says it does not fit, the backward when the forward was one); tile_need / tile_need_out: walk hint (sgr_forward_opts)
 void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
                           uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
-                          uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, const uint32_t* launch_order, hipStream_t s);
+                          uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, const uint32_t* launch_order, hipStream_t s,
+                          uint32_t* repair_flag = nullptr, uint32_t* repair_list = nullptr);
+// Walk-hint repair: the tiles the first pass listed (they outran their hint) once more, over their full lists (written meanwhile
+// by a list-write pass gated on the same count).  A no-op launch when the list is empty.
+#define SGR_REPAIR_TILES 1024
+void sgr_launch_blend_fwd_repair(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
+                                 const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
+                                 uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
+                                 uint32_t* header, uint32_t list_cap, const uint32_t* repair_list, hipStream_t s);
 void sgr_launch_blend_fwd_post(int gx, int gy, const uint32_t* tile_maxc, const uint32_t* tile_walked, uint32_t* header, uint32_t list_cap,
                                uint32_t* tile_need_out, float hint_margin, uint32_t* header_host_dev, uint32_t* order_scratch,
                                uint32_t* order_out, hipStream_t s);

@@ -561,7 +561,9 @@ class NativeTrainer:
 
     Validity without a host wait.  The forward runs with a list capacity and, from a camera's second visit on, with a WALK
     HINT (per tile: how many list entries it walked last time, times 1 + hint_margin, + 64): the list-write pass then skips the
-    chunks nobody will read.  Three misses within 32 forwards switch the hints off for the next 64 (a scene that changes this
+    chunks nobody will read.  Since round 5 a tile that outruns its hint is rendered again INSIDE the same forward (its list is
+    completed and its blocks re-blended by two gated launches: `repaired_tiles`); only more than 1024 such tiles in one view
+    count as a miss.  Three misses within 32 forwards switch the hints off for the next 64 (a scene that changes this
     fast is cheaper to bin in full than to render twice).  A forward that outgrew the capacity or the hint makes every later kernel of the step -- backward and Adam
     included -- a no-op on the device; the host finds out when it next looks at the pinned header (before enqueueing the
     following step, when the copy has long arrived), enlarges the capacity / drops the hint and repeats the step.
@@ -608,6 +610,7 @@ class NativeTrainer:
         self._pending = None   # (cam, gt, key) of the step whose forward has not been validated yet
         self.redone = 0
         self.last_num_rendered = 0
+        self.repaired_tiles, self.last_repaired_tiles = 0, 0
         self.T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
         self._h = None
         self._allocate()
@@ -787,6 +790,9 @@ class NativeTrainer:
             raise RuntimeError("sgr_trainer_forward_valid failed")
         self.last_num_rendered = int(hdr[0])
         self._last_chunks = int(hdr[5])
+        self.last_repaired_tiles = int(hdr[8 + 7])   # tiles that outran their walk hint and were rendered again in place
+        if ok:
+            self.repaired_tiles += self.last_repaired_tiles
         return bool(ok), (int(hdr[0]) if int(hdr[0]) > self.capacity else 0), bool(hdr[8 + 3])
 
     def _hint_feedback(self, missed):
