@@ -139,7 +139,8 @@ LOSS_LINE = re.compile(r"loss:\s*([-+0-9.eE]+|nan|inf)\s*\[\s*(\d+)/\s*(\d+)\]")
 
 
 def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: str | None = None, patch_losses: bool = False,
-        patch_optimizer: bool = False, trainer: str = "coarse_sdf", profile_window=None, patch_gathers: bool = False):
+        patch_optimizer: bool = False, trainer: str = "coarse_sdf", profile_window=None, patch_gathers: bool = False,
+        patch_densifier: bool = False):
     """Runs the unmodified trainer on `data` until its iteration counter reaches `stop_at` (or 15 000).  Returns a dict with the
     (iteration, loss) pairs the trainer printed, the host time stamps of each iteration and the events it announced."""
     from rich.console import Console
@@ -153,6 +154,9 @@ def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: st
     if patch_optimizer:
         from sugar_amd import shims as _shims
         _shims.install_optimizer()   # SuGaROptimizer's torch.optim.Adam -> FusedAdam
+    if patch_densifier:
+        from sugar_amd import shims as _dshims
+        _dshims.install_densifier()  # SuGaRDensifier.update_densification_stats without boolean-mask indexing
     log_path = log_path or os.path.join(out_dir, "trainer_console.log")
     os.makedirs(out_dir, exist_ok=True)
     log_file = open(log_path, "w")
@@ -203,6 +207,8 @@ def run(data, out_dir: str, stop_at: int, patch_sugar: bool = True, log_path: st
             _shims.uninstall_optimizer()
         if patch_gathers:
             _sp.uninstall_row_gathers(sm)
+        if patch_densifier:
+            _dshims.uninstall_densifier()
         if patch_sugar:
             from sugar_amd import sugar_patch
             sugar_patch.uninstall(sm)

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--patch-gathers", action="store_true", help="also give SuGaR's per-Gaussian tensors a HIP row-gather backward")
     ap.add_argument("--trainer", default="coarse_sdf", choices=["coarse_sdf", "coarse_density"])
     ap.add_argument("--patch-optimizer", action="store_true", help="also let SuGaROptimizer's torch.optim.Adam step on the HIP Adam")
+    ap.add_argument("--patch-densifier", action="store_true", help="also the densification statistics without boolean-mask indexing (shims.install_densifier)")
     ap.add_argument("--extract", action="store_true",
                     help="then run the reference's coarse-mesh extractor (sugar_extractors/coarse_mesh.py, untouched) up to its "
                          "Poisson step: on the trained model if the training ran to 15000, else on the 3DGS checkpoint")
@@ -48,10 +49,10 @@ def main():
     try:
         data = rt.write_dataset(work, P=a.gaussians, n_cams=a.cameras, W=a.width, H=a.height)
         os.makedirs(a.out, exist_ok=True)
-        tag = ("" if a.trainer == "coarse_sdf" else a.trainer + "_") + ("dropins_only" if a.no_patch else "patched") + ("_losses" if a.patch_losses else "") + ("_adam" if a.patch_optimizer else "") + ("_gathers" if a.patch_gathers else "")
+        tag = ("" if a.trainer == "coarse_sdf" else a.trainer + "_") + ("dropins_only" if a.no_patch else "patched") + ("_losses" if a.patch_losses else "") + ("_adam" if a.patch_optimizer else "") + ("_gathers" if a.patch_gathers else "") + ("_densifier" if a.patch_densifier else "")
         res = {"finished": False, "model_path": None}
         if not a.skip_training:
-          res = rt.run(data, os.path.join(work, "out"), stop_at=a.stop_at, patch_sugar=not a.no_patch, patch_losses=a.patch_losses, patch_optimizer=a.patch_optimizer, trainer=a.trainer, profile_window=a.profile_window, patch_gathers=a.patch_gathers,
+          res = rt.run(data, os.path.join(work, "out"), stop_at=a.stop_at, patch_sugar=not a.no_patch, patch_losses=a.patch_losses, patch_optimizer=a.patch_optimizer, trainer=a.trainer, profile_window=a.profile_window, patch_gathers=a.patch_gathers, patch_densifier=a.patch_densifier,
                      log_path=os.path.join(a.out, f"trainer_console_{tag}.log"))
         table = res.pop("profile_table", None)
         if table:

@@ -6,6 +6,7 @@
 #include "sgr_common.h"
 #include "tile_order.h"
 
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 #include <string>
@@ -246,6 +247,8 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     // speculative: sync-free launches with the caller's capacity, then ONE wait for the tile scan's header at the END of the call,
     // when the list-write pass and the blend kernel are already queued behind it: the host round trip of rasterizer_impl.cu:280-281
     // without the idle GPU, and the true instance count as the return value
+    // (SGR_NO_HINT_REPAIR=1: a tile that outruns its walk hint invalidates the forward, as until round 4 -- an A/B switch)
+    static const bool hint_repair = getenv("SGR_NO_HINT_REPAIR") == nullptr;
     const bool speculative = (flags & SGR_FLAG_SPECULATIVE) && binning_capacity > 0 && binning_mode == 0 && !(flags & SGR_FLAG_DEFER_POST);
     const bool will_sync = !(binning_capacity > 0 && binning_mode == 0) || speculative;
     uint32_t* pin_dev = nullptr;
@@ -265,7 +268,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
             sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
         }
         sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, tile_maxc, tile_walked, two_level ? 0 : 1, hh_dev, pin_dev, s,
-                             opts->tile_need ? repair_flag : nullptr);
+                             (opts->tile_need && hint_repair) ? repair_flag : nullptr);
     }
     STAGE_CHECK("bin_count");
     // the header for a caller that checks late: right behind the tile scan (words 0 and 6 are final) -- written by the scan
@@ -305,8 +308,8 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
             StageTimer t(s, SGR_STAGE_BLEND_FWD);
             sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
                                  tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, (uint32_t)R_, opts->tile_need,
-                                 opts->tile_order, s, repair_flag, repair_list);
-            if (opts->tile_need && two_level && R_ > 0) {
+                                 opts->tile_order, s, hint_repair ? repair_flag : nullptr, repair_list);
+            if (opts->tile_need && two_level && R_ > 0 && hint_repair) {
                 // Walk-hint repair: tiles that outran their hint are on the device's repair list now.  The list-write pass once more
                 // with the repair flags as ITS hint (0: nothing needed; 0xFFFFFFFF: the whole list) and the blend once more over the
                 // listed tiles' full lists -- both gated on the list's count, i.e. two empty launches when every hint held.  A hint

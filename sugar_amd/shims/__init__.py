@@ -21,7 +21,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def install(patch_sugar=False, patch_losses=False, patch_optimizer=False, patch_gathers=False) -> str:
+def install(patch_sugar=False, patch_losses=False, patch_optimizer=False, patch_gathers=False, patch_densifier=False) -> str:
     """Returns "patched" (real pytorch3d found, knn_points redirected) or "shim" (stand-in package activated).
 
     `patch_sugar`: also route SuGaR's own Gaussian-buffer-sharing tensor code -- `get_points_rgb`, `get_covariance(return_sqrt)`,
@@ -32,7 +32,9 @@ def install(patch_sugar=False, patch_losses=False, patch_optimizer=False, patch_
     `patch_losses`: also replace the reference's `ssim` by the fused HIP loss kernels (see install_losses).
     `patch_optimizer`: the `torch.optim.Adam` instances the reference builds step on the one-launch HIP Adam (install_optimizer).
     `patch_gathers`: `SuGaR.points / scaling / quaternions / get_normals()` return tensors whose row gathers `x[idx]` have a HIP
-    backward (sugar_amd.sugar_patch.install_row_gathers); pass the module like `patch_sugar`, or True."""
+    backward (sugar_amd.sugar_patch.install_row_gathers); pass the module like `patch_sugar`, or True.
+    `patch_densifier`: the per-iteration densification statistics (`SuGaRDensifier.update_densification_stats`,
+    `GaussianModel.add_densification_stats`) without boolean-mask indexing (install_densifier)."""
     real_plyfile = _real_package("plyfile")  # (probed BEFORE the stand-in directory can shadow it on sys.path)
     mode = _install_pytorch3d()
     _install_plyfile(real_plyfile)
@@ -40,6 +42,8 @@ def install(patch_sugar=False, patch_losses=False, patch_optimizer=False, patch_
         install_losses()
     if patch_optimizer:
         install_optimizer()
+    if patch_densifier:
+        install_densifier()
     if patch_sugar:
         from .. import sugar_patch
         module = importlib.import_module("sugar_scene.sugar_model") if patch_sugar is True else patch_sugar
@@ -138,6 +142,85 @@ def install_optimizer() -> int:
 def uninstall_optimizer() -> int:
     count = 0
     for modname, clsname, method in _OPTIMIZER_SITES:
+        cls = getattr(sys.modules.get(modname), clsname, None)
+        f = cls.__dict__.get(method) if cls is not None else None
+        if hasattr(f, "_sugar_amd_original"):
+            setattr(cls, method, f._sugar_amd_original)
+            count += 1
+    return count
+
+
+# ---- densification statistics (sugar_densifier.py:156-164, gaussian_model.py:405-407)
+def _is_mask(t, n):
+    import torch
+    return torch.is_tensor(t) and t.dtype == torch.bool and t.dim() == 1 and t.shape[0] == n
+
+
+def _update_densification_stats(self, viewspace_point_tensor, radii, visibility_filter, _orig=None):
+    """sugar_densifier.py:156-164 for a boolean `visibility_filter`, as full-length masked updates: `x[mask] op= y[mask]` costs a
+    `nonzero` (a device-to-host round trip), a gather and an index_put per statement -- ~0.7 ms per iteration at 1M Gaussians on an
+    MI355X, a fifth of a coarse iteration before the SDF phase.  Same values: rows outside the mask are left as they are."""
+    import torch
+    g = viewspace_point_tensor.grad
+    if not _is_mask(visibility_filter, self.max_radii2D.shape[0]) or g is None:
+        return _orig(self, viewspace_point_tensor, radii, visibility_filter)
+    vis = visibility_filter
+    r = radii.to(self.max_radii2D.dtype)
+    self.max_radii2D.copy_(torch.where(vis, torch.max(self.max_radii2D, r), self.max_radii2D))
+    gn = torch.norm(g[:, :2], dim=-1, keepdim=True)
+    self.points_gradient_accum.add_(torch.where(vis[:, None], gn, torch.zeros_like(gn)))
+    self.denom.add_(vis[:, None].to(self.denom.dtype))
+
+
+def _add_densification_stats(self, viewspace_point_tensor, update_filter, _orig=None):
+    """gaussian_model.py:405-407, same idea"""
+    import torch
+    g = viewspace_point_tensor.grad
+    if not _is_mask(update_filter, self.denom.shape[0]) or g is None:
+        return _orig(self, viewspace_point_tensor, update_filter)
+    gn = torch.norm(g[:, :2], dim=-1, keepdim=True)
+    self.xyz_gradient_accum.add_(torch.where(update_filter[:, None], gn, torch.zeros_like(gn)))
+    self.denom.add_(update_filter[:, None].to(self.denom.dtype))
+
+
+_DENSIFIER_SITES = (("sugar_scene.sugar_densifier", "SuGaRDensifier", "update_densification_stats", _update_densification_stats),
+                    ("scene.gaussian_model", "GaussianModel", "add_densification_stats", _add_densification_stats))
+
+
+def install_densifier() -> int:
+    """`patch_densifier`: the two statistics methods the trainers call every iteration are rebound to mask-free equivalents (see
+    `_update_densification_stats`); an index-tensor filter, or anything else the replacement does not cover, goes to the original.
+    (The `max_radii2D[visibility_filter] = ...` line of the vanilla loop, train.py:114, is inline trainer code and stays as it is.)
+    Returns the number of methods rebound; `uninstall_densifier()` undoes it."""
+    import functools
+    count = 0
+    for modname, clsname, method, impl in _DENSIFIER_SITES:
+        mod = sys.modules.get(modname)
+        if mod is None and modname.startswith("sugar_scene."):
+            try:
+                mod = importlib.import_module(modname)
+            except ImportError:
+                mod = None
+        cls = getattr(mod, clsname, None) if mod is not None else None
+        if cls is None or hasattr(cls.__dict__.get(method), "_sugar_amd_original"):
+            continue
+        original = getattr(cls, method)
+        wrapped = functools.wraps(original)(functools.partial(impl, _orig=original))
+
+        def make(f, original):
+            def bound(self, *a, **k):
+                return f(self, *a, **k)
+            bound.__name__, bound.__doc__ = original.__name__, f.func.__doc__
+            bound._sugar_amd_original = original
+            return bound
+        setattr(cls, method, make(wrapped, original))
+        count += 1
+    return count
+
+
+def uninstall_densifier() -> int:
+    count = 0
+    for modname, clsname, method, _impl in _DENSIFIER_SITES:
         cls = getattr(sys.modules.get(modname), clsname, None)
         f = cls.__dict__.get(method) if cls is not None else None
         if hasattr(f, "_sugar_amd_original"):

@@ -367,4 +367,4 @@ def test_densify_and_resize_keep_training_and_follow_the_reference_model():
         loss = nt.step(cams[i % 8], gts[i % 8], cam_key=i % 8)
         nt.synchronize()
         losses.append(float(loss))
-    assert np.mean(losses[8:]) < np.mean(losses[:8]) and float(nt.denom.max()) == 2.0
+    assert np.mean(losses[8:]) < np.mean(losses[:8]) and float(nt.denom.max()) == 16.0   # (a Gaussian in front of all eight cameras was counted by every step)

@@ -278,3 +278,51 @@ def test_patch_optimizer_adopts_the_reference_optimizers_and_keeps_adam_semantic
     finally:
         assert shims.uninstall_optimizer() >= 1
     assert not hasattr(so.SuGaROptimizer.__dict__["__init__"], "_sugar_amd_original")
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference tree")
+def test_patch_densifier_updates_the_statistics_exactly_as_the_reference_methods_do():
+    """shims.install(patch_densifier=True): `SuGaRDensifier.update_densification_stats` (sugar_densifier.py:156-164) and
+    `GaussianModel.add_densification_stats` (gaussian_model.py:405-407) as full-length masked updates -- bit-identical statistics,
+    no boolean-mask indexing; an index-tensor filter still goes to the reference's own method."""
+    import types
+    from sugar_amd import shims
+    from tests import ref_env
+    ref_env.import_sugar_model()
+    ref_env.import_gaussian_splatting()
+    import sugar_scene.sugar_densifier as sd
+    import scene.gaussian_model as gmod
+    g = torch.Generator().manual_seed(0)
+    n = 500
+    grad = torch.randn(n, 3, generator=g)
+    grad[7] = float("nan")                     # a Gaussian outside the mask may carry anything
+    vis = torch.rand(n, generator=g) > 0.4
+    vis[7] = False
+    radii = torch.randint(0, 40, (n,), generator=g).float()
+    vsp = types.SimpleNamespace(grad=grad)
+
+    def fresh():
+        return (types.SimpleNamespace(max_radii2D=torch.rand(n, generator=torch.Generator().manual_seed(1)) * 30,
+                                      points_gradient_accum=torch.rand(n, 1, generator=torch.Generator().manual_seed(2)),
+                                      denom=torch.ones(n, 1)),
+                types.SimpleNamespace(xyz_gradient_accum=torch.rand(n, 1, generator=torch.Generator().manual_seed(3)), denom=torch.ones(n, 1)))
+    a_s, a_g = fresh()
+    sd.SuGaRDensifier.update_densification_stats(a_s, vsp, radii, vis)
+    gmod.GaussianModel.add_densification_stats(a_g, vsp, vis)
+    assert shims.install_densifier() == 2 and shims.install_densifier() == 0
+    try:
+        b_s, b_g = fresh()
+        sd.SuGaRDensifier.update_densification_stats(b_s, vsp, radii, vis)
+        gmod.GaussianModel.add_densification_stats(b_g, vsp, vis)
+        for name in ("max_radii2D", "points_gradient_accum", "denom"):
+            assert torch.equal(getattr(a_s, name), getattr(b_s, name)), name
+        assert torch.equal(a_g.xyz_gradient_accum, b_g.xyz_gradient_accum) and torch.equal(a_g.denom, b_g.denom)
+        assert not torch.isnan(b_s.points_gradient_accum).any()
+        # an index tensor instead of a mask: the reference's own statements
+        c_s, _ = fresh()
+        idx = vis.nonzero(as_tuple=True)[0]
+        sd.SuGaRDensifier.update_densification_stats(c_s, vsp, radii, idx)
+        assert torch.equal(c_s.points_gradient_accum, a_s.points_gradient_accum)
+    finally:
+        assert shims.uninstall_densifier() == 2
+    assert not hasattr(sd.SuGaRDensifier.update_densification_stats, "_sugar_amd_original")
