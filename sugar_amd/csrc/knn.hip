@@ -127,7 +127,7 @@ int sgr_knn(int N, const float* query, int M, const float* ref, int K, float* di
 namespace {
 
 // order-preserving uint encodings of the bbox; far_count: queries handed to the exhaustive kernels, ball_count: to the ball scan
-struct GridHdr { unsigned int minb[3], maxb[3], far_count, ball_count; };
+struct GridHdr { unsigned int minb[3], maxb[3], far_count, ball_count, occupied, pad; };  // occupied: non-empty cells (k_grid_count)
 // Rings a lane walks on its own before it hands its query to k_knn_ball (with K candidates in hand) -- measured, 124k queries
 // against 1M points, 0 / 10 / 30 % of them outside the cloud: cap 1: 1.06 / 1.39 / 2.02 ms, 2: 1.12 / 1.85 / 2.46, 3: 1.13 / 2.57 /
 // 3.15, 4: 1.13 / 3.49 / 4.15 (round 3, exhaustive fallback after 4 rings: 14.3 ms at 10 %).  Self queries (the neighbour rebuild,
@@ -149,7 +149,7 @@ __device__ __forceinline__ float ord2f(unsigned int o)
 __global__ void k_grid_init(GridHdr* h)
 {
     if (threadIdx.x < 3) { h->minb[threadIdx.x] = 0xFFFFFFFFu; h->maxb[threadIdx.x] = 0u; }
-    if (threadIdx.x == 3) { h->far_count = 0u; h->ball_count = 0u; }
+    if (threadIdx.x == 3) { h->far_count = 0u; h->ball_count = 0u; h->occupied = 0u; h->pad = 0u; }
 }
 
 // Far queries, Q per workgroup (grid-stride over the fallback list): the 256 threads split the reference set -- every point is
@@ -266,7 +266,7 @@ __device__ __forceinline__ int cell_coord(float v, float o, const GridGeom& g)
     return min(max(c, 0), g.G - 1);
 }
 
-__global__ void __launch_bounds__(256) k_grid_count(int M, const float* __restrict__ pts, const GridHdr* __restrict__ hdr, int G,
+__global__ void __launch_bounds__(256) k_grid_count(int M, const float* __restrict__ pts, GridHdr* __restrict__ hdr, int G,
                                                     unsigned int* __restrict__ cell_count, unsigned int* __restrict__ cell_of)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256) k_grid_count(int M, const float* __restri
               cz = cell_coord(pts[3 * (size_t)i + 2], g.oz, g);
     const unsigned int c = ((unsigned int)cz * G + cy) * G + cx;
     cell_of[i] = c;
-    atomicAdd(&cell_count[c], 1u);
+    if (atomicAdd(&cell_count[c], 1u) == 0u) atomicAdd(&hdr->occupied, 1u);
 }
 
 // exclusive scan of the cell counts (G^3 <= 2M cells), two launches: sums of 4096-cell blocks, then every block adds up the sums
@@ -507,15 +507,22 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
         const float qx = query[3 * (size_t)q], qy = query[3 * (size_t)q + 1], qz = query[3 * (size_t)q + 2];
         const float ext = (float)G * g.h;
         float u2 = qu2[w];
+        float bd[K];
+        int bi[K];
         if (!(u2 < 3.0e+38f)) {
-            // No bound from the ring walk: take one from BALL_SAMPLES points spread evenly over the cell-sorted array (i.e. over the
-            // cloud).  Every lane keeps the nearest of its share; the K-th smallest of the 64 lane minima is the distance of K
-            // DISTINCT reference points, hence an upper bound of the K-th nearest distance.  With fewer than K finite minima (a set
-            // smaller than K) the bound stays infinite and the cover below is the whole grid: still exact.
+            // No bound from the ring walk.  (1) BALL_SAMPLES points spread evenly over the cell-sorted array (i.e. over the cloud):
+            // every lane keeps the nearest of its share; the K-th smallest of the 64 lane minima is the distance of K DISTINCT
+            // reference points, hence an upper bound of the K-th nearest distance -- but a loose one (the samples are ~0.06 of the
+            // cloud's extent apart: the ball it gives cuts thousands of points out of a surface).  (2) A descent from the nearest
+            // sample: look at the 27 cells around the current best point, move to the nearest point found there, repeat until it
+            // stays in its cell; the K-th nearest of the LAST neighbourhood (no point counted twice) is a bound of the size of the
+            // answer itself.  Both are distances of K distinct points: the smaller one is used.  With fewer than K points in reach
+            // the bound stays infinite and the cover below is the whole grid: still exact.
             const unsigned int Mtot = cell_start[(unsigned int)G * G * G];
             const unsigned int per_lane = BALL_SAMPLES / 64;
             const float stride = (float)Mtot / (float)BALL_SAMPLES;
             float best = 3.402823466e+38f;
+            unsigned int best_at = 0u;
             for (unsigned int j = 0; j < per_lane; j++) {
                 unsigned int sidx = (unsigned int)(((float)(j * 64u + (unsigned int)lane) + 0.5f) * stride);
                 if (Mtot <= BALL_SAMPLES) sidx = j * 64u + (unsigned int)lane;  // (a small set: every point once)
@@ -523,8 +530,15 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
                 const float4 p = sorted[sidx];
                 if (EXCLUDE_SELF && __float_as_int(p.w) == q) continue;
                 const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
-                best = fminf(best, dx * dx + dy * dy + dz * dz);
+                const float d = dx * dx + dy * dy + dz * dz;
+                if (d < best) { best = d; best_at = sidx; }
             }
+            // the nearest sample of all (lowest lane on ties), then the K-th smallest lane minimum
+            float nearest = best;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) nearest = fminf(nearest, __shfl_xor(nearest, o));
+            const unsigned long long holders = __ballot(best == nearest);
+            unsigned int cur_at = (unsigned int)__shfl((int)best_at, holders ? (int)__builtin_ctzll(holders) : 0);
             float kth = 3.402823466e+38f;
             for (int k = 0; k < K; k++) {   // K rounds: the smallest remaining lane minimum
                 float m = best;
@@ -535,6 +549,71 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
                 if (lane == (int)__builtin_ctzll(eq | (1ull << 63))) best = 3.402823466e+38f;  // retire ONE holder of the minimum
             }
             u2 = K <= 64 ? kth : 3.402823466e+38f;
+            if (nearest < 3.0e+38f) {
+                float cur_d = nearest;
+                for (int it = 0; it < 12; it++) {
+                    const float4 cp = sorted[cur_at];
+                    const int ccx = cell_coord(cp.x, g.ox, g), ccy = cell_coord(cp.y, g.oy, g), ccz = cell_coord(cp.z, g.oz, g);
+#pragma unroll
+                    for (int k = 0; k < K; k++) { bd[k] = 3.402823466e+38f; bi[k] = 0x7FFFFFFF; }
+                    // lanes 0..8: the nine rows (z, y) of the neighbourhood; a row's three cells are one contiguous range of points
+                    unsigned int rb = 0u, re = 0u;
+                    if (lane < 9) {
+                        const int z = ccz + lane / 3 - 1, y = ccy + lane % 3 - 1;
+                        if (z >= 0 && z < G && y >= 0 && y < G) {
+                            const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, G - 1);
+                            const unsigned int c0 = ((unsigned int)z * G + y) * G + x0;
+                            rb = cell_start[c0]; re = cell_start[c0 + (unsigned int)(x1 - x0) + 1u];
+                        }
+                    }
+                    float lbest = 3.402823466e+38f;
+                    unsigned int lat = cur_at;
+                    unsigned long long rows = __ballot(re > rb);
+                    while (rows) {
+                        const int r = (int)__builtin_ctzll(rows);
+                        rows &= rows - 1ull;
+                        const unsigned int b0 = (unsigned int)__shfl((int)rb, r), e0 = (unsigned int)__shfl((int)re, r);
+                        for (unsigned int sidx = b0 + (unsigned int)lane; sidx < e0; sidx += 64u) {   // (coalesced: 64 consecutive points)
+                            const float4 p = sorted[sidx];
+                            int id = __float_as_int(p.w);
+                            if (EXCLUDE_SELF && id == q) continue;
+                            const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+                            float d = dx * dx + dy * dy + dz * dz;
+                            if (d < lbest) { lbest = d; lat = sidx; }
+                            if (!(d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]))) continue;
+#pragma unroll
+                            for (int k = 0; k < K; k++) {
+                                if (d < bd[k] || (d == bd[k] && id < bi[k])) {
+                                    const float td = bd[k]; const int ti = bi[k];
+                                    bd[k] = d; bi[k] = id; d = td; id = ti;
+                                }
+                            }
+                        }
+                    }
+                    float nb = lbest;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) nb = fminf(nb, __shfl_xor(nb, o));
+                    if (!(nb < cur_d)) break;   // the neighbourhood holds nothing nearer than the point it was built around
+                    const unsigned long long hb = __ballot(lbest == nb);
+                    cur_at = (unsigned int)__shfl((int)lat, (int)__builtin_ctzll(hb | (1ull << 63)));
+                    cur_d = nb;
+                }
+                // K-th smallest of the last neighbourhood's points: K rounds over the heads of the 64 sorted lists
+                float kth2 = 3.402823466e+38f;
+                for (int k = 0; k < K; k++) {
+                    float m = bd[0];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+                    kth2 = m;
+                    const unsigned long long eq = __ballot(bd[0] == m);
+                    if (lane == (int)__builtin_ctzll(eq | (1ull << 63))) {
+#pragma unroll
+                        for (int j = 0; j + 1 < K; j++) { bd[j] = bd[j + 1]; bi[j] = bi[j + 1]; }
+                        bd[K - 1] = 3.402823466e+38f; bi[K - 1] = 0x7FFFFFFF;
+                    }
+                }
+                u2 = fminf(u2, kth2);
+            }
         }
         const bool unbounded = !(u2 < 3.0e+38f);
         const float U = unbounded ? 4.0f * (ext + fabsf(qx - g.ox) + fabsf(qy - g.oy) + fabsf(qz - g.oz))
@@ -549,8 +628,6 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
         const int z0 = cell_coord(qz - Uz, g.oz, g), z1 = cell_coord(qz + Uz, g.oz, g);
         const int y0 = cell_coord(qy - Uy, g.oy, g), y1 = cell_coord(qy + Uy, g.oy, g);
         const int ny = y1 - y0 + 1, rows = (z1 - z0 + 1) * ny;
-        float bd[K];
-        int bi[K];
 #pragma unroll
         for (int k = 0; k < K; k++) { bd[k] = 3.402823466e+38f; bi[k] = 0x7FFFFFFF; }
         for (int row = lane; row < rows; row += 64) {
@@ -617,12 +694,27 @@ int grid_res(int M)
     if (G > 128) G = 128;
     return G;
 }
+// The resolution above gives ~6 points per cell when the points FILL their bounding box.  The clouds this library meets in
+// practice lie on surfaces (Gaussians of a reconstructed scene; BASELINE config 4 binds them to a mesh): then only ~3 G^2 of the
+// G^3 cells hold anything, each ~M / (3 G^2) points -- 110 at 1M -- and a query's first ring of 27 cells scans thousands of
+// points (3.6 ms per 124k queries, self query 3.9 ms against 2.3 for a volume).  The finest resolution worth having for such a
+// set, ~6 points per OCCUPIED cell of a surface: the scratch is sized for it, and build_grid picks between the two after
+// counting how many cells the coarse grid actually fills (one 4-byte read-back: the only host round trip of a query).
+int grid_res_max(int M)
+{
+    int G = (int)ceil(sqrt((double)M / 18.0));
+    const int G0 = grid_res(M);
+    if (G < G0) G = G0;
+    if (G > 128) G = 128;
+    return G;
+}
+#define GRID_PROBE_MIN_POINTS 50000  // below this a query costs microseconds either way: no probe, no round trip
 
 struct GridScratch { GridHdr* hdr; unsigned int *cell_count, *cursor, *cell_start, *cell_of, *scan_part; float4* sorted; int* far_list;
                      int* ball_list; float* ball_u2; unsigned int far_cap; size_t total; };
 GridScratch carve_grid(char* base, int M)
 {
-    const int G = grid_res(M);
+    const int G = grid_res_max(M);
     const size_t cells = (size_t)G * G * G;
     GridScratch s;
     size_t off = 0;
@@ -641,31 +733,63 @@ GridScratch carve_grid(char* base, int M)
     return s;
 }
 
-int build_grid(int M, const float* ref, const GridScratch& gs, hipStream_t s)
+struct ProbeSlot {
+    unsigned int* p = nullptr;
+    ~ProbeSlot() { /* leaked on purpose: the HIP runtime may be gone at thread exit */ }
+};
+thread_local ProbeSlot g_probe;
+
+int count_cells(int M, const float* ref, const GridScratch& gs, int G, hipStream_t s)
 {
-    const int G = grid_res(M);
-    const size_t cells = (size_t)G * G * G;
-    // cell_count and cursor are adjacent: one memset
+    // cell_count and cursor are adjacent: one memset (sized for the finest grid the scratch was carved for)
     if (hipMemsetAsync(gs.cell_count, 0, reinterpret_cast<char*>(gs.cell_start) - reinterpret_cast<char*>(gs.cell_count), s) != hipSuccess)
         return SGR_E_HIP;
+    hipLaunchKernelGGL(k_grid_count, dim3((M + 255) / 256), dim3(256), 0, s, M, ref, gs.hdr, G, gs.cell_count, gs.cell_of);
+    return 0;
+}
+
+// returns the resolution the grid was built with (> 0), or a negative error code
+int build_grid(int M, const float* ref, const GridScratch& gs, hipStream_t s)
+{
+    int G = grid_res(M);
     hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(64), 0, s, gs.hdr);
     hipLaunchKernelGGL(k_grid_bbox, dim3(min((M + 255) / 256, 1024)), dim3(256), 0, s, M, ref, gs.hdr);
-    hipLaunchKernelGGL(k_grid_count, dim3((M + 255) / 256), dim3(256), 0, s, M, ref, gs.hdr, G, gs.cell_count, gs.cell_of);
+    int rc = count_cells(M, ref, gs, G, s);
+    if (rc < 0) return rc;
+    const int Gmax = grid_res_max(M);
+    if (M >= GRID_PROBE_MIN_POINTS && Gmax > G) {
+        // how full is the coarse grid?  ~6 points per occupied cell: the set fills its box, keep it.  Many more: the set is a
+        // surface (or a few clusters): refine until an occupied cell holds ~6 again -- occupied cells of a surface grow with G^2
+        if (!g_probe.p && hipHostMalloc(reinterpret_cast<void**>(&g_probe.p), 64, hipHostMallocDefault) != hipSuccess) return SGR_E_HIP;
+        if (hipMemcpyAsync(g_probe.p, &gs.hdr->occupied, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return SGR_E_HIP;
+        if (hipStreamSynchronize(s) != hipSuccess) return SGR_E_HIP;
+        const double per_cell = (double)M / (double)(g_probe.p[0] ? g_probe.p[0] : 1u);
+        if (per_cell > 24.0) {
+            int G2 = (int)ceil((double)G * sqrt(per_cell / 6.0));
+            if (G2 > Gmax) G2 = Gmax;
+            if (G2 > G) {
+                G = G2;
+                rc = count_cells(M, ref, gs, G, s);
+                if (rc < 0) return rc;
+            }
+        }
+    }
+    const size_t cells = (size_t)G * G * G;
     const int scan_blocks = (int)((cells + GRID_SCAN_BLOCK - 1) / GRID_SCAN_BLOCK);
     hipLaunchKernelGGL(k_grid_blocksum, dim3(scan_blocks), dim3(256), 0, s, (int)cells, gs.cell_count, gs.scan_part);
     hipLaunchKernelGGL(k_grid_scan, dim3(scan_blocks), dim3(256), 0, s, (int)cells, gs.cell_count, gs.scan_part, gs.cell_start);
     hipLaunchKernelGGL(k_grid_scatter, dim3((M + 255) / 256), dim3(256), 0, s, M, ref, gs.cell_of, gs.cell_start, gs.cursor, gs.sorted);
-    return 0;
+    return G;
 }
 
 // the two exhaustive fallbacks of a grid query (each looks at the far count and takes its own regime)
 template <int K, bool EXCLUDE_SELF>
-void launch_far(int N, const float* query, int M, const float* ref, const GridScratch& gs, float* d, int64_t* i, float* mean, hipStream_t s)
+void launch_far(int N, const float* query, int M, const float* ref, const GridScratch& gs, int G, float* d, int64_t* i, float* mean, hipStream_t s)
 {
     const unsigned int cap = gs.far_cap < (unsigned int)N ? gs.far_cap : (unsigned int)N;
     const unsigned int ball_groups = (cap + 3) / 4;  // one wave per query, four per workgroup, grid-stride over the (device-side) count
     hipLaunchKernelGGL((k_knn_ball<K, EXCLUDE_SELF>), dim3(ball_groups < 8192u ? ball_groups : 8192u), dim3(256), 0, s, query, gs.hdr,
-                       grid_res(M), gs.cell_start, gs.sorted, d, i, mean, gs.ball_list, gs.ball_u2, &gs.hdr->ball_count, cap);
+                       G, gs.cell_start, gs.sorted, d, i, mean, gs.ball_list, gs.ball_u2, &gs.hdr->ball_count, cap);
     constexpr int Q = K <= 4 ? 8 : (K <= 16 ? 4 : 2);  // queries per workgroup: Q * K (distance, index) pairs per thread in registers
     const unsigned int groups = (cap + Q - 1) / Q;
     hipLaunchKernelGGL((k_knn_far<K, EXCLUDE_SELF, Q>), dim3(groups < 4096u ? groups : 4096u), dim3(256), 0, s, query, M, gs.sorted, d, i,
@@ -686,7 +810,7 @@ void launch_grid_query(bool self, int N, const float* query, int M, const float*
         hipLaunchKernelGGL((k_grid_query<K, false, false>), dim3((N + 127) / 128), dim3(128), 0, s, N, query, gs.hdr, G, gs.cell_start,
                            gs.sorted, d, i, (float*)nullptr, &gs.hdr->far_count, gs.far_list, gs.far_cap, grid_max_ring(), &gs.hdr->ball_count,
                            gs.ball_list, gs.ball_u2);
-    launch_far<K, false>(N, query, M, ref, gs, d, i, nullptr, s);
+    launch_far<K, false>(N, query, M, ref, gs, G, d, i, nullptr, s);
 }
 
 }  // namespace
@@ -701,9 +825,8 @@ int sgr_knn_grid(int N, const float* query, int M, const float* ref, int K, floa
     if (!query || !ref || !dists || !idx || !scratch || M <= 0) return SGR_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const GridScratch gs = carve_grid(scratch, M);
-    const int rc = build_grid(M, ref, gs, s);
-    if (rc < 0) return rc;
-    const int G = grid_res(M);
+    const int G = build_grid(M, ref, gs, s);
+    if (G < 0) return G;
     const bool self = (query == ref && N == M);
     switch (K) {
         case 1: launch_grid_query<1>(self, N, query, M, ref, gs, G, dists, idx, s); break;
@@ -724,12 +847,12 @@ int sgr_dist2_grid(int P, const float* points, float* meanDists, char* scratch, 
     if (!points || !meanDists || !scratch) return SGR_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const GridScratch gs = carve_grid(scratch, P);
-    const int rc = build_grid(P, points, gs, s);
-    if (rc < 0) return rc;
-    hipLaunchKernelGGL((k_grid_query<3, true, true>), dim3((P + 127) / 128), dim3(128), 0, s, P, points, gs.hdr, grid_res(P),
+    const int G = build_grid(P, points, gs, s);
+    if (G < 0) return G;
+    hipLaunchKernelGGL((k_grid_query<3, true, true>), dim3((P + 127) / 128), dim3(128), 0, s, P, points, gs.hdr, G,
                        gs.cell_start, gs.sorted, (float*)nullptr, (int64_t*)nullptr, meanDists, &gs.hdr->far_count, gs.far_list,
                        gs.far_cap, grid_max_ring(), &gs.hdr->ball_count, gs.ball_list, gs.ball_u2);
-    launch_far<3, true>(P, points, P, points, gs, nullptr, nullptr, meanDists, s);
+    launch_far<3, true>(P, points, P, points, gs, G, nullptr, nullptr, meanDists, s);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 
