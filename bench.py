@@ -108,6 +108,10 @@ def main():
     from sugar_amd import build, _lib, synthetic as syn
     if rank == 0:
         build.build()
+        try:
+            build.build_torch_ext()   # (host-side accelerator of the reference-shaped API; the ctypes binding serves without it)
+        except Exception as e:
+            print(f"[bench] torch extension not built: {e!r}"[:300], file=sys.stderr)
     if world > 1:
         dist.barrier()
     lib = _lib.load()
@@ -413,7 +417,9 @@ def main():
         # counter-derived figures come from a committed reduction of separate rocprofv3 --pmc passes over THIS command
         # (scripts/pmc_on_box.sh -> profiles/pmc_blend_fwd.json); they are per workload: another --workload gets null
         traffic, valu, pmc_src = None, None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_blend_fwd.json")
+        pmc = os.path.join(ROOT, "profiles", f"pmc_blend_fwd_{args.workload}.json")
+        if not os.path.exists(pmc):
+            pmc = os.path.join(ROOT, "profiles", "pmc_blend_fwd.json")
         if os.path.exists(pmc):
             try:
                 pj = json.load(open(pmc))
@@ -484,7 +490,7 @@ def main():
             "roofline": {
                 "kernel": "k_blend_fwd_w", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": (f"profiles/pmc_blend_fwd.json ({pmc_src}): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
+                "traffic_source": (f"profiles/{os.path.basename(pmc)} ({pmc_src}): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
                                    "command, NOT measured in this run" if traffic is not None else
                                    "null: no committed PMC reduction for this workload"),
                 "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": blend_ms,

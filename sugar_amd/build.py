@@ -92,5 +92,47 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return OUT
 
 
+# ---- the PyTorch C++ extension `_C` (csrc/torch_ext.cpp): host code only, compiled with g++ against the torch headers and linked to
+# libsugar_raster.so by name (rpath $ORIGIN); built in-tree next to it
+EXT_OUT = os.path.join(HERE, "_C_ext.so")
+
+
+def build_torch_ext(force: bool = False, verbose: bool = False) -> str:
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    src = os.path.join(CSRC, "torch_ext.cpp")
+    h = hashlib.sha256()
+    for p in (src, os.path.join(HERE, "..", "include", "sugar_raster.h")):
+        h.update(open(p, "rb").read())
+    h.update(torch.__version__.encode())
+    dig = h.hexdigest()
+    stamp = EXT_OUT + ".stamp"
+    if not force and os.path.exists(EXT_OUT) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return EXT_OUT
+    if not os.path.exists(os.path.join(HERE, "libsugar_raster.so")):
+        build()
+    libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+    try:
+        inc = ce.include_paths(device_type="cuda")
+    except TypeError:
+        inc = ce.include_paths(True)
+    cxx = os.environ.get("CXX") or shutil.which("g++") or "g++"
+    cmd = [cxx, "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_C_ext",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
+           *["-I" + i for i in inc], "-I" + sysconfig.get_paths()["include"], "-I/opt/rocm/include", src, "-o", EXT_OUT,
+           "-L" + libdir, "-lc10", "-ltorch", "-ltorch_cpu", "-ltorch_python", "-lc10_hip", "-ltorch_hip",
+           "-L" + HERE, "-l:libsugar_raster.so", "-Wl,-rpath," + libdir, "-Wl,-rpath,$ORIGIN", "-Wl,--no-as-needed"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("building the torch C++ extension failed:\n" + r.stdout.decode())
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return EXT_OUT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_torch_ext(force="--force" in sys.argv, verbose=True))

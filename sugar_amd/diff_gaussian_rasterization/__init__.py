@@ -53,6 +53,37 @@ def _spec_capacity(key):
     return 0 if not r else r + r // 2 + 65536
 
 
+# The PyTorch C++ extension (csrc/torch_ext.cpp -> sugar_amd/_C_ext.so, built by sugar_amd.build.build_torch_ext): the reference's
+# `_C` module as a torch extension -- same three functions, same argument orders (DGR/ext.cpp:15-19) -- taking tensors and the current
+# stream straight to the C ABI.  The plain reference-shaped call (no grad_sink extension in effect) goes through it: no ctypes
+# marshalling of ~35 arguments per call, no Python re-entry for the three scratch allocations.  SGR_TORCH_EXT=0 keeps everything on
+# the ctypes binding; a missing extension does the same (the HIP library itself is never optional).
+_EXT = None
+_EXT_TRIED = False
+_PLAIN_SINK_KEYS = frozenset(("speculative",))
+
+
+def _ext():
+    global _EXT, _EXT_TRIED
+    if _EXT_TRIED:
+        return _EXT
+    _EXT_TRIED = True
+    if _os.environ.get("SGR_TORCH_EXT", "1") == "0" or _os.environ.get("SGR_LIB_PATH"):
+        return None   # (SGR_LIB_PATH: an A/B variant of the library is loaded through ctypes; the extension is linked to the default one)
+    path = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "_C_ext.so")
+    if not _os.path.exists(path):
+        return None
+    import importlib.util
+    _lib.load()  # (the extension links libsugar_raster.so by name: make sure it is THIS tree's copy that is already mapped)
+    spec = importlib.util.spec_from_file_location("_C_ext", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if mod.abi_version() != _lib.ABI_VERSION:
+        raise ImportError(f"{path}: built against ABI {mod.abi_version()}, bindings are {_lib.ABI_VERSION} (rebuild: python -m sugar_amd.build)")
+    _EXT = mod
+    return mod
+
+
 @contextlib.contextmanager
 def grad_sink(**buffers):
     global _GRAD_SINK
@@ -153,6 +184,22 @@ class _CModule:
         lib = _lib.load()
         dev = means3D.device
         P, H, W = means3D.size(0), int(image_height), int(image_width)
+        sink0 = _GRAD_SINK or {}
+        ext = _ext() if (P != 0 and _PLAIN_SINK_KEYS.issuperset(sink0)) else None
+        if ext is not None:
+            # the plain reference-shaped call: through the torch C++ extension
+            spec_key = (dev.index, P, W, H)
+            cap = _spec_capacity(spec_key) if (_SPECULATE and sink0.get("speculative", True)) else 0
+            rendered, out_color, radii, geom, binning, img = ext.rasterize_gaussians_ex(
+                int(cap), background, means3D, colors, opacity, scales, rotations, float(scale_modifier), cov3D_precomp, viewmatrix,
+                projmatrix, float(tan_fovx), float(tan_fovy), H, W, sh, int(degree), campos, bool(prefiltered), bool(debug))
+            mode, sync_free, speculation, list_cap = ext.last_forward_info()
+            if _SPECULATE and int(rendered) > _SPEC_CAP.get(spec_key, 0):
+                _SPEC_CAP[spec_key] = int(rendered)
+            _CModule.last_forward = dict(num_rendered=int(rendered), W=W, H=H, P=P, geom=geom, binning=binning, img=img,
+                                         binning_mode=int(mode), sync_free=bool(sync_free), speculative=cap > 0,
+                                         speculation_missed=int(speculation) == 2, list_capacity=int(list_cap), torch_ext=True)
+            return int(rendered), out_color, radii, geom, binning, img
         if P == 0:  # rasterize_points.cu:68-69,81
             empty = torch.empty(0, dtype=torch.uint8, device=dev)
             return (0, torch.zeros(3, H, W, dtype=torch.float32, device=dev),
@@ -222,7 +269,7 @@ class _CModule:
         _CModule.last_forward = dict(num_rendered=int(rendered), W=W, H=H, P=P, geom=t["geom"], binning=t["binning"],
                                      img=t["img"], binning_mode=int(info.binning_mode), sync_free=bool(info.sync_free),
                                      speculative=bool(speculate), speculation_missed=int(info.speculation) == 2,
-                                     list_capacity=capacity if (speculate and int(info.speculation) == 1) else int(rendered))
+                                     list_capacity=capacity if (speculate and int(info.speculation) == 1) else int(rendered), torch_ext=False)
         return int(rendered), out_color, radii, t["geom"], t["binning"], t["img"]
 
     @staticmethod
@@ -232,6 +279,13 @@ class _CModule:
         lib = _lib.load()
         dev = means3D.device
         P = means3D.size(0)
+        if not grad_out and P != 0:
+            ext = _ext()
+            if ext is not None:  # the plain call: through the torch C++ extension
+                return ext.rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, float(scale_modifier),
+                                                        cov3D_precomp, viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy),
+                                                        dL_dout_color, sh, int(degree), campos, geomBuffer, int(R), binningBuffer,
+                                                        imageBuffer, bool(debug))
         H, W = dL_dout_color.size(1), dL_dout_color.size(2)
         M = sh.size(1) if sh.dim() == 3 else 0  # (the reference takes 0 for an empty tensor and then fails in autograd when P == 0)
         f = dict(dtype=torch.float32, device=dev)

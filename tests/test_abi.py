@@ -139,3 +139,26 @@ def test_product_never_imports_the_oracle():
             if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "liboracle" in src:
                 bad.append(path)
     assert not bad, bad
+
+
+def test_torch_extension_has_the_reference_module_surface(hip_lib):
+    """sugar_amd/_C_ext.so (csrc/torch_ext.cpp): the reference's pybind module `_C` (DGR/ext.cpp:15-19) as a PyTorch C++ extension
+    over the C ABI -- the three entry points by the reference's names, built against this ABI version; no CPU path."""
+    import pytest
+    import torch
+    from sugar_amd import build
+    build.build_torch_ext()
+    import sugar_amd.diff_gaussian_rasterization as dgr
+    ext = dgr._ext()
+    assert ext is not None and ext.abi_version() == hip_lib.sgr_abi_version()
+    for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible"):
+        assert callable(getattr(ext, name))
+    e = torch.empty(0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ext.rasterize_gaussians(torch.zeros(3), torch.zeros(5, 3), e, torch.zeros(5, 1), torch.ones(5, 3), torch.zeros(5, 4), 1.0, e,
+                                torch.eye(4), torch.eye(4), 0.5, 0.5, 16, 16, torch.zeros(5, 16, 3), 3, torch.zeros(3), False, False)
+    with pytest.raises(RuntimeError, match="num_points, 3"):
+        ext.rasterize_gaussians(torch.zeros(3), torch.zeros(5, 2), e, torch.zeros(5, 1), torch.ones(5, 3), torch.zeros(5, 4), 1.0, e,
+                                torch.eye(4), torch.eye(4), 0.5, 0.5, 16, 16, torch.zeros(5, 16, 3), 3, torch.zeros(3), False, False)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ext.mark_visible(torch.zeros(5, 3), torch.eye(4), torch.eye(4))

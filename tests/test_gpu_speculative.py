@@ -106,3 +106,30 @@ def test_a_trainer_shaped_loop_never_takes_the_mid_forward_round_trip_after_its_
             for t in leaves + [m2]:
                 t.grad = None
     assert spec == [False] + [True] * 11 and not any(missed)
+
+
+@pytest.mark.parametrize("use_sh,use_cov", [(True, False), (False, False), (True, True)])
+def test_the_torch_extension_path_equals_the_ctypes_path(use_sh, use_cov):
+    """The plain reference-shaped call goes through the PyTorch C++ extension (csrc/torch_ext.cpp: DGR/ext.cpp's `_C` over the C
+    ABI); with a grad_sink extension in effect, or SGR_TORCH_EXT=0, through the ctypes binding.  Same library underneath: same lists,
+    same image bit for bit, gradients equal up to the float-atomic order."""
+    from sugar_amd import diff_gaussian_rasterization as dgr
+    from sugar_amd.diff_gaussian_rasterization import _C
+    ext = dgr._ext()
+    assert ext is not None, "sugar_amd/_C_ext.so missing: python -m sugar_amd.build"
+    W, H, P = 512, 320, 40_007
+    scene = syn.make_scene(P, 5, 0.004, 0.05)
+    cam = syn.orbit_cameras(W, H)[6]
+    bg = torch.tensor([0.0, 0.5, 1.0])
+    g = np.random.default_rng(1).standard_normal((3, H, W)).astype(np.float32)
+    a = pu.run_hip(scene, cam, bg, use_sh=use_sh, use_cov=use_cov, grad_out=g)
+    assert _C.last_forward["torch_ext"]
+    saved = (dgr._EXT, dgr._EXT_TRIED)
+    dgr._EXT, dgr._EXT_TRIED = None, True
+    try:
+        b = pu.run_hip(scene, cam, bg, use_sh=use_sh, use_cov=use_cov, grad_out=g)
+        assert not _C.last_forward["torch_ext"]
+    finally:
+        dgr._EXT, dgr._EXT_TRIED = saved
+    _same(b, a)
+    assert set(a["grads"]) == set(b["grads"])
