@@ -13,8 +13,9 @@
 // forward waits for num_rendered at the END of the call instead of in the middle (SGR_FLAG_SPECULATIVE, see the header) from the
 // second call with the same (device, P, W, H) on.  No CPU path: CPU tensors raise.
 #include <torch/extension.h>
-#include <c10/hip/HIPStream.h>
-#include <c10/hip/HIPGuard.h>
+// PyTorch-ROCm presents its devices as DeviceType::CUDA: the guard and the current stream come from the "masquerading" variants
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <map>
 #include <mutex>
@@ -77,7 +78,7 @@ RasterizeImpl(long long capacity_in, const torch::Tensor& background, const torc
     if (P == 0)  // rasterize_points.cu:68-69,81
         return std::make_tuple((int64_t)0, torch::zeros({3, H, W}, f32), torch::zeros({0}, i32), torch::empty({0}, u8), torch::empty({0}, u8),
                                torch::empty({0}, u8));
-    c10::hip::HIPGuard guard(dev);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     const auto m3 = dev_f32(means3D, dev, "means3D"), bg = dev_f32(background, dev, "bg"), col = dev_f32(colors, dev, "colors_precomp"),
                op = dev_f32(opacity, dev, "opacities"), sc = dev_f32(scales, dev, "scales"), ro = dev_f32(rotations, dev, "rotations"),
                cov = dev_f32(cov3D_precomp, dev, "cov3D_precomp"), vm = dev_f32(viewmatrix, dev, "viewmatrix"),
@@ -99,7 +100,7 @@ RasterizeImpl(long long capacity_in, const torch::Tensor& background, const torc
     opts.binning_capacity = capacity;
     opts.flags = capacity > 0 ? SGR_FLAG_SPECULATIVE : 0;
     opts.info = &info;
-    hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+    hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
     const int64_t rendered = sgr_forward_ex(alloc_cb, &geom, alloc_cb, &binning, alloc_cb, &img, P, degree, M, fptr(bg), W, H, fptr(m3),
                                             fptr(shs), fptr(col), fptr(op), fptr(sc), scale_modifier, fptr(ro), fptr(cov), fptr(vm),
                                             fptr(pm), fptr(cam), tan_fovx, tan_fovy, prefiltered ? 1 : 0, out_color.data_ptr<float>(),
@@ -148,13 +149,13 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
     torch::Tensor dL_dscales = use_cov ? torch::zeros({P, 3}, f32) : torch::empty({P, 3}, f32);
     torch::Tensor dL_drotations = use_cov ? torch::zeros({P, 4}, f32) : torch::empty({P, 4}, f32);
     if (P != 0) {
-        c10::hip::HIPGuard guard(dev);
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
         const auto m3 = dev_f32(means3D, dev, "means3D"), bg = dev_f32(background, dev, "bg"), col = dev_f32(colors, dev, "colors_precomp"),
                    sc = dev_f32(scales, dev, "scales"), ro = dev_f32(rotations, dev, "rotations"),
                    cov = dev_f32(cov3D_precomp, dev, "cov3D_precomp"), vm = dev_f32(viewmatrix, dev, "viewmatrix"),
                    pm = dev_f32(projmatrix, dev, "projmatrix"), shs = dev_f32(sh, dev, "shs"), cam = dev_f32(campos, dev, "campos"),
                    dL = dev_f32(dL_dout_color, dev, "dL_dout_color");
-        hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+        hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
         const int rc = sgr_backward(P, degree, M, (int64_t)R, fptr(bg), W, H, fptr(m3), fptr(shs), fptr(col), fptr(sc), scale_modifier, fptr(ro),
                                     fptr(cov), fptr(vm), fptr(pm), fptr(cam), tan_fovx, tan_fovy, radii.data_ptr<int>(),
                                     reinterpret_cast<char*>(geomBuffer.data_ptr()), reinterpret_cast<char*>(binningBuffer.data_ptr()),
@@ -174,9 +175,9 @@ torch::Tensor markVisible(const torch::Tensor& means3D, const torch::Tensor& vie
     const int P = (int)means3D.size(0);
     torch::Tensor present = torch::zeros({P}, torch::TensorOptions().dtype(torch::kBool).device(dev));
     if (P != 0) {
-        c10::hip::HIPGuard guard(dev);
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
         const auto m3 = dev_f32(means3D, dev, "means3D"), vm = dev_f32(viewmatrix, dev, "viewmatrix"), pm = dev_f32(projmatrix, dev, "projmatrix");
-        hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+        hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
         const int rc = sgr_mark_visible(P, fptr(m3), fptr(vm), fptr(pm), reinterpret_cast<uint8_t*>(present.data_ptr<bool>()), (void*)stream);
         if (rc < 0) throw std::runtime_error(std::string("sgr_mark_visible failed: ") + sgr_last_error());
     }
