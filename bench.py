@@ -872,6 +872,28 @@ def unmodified_path_legs(scene, cams, gts, bg_d, dev, n_steps):
                         "what": "additionally GaussianModel.optimizer (the torch.optim.Adam the reference constructs) adopted by "
                                 "sugar_amd.fused_adam.FusedAdam: one k_adam launch per parameter tensor instead of ~50 multi-tensor kernels"}
                     del loop, gaussians
+                    # ... and the loop's per-iteration densification statistics (GaussianModel.add_densification_stats, reached
+                    # from train.py:115) without boolean-mask indexing (shims.install(patch_densifier=True))
+                    shims.install_densifier()
+                    try:
+                        gaussians = rl.make_gaussians(ref2, scene, dev, opt)
+                        loop = rl.Loop(ref2, gaussians, [rl.make_viewpoint(c, gt, dev) for c, gt in zip(cams, gts)], bg_d, opt=opt)
+                        for _ in range(len(cams)):
+                            loop.loop_body()
+                        torch.cuda.synchronize(dev)
+                        t0 = time.perf_counter()
+                        for _ in range(n_steps):
+                            loss4 = loop.loop_body()
+                        torch.cuda.synchronize(dev)
+                        dt4 = (time.perf_counter() - t0) / n_steps
+                        out["reference_loop"]["with_patch_losses_optimizer_and_densifier"] = {
+                            "images_per_sec": 1.0 / dt4, "ms_per_step": 1e3 * dt4, "final_loss": float(loss4),
+                            "what": "additionally GaussianModel.add_densification_stats as full-length masked updates (no nonzero / "
+                                    "index / index_put per statement); the `max_radii2D[visibility_filter] = ...` line of train.py:114 "
+                                    "is inline trainer code and stays"}
+                        del loop, gaussians
+                    finally:
+                        shims.uninstall_densifier()
                 finally:
                     shims.uninstall_optimizer()
             finally:

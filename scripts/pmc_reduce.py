@@ -21,7 +21,7 @@ def avg(path, counter, kernel):
 d = sys.argv[1]
 workload = sys.argv[2] if len(sys.argv) > 2 else "metric"
 prefix = sys.argv[3] if len(sys.argv) > 3 else "pmc_"
-tag = os.path.basename(os.path.normpath(d))
+tag = sys.argv[4] if len(sys.argv) > 4 else os.path.basename(os.path.normpath(d))   # the rNN the pass files are committed under
 fetch = avg(os.path.join(d, prefix + "FETCH_SIZE.txt"), "FETCH_SIZE", "k_blend_fwd_w")
 write = avg(os.path.join(d, prefix + "WRITE_SIZE.txt"), "WRITE_SIZE", "k_blend_fwd_w")
 try:

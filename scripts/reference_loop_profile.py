@@ -10,10 +10,14 @@ from oracle import reference_loop as rl
 dev = torch.device("cuda:0")
 scene, cams, bg = syn.make_config("metric")
 patch = "--no-patch-losses" not in sys.argv
+all_patches = "--all-patches" in sys.argv   # + the optimiser and the densification statistics (round 5)
 ref = rl.import_reference()
 if patch:
     shims.install_losses()
     ref = rl.import_reference()
+if all_patches:
+    shims.install_optimizer()
+    shims.install_densifier()
 opt = rl.optimization_params()
 gaussians = rl.make_gaussians(ref, scene, dev, opt)
 gts = [torch.rand(3, c.image_height, c.image_width) for c in cams]
@@ -27,6 +31,6 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     for _ in range(N):
         loop.loop_body()
     torch.cuda.synchronize()
-print(f"patch_losses={patch}; {N} iterations")
+print(f"patch_losses={patch}; all_patches={all_patches}; {N} iterations; optimizer {type(gaussians.optimizer).__name__}")
 print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=70))
 print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=14, max_name_column_width=70))
