@@ -161,7 +161,8 @@ __device__ __forceinline__ void fwd_walk(uint32_t addr, int& n, unsigned long lo
           "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc", "memory");
 }
 
-__global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_start,
+template <bool REPAIR>
+__device__ __forceinline__ void blend_fwd_body(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_start,
                                                     const uint32_t* __restrict__ point_list, const GeomRec* __restrict__ rec,
                                                     const float* __restrict__ bg, float* __restrict__ final_T,
                                                     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_maxc,
@@ -169,8 +170,7 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
                                                     unsigned long long* __restrict__ blk_mask, uint32_t* __restrict__ blk_nb,
                                                     uint32_t* __restrict__ header, uint32_t list_cap,
                                                     const uint32_t* __restrict__ tile_need, const uint32_t* __restrict__ launch_order,
-                                                    uint32_t* __restrict__ repair_flag, uint32_t* __restrict__ repair_list,
-                                                    int repair_pass)
+                                                    uint32_t* __restrict__ repair_flag, uint32_t* __restrict__ repair_list)
 {
     // sync-free forward: the list did not fit the caller's capacity (or the level-1 binning overflowed) -> leave everything
     // untouched; the caller repeats the forward and every later kernel of the step reads the same header
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
     int slot, sub;
     sgr_slot_of_workgroup((int)blockIdx.x, slot, sub);
     if (slot >= T_tiles) return;
-    if (repair_pass) {
+    if (REPAIR) {
         // the repair pass of the walk hint: launch_order = the tiles the first pass listed, header word SGR_HDR_REPAIR their count
         const uint32_t n_rep = header[SGR_HDR_REPAIR];
         if (n_rep > (uint32_t)SGR_REPAIR_TILES) {  // more than this launch covers: the forward is invalid after all
@@ -217,17 +217,47 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
     // the data lands.)
     // (loads are unconditional with clamped indices: a load under a lane predicate makes the compiler's wait counts
     // path-dependent and it then drains everything at the first use)
-    uint32_t id_next = 0u;
-    if (total > 0) id_next = point_list[r0 + (uint32_t)min(lane, total - 1)];  // (uniform branch)
+    // (round 5: the ids run TWO batches ahead.  With one batch of lead the id load of batch b + 1, issued at the top of iteration b,
+    // had only that iteration's cull and walk to come back in -- a fraction of a microsecond when few entries survive the cull --
+    // so every batch paid two dependent memory round trips, ids then records: a tile that walks thousands of entries, a silhouette
+    // tile of BASELINE config 4's flat splats walks 4 700, is a chain of ~3 us links and the whole launch waits for it.)
+    uint32_t id_next = 0u, id_next2 = 0u;
+    if (total > 0) {  // (uniform branch)
+        id_next = point_list[r0 + (uint32_t)min(lane, total - 1)];
+        id_next2 = point_list[r0 + (uint32_t)min(64 + lane, total - 1)];
+    }
     const uint32_t lds0 = (uint32_t)(uintptr_t)s_e;  // LDS byte address of the staging area
     // for the backward: which lanes of every 64-entry batch survived this block's cull (one 64-bit mask per batch and block;
     // batch b of the tile sits in slot (r0 >> 6) + tile + b: slots of different tiles never overlap)
     unsigned long long* my_mask = blk_mask + 4 * ((size_t)(r0 >> 6) + (size_t)tile) + sub;
     int n_batches = 0;
+#ifdef SGR_FWD_PREFETCH_RECORDS
+    // (A/B build option, round 5: the RECORDS of batch b + 1 are requested before batch b is culled and walked -- twelve more live
+    // registers across the walk.  For the one wave of a tile that walks thousands of entries the gather's round trip is then off
+    // the chain; see DESIGN.md for what it did to the metric workload and to config 4)
+    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0;
+    if (total > 0) {
+        const float4* rp0 = reinterpret_cast<const float4*>(rec + id_next);
+        p0 = rp0[0]; p1 = rp0[1]; p2 = rp0[2];
+        id_next = id_next2;
+        id_next2 = point_list[r0 + (uint32_t)min(128 + lane, total - 1)];
+    }
+#endif
     for (int base = 0; base < total && live != 0ull; base += 64) {
+#ifdef SGR_FWD_PREFETCH_RECORDS
+        const float4 v0 = p0, v1 = p1, v2 = p2;
+        {
+            const float4* rp = reinterpret_cast<const float4*>(rec + id_next);   // batch b + 1 (clamped ids past the end: a cached line)
+            p0 = rp[0]; p1 = rp[1]; p2 = rp[2];
+        }
+        id_next = id_next2;
+        id_next2 = point_list[r0 + (uint32_t)min(base + 192 + lane, total - 1)];
+#else
         const float4* rp = reinterpret_cast<const float4*>(rec + id_next);
         const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
-        id_next = point_list[r0 + (uint32_t)min(base + 64 + lane, total - 1)];
+        id_next = id_next2;
+        id_next2 = point_list[r0 + (uint32_t)min(base + 128 + lane, total - 1)];
+#endif
         const bool hit = (base + lane < total) && block_hit(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)bx0, (float)by0);
         const unsigned long long m = __ballot(hit);
         int n = __popcll(m);
@@ -280,6 +310,34 @@ __global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_
         atomicMax(&tile_walked[tile], __ballot(inside) ? walked : 0u);
         blk_nb[4 * tile + sub] = mc ? (uint32_t)n_batches : 0u;  // batches with a mask (0: nothing contributed to the block)
     }
+}
+
+__global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_start,
+                                                    const uint32_t* __restrict__ point_list, const GeomRec* __restrict__ rec,
+                                                    const float* __restrict__ bg, float* __restrict__ final_T,
+                                                    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_maxc,
+                                                    uint32_t* __restrict__ tile_walked, float* __restrict__ out_color,
+                                                    unsigned long long* __restrict__ blk_mask, uint32_t* __restrict__ blk_nb,
+                                                    uint32_t* __restrict__ header, uint32_t list_cap,
+                                                    const uint32_t* __restrict__ tile_need, const uint32_t* __restrict__ launch_order,
+                                                    uint32_t* __restrict__ repair_flag, uint32_t* __restrict__ repair_list)
+{
+    blend_fwd_body<false>(W, H, gx, T_tiles, tile_start, point_list, rec, bg, final_T, n_contrib, tile_maxc, tile_walked, out_color, blk_mask,
+                          blk_nb, header, list_cap, tile_need, launch_order, repair_flag, repair_list);
+}
+
+// the repair pass of the walk hint (a kernel name of its own, so that a trace tells the gated, usually empty launch from the blend)
+__global__ void __launch_bounds__(64) k_blend_fwd_repair(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_start,
+                                                         const uint32_t* __restrict__ point_list, const GeomRec* __restrict__ rec,
+                                                         const float* __restrict__ bg, float* __restrict__ final_T,
+                                                         uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_maxc,
+                                                         uint32_t* __restrict__ tile_walked, float* __restrict__ out_color,
+                                                         unsigned long long* __restrict__ blk_mask, uint32_t* __restrict__ blk_nb,
+                                                         uint32_t* __restrict__ header, uint32_t list_cap,
+                                                         const uint32_t* __restrict__ repair_list)
+{
+    blend_fwd_body<true>(W, H, gx, T_tiles, tile_start, point_list, rec, bg, final_T, n_contrib, tile_maxc, tile_walked, out_color, blk_mask,
+                         blk_nb, header, list_cap, nullptr, repair_list, nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -547,8 +605,12 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
     // b - 1 and the records of batch b are ISSUED, the groups already queued are processed while those loads travel, and only
     // then are the records staged.  (Plain compiler-scheduled loads, issued and consumed inside one iteration, unconditional
     // with clamped addresses: see k_blend_fwd_w.  Lanes outside the mask re-read record 0 of the list: one cached line.)
+    // (round 5: masks and ids run TWO batches ahead, as in the forward: with one batch of lead a tile whose batches hold few
+    // survivors paid two dependent round trips per batch, ids then records)
     unsigned long long m_next = my_mask[4 * (size_t)(nb - 1)];
     uint32_t id_next = point_list[r0 + (uint32_t)min(64 * (nb - 1) + lane, total - 1)];
+    unsigned long long m_next2 = my_mask[4 * (size_t)max(nb - 2, 0)];
+    uint32_t id_next2 = point_list[r0 + (uint32_t)min(64 * max(nb - 2, 0) + lane, total - 1)];
     for (int b = nb - 1; b >= 0; b--) {
         const unsigned long long m_all = m_next;
         const uint32_t pos = (uint32_t)(64 * b + lane + 1);  // 1-based list position of this lane's entry
@@ -556,8 +618,10 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
         const uint32_t id_cur = take ? id_next : point_list[r0];
         const float4* rp = reinterpret_cast<const float4*>(rec + id_cur);
         const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
-        m_next = my_mask[4 * (size_t)max(b - 1, 0)];
-        id_next = point_list[r0 + (uint32_t)min(64 * max(b - 1, 0) + lane, total - 1)];
+        m_next = m_next2;
+        id_next = id_next2;
+        m_next2 = my_mask[4 * (size_t)max(b - 2, 0)];
+        id_next2 = point_list[r0 + (uint32_t)min(64 * max(b - 2, 0) + lane, total - 1)];
         drain(false);
         const unsigned long long m = __ballot(take);
         if (take) {
@@ -606,7 +670,7 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
     const int T = gx * gy;  // (tile_maxc and tile_walked were zeroed by the tile scan: the blocks of a tile combine with atomicMax)
     hipLaunchKernelGGL(k_blend_fwd_w, dim3(sgr_blend_grid(T)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg, final_T,
                        n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap, tile_need, launch_order,
-                       tile_need ? repair_flag : nullptr, repair_list, 0);
+                       tile_need ? repair_flag : nullptr, repair_list);
 }
 
 void sgr_launch_blend_fwd_repair(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
@@ -617,9 +681,8 @@ void sgr_launch_blend_fwd_repair(int W, int H, int gx, int gy, const uint32_t* t
     const int T = gx * gy;
     const int cover = T < SGR_REPAIR_TILES ? T : SGR_REPAIR_TILES;
     // (T_tiles stays the tile count: it clamps the list's entries; the slots beyond the listed tiles leave at once)
-    hipLaunchKernelGGL(k_blend_fwd_w, dim3(sgr_blend_grid(cover)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg, final_T,
-                       n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap, (const uint32_t*)nullptr,
-                       repair_list, (uint32_t*)nullptr, (uint32_t*)nullptr, 1);
+    hipLaunchKernelGGL(k_blend_fwd_repair, dim3(sgr_blend_grid(cover)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg,
+                       final_T, n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap, repair_list);
 }
 
 // behind the blend: this view's launch order (for its backward: order_scratch; for the camera's next forward: order_out), the walk
