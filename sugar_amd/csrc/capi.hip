@@ -223,6 +223,8 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     }
     if ((flags & SGR_FLAG_DEFER_POST) && opts->header_host && !hh_dev)  // (checked before anything is enqueued)
         return fail(SGR_E_INVALID, "SGR_FLAG_DEFER_POST needs a device-mapped header_host");
+    // (SGR_NO_HINT_REPAIR=1: a tile that outruns its walk hint invalidates the forward, as until round 4 -- an A/B switch)
+    static const bool hint_repair = getenv("SGR_NO_HINT_REPAIR") == nullptr;
     PreprocessArgs pa;
     pa.P = P; pa.D = D; pa.M = shs ? M : 0;
     pa.means3D = means3D; pa.scales = scales; pa.scale_modifier = scale_modifier; pa.rotations = rotations;
@@ -237,6 +239,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     pa.rect_by_id = reinterpret_cast<uint2*>(sort_scratch + sgr_sort_rect_by_id_offset(P));
     pa.key_minmax = reinterpret_cast<uint2*>(sort_scratch + sgr_sort_minmax_offset(P));
     pa.sort_counters = reinterpret_cast<uint32_t*>(sort_scratch + sgr_sort_counters_offset(P)); pa.n_sort_counters = sgr_sort_counter_words();
+    if (opts->tile_need && hint_repair) { pa.zero_words = repair_flag; pa.n_zero_words = IL.T; }  // (the walk hint's repair flags start from zero)
     { StageTimer t(s, SGR_STAGE_PREPROCESS); sgr_launch_preprocess_fwd(pa, s); }
     STAGE_CHECK("preprocess");
 
@@ -247,8 +250,6 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     // speculative: sync-free launches with the caller's capacity, then ONE wait for the tile scan's header at the END of the call,
     // when the list-write pass and the blend kernel are already queued behind it: the host round trip of rasterizer_impl.cu:280-281
     // without the idle GPU, and the true instance count as the return value
-    // (SGR_NO_HINT_REPAIR=1: a tile that outruns its walk hint invalidates the forward, as until round 4 -- an A/B switch)
-    static const bool hint_repair = getenv("SGR_NO_HINT_REPAIR") == nullptr;
     const bool speculative = (flags & SGR_FLAG_SPECULATIVE) && binning_capacity > 0 && binning_mode == 0 && !(flags & SGR_FLAG_DEFER_POST);
     const bool will_sync = !(binning_capacity > 0 && binning_mode == 0) || speculative;
     uint32_t* pin_dev = nullptr;
@@ -267,8 +268,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
             sgr_launch_bin_count(P, IL.gx, IL.gy, IL.n_blocks, per_block, order, rects, blk_hist, s);
             sgr_launch_hist_scan(IL.T, IL.n_blocks, blk_hist, tile_cursor, s);
         }
-        sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, tile_maxc, tile_walked, two_level ? 0 : 1, hh_dev, pin_dev, s,
-                             (opts->tile_need && hint_repair) ? repair_flag : nullptr);
+        sgr_launch_tile_scan(IL.T, tile_cursor, tile_start, header, tile_maxc, tile_walked, two_level ? 0 : 1, hh_dev, pin_dev, s);
     }
     STAGE_CHECK("bin_count");
     // the header for a caller that checks late: right behind the tile scan (words 0 and 6 are final) -- written by the scan

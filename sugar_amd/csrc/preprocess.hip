@@ -320,6 +320,8 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreprocessArgs a)
 
     if (blockIdx.x == 0)  // the depth sort's histograms and chunk tickets start from zero (binning.hip)
         for (int i = threadIdx.x; i < a.n_sort_counters; i += 256) a.sort_counters[i] = 0u;
+    if (a.zero_words && blockIdx.x == gridDim.x - 1)
+        for (int i = threadIdx.x; i < a.n_zero_words; i += 256) a.zero_words[i] = 0u;
     const float cam_raw = cam_request(a.viewmatrix, a.projmatrix, a.cam_pos);
     const V3 p_orig = {a.means3D[i3], a.means3D[i3 + 1], a.means3D[i3 + 2]};
     float c6[6], sc[3] = {0.f, 0.f, 0.f};

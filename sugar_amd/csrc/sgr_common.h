@@ -129,6 +129,8 @@ struct PreprocessArgs {
     uint2* rect_by_id;    // [P] packed tile rectangle of every Gaussian (w == 0: culled)
     uint2* key_minmax;    // [ceil(P / 256)] smallest / largest depth key of every workgroup's visible Gaussians
     uint32_t* sort_counters; int n_sort_counters;  // zeroed by workgroup 0 (histograms and tickets of the depth sort)
+    uint32_t* zero_words = nullptr; int n_zero_words = 0;  // more words to zero, by the last workgroup (the walk hint's repair flags:
+                                                           // as a store stream of the single-workgroup tile scan they cost it 9 us)
 };
 void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 void sgr_launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
