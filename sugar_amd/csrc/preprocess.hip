@@ -447,8 +447,10 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreprocessArgs a)
 #ifndef SGR_PRE_BWD_BLOCKS
 #define SGR_PRE_BWD_BLOCKS 3
 #endif
+// `stage` (STORE_SH only): this lane's column of its wave's LDS staging panel -- element e of the Gaussian's 48 SH-gradient floats at
+// stage[65 e] -- or NULL for the direct stores (see k_preprocess_bwd below)
 template <bool STORE_SH, int SH>
-__global__ void __launch_bounds__(256, SGR_PRE_BWD_BLOCKS) k_preprocess_bwd(PreprocessBwdArgs a)
+__device__ __forceinline__ void preprocess_bwd_lane(const PreprocessBwdArgs& a, float* __restrict__ stage)
 {
     const int idx0 = blockIdx.x * 256 + threadIdx.x;
     if (a.campos_row && idx0 < 3) a.campos_row[idx0] = a.cam_pos[idx0];  // (see sgr_backward_opts)
@@ -495,7 +497,14 @@ __global__ void __launch_bounds__(256, SGR_PRE_BWD_BLOCKS) k_preprocess_bwd(Prep
         if (a.dL_dcolor) { a.dL_dcolor[i3] = 0; a.dL_dcolor[i3 + 1] = 0; a.dL_dcolor[i3 + 2] = 0; }
         a.dL_dmean3D[i3] = 0; a.dL_dmean3D[i3 + 1] = 0; a.dL_dmean3D[i3 + 2] = 0;
         if (a.dL_dcov3D) for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = 0;
-        if (STORE_SH) for (int k = 0; k < n_sh; k++) a.dL_dsh[(size_t)idx * n_sh + k] = 0;
+        if (STORE_SH) {
+            if (stage) {
+#pragma unroll
+                for (int k = 0; k < 48; k++) stage[65 * k] = 0.0f;
+            } else {
+                for (int k = 0; k < n_sh; k++) a.dL_dsh[(size_t)idx * n_sh + k] = 0;
+            }
+        }
         if (a.dL_dscale) { a.dL_dscale[i3] = 0; a.dL_dscale[i3 + 1] = 0; a.dL_dscale[i3 + 2] = 0; }
         if (a.dL_drot) { float4 z = {0, 0, 0, 0}; *reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = z; }
         return;
@@ -615,7 +624,13 @@ __global__ void __launch_bounds__(256, SGR_PRE_BWD_BLOCKS) k_preprocess_bwd(Prep
             sh_basis16(deg, x, y, z, b);
             const int n_act = (deg + 1) * (deg + 1);
             float* dst = a.dL_dsh + (size_t)idx * n_sh;
-            if (n_sh == 48 && ((uintptr_t)dst & 15) == 0) {
+            if (stage) {
+                // (round 5) through the wave's LDS panel: the kernel's epilogue writes the wave's 64 rows as ONE contiguous 12 KB
+                // stream.  Stored from here, every instruction put 16 bytes into each of 64 rows 192 bytes apart: the kernel ran at
+                // 2.6 TB/s for its 430 MB where the compact variant, which does not write the 192 MB, runs at 4.8
+#pragma unroll
+                for (int e = 0; e < 48; e++) stage[65 * e] = (e / 3) < n_act ? b[e / 3] * dLm[e % 3] : 0.0f;
+            } else if (n_sh == 48 && ((uintptr_t)dst & 15) == 0) {
                 float4* d4 = reinterpret_cast<float4*>(dst);
 #pragma unroll
                 for (int i = 0; i < 12; i++) {
@@ -718,6 +733,36 @@ __global__ void __launch_bounds__(256, SGR_PRE_BWD_BLOCKS) k_preprocess_bwd(Prep
     if (a.dL_dcov3D) {
 #pragma unroll
         for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+    }
+}
+
+template <bool STORE_SH, int SH>
+__global__ void __launch_bounds__(256, SGR_PRE_BWD_BLOCKS) k_preprocess_bwd(PreprocessBwdArgs a)
+{
+    // The full SH gradient (dL_dsh[P,16,3]: what every caller of the reference-shaped API receives) leaves through LDS: a lane
+    // owns a Gaussian, i.e. a 192-byte row; the wave's 64 rows are contiguous in memory, so each lane drops its 48 values into its
+    // column of a [48][65] panel (conflict-free both ways) and the wave then streams the 12 KB out as 16-byte stores of 64
+    // consecutive lanes.  4 panels of 12.5 KB per block, 3 blocks per CU: 150 KB of the 160.
+    __shared__ float s_stage[STORE_SH ? 4 * 48 * 65 : 1];
+    const bool staged = STORE_SH && a.M == 16 && (((uintptr_t)a.dL_dsh) & 15) == 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* panel = s_stage + (STORE_SH ? wave * (48 * 65) : 0);
+    preprocess_bwd_lane<STORE_SH, SH>(a, staged ? panel + lane : nullptr);
+    if (STORE_SH && staged) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const long long row0 = (long long)blockIdx.x * 256 + wave * 64;
+        const int rows = (int)min(64ll, (long long)a.P - row0);          // (<= 0: the wave lies past the last Gaussian)
+        float4* out4 = reinterpret_cast<float4*>(a.dL_dsh + (size_t)(row0 > 0 ? row0 : 0) * 48);
+#pragma unroll
+        for (int it = 0; it < 12; it++) {
+            const int j4 = it * 64 + lane;                                // float4 index in the wave's stream
+            if (j4 < rows * 12) {
+                const int row = j4 / 12, e0 = (j4 % 12) * 4;
+                const float* src = panel + 65 * e0 + row;
+                out4[j4] = make_float4(src[0], src[65], src[130], src[195]);
+            }
+        }
     }
 }
 
