@@ -133,6 +133,10 @@ struct GridHdr { unsigned int minb[3], maxb[3], far_count, ball_count, occupied,
 // 3.15, 4: 1.13 / 3.49 / 4.15 (round 3, exhaustive fallback after 4 rings: 14.3 ms at 10 %).  Self queries (the neighbour rebuild,
 // distCUDA2) do not depend on it: 2.3 / 0.8 ms at 1M.
 #define GRID_MAX_RING 1
+// Occupancy of the grid at a quarter of its resolution, for the ball cover of k_knn_ball: word (z / 4) * 32 + (y / 4), bit x / 4 = some cell
+// of that 4 x 4 x 4 group holds a point (G <= 128: at most 32 x 32 words of 32 bits).  A far query's ball is mostly empty space: its
+// cell rows are tested against these 4 KB (in LDS) before the two dependent look-ups of their point range.
+#define GRID_COARSE_WORDS 1024
 #define BALL_SAMPLES 4096u     // reference points a query without a bound is compared with in k_knn_ball (64 per lane)
 #define FAR_SINGLE_MAX 16384u  // up to this many far queries: one workgroup each; more: the tiled exhaustive kernel
 
@@ -497,9 +501,15 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
                                                   const unsigned int* __restrict__ cell_start, const float4* __restrict__ sorted,
                                                   float* __restrict__ out_d, int64_t* __restrict__ out_i, float* __restrict__ out_mean,
                                                   const int* __restrict__ qlist, const float* __restrict__ qu2,
-                                                  const unsigned int* __restrict__ qcount, unsigned int cap)
+                                                  const unsigned int* __restrict__ qcount, unsigned int cap,
+                                                  const unsigned int* __restrict__ coarse)
 {
+    __shared__ unsigned int s_occ[GRID_COARSE_WORDS];
     const unsigned int n = min(*qcount, cap);
+    if (blockIdx.x * 4u >= n) return;   // (no query for this workgroup: uniform over the block)
+#pragma unroll
+    for (int i = 0; i < GRID_COARSE_WORDS / 256; i++) s_occ[i * 256 + threadIdx.x] = coarse[i * 256 + threadIdx.x];
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const GridGeom g = grid_geom(hdr, G);
     for (unsigned int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
@@ -640,6 +650,12 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
             const float xr = sqrtf(rem);
             if (qx - xr > g.ox + ext || qx + xr < g.ox) continue;  // the row's x-interval misses the grid (the clamp below would scan its end cell)
             const int x0 = cell_coord(qx - xr, g.ox, g), x1 = cell_coord(qx + xr, g.ox, g);
+            {   // nothing in any 4 x 4 x 4 group the row's x-interval passes through: no look-up
+                const unsigned int occ = s_occ[(z >> 2) * 32 + (y >> 2)];
+                const int xa = x0 >> 2, xb = x1 >> 2;
+                const unsigned int upto = xb >= 31 ? 0xFFFFFFFFu : ((1u << (xb + 1)) - 1u);
+                if ((occ & upto & ~((1u << xa) - 1u)) == 0u) continue;
+            }
             const unsigned int c0 = ((unsigned int)z * G + y) * G + x0;
             const unsigned int b = cell_start[c0], e = cell_start[c0 + (unsigned int)(x1 - x0) + 1u];
             for (unsigned int sidx = b; sidx < e; sidx++) {
@@ -710,7 +726,7 @@ int grid_res_max(int M)
 }
 #define GRID_PROBE_MIN_POINTS 50000  // below this a query costs microseconds either way: no probe, no round trip
 
-struct GridScratch { GridHdr* hdr; unsigned int *cell_count, *cursor, *cell_start, *cell_of, *scan_part; float4* sorted; int* far_list;
+struct GridScratch { GridHdr* hdr; unsigned int* coarse; unsigned int *cell_count, *cursor, *cell_start, *cell_of, *scan_part; float4* sorted; int* far_list;
                      int* ball_list; float* ball_u2; unsigned int far_cap; size_t total; };
 GridScratch carve_grid(char* base, int M)
 {
@@ -719,6 +735,7 @@ GridScratch carve_grid(char* base, int M)
     GridScratch s;
     size_t off = 0;
     s.hdr = reinterpret_cast<GridHdr*>(base + off); off = sgr_align(off + sizeof(GridHdr));
+    s.coarse = reinterpret_cast<unsigned int*>(base + off); off = sgr_align(off + GRID_COARSE_WORDS * 4);
     s.cell_count = reinterpret_cast<unsigned int*>(base + off); off = sgr_align(off + cells * 4);
     s.cursor = reinterpret_cast<unsigned int*>(base + off); off = sgr_align(off + cells * 4);
     s.cell_start = reinterpret_cast<unsigned int*>(base + off); off = sgr_align(off + (cells + 1) * 4);
@@ -731,6 +748,17 @@ GridScratch carve_grid(char* base, int M)
     s.ball_u2 = reinterpret_cast<float*>(base + off); off = sgr_align(off + (size_t)s.far_cap * 4);
     s.total = off;
     return s;
+}
+
+__global__ void __launch_bounds__(256) k_grid_coarse(int G, const unsigned int* __restrict__ cell_start, unsigned int* __restrict__ coarse)
+{
+    const int Gc = (G + 3) >> 2;
+    const int t = blockIdx.x * 256 + threadIdx.x;       // (fine row (z, y), coarse x)
+    if (t >= G * G * Gc) return;
+    const int xc = t % Gc, row = t / Gc, y = row % G, z = row / G;
+    const unsigned int base = ((unsigned int)z * G + y) * G;
+    const int xa = 4 * xc, xb = min(4 * xc + 4, G);
+    if (cell_start[base + xb] > cell_start[base + xa]) atomicOr(&coarse[(z >> 2) * 32 + (y >> 2)], 1u << xc);
 }
 
 struct ProbeSlot {
@@ -779,6 +807,9 @@ int build_grid(int M, const float* ref, const GridScratch& gs, hipStream_t s)
     hipLaunchKernelGGL(k_grid_blocksum, dim3(scan_blocks), dim3(256), 0, s, (int)cells, gs.cell_count, gs.scan_part);
     hipLaunchKernelGGL(k_grid_scan, dim3(scan_blocks), dim3(256), 0, s, (int)cells, gs.cell_count, gs.scan_part, gs.cell_start);
     hipLaunchKernelGGL(k_grid_scatter, dim3((M + 255) / 256), dim3(256), 0, s, M, ref, gs.cell_of, gs.cell_start, gs.cursor, gs.sorted);
+    if (hipMemsetAsync(gs.coarse, 0, GRID_COARSE_WORDS * 4, s) != hipSuccess) return SGR_E_HIP;
+    const int coarse_threads = G * G * ((G + 3) >> 2);
+    hipLaunchKernelGGL(k_grid_coarse, dim3((coarse_threads + 255) / 256), dim3(256), 0, s, G, gs.cell_start, gs.coarse);
     return G;
 }
 
@@ -789,7 +820,7 @@ void launch_far(int N, const float* query, int M, const float* ref, const GridSc
     const unsigned int cap = gs.far_cap < (unsigned int)N ? gs.far_cap : (unsigned int)N;
     const unsigned int ball_groups = (cap + 3) / 4;  // one wave per query, four per workgroup, grid-stride over the (device-side) count
     hipLaunchKernelGGL((k_knn_ball<K, EXCLUDE_SELF>), dim3(ball_groups < 8192u ? ball_groups : 8192u), dim3(256), 0, s, query, gs.hdr,
-                       G, gs.cell_start, gs.sorted, d, i, mean, gs.ball_list, gs.ball_u2, &gs.hdr->ball_count, cap);
+                       G, gs.cell_start, gs.sorted, d, i, mean, gs.ball_list, gs.ball_u2, &gs.hdr->ball_count, cap, gs.coarse);
     constexpr int Q = K <= 4 ? 8 : (K <= 16 ? 4 : 2);  // queries per workgroup: Q * K (distance, index) pairs per thread in registers
     const unsigned int groups = (cap + Q - 1) / Q;
     hipLaunchKernelGGL((k_knn_far<K, EXCLUDE_SELF, Q>), dim3(groups < 4096u ? groups : 4096u), dim3(256), 0, s, query, M, gs.sorted, d, i,
