@@ -526,16 +526,20 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
             // cloud's extent apart: the ball it gives cuts thousands of points out of a surface).  (2) A descent from the nearest
             // sample: look at the 27 cells around the current best point, move to the nearest point found there, repeat until it
             // stays in its cell; the K-th nearest of the LAST neighbourhood (no point counted twice) is a bound of the size of the
-            // answer itself.  Both are distances of K distinct points: the smaller one is used.  With fewer than K points in reach
+            // answer itself -- when the descent ends at the GLOBAL minimum.  Measured (scripts/knn_offset_probe.py, 124k queries over
+            // config 4's lobed surface): 2 ms on the surface, 8 ms at 0.05 off it, 31 ms at 1.0 -- a far query's distance field over
+            // a bumpy surface has local minima, the descent stops in one, and the ball of that bound still cuts several percent of
+            // the cloud (SQ_INSTS_VALU 5.6 G wave-instructions per launch, nearly all candidate insertions).  A best-first walk over
+            // the quarter-resolution groups -- nearest group first, bound shrinking as it goes -- is the next step.  Both are distances of K distinct points: the smaller one is used.  With fewer than K points in reach
             // the bound stays infinite and the cover below is the whole grid: still exact.
             const unsigned int Mtot = cell_start[(unsigned int)G * G * G];
             const unsigned int per_lane = BALL_SAMPLES / 64;
-            const float stride = (float)Mtot / (float)BALL_SAMPLES;
+            const float stride = (float)Mtot / (float)(per_lane * 64u);
             float best = 3.402823466e+38f;
             unsigned int best_at = 0u;
             for (unsigned int j = 0; j < per_lane; j++) {
                 unsigned int sidx = (unsigned int)(((float)(j * 64u + (unsigned int)lane) + 0.5f) * stride);
-                if (Mtot <= BALL_SAMPLES) sidx = j * 64u + (unsigned int)lane;  // (a small set: every point once)
+                if (Mtot <= per_lane * 64u) sidx = j * 64u + (unsigned int)lane;  // (a small set: every point once)
                 if (sidx >= Mtot) continue;
                 const float4 p = sorted[sidx];
                 if (EXCLUDE_SELF && __float_as_int(p.w) == q) continue;
@@ -561,13 +565,14 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
             u2 = K <= 64 ? kth : 3.402823466e+38f;
             if (nearest < 3.0e+38f) {
                 float cur_d = nearest;
-                for (int it = 0; it < 12; it++) {
+                // (the K best are only collected over the LAST neighbourhood; on the way there a lane keeps its nearest point and
+                // nothing else: maintaining K sorted candidates per lane in every step was most of this kernel's time)
+                unsigned int rb = 0u, re = 0u;
+                for (int it = 0; it < 16; it++) {
                     const float4 cp = sorted[cur_at];
                     const int ccx = cell_coord(cp.x, g.ox, g), ccy = cell_coord(cp.y, g.oy, g), ccz = cell_coord(cp.z, g.oz, g);
-#pragma unroll
-                    for (int k = 0; k < K; k++) { bd[k] = 3.402823466e+38f; bi[k] = 0x7FFFFFFF; }
                     // lanes 0..8: the nine rows (z, y) of the neighbourhood; a row's three cells are one contiguous range of points
-                    unsigned int rb = 0u, re = 0u;
+                    rb = 0u; re = 0u;
                     if (lane < 9) {
                         const int z = ccz + lane / 3 - 1, y = ccy + lane % 3 - 1;
                         if (z >= 0 && z < G && y >= 0 && y < G) {
@@ -585,11 +590,35 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
                         const unsigned int b0 = (unsigned int)__shfl((int)rb, r), e0 = (unsigned int)__shfl((int)re, r);
                         for (unsigned int sidx = b0 + (unsigned int)lane; sidx < e0; sidx += 64u) {   // (coalesced: 64 consecutive points)
                             const float4 p = sorted[sidx];
+                            if (EXCLUDE_SELF && __float_as_int(p.w) == q) continue;
+                            const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+                            const float d = dx * dx + dy * dy + dz * dz;
+                            if (d < lbest) { lbest = d; lat = sidx; }
+                        }
+                    }
+                    float nb = lbest;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) nb = fminf(nb, __shfl_xor(nb, o));
+                    if (!(nb < cur_d)) break;   // the neighbourhood holds nothing nearer than the point it was built around
+                    const unsigned long long hb = __ballot(lbest == nb);
+                    cur_at = (unsigned int)__shfl((int)lat, (int)__builtin_ctzll(hb | (1ull << 63)));
+                    cur_d = nb;
+                }
+                // the K best of the neighbourhood the descent ended in (rb / re still describe its nine rows)
+#pragma unroll
+                for (int k = 0; k < K; k++) { bd[k] = 3.402823466e+38f; bi[k] = 0x7FFFFFFF; }
+                {
+                    unsigned long long rows = __ballot(re > rb);
+                    while (rows) {
+                        const int r = (int)__builtin_ctzll(rows);
+                        rows &= rows - 1ull;
+                        const unsigned int b0 = (unsigned int)__shfl((int)rb, r), e0 = (unsigned int)__shfl((int)re, r);
+                        for (unsigned int sidx = b0 + (unsigned int)lane; sidx < e0; sidx += 64u) {
+                            const float4 p = sorted[sidx];
                             int id = __float_as_int(p.w);
                             if (EXCLUDE_SELF && id == q) continue;
                             const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
                             float d = dx * dx + dy * dy + dz * dz;
-                            if (d < lbest) { lbest = d; lat = sidx; }
                             if (!(d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]))) continue;
 #pragma unroll
                             for (int k = 0; k < K; k++) {
@@ -600,13 +629,6 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
                             }
                         }
                     }
-                    float nb = lbest;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) nb = fminf(nb, __shfl_xor(nb, o));
-                    if (!(nb < cur_d)) break;   // the neighbourhood holds nothing nearer than the point it was built around
-                    const unsigned long long hb = __ballot(lbest == nb);
-                    cur_at = (unsigned int)__shfl((int)lat, (int)__builtin_ctzll(hb | (1ull << 63)));
-                    cur_d = nb;
                 }
                 // K-th smallest of the last neighbourhood's points: K rounds over the heads of the 64 sorted lists
                 float kth2 = 3.402823466e+38f;
@@ -640,8 +662,17 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
         const int ny = y1 - y0 + 1, rows = (z1 - z0 + 1) * ny;
 #pragma unroll
         for (int k = 0; k < K; k++) { bd[k] = 3.402823466e+38f; bi[k] = 0x7FFFFFFF; }
-        for (int row = lane; row < rows; row += 64) {
-            const int z = z0 + row / ny, y = y0 + row % ny;
+        // (round 5: the rows are enumerated without integer division -- `row / ny`, `row % ny` with a run-time ny were ~100 of the
+        // ~300 vector instructions a row cost, and a far query's ball has tens of thousands of rows: 5.6 G wave-instructions per
+        // 124k queries by SQ_INSTS_VALU.  A slice z takes 8 / 16 / 32 / 64 lanes by how many rows y it has, several slices per step.)
+        (void)rows;
+        const int nz = z1 - z0 + 1;
+        const int sh = ny <= 8 ? 3 : (ny <= 16 ? 4 : (ny <= 32 ? 5 : 6));
+        const int ly = lane & ((1 << sh) - 1), lz = lane >> sh, zstep = 64 >> sh;
+        for (int zb = 0; zb < nz; zb += zstep)
+        for (int yb = 0; yb < ny; yb += (1 << sh)) {
+            const int z = z0 + zb + lz, y = y0 + yb + ly;
+            if (z > z1 || y > y1) continue;
             // distance of the query to the slab of cell row (z, y) along each axis (zero inside the slab)
             const float zl = g.oz + (float)z * g.h, yl = g.oy + (float)y * g.h;
             const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + g.h)), 0.0f), dy = fmaxf(fmaxf(yl - qy, qy - (yl + g.h)), 0.0f);
