@@ -14,7 +14,7 @@ cd "$R"
 { echo "# partition modes"; rocm-smi --showcomputepartition --showmemorypartition 2>&1 | grep -v "^=\|^$" | head -8; echo "# rocm-smi before"; rocm-smi --showclocks --showpower --showtemp --showmemuse --showperflevel 2>&1 | grep -v "^=\|^$" | head -40; } > "$OUT/box_state.txt"
 python -m pytest tests -m gpu -q 2>&1 | tail -12 > "$OUT/gpu_tests.log"
 cp gpurun_out/fullsize_parity.json "$OUT/fullsize_parity.json" 2>/dev/null
-python bench.py --steps 20 --warmup 5 > "$OUT/bench_metric.json" 2> "$OUT/bench_metric.err"
+( time python bench.py --steps 20 --warmup 5 > "$OUT/bench_metric.json" 2> "$OUT/bench_metric.err" ) 2> "$OUT/bench_metric_wall_time.txt"
 for w in config2 config3 config4 config5; do
   python bench.py --workload $w --steps 20 --warmup 5 --preroll 64 --drift-steps 0 --no-densify-variant --no-reference-loop > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"
 done
