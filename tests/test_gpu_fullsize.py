@@ -10,6 +10,8 @@ and, since round 5, the two BASELINE configs AS THE TRAINERS THAT DEFINE THEM ca
                          sugar_model.py:839-883, 2187-2200; coarse_sdf.py:51), sh_degree 0 at the boundary
     config 3 / depth     its second call: view-space depth as the colour, background = the largest depth
                          (coarse_sdf.py:575-590) -- colours and a background far outside [0,1]
+    metric / cov         `cov3D_precomp` instead of scales + rotations (with a 0.7 scale modifier folded in), SH colours
+    metric / scalemod    `scale_modifier = 1.3` at the boundary
     config 4             1M FLAT Gaussians bound to a triangle mesh (sugar_model.py:149-228, 384-475: first scale =
                          thickness = extent / 1e6): where the 0.3-pixel low-pass and the conic inversion of
                          forward.cu:74-113 dominate
@@ -37,7 +39,7 @@ from sugar_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 GRADS = dict(means3D="dL_dmeans3D", means2D="dL_dmeans2D", opacities="dL_dopacity", shs="dL_dsh", scales="dL_dscales",
-             rotations="dL_drotations", colors_precomp="dL_dcolors")
+             rotations="dL_drotations", colors_precomp="dL_dcolors", cov3D_precomp="dL_dcov3D")
 REPORT = {}
 
 
@@ -64,15 +66,27 @@ def _inputs(scene, cam, bg, mode, dev):
     """the tensors that cross the boundary: (kwargs shared by both sides, bg, sh_degree)"""
     t = dict(means3D=scene.means3D.to(dev), opacities=scene.opacities.to(dev), scales=scene.scales.to(dev),
              rotations=scene.rotations.to(dev))
-    if mode == "sh":
+    if mode in ("sh", "scalemod"):   # scalemod: scale_modifier = 1.3 at the boundary (the viewers' knob, forward.cu:118-152)
         t["shs"] = scene.shs.to(dev)
         return t, bg.to(dev), 3
     if mode == "precomp":
         t["colors_precomp"] = syn.sh_to_rgb(scene.shs.to(dev), t["means3D"], cam.campos.to(dev))
         return t, bg.to(dev), 0
-    assert mode == "depth"
-    t["colors_precomp"], bg_d = syn.depth_as_colour(t["means3D"], cam.viewmatrix.to(dev))
-    return t, bg_d, 0
+    if mode == "depth":
+        t["colors_precomp"], bg_d = syn.depth_as_colour(t["means3D"], cam.viewmatrix.to(dev))
+        return t, bg_d, 0
+    assert mode == "cov"
+    # `cov3D_precomp` (DGR/__init__.py:191-207): the covariance the reference's own Python forms (gaussian_model.py:27-31,
+    # general_utils.py:64-110: L = R S, Sigma = L L^T, upper triangle), with a scale modifier of 0.7 folded in, next to SH colours
+    from tests.parity_utils import precomputed_cov
+    t["cov3D_precomp"] = precomputed_cov(scene, 0.7).to(dev)
+    del t["scales"], t["rotations"]
+    t["shs"] = scene.shs.to(dev)
+    return t, bg.to(dev), 3
+
+
+def _scale_modifier(mode):
+    return 1.3 if mode == "scalemod" else 1.0
 
 
 def _ref(scene, cam, bg, g, mode="sh"):
@@ -80,9 +94,10 @@ def _ref(scene, cam, bg, g, mode="sh"):
     dev = torch.device(DEV)
     t, bg_d, deg = _inputs(scene, cam, bg, mode, dev)
     st = ref_gpu.forward(t["means3D"], t["opacities"], shs=t.get("shs"), colors_precomp=t.get("colors_precomp"),
-                         scales=t["scales"], rotations=t["rotations"], viewmatrix=cam.viewmatrix.to(dev),
-                         projmatrix=cam.projmatrix.to(dev), campos=cam.campos.to(dev), bg=bg_d, W=cam.image_width,
-                         H=cam.image_height, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, sh_degree=deg)
+                         scales=t.get("scales"), rotations=t.get("rotations"), cov3D_precomp=t.get("cov3D_precomp"),
+                         viewmatrix=cam.viewmatrix.to(dev), projmatrix=cam.projmatrix.to(dev), campos=cam.campos.to(dev), bg=bg_d,
+                         W=cam.image_width, H=cam.image_height, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, sh_degree=deg,
+                         scale_modifier=_scale_modifier(mode))
     grads = ref_gpu.backward(st, g) if g is not None else None
     return st, grads
 
@@ -108,13 +123,13 @@ def _product(scene, cam, bg, g, mode="sh"):
     lib = _lib.load()
     H, W = cam.image_height, cam.image_width
     t, bg_d, deg = _inputs(scene, cam, bg, mode, dev)
-    settings = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, bg_d, 1.0, cam.viewmatrix.to(dev),
+    settings = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, bg_d, _scale_modifier(mode), cam.viewmatrix.to(dev),
                                              cam.projmatrix.to(dev), deg, cam.campos.to(dev), False, False)
     leaves = {k: v.requires_grad_(g is not None) for k, v in t.items()}
     leaves["means2D"] = torch.zeros(scene.means3D.shape[0], 3, device=dev, requires_grad=g is not None)
     color, radii = GaussianRasterizer(settings)(leaves["means3D"], leaves["means2D"], leaves["opacities"], shs=leaves.get("shs"),
-                                                colors_precomp=leaves.get("colors_precomp"), scales=leaves["scales"],
-                                                rotations=leaves["rotations"])
+                                                colors_precomp=leaves.get("colors_precomp"), scales=leaves.get("scales"),
+                                                rotations=leaves.get("rotations"), cov3D_precomp=leaves.get("cov3D_precomp"))
     from sugar_amd.diff_gaussian_rasterization import _C
     lf = _C.last_forward
     R, T = lf["num_rendered"], ((W + 15) // 16) * ((H + 15) // 16)
@@ -134,7 +149,8 @@ def _product(scene, cam, bg, g, mode="sh"):
 @pytest.mark.parametrize("config,cam_id,backward,mode", [
     ("config2", 0, True, "sh"), ("metric", 0, True, "sh"), ("metric", 5, True, "sh"), ("config3", 2, True, "sh"),
     ("config5", 1, False, "sh"),
-    ("config4", 1, True, "sh"), ("config4", 6, True, "precomp"), ("config3", 4, True, "precomp"), ("config3", 6, True, "depth")])
+    ("config4", 1, True, "sh"), ("config4", 6, True, "precomp"), ("config3", 4, True, "precomp"), ("config3", 6, True, "depth"),
+    ("metric", 3, True, "cov"), ("metric", 6, True, "scalemod")])
 def test_full_size_parity_with_the_reference(config, cam_id, backward, mode):
     scene, cams, bg = syn.make_config(config)
     cam = cams[cam_id]
