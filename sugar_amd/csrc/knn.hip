@@ -11,6 +11,7 @@
 // (dx*dx + dy*dy) + dz*dz with individually rounded ops (-ffp-contract=off), identical to the oracle.
 #include "../../include/sugar_raster.h"
 #include "sgr_common.h"
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 
@@ -127,7 +128,11 @@ int sgr_knn(int N, const float* query, int M, const float* ref, int K, float* di
 namespace {
 
 // order-preserving uint encodings of the bbox; far_count: queries handed to the exhaustive kernels, ball_count: to the ball scan
-struct GridHdr { unsigned int minb[3], maxb[3], far_count, ball_count, occupied, pad; };  // occupied: non-empty cells (k_grid_count)
+struct GridHdr { unsigned int minb[3], maxb[3], far_count, ball_count, occupied, pad;
+#ifdef SGR_KNN_STATS
+                 unsigned long long st[8];  // development build: unbounded queries, descent steps, rows, rows past the mask, points scanned, insertions, cycles (sample / descent / cover)
+#endif
+};  // occupied: non-empty cells (k_grid_count)
 // Rings a lane walks on its own before it hands its query to k_knn_ball (with K candidates in hand) -- measured, 124k queries
 // against 1M points, 0 / 10 / 30 % of them outside the cloud: cap 1: 1.06 / 1.39 / 2.02 ms, 2: 1.12 / 1.85 / 2.46, 3: 1.13 / 2.57 /
 // 3.15, 4: 1.13 / 3.49 / 4.15 (round 3, exhaustive fallback after 4 rings: 14.3 ms at 10 %).  Self queries (the neighbour rebuild,
@@ -154,6 +159,9 @@ __global__ void k_grid_init(GridHdr* h)
 {
     if (threadIdx.x < 3) { h->minb[threadIdx.x] = 0xFFFFFFFFu; h->maxb[threadIdx.x] = 0u; }
     if (threadIdx.x == 3) { h->far_count = 0u; h->ball_count = 0u; h->occupied = 0u; h->pad = 0u; }
+#ifdef SGR_KNN_STATS
+    if (threadIdx.x < 8) h->st[threadIdx.x] = 0ull;
+#endif
 }
 
 // Far queries, Q per workgroup (grid-stride over the fallback list): the 256 threads split the reference set -- every point is
@@ -490,6 +498,30 @@ __global__ void __launch_bounds__(128) k_grid_query(int N, const float* __restri
     }
 }
 
+// The points of up to 64 cell rows -- lane r holds row r as the contiguous range [b, e) of the cell-sorted array -- visited by the
+// WHOLE wave: the ranges are concatenated (exclusive scan of their lengths) and lane l takes elements l, l + 64, ... of the
+// concatenation (a 6-step search over the scanned offsets through ds_bpermute finds the row an element belongs to).  Every lane
+// works whatever the rows' lengths are, and a step is one batch of 64 independent loads.  (round 5: before, a lane walked its own
+// row serially -- one dependent load per point, and a surface cloud puts the points of a ball into ~15 of the 64 lanes: 355k cycles
+// per query by the cycle counter of a development build, -DSGR_KNN_STATS, almost all of it waiting.)  Call it wave-uniformly.
+template <class F>
+__device__ __forceinline__ void visit_rows(unsigned int b, unsigned int e, int lane, F&& f)
+{
+    const unsigned int cnt = e > b ? e - b : 0u;
+    unsigned int inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    const unsigned int total = __shfl(inc, 63), excl = inc - cnt;
+    for (unsigned int base = 0; base < total; base += 64u) {
+        const unsigned int sl = base + (unsigned int)lane;
+        int r = 0;   // the last row whose offset is <= sl (empty rows share their successor's offset and are stepped over)
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) { const unsigned int o = __shfl(excl, r + step); if (o <= sl) r += step; }
+        const unsigned int rb = __shfl(b, r), ro = __shfl(excl, r);
+        if (sl < total) f(rb + (sl - ro));
+    }
+}
+
 // Queries the ring walk handed over with an upper bound U^2 on their K-th nearest distance: ONE WAVE per query.  The K nearest
 // lie in the ball (q, U); a lane takes a row of cells (fixed z, y), intersects it with the ball -- rows farther than U in the
 // (y, z) plane are skipped, the others contribute the x-interval sqrt(U^2 - dy^2 - dz^2) around the query -- and the cells of
@@ -519,6 +551,11 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
         float u2 = qu2[w];
         float bd[K];
         int bi[K];
+#ifdef SGR_KNN_STATS
+        unsigned long long* st = const_cast<GridHdr*>(hdr)->st;
+        unsigned long long c_t0 = __builtin_readcyclecounter(), n_desc = 0, n_rows = 0, n_pass = 0, n_pts = 0, n_ins = 0;
+        if (lane == 0 && !(u2 < 3.0e+38f)) atomicAdd(&st[0], 1ull);
+#endif
         if (!(u2 < 3.0e+38f)) {
             // No bound from the ring walk.  (1) BALL_SAMPLES points spread evenly over the cell-sorted array (i.e. over the cloud):
             // every lane keeps the nearest of its share; the K-th smallest of the 64 lane minima is the distance of K DISTINCT
@@ -537,14 +574,15 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
             const float stride = (float)Mtot / (float)(per_lane * 64u);
             float best = 3.402823466e+38f;
             unsigned int best_at = 0u;
-            for (unsigned int j = 0; j < per_lane; j++) {
+            if (Mtot)
+#pragma unroll 8
+            for (unsigned int j = 0; j < per_lane; j++) {   // (no branch around the load: eight stay in flight)
                 unsigned int sidx = (unsigned int)(((float)(j * 64u + (unsigned int)lane) + 0.5f) * stride);
                 if (Mtot <= per_lane * 64u) sidx = j * 64u + (unsigned int)lane;  // (a small set: every point once)
-                if (sidx >= Mtot) continue;
-                const float4 p = sorted[sidx];
-                if (EXCLUDE_SELF && __float_as_int(p.w) == q) continue;
+                const bool ok = sidx < Mtot;
+                const float4 p = sorted[ok ? sidx : 0u];
                 const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
-                const float d = dx * dx + dy * dy + dz * dz;
+                const float d = (ok && !(EXCLUDE_SELF && __float_as_int(p.w) == q)) ? dx * dx + dy * dy + dz * dz : 3.402823466e+38f;
                 if (d < best) { best = d; best_at = sidx; }
             }
             // the nearest sample of all (lowest lane on ties), then the K-th smallest lane minimum
@@ -583,22 +621,19 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
                     }
                     float lbest = 3.402823466e+38f;
                     unsigned int lat = cur_at;
-                    unsigned long long rows = __ballot(re > rb);
-                    while (rows) {
-                        const int r = (int)__builtin_ctzll(rows);
-                        rows &= rows - 1ull;
-                        const unsigned int b0 = (unsigned int)__shfl((int)rb, r), e0 = (unsigned int)__shfl((int)re, r);
-                        for (unsigned int sidx = b0 + (unsigned int)lane; sidx < e0; sidx += 64u) {   // (coalesced: 64 consecutive points)
-                            const float4 p = sorted[sidx];
-                            if (EXCLUDE_SELF && __float_as_int(p.w) == q) continue;
-                            const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
-                            const float d = dx * dx + dy * dy + dz * dz;
-                            if (d < lbest) { lbest = d; lat = sidx; }
-                        }
-                    }
+                    visit_rows(rb, re, lane, [&](unsigned int sidx) {
+                        const float4 p = sorted[sidx];
+                        if (EXCLUDE_SELF && __float_as_int(p.w) == q) return;
+                        const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+                        const float d = dx * dx + dy * dy + dz * dz;
+                        if (d < lbest || (d == lbest && sidx < lat)) { lbest = d; lat = sidx; }
+                    });
                     float nb = lbest;
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) nb = fminf(nb, __shfl_xor(nb, o));
+#ifdef SGR_KNN_STATS
+                    n_desc++;
+#endif
                     if (!(nb < cur_d)) break;   // the neighbourhood holds nothing nearer than the point it was built around
                     const unsigned long long hb = __ballot(lbest == nb);
                     cur_at = (unsigned int)__shfl((int)lat, (int)__builtin_ctzll(hb | (1ull << 63)));
@@ -607,29 +642,21 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
                 // the K best of the neighbourhood the descent ended in (rb / re still describe its nine rows)
 #pragma unroll
                 for (int k = 0; k < K; k++) { bd[k] = 3.402823466e+38f; bi[k] = 0x7FFFFFFF; }
-                {
-                    unsigned long long rows = __ballot(re > rb);
-                    while (rows) {
-                        const int r = (int)__builtin_ctzll(rows);
-                        rows &= rows - 1ull;
-                        const unsigned int b0 = (unsigned int)__shfl((int)rb, r), e0 = (unsigned int)__shfl((int)re, r);
-                        for (unsigned int sidx = b0 + (unsigned int)lane; sidx < e0; sidx += 64u) {
-                            const float4 p = sorted[sidx];
-                            int id = __float_as_int(p.w);
-                            if (EXCLUDE_SELF && id == q) continue;
-                            const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
-                            float d = dx * dx + dy * dy + dz * dz;
-                            if (!(d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]))) continue;
+                visit_rows(rb, re, lane, [&](unsigned int sidx) {
+                    const float4 p = sorted[sidx];
+                    int id = __float_as_int(p.w);
+                    if (EXCLUDE_SELF && id == q) return;
+                    const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+                    float d = dx * dx + dy * dy + dz * dz;
+                    if (!(d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]))) return;
 #pragma unroll
-                            for (int k = 0; k < K; k++) {
-                                if (d < bd[k] || (d == bd[k] && id < bi[k])) {
-                                    const float td = bd[k]; const int ti = bi[k];
-                                    bd[k] = d; bi[k] = id; d = td; id = ti;
-                                }
-                            }
+                    for (int k = 0; k < K; k++) {
+                        if (d < bd[k] || (d == bd[k] && id < bi[k])) {
+                            const float td = bd[k]; const int ti = bi[k];
+                            bd[k] = d; bi[k] = id; d = td; id = ti;
                         }
                     }
-                }
+                });
                 // K-th smallest of the last neighbourhood's points: K rounds over the heads of the 64 sorted lists
                 float kth2 = 3.402823466e+38f;
                 for (int k = 0; k < K; k++) {
@@ -647,6 +674,9 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
                 u2 = fminf(u2, kth2);
             }
         }
+#ifdef SGR_KNN_STATS
+        const unsigned long long c_t1 = __builtin_readcyclecounter();
+#endif
         const bool unbounded = !(u2 < 3.0e+38f);
         const float U = unbounded ? 4.0f * (ext + fabsf(qx - g.ox) + fabsf(qy - g.oy) + fabsf(qz - g.oz))
                                   : sqrtf(u2) * (1.0f + 1e-5f) + 1e-5f * (ext + fabsf(qx) + fabsf(qy) + fabsf(qz));
@@ -672,30 +702,45 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
         for (int zb = 0; zb < nz; zb += zstep)
         for (int yb = 0; yb < ny; yb += (1 << sh)) {
             const int z = z0 + zb + lz, y = y0 + yb + ly;
-            if (z > z1 || y > y1) continue;
-            // distance of the query to the slab of cell row (z, y) along each axis (zero inside the slab)
-            const float zl = g.oz + (float)z * g.h, yl = g.oy + (float)y * g.h;
-            const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + g.h)), 0.0f), dy = fmaxf(fmaxf(yl - qy, qy - (yl + g.h)), 0.0f);
-            const float rem = U2 - dz * dz - dy * dy;
-            if (rem < 0.0f) continue;
-            const float xr = sqrtf(rem);
-            if (qx - xr > g.ox + ext || qx + xr < g.ox) continue;  // the row's x-interval misses the grid (the clamp below would scan its end cell)
-            const int x0 = cell_coord(qx - xr, g.ox, g), x1 = cell_coord(qx + xr, g.ox, g);
-            {   // nothing in any 4 x 4 x 4 group the row's x-interval passes through: no look-up
-                const unsigned int occ = s_occ[(z >> 2) * 32 + (y >> 2)];
-                const int xa = x0 >> 2, xb = x1 >> 2;
-                const unsigned int upto = xb >= 31 ? 0xFFFFFFFFu : ((1u << (xb + 1)) - 1u);
-                if ((occ & upto & ~((1u << xa) - 1u)) == 0u) continue;
+            unsigned int b = 0u, e = 0u;   // this lane's row as a range of the cell-sorted array (empty: nothing to look at)
+            if (z <= z1 && y <= y1) {
+#ifdef SGR_KNN_STATS
+                n_rows++;
+#endif
+                // distance of the query to the slab of cell row (z, y) along each axis (zero inside the slab)
+                const float zl = g.oz + (float)z * g.h, yl = g.oy + (float)y * g.h;
+                const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + g.h)), 0.0f), dy = fmaxf(fmaxf(yl - qy, qy - (yl + g.h)), 0.0f);
+                const float rem = U2 - dz * dz - dy * dy;
+                const float xr = sqrtf(fmaxf(rem, 0.0f));
+                // (a row whose x-interval misses the grid is dropped: the clamp of cell_coord would scan its end cell)
+                if (rem >= 0.0f && !(qx - xr > g.ox + ext || qx + xr < g.ox)) {
+                    const int x0 = cell_coord(qx - xr, g.ox, g), x1 = cell_coord(qx + xr, g.ox, g);
+                    // nothing in any 4 x 4 x 4 group the row's x-interval passes through: no look-up
+                    const unsigned int occ = s_occ[(z >> 2) * 32 + (y >> 2)];
+                    const int xa = x0 >> 2, xb = x1 >> 2;
+                    const unsigned int upto = xb >= 31 ? 0xFFFFFFFFu : ((1u << (xb + 1)) - 1u);
+                    if ((occ & upto & ~((1u << xa) - 1u)) != 0u) {
+                        const unsigned int c0 = ((unsigned int)z * G + y) * G + x0;
+                        b = cell_start[c0]; e = cell_start[c0 + (unsigned int)(x1 - x0) + 1u];
+#ifdef SGR_KNN_STATS
+                        n_pass++; n_pts += e - b;
+#endif
+                    }
+                }
             }
-            const unsigned int c0 = ((unsigned int)z * G + y) * G + x0;
-            const unsigned int b = cell_start[c0], e = cell_start[c0 + (unsigned int)(x1 - x0) + 1u];
-            for (unsigned int sidx = b; sidx < e; sidx++) {
+            visit_rows(b, e, lane, [&](unsigned int sidx) {
                 const float4 p = sorted[sidx];
                 int id = __float_as_int(p.w);
-                if (EXCLUDE_SELF && id == q) continue;
+                if (EXCLUDE_SELF && id == q) return;
                 const float dx = p.x - qx, ddy = p.y - qy, ddz = p.z - qz;
                 float d = dx * dx + ddy * ddy + ddz * ddz;
-                if (!(d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]))) continue;
+                // U2 bounds the K-th nearest distance from above (with the margin taken on U): a point beyond it is not among the
+                // answer -- the cells of the cover hold ~8 times the points of the ball itself on a surface
+                if (d > U2) return;
+                if (!(d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]))) return;
+#ifdef SGR_KNN_STATS
+                n_ins++;
+#endif
 #pragma unroll
                 for (int k = 0; k < K; k++) {
                     if (d < bd[k] || (d == bd[k] && id < bi[k])) {
@@ -703,8 +748,18 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
                         bd[k] = d; bi[k] = id; d = td; id = ti;
                     }
                 }
+            });
+        }
+#ifdef SGR_KNN_STATS
+        {
+            const unsigned long long c_t2 = __builtin_readcyclecounter();
+            for (int o = 32; o > 0; o >>= 1) { n_rows += __shfl_xor(n_rows, o); n_pass += __shfl_xor(n_pass, o); n_pts += __shfl_xor(n_pts, o); n_ins += __shfl_xor(n_ins, o); }
+            if (lane == 0) {
+                atomicAdd(&st[1], n_desc); atomicAdd(&st[2], n_rows); atomicAdd(&st[3], n_pass); atomicAdd(&st[4], n_pts); atomicAdd(&st[5], n_ins);
+                atomicAdd(&st[6], c_t1 - c_t0); atomicAdd(&st[7], c_t2 - c_t1);
             }
         }
+#endif
         // the K best of the 64 sorted lists: K rounds of a wave-wide arg-min of the heads on (distance, index)
         float sum3 = 0.f;
         for (int k = 0; k < K; k++) {
@@ -900,6 +955,16 @@ int sgr_knn_grid(int N, const float* query, int M, const float* ref, int K, floa
         case 32: launch_grid_query<32>(self, N, query, M, ref, gs, G, dists, idx, s); break;
         default: return SGR_E_INVALID;
     }
+#ifdef SGR_KNN_STATS
+    {
+        unsigned long long st[8]; unsigned int bc = 0;
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(st, gs.hdr->st, sizeof(st), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&bc, &gs.hdr->ball_count, 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[knn stats] N %d G %d ball %u unbounded %llu descent_steps %llu rows %llu past_mask %llu points %llu insertions %llu cyc_bound %llu cyc_cover %llu\n",
+                N, G, bc, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
+    }
+#endif
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 
