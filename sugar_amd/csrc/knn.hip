@@ -408,10 +408,43 @@ __global__ void __launch_bounds__(128) k_grid_query(int N, const float* __restri
     int bi[K];
 #pragma unroll
     for (int k = 0; k < K; k++) { bd[k] = 3.402823466e+38f; bi[k] = 0x7FFFFFFF; }
-    for (int r = 0; r < G; r++) {
+    auto consider = [&](const float4 p) {
+        int id = __float_as_int(p.w);
+        if (EXCLUDE_SELF && id == q) return;
+        const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+        float d = dx * dx + dy * dy + dz * dz;
+        if (!(d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]))) return;
+#pragma unroll
+        for (int k = 0; k < K; k++) {  // ordered on (distance, index): independent of the visiting order
+            if (d < bd[k] || (d == bd[k] && id < bi[k])) {
+                const float td = bd[k]; const int ti = bi[k];
+                bd[k] = d; bi[k] = id; d = td; id = ti;
+            }
+        }
+    };
+    {   // Rings 0 and 1 together, as the nine cell rows (z, y) of the 3 x 3 x 3 box: a row's cells are consecutive in the cell-sorted
+        // array, so a row is ONE range -- 18 independent look-ups issued together instead of 27 cells x two dependent ones (round 5:
+        // this walk was 1.0 ms of the level-set sampler's 124k queries, most of it waiting on look-ups of empty cells).  The K
+        // best are ordered on (distance, index): visiting ring 1 before knowing whether ring 0 sufficed changes nothing.
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G - 1);
+        unsigned int rb[9], re[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            const int z = cz + j / 3 - 1, y = cy + j % 3 - 1;
+            const bool in = z >= 0 && z < G && y >= 0 && y < G;
+            const unsigned int c0 = in ? ((unsigned int)z * G + y) * G + x0 : 0u;
+            rb[j] = cell_start[c0];
+            re[j] = in ? cell_start[c0 + (unsigned int)(x1 - x0) + 1u] : rb[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+            for (unsigned int s = rb[j]; s < re[j]; s++) consider(sorted[s]);
+    }
+    for (int r = 1; r < G; r++) {
         const int z0 = max(cz - r, 0), z1 = min(cz + r, G - 1);
         const int y0 = max(cy - r, 0), y1 = min(cy + r, G - 1);
         const int x0 = max(cx - r, 0), x1 = min(cx + r, G - 1);
+        if (r >= 2)
         for (int z = z0; z <= z1; z++)
             for (int y = y0; y <= y1; y++) {
                 const bool shell_row = (z == cz - r) || (z == cz + r) || (y == cy - r) || (y == cy + r);
@@ -420,21 +453,7 @@ __global__ void __launch_bounds__(128) k_grid_query(int N, const float* __restri
                     if (!shell_row && x != cx - r && x != cx + r) continue;
                     const unsigned int c = ((unsigned int)z * G + y) * G + x;
                     const unsigned int b = cell_start[c], e = cell_start[c + 1];
-                    for (unsigned int s = b; s < e; s++) {
-                        const float4 p = sorted[s];
-                        int id = __float_as_int(p.w);
-                        if (EXCLUDE_SELF && id == q) continue;
-                        const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
-                        float d = dx * dx + dy * dy + dz * dz;
-                        if (!(d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]))) continue;
-#pragma unroll
-                        for (int k = 0; k < K; k++) {  // ordered on (distance, index): independent of the visiting order
-                            if (d < bd[k] || (d == bd[k] && id < bi[k])) {
-                                const float td = bd[k]; const int ti = bi[k];
-                                bd[k] = d; bi[k] = id; d = td; id = ti;
-                            }
-                        }
-                    }
+                    for (unsigned int s = b; s < e; s++) consider(sorted[s]);
                 }
             }
         if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == G - 1 && y1 == G - 1 && z1 == G - 1) break;  // whole grid searched
@@ -528,23 +547,48 @@ __device__ __forceinline__ void visit_rows(unsigned int b, unsigned int e, int l
 // a row are consecutive in the cell-sorted array, so a row is one contiguous range of points.  Every lane keeps its K best in
 // registers, the wave then draws the K best of the 64 sorted lists with arg-min rounds on (distance, index).  The cover is taken
 // with a margin (float rounding of planes and cell assignment); a larger cover only costs time.
+#define BALL_WAVES 8           // waves of a k_knn_ball workgroup: they share the staged samples and the occupancy mask
+#define BALL_ROW_LIST 128      // per-wave list of cell rows waiting to be scanned (a flush takes 64)
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// sorted index of sample j of BALL_SAMPLES spread evenly over the M points of the cell-sorted array (every point once for a small set)
+__device__ __forceinline__ unsigned int ball_sample_at(unsigned int j, unsigned int M)
+{
+    return M <= BALL_SAMPLES ? j : (unsigned int)(((float)j + 0.5f) * ((float)M / (float)BALL_SAMPLES));
+}
+// The samples as one dense array (64 KB): k_knn_ball stages it in LDS once per workgroup.  (round 5: read in place, 4096 strided
+// 16-byte loads per query each pulled their own cache line through L2 -- 0.5 MB per query, more than everything else it read.)
+__global__ void __launch_bounds__(256) k_grid_samples(int G, const unsigned int* __restrict__ cell_start, const float4* __restrict__ sorted,
+                                                      float4* __restrict__ samples)
+{
+    const unsigned int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= BALL_SAMPLES) return;
+    const unsigned int M = cell_start[(unsigned int)G * G * G], at = ball_sample_at(j, M);
+    samples[j] = at < M ? sorted[at] : make_float4(3.0e+38f, 3.0e+38f, 3.0e+38f, __int_as_float(0x7FFFFFFF));  // (distance +inf to anything)
+}
+
 template <int K, bool EXCLUDE_SELF>
-__global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ query, const GridHdr* __restrict__ hdr, int G,
+__global__ void __launch_bounds__(64 * BALL_WAVES) k_knn_ball(const float* __restrict__ query, const GridHdr* __restrict__ hdr, int G,
                                                   const unsigned int* __restrict__ cell_start, const float4* __restrict__ sorted,
                                                   float* __restrict__ out_d, int64_t* __restrict__ out_i, float* __restrict__ out_mean,
                                                   const int* __restrict__ qlist, const float* __restrict__ qu2,
                                                   const unsigned int* __restrict__ qcount, unsigned int cap,
-                                                  const unsigned int* __restrict__ coarse)
+                                                  const unsigned int* __restrict__ coarse, const float4* __restrict__ samples)
 {
     __shared__ unsigned int s_occ[GRID_COARSE_WORDS];
+    __shared__ float4 s_samp[BALL_SAMPLES];
+    __shared__ uint2 s_rows[BALL_WAVES][BALL_ROW_LIST];
     const unsigned int n = min(*qcount, cap);
-    if (blockIdx.x * 4u >= n) return;   // (no query for this workgroup: uniform over the block)
-#pragma unroll
-    for (int i = 0; i < GRID_COARSE_WORDS / 256; i++) s_occ[i * 256 + threadIdx.x] = coarse[i * 256 + threadIdx.x];
+    if (blockIdx.x * (unsigned int)BALL_WAVES >= n) return;   // (no query for this workgroup: uniform over the block)
+    for (int i = threadIdx.x; i < GRID_COARSE_WORDS; i += 64 * BALL_WAVES) s_occ[i] = coarse[i];
+    for (int i = threadIdx.x; i < (int)BALL_SAMPLES; i += 64 * BALL_WAVES) s_samp[i] = samples[i];
     __syncthreads();
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const GridGeom g = grid_geom(hdr, G);
-    for (unsigned int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
+    for (unsigned int w = blockIdx.x * BALL_WAVES + wv; w < n; w += gridDim.x * BALL_WAVES) {
         const int q = qlist[w];
         const float qx = query[3 * (size_t)q], qy = query[3 * (size_t)q + 1], qz = query[3 * (size_t)q + 2];
         const float ext = (float)G * g.h;
@@ -563,34 +607,26 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
             // cloud's extent apart: the ball it gives cuts thousands of points out of a surface).  (2) A descent from the nearest
             // sample: look at the 27 cells around the current best point, move to the nearest point found there, repeat until it
             // stays in its cell; the K-th nearest of the LAST neighbourhood (no point counted twice) is a bound of the size of the
-            // answer itself -- when the descent ends at the GLOBAL minimum.  Measured (scripts/knn_offset_probe.py, 124k queries over
-            // config 4's lobed surface): 2 ms on the surface, 8 ms at 0.05 off it, 31 ms at 1.0 -- a far query's distance field over
-            // a bumpy surface has local minima, the descent stops in one, and the ball of that bound still cuts several percent of
-            // the cloud (SQ_INSTS_VALU 5.6 G wave-instructions per launch, nearly all candidate insertions).  A best-first walk over
-            // the quarter-resolution groups -- nearest group first, bound shrinking as it goes -- is the next step.  Both are distances of K distinct points: the smaller one is used.  With fewer than K points in reach
-            // the bound stays infinite and the cover below is the whole grid: still exact.
+            // answer itself when the descent ends near the global minimum (a far query's distance field over a bumpy surface has
+            // local minima: the bound of one is looser, the answer is the same).  Both are distances of K distinct points: the
+            // smaller one is used.  With fewer than K points in reach the bound stays infinite and the cover below is the whole
+            // grid: still exact.
             const unsigned int Mtot = cell_start[(unsigned int)G * G * G];
-            const unsigned int per_lane = BALL_SAMPLES / 64;
-            const float stride = (float)Mtot / (float)(per_lane * 64u);
             float best = 3.402823466e+38f;
-            unsigned int best_at = 0u;
-            if (Mtot)
+            unsigned int best_j = 0u;
 #pragma unroll 8
-            for (unsigned int j = 0; j < per_lane; j++) {   // (no branch around the load: eight stay in flight)
-                unsigned int sidx = (unsigned int)(((float)(j * 64u + (unsigned int)lane) + 0.5f) * stride);
-                if (Mtot <= per_lane * 64u) sidx = j * 64u + (unsigned int)lane;  // (a small set: every point once)
-                const bool ok = sidx < Mtot;
-                const float4 p = sorted[ok ? sidx : 0u];
+            for (unsigned int j = 0; j < BALL_SAMPLES / 64u; j++) {
+                const float4 p = s_samp[j * 64u + (unsigned int)lane];
                 const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
-                const float d = (ok && !(EXCLUDE_SELF && __float_as_int(p.w) == q)) ? dx * dx + dy * dy + dz * dz : 3.402823466e+38f;
-                if (d < best) { best = d; best_at = sidx; }
+                const float d = (EXCLUDE_SELF && __float_as_int(p.w) == q) ? 3.402823466e+38f : dx * dx + dy * dy + dz * dz;
+                if (d < best) { best = d; best_j = j * 64u + (unsigned int)lane; }
             }
             // the nearest sample of all (lowest lane on ties), then the K-th smallest lane minimum
             float nearest = best;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) nearest = fminf(nearest, __shfl_xor(nearest, o));
             const unsigned long long holders = __ballot(best == nearest);
-            unsigned int cur_at = (unsigned int)__shfl((int)best_at, holders ? (int)__builtin_ctzll(holders) : 0);
+            unsigned int cur_at = ball_sample_at((unsigned int)__shfl((int)best_j, holders ? (int)__builtin_ctzll(holders) : 0), Mtot);
             float kth = 3.402823466e+38f;
             for (int k = 0; k < K; k++) {   // K rounds: the smallest remaining lane minimum
                 float m = best;
@@ -626,7 +662,7 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
                         if (EXCLUDE_SELF && __float_as_int(p.w) == q) return;
                         const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
                         const float d = dx * dx + dy * dy + dz * dz;
-                        if (d < lbest || (d == lbest && sidx < lat)) { lbest = d; lat = sidx; }
+                        if (d < lbest) { lbest = d; lat = sidx; }
                     });
                     float nb = lbest;
 #pragma unroll
@@ -689,66 +725,90 @@ __global__ void __launch_bounds__(256) k_knn_ball(const float* __restrict__ quer
         const float Uz = sqrtf(fmaxf(U2 - gx * gx - gy * gy, 0.0f)), Uy = sqrtf(fmaxf(U2 - gx * gx - gz * gz, 0.0f));
         const int z0 = cell_coord(qz - Uz, g.oz, g), z1 = cell_coord(qz + Uz, g.oz, g);
         const int y0 = cell_coord(qy - Uy, g.oy, g), y1 = cell_coord(qy + Uy, g.oy, g);
-        const int ny = y1 - y0 + 1, rows = (z1 - z0 + 1) * ny;
+        const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
 #pragma unroll
         for (int k = 0; k < K; k++) { bd[k] = 3.402823466e+38f; bi[k] = 0x7FFFFFFF; }
-        // (round 5: the rows are enumerated without integer division -- `row / ny`, `row % ny` with a run-time ny were ~100 of the
-        // ~300 vector instructions a row cost, and a far query's ball has tens of thousands of rows: 5.6 G wave-instructions per
-        // 124k queries by SQ_INSTS_VALU.  A slice z takes 8 / 16 / 32 / 64 lanes by how many rows y it has, several slices per step.)
-        (void)rows;
-        const int nz = z1 - z0 + 1;
+        // The rows are enumerated 64 at a time without integer division (a slice z takes 8 / 16 / 32 / 64 lanes by how many rows y
+        // it has, several slices per step).  (round 5) Enumeration and scanning are decoupled: a row that the ball reaches and
+        // whose 4 x 4 x 4 groups hold anything -- LDS and arithmetic only -- is appended to a per-wave list, and the list is
+        // scanned 64 rows at a time.  A far query's ball has thousands of rows of which a tenth pass: before, each step of 64
+        // rows paid the latency of the cell_start look-up and of the points for the few that passed.
         const int sh = ny <= 8 ? 3 : (ny <= 16 ? 4 : (ny <= 32 ? 5 : 6));
         const int ly = lane & ((1 << sh) - 1), lz = lane >> sh, zstep = 64 >> sh;
-        for (int zb = 0; zb < nz; zb += zstep)
-        for (int yb = 0; yb < ny; yb += (1 << sh)) {
-            const int z = z0 + zb + lz, y = y0 + yb + ly;
-            unsigned int b = 0u, e = 0u;   // this lane's row as a range of the cell-sorted array (empty: nothing to look at)
-            if (z <= z1 && y <= y1) {
+        unsigned int pending = 0u;
+        int zb = 0, yb = 0;
+        for (;;) {
+            const bool more = zb < nz;
+            if (more) {
+                const int z = z0 + zb + lz, y = y0 + yb + ly;
+                bool pass = false;
+                unsigned int c0 = 0u, ncell = 0u;
+                if (z <= z1 && y <= y1) {
 #ifdef SGR_KNN_STATS
-                n_rows++;
+                    n_rows++;
 #endif
-                // distance of the query to the slab of cell row (z, y) along each axis (zero inside the slab)
-                const float zl = g.oz + (float)z * g.h, yl = g.oy + (float)y * g.h;
-                const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + g.h)), 0.0f), dy = fmaxf(fmaxf(yl - qy, qy - (yl + g.h)), 0.0f);
-                const float rem = U2 - dz * dz - dy * dy;
-                const float xr = sqrtf(fmaxf(rem, 0.0f));
-                // (a row whose x-interval misses the grid is dropped: the clamp of cell_coord would scan its end cell)
-                if (rem >= 0.0f && !(qx - xr > g.ox + ext || qx + xr < g.ox)) {
-                    const int x0 = cell_coord(qx - xr, g.ox, g), x1 = cell_coord(qx + xr, g.ox, g);
-                    // nothing in any 4 x 4 x 4 group the row's x-interval passes through: no look-up
-                    const unsigned int occ = s_occ[(z >> 2) * 32 + (y >> 2)];
-                    const int xa = x0 >> 2, xb = x1 >> 2;
-                    const unsigned int upto = xb >= 31 ? 0xFFFFFFFFu : ((1u << (xb + 1)) - 1u);
-                    if ((occ & upto & ~((1u << xa) - 1u)) != 0u) {
-                        const unsigned int c0 = ((unsigned int)z * G + y) * G + x0;
-                        b = cell_start[c0]; e = cell_start[c0 + (unsigned int)(x1 - x0) + 1u];
-#ifdef SGR_KNN_STATS
-                        n_pass++; n_pts += e - b;
-#endif
+                    // distance of the query to the slab of cell row (z, y) along each axis (zero inside the slab)
+                    const float zl = g.oz + (float)z * g.h, yl = g.oy + (float)y * g.h;
+                    const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + g.h)), 0.0f), dy = fmaxf(fmaxf(yl - qy, qy - (yl + g.h)), 0.0f);
+                    const float rem = U2 - dz * dz - dy * dy;
+                    const float xr = sqrtf(fmaxf(rem, 0.0f));
+                    // (a row whose x-interval misses the grid is dropped: the clamp of cell_coord would scan its end cell)
+                    if (rem >= 0.0f && !(qx - xr > g.ox + ext || qx + xr < g.ox)) {
+                        const int x0 = cell_coord(qx - xr, g.ox, g), x1 = cell_coord(qx + xr, g.ox, g);
+                        // nothing in any 4 x 4 x 4 group the row's x-interval passes through: no look-up
+                        const unsigned int occ = s_occ[(z >> 2) * 32 + (y >> 2)];
+                        const int xa = x0 >> 2, xb = x1 >> 2;
+                        const unsigned int upto = xb >= 31 ? 0xFFFFFFFFu : ((1u << (xb + 1)) - 1u);
+                        pass = (occ & upto & ~((1u << xa) - 1u)) != 0u;
+                        c0 = ((unsigned int)z * G + y) * G + x0;
+                        ncell = (unsigned int)(x1 - x0) + 1u;
                     }
                 }
+                const unsigned long long pm = __ballot(pass);
+                if (pass) s_rows[wv][pending + (unsigned int)__popcll(pm & ((1ull << lane) - 1ull))] = make_uint2(c0, ncell);
+                pending += (unsigned int)__popcll(pm);
+                yb += 1 << sh;
+                if (yb >= ny) { yb = 0; zb += zstep; }
+                wave_lds_fence();
             }
-            visit_rows(b, e, lane, [&](unsigned int sidx) {
-                const float4 p = sorted[sidx];
-                int id = __float_as_int(p.w);
-                if (EXCLUDE_SELF && id == q) return;
-                const float dx = p.x - qx, ddy = p.y - qy, ddz = p.z - qz;
-                float d = dx * dx + ddy * ddy + ddz * ddz;
-                // U2 bounds the K-th nearest distance from above (with the margin taken on U): a point beyond it is not among the
-                // answer -- the cells of the cover hold ~8 times the points of the ball itself on a surface
-                if (d > U2) return;
-                if (!(d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]))) return;
+            if (pending >= 64u || (!more && pending > 0u)) {
+                const unsigned int take = pending < 64u ? pending : 64u;
+                unsigned int b = 0u, e = 0u;
+                if ((unsigned int)lane < take) {
+                    const uint2 r = s_rows[wv][lane];
+                    b = cell_start[r.x]; e = cell_start[r.x + r.y];
 #ifdef SGR_KNN_STATS
-                n_ins++;
+                    n_pass++; n_pts += e - b;
+#endif
+                }
+                pending -= take;
+                uint2 keep = make_uint2(0u, 0u);
+                if ((unsigned int)lane < pending) keep = s_rows[wv][64 + lane];
+                wave_lds_fence();
+                if ((unsigned int)lane < pending) s_rows[wv][lane] = keep;
+                wave_lds_fence();
+                visit_rows(b, e, lane, [&](unsigned int sidx) {
+                    const float4 p = sorted[sidx];
+                    int id = __float_as_int(p.w);
+                    if (EXCLUDE_SELF && id == q) return;
+                    const float dx = p.x - qx, ddy = p.y - qy, ddz = p.z - qz;
+                    float d = dx * dx + ddy * ddy + ddz * ddz;
+                    // U2 bounds the K-th nearest distance from above (with the margin taken on U): a point beyond it is not among
+                    // the answer -- the cells of the cover hold ~8 times the points of the ball itself on a surface
+                    if (d > U2) return;
+                    if (!(d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]))) return;
+#ifdef SGR_KNN_STATS
+                    n_ins++;
 #endif
 #pragma unroll
-                for (int k = 0; k < K; k++) {
-                    if (d < bd[k] || (d == bd[k] && id < bi[k])) {
-                        const float td = bd[k]; const int ti = bi[k];
-                        bd[k] = d; bi[k] = id; d = td; id = ti;
+                    for (int k = 0; k < K; k++) {
+                        if (d < bd[k] || (d == bd[k] && id < bi[k])) {
+                            const float td = bd[k]; const int ti = bi[k];
+                            bd[k] = d; bi[k] = id; d = td; id = ti;
+                        }
                     }
-                }
-            });
+                });
+            } else if (!more) break;
         }
 #ifdef SGR_KNN_STATS
         {
@@ -813,7 +873,7 @@ int grid_res_max(int M)
 #define GRID_PROBE_MIN_POINTS 50000  // below this a query costs microseconds either way: no probe, no round trip
 
 struct GridScratch { GridHdr* hdr; unsigned int* coarse; unsigned int *cell_count, *cursor, *cell_start, *cell_of, *scan_part; float4* sorted; int* far_list;
-                     int* ball_list; float* ball_u2; unsigned int far_cap; size_t total; };
+                     int* ball_list; float* ball_u2; float4* samples; unsigned int far_cap; size_t total; };
 GridScratch carve_grid(char* base, int M)
 {
     const int G = grid_res_max(M);
@@ -832,6 +892,7 @@ GridScratch carve_grid(char* base, int M)
     s.far_list = reinterpret_cast<int*>(base + off); off = sgr_align(off + (size_t)s.far_cap * 4);
     s.ball_list = reinterpret_cast<int*>(base + off); off = sgr_align(off + (size_t)s.far_cap * 4);
     s.ball_u2 = reinterpret_cast<float*>(base + off); off = sgr_align(off + (size_t)s.far_cap * 4);
+    s.samples = reinterpret_cast<float4*>(base + off); off = sgr_align(off + (size_t)BALL_SAMPLES * 16);
     s.total = off;
     return s;
 }
@@ -896,6 +957,7 @@ int build_grid(int M, const float* ref, const GridScratch& gs, hipStream_t s)
     if (hipMemsetAsync(gs.coarse, 0, GRID_COARSE_WORDS * 4, s) != hipSuccess) return SGR_E_HIP;
     const int coarse_threads = G * G * ((G + 3) >> 2);
     hipLaunchKernelGGL(k_grid_coarse, dim3((coarse_threads + 255) / 256), dim3(256), 0, s, G, gs.cell_start, gs.coarse);
+    hipLaunchKernelGGL(k_grid_samples, dim3(BALL_SAMPLES / 256), dim3(256), 0, s, G, gs.cell_start, gs.sorted, gs.samples);
     return G;
 }
 
@@ -904,9 +966,11 @@ template <int K, bool EXCLUDE_SELF>
 void launch_far(int N, const float* query, int M, const float* ref, const GridScratch& gs, int G, float* d, int64_t* i, float* mean, hipStream_t s)
 {
     const unsigned int cap = gs.far_cap < (unsigned int)N ? gs.far_cap : (unsigned int)N;
-    const unsigned int ball_groups = (cap + 3) / 4;  // one wave per query, four per workgroup, grid-stride over the (device-side) count
-    hipLaunchKernelGGL((k_knn_ball<K, EXCLUDE_SELF>), dim3(ball_groups < 8192u ? ball_groups : 8192u), dim3(256), 0, s, query, gs.hdr,
-                       G, gs.cell_start, gs.sorted, d, i, mean, gs.ball_list, gs.ball_u2, &gs.hdr->ball_count, cap, gs.coarse);
+    // one wave per query, BALL_WAVES per workgroup, grid-stride over the (device-side) count: two workgroups per CU hold their 76 KB of LDS
+    const unsigned int ball_groups = (cap + BALL_WAVES - 1) / BALL_WAVES;
+    hipLaunchKernelGGL((k_knn_ball<K, EXCLUDE_SELF>), dim3(ball_groups < 512u ? ball_groups : 512u), dim3(64 * BALL_WAVES), 0, s, query,
+                       gs.hdr, G, gs.cell_start, gs.sorted, d, i, mean, gs.ball_list, gs.ball_u2, &gs.hdr->ball_count, cap, gs.coarse,
+                       gs.samples);
     constexpr int Q = K <= 4 ? 8 : (K <= 16 ? 4 : 2);  // queries per workgroup: Q * K (distance, index) pairs per thread in registers
     const unsigned int groups = (cap + Q - 1) / Q;
     hipLaunchKernelGGL((k_knn_far<K, EXCLUDE_SELF, Q>), dim3(groups < 4096u ? groups : 4096u), dim3(256), 0, s, query, M, gs.sorted, d, i,
