@@ -142,7 +142,7 @@ struct GridHdr { unsigned int minb[3], maxb[3], far_count, ball_count, occupied,
 // of that 4 x 4 x 4 group holds a point (G <= 128: at most 32 x 32 words of 32 bits).  A far query's ball is mostly empty space: its
 // cell rows are tested against these 4 KB (in LDS) before the two dependent look-ups of their point range.
 #define GRID_COARSE_WORDS 1024
-#define BALL_SAMPLES 4096u     // reference points a query without a bound is compared with in k_knn_ball (64 per lane)
+#define BALL_SAMPLES 2048u     // reference points a query without a bound is compared with in k_knn_ball (32 per lane; 32 KB of LDS)
 #define FAR_SINGLE_MAX 16384u  // up to this many far queries: one workgroup each; more: the tiled exhaustive kernel
 
 __device__ __forceinline__ unsigned int f2ord(float f)
@@ -520,35 +520,53 @@ __global__ void __launch_bounds__(128) k_grid_query(int N, const float* __restri
 // The points of up to 64 cell rows -- lane r holds row r as the contiguous range [b, e) of the cell-sorted array -- visited by the
 // WHOLE wave: the ranges are concatenated (exclusive scan of their lengths) and lane l takes elements l, l + 64, ... of the
 // concatenation (a 6-step search over the scanned offsets through ds_bpermute finds the row an element belongs to).  Every lane
-// works whatever the rows' lengths are, and a step is one batch of 64 independent loads.  (round 5: before, a lane walked its own
-// row serially -- one dependent load per point, and a surface cloud puts the points of a ball into ~15 of the 64 lanes: 355k cycles
-// per query by the cycle counter of a development build, -DSGR_KNN_STATS, almost all of it waiting.)  Call it wave-uniformly.
+// works whatever the rows' lengths are; a step is two batches of 64 independent loads, both in flight before either is used.
+// (round 5: before, a lane walked its own row serially -- one dependent load per point, and a surface cloud puts the points of a
+// ball into ~15 of the 64 lanes: 355k cycles per query by the cycle counter of a development build, -DSGR_KNN_STATS, almost all
+// of it waiting.)  `f(point, valid)` is called by ALL lanes (it may ballot); call visit_rows wave-uniformly.
 template <class F>
-__device__ __forceinline__ void visit_rows(unsigned int b, unsigned int e, int lane, F&& f)
+__device__ __forceinline__ void visit_rows(const float4* __restrict__ sorted, unsigned int b, unsigned int e, int lane, F&& f)
 {
     const unsigned int cnt = e > b ? e - b : 0u;
     unsigned int inc = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
     const unsigned int total = __shfl(inc, 63), excl = inc - cnt;
-    for (unsigned int base = 0; base < total; base += 64u) {
-        const unsigned int sl = base + (unsigned int)lane;
-        int r = 0;   // the last row whose offset is <= sl (empty rows share their successor's offset and are stepped over)
+    for (unsigned int base = 0; base < total; base += 128u) {
+        const unsigned int s0 = base + (unsigned int)lane, s1 = s0 + 64u;
+        int r0 = 0, r1 = 0;   // the last row whose offset is <= s (empty rows share their successor's offset and are stepped over)
 #pragma unroll
-        for (int step = 32; step > 0; step >>= 1) { const unsigned int o = __shfl(excl, r + step); if (o <= sl) r += step; }
-        const unsigned int rb = __shfl(b, r), ro = __shfl(excl, r);
-        if (sl < total) f(rb + (sl - ro));
+        for (int step = 32; step > 0; step >>= 1) {
+            const unsigned int o0 = __shfl(excl, r0 + step), o1 = __shfl(excl, r1 + step);
+            if (o0 <= s0) r0 += step;
+            if (o1 <= s1) r1 += step;
+        }
+        const unsigned int at0 = __shfl(b, r0) + (s0 - __shfl(excl, r0)), at1 = __shfl(b, r1) + (s1 - __shfl(excl, r1));
+        const bool v0 = s0 < total, v1 = s1 < total;
+        const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 p0 = v0 ? sorted[at0] : none, p1 = v1 ? sorted[at1] : none;
+        f(p0, v0);
+        if (base + 64u < total) f(p1, v1);   // (uniform)
     }
 }
 
-// Queries the ring walk handed over with an upper bound U^2 on their K-th nearest distance: ONE WAVE per query.  The K nearest
-// lie in the ball (q, U); a lane takes a row of cells (fixed z, y), intersects it with the ball -- rows farther than U in the
-// (y, z) plane are skipped, the others contribute the x-interval sqrt(U^2 - dy^2 - dz^2) around the query -- and the cells of
-// a row are consecutive in the cell-sorted array, so a row is one contiguous range of points.  Every lane keeps its K best in
-// registers, the wave then draws the K best of the 64 sorted lists with arg-min rounds on (distance, index).  The cover is taken
-// with a margin (float rounding of planes and cell assignment); a larger cover only costs time.
+// the k-th smallest (k = 0: the smallest) of the 64 lanes' values, ties by lane: every lane counts the lanes ordered before it --
+// 64 independent v_readlane + compare pairs instead of k + 1 dependent six-step butterflies
+__device__ __forceinline__ float wave_kth_smallest(float v, int lane, int k)
+{
+    int rank = 0;
+#pragma unroll 8
+    for (int i = 0; i < 64; i++) {   // (eight at a time: all 64 at once spill scalar registers)
+        const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
+        rank += (o < v || (o == v && i < lane)) ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(rank == k);
+    return __shfl(v, (int)__builtin_ctzll(m | (1ull << 63)));
+}
+
 #define BALL_WAVES 8           // waves of a k_knn_ball workgroup: they share the staged samples and the occupancy mask
 #define BALL_ROW_LIST 128      // per-wave list of cell rows waiting to be scanned (a flush takes 64)
+#define BALL_CAND 128          // per-wave list of candidates (distance, index) within the bound; reduced to the K best when it fills
 __device__ __forceinline__ void wave_lds_fence()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -559,8 +577,8 @@ __device__ __forceinline__ unsigned int ball_sample_at(unsigned int j, unsigned 
 {
     return M <= BALL_SAMPLES ? j : (unsigned int)(((float)j + 0.5f) * ((float)M / (float)BALL_SAMPLES));
 }
-// The samples as one dense array (64 KB): k_knn_ball stages it in LDS once per workgroup.  (round 5: read in place, 4096 strided
-// 16-byte loads per query each pulled their own cache line through L2 -- 0.5 MB per query, more than everything else it read.)
+// The samples as one dense array (32 KB): k_knn_ball stages it in LDS once per workgroup.  (round 5: read in place, the strided
+// 16-byte loads of a query each pulled their own cache line through L2 -- 0.5 MB per query, more than everything else it read.)
 __global__ void __launch_bounds__(256) k_grid_samples(int G, const unsigned int* __restrict__ cell_start, const float4* __restrict__ sorted,
                                                       float4* __restrict__ samples)
 {
@@ -570,6 +588,40 @@ __global__ void __launch_bounds__(256) k_grid_samples(int G, const unsigned int*
     samples[j] = at < M ? sorted[at] : make_float4(3.0e+38f, 3.0e+38f, 3.0e+38f, __int_as_float(0x7FFFFFFF));  // (distance +inf to anything)
 }
 
+// Orders the C (<= BALL_CAND) candidates of a wave's list on (distance, index) and keeps the first min(C, K) at the head of the
+// list: every candidate counts the candidates ordered before it (indices are distinct, so the counts are a permutation) and moves
+// to that place.  Broadcast LDS reads and compares only -- no dependent cross-lane steps.  Returns the new count.
+template <int K>
+__device__ __forceinline__ unsigned int ball_select(uint2* __restrict__ cand, unsigned int C, int lane)
+{
+    const uint2 none = make_uint2(__float_as_uint(3.402823466e+38f), 0x7FFFFFFFu);
+    const bool h0 = (unsigned int)lane < C, h1 = (unsigned int)lane + 64u < C;
+    const uint2 e0 = h0 ? cand[lane] : none, e1 = h1 ? cand[lane + 64] : none;
+    const float d0 = __uint_as_float(e0.x), d1 = __uint_as_float(e1.x);
+    const int i0 = (int)e0.y, i1 = (int)e1.y;
+    int r0 = 0, r1 = 0;
+    for (unsigned int j = 0; j < C; j++) {
+        const uint2 o = cand[j];
+        const float od = __uint_as_float(o.x);
+        const int oi = (int)o.y;
+        r0 += (od < d0 || (od == d0 && oi < i0)) ? 1 : 0;
+        r1 += (od < d1 || (od == d1 && oi < i1)) ? 1 : 0;
+    }
+    wave_lds_fence();
+    if (h0 && r0 < K) cand[r0] = e0;
+    if (h1 && r1 < K) cand[r1] = e1;
+    wave_lds_fence();
+    return C < (unsigned int)K ? C : (unsigned int)K;
+}
+
+// Queries the ring walk handed over, with an upper bound U^2 on their K-th nearest distance or without one: ONE WAVE per query.
+// The K nearest lie in the ball (q, U); cell rows (fixed z, y) farther than U in the (y, z) plane are skipped, the others contribute
+// the x-interval sqrt(U^2 - dy^2 - dz^2) around the query, and the cells of a row are consecutive in the cell-sorted array: a row
+// is one contiguous range of points.  The wave visits the rows' points together (visit_rows); a point within the bound is appended
+// to a candidate list in LDS, which is cut to its K best on (distance, index) -- tightening the bound -- when it fills and at the
+// end: the answer, in order.  The cover is taken with a margin (float rounding of planes and cell assignment); a larger cover
+// only costs time.  (round 5, third form of this kernel: per-lane sorted lists in registers and a K-round cross-lane merge before;
+// 2 x K sorted (distance, index) registers per lane, an insertion network per visited batch and 18 K dependent ds_bpermute at the end.)
 template <int K, bool EXCLUDE_SELF>
 __global__ void __launch_bounds__(64 * BALL_WAVES) k_knn_ball(const float* __restrict__ query, const GridHdr* __restrict__ hdr, int G,
                                                   const unsigned int* __restrict__ cell_start, const float4* __restrict__ sorted,
@@ -578,23 +630,25 @@ __global__ void __launch_bounds__(64 * BALL_WAVES) k_knn_ball(const float* __res
                                                   const unsigned int* __restrict__ qcount, unsigned int cap,
                                                   const unsigned int* __restrict__ coarse, const float4* __restrict__ samples)
 {
+    static_assert(K <= 64 && K <= BALL_CAND - 64, "the candidate list takes a batch of 64 on top of the K kept");
     __shared__ unsigned int s_occ[GRID_COARSE_WORDS];
     __shared__ float4 s_samp[BALL_SAMPLES];
     __shared__ uint2 s_rows[BALL_WAVES][BALL_ROW_LIST];
+    __shared__ uint2 s_cand[BALL_WAVES][BALL_CAND];
     const unsigned int n = min(*qcount, cap);
     if (blockIdx.x * (unsigned int)BALL_WAVES >= n) return;   // (no query for this workgroup: uniform over the block)
     for (int i = threadIdx.x; i < GRID_COARSE_WORDS; i += 64 * BALL_WAVES) s_occ[i] = coarse[i];
     for (int i = threadIdx.x; i < (int)BALL_SAMPLES; i += 64 * BALL_WAVES) s_samp[i] = samples[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint2* const cand = s_cand[wv];
     const GridGeom g = grid_geom(hdr, G);
+    const unsigned long long lt = (1ull << lane) - 1ull;
     for (unsigned int w = blockIdx.x * BALL_WAVES + wv; w < n; w += gridDim.x * BALL_WAVES) {
         const int q = qlist[w];
         const float qx = query[3 * (size_t)q], qy = query[3 * (size_t)q + 1], qz = query[3 * (size_t)q + 2];
         const float ext = (float)G * g.h;
         float u2 = qu2[w];
-        float bd[K];
-        int bi[K];
 #ifdef SGR_KNN_STATS
         unsigned long long* st = const_cast<GridHdr*>(hdr)->st;
         unsigned long long c_t0 = __builtin_readcyclecounter(), n_desc = 0, n_rows = 0, n_pass = 0, n_pts = 0, n_ins = 0;
@@ -603,50 +657,33 @@ __global__ void __launch_bounds__(64 * BALL_WAVES) k_knn_ball(const float* __res
         if (!(u2 < 3.0e+38f)) {
             // No bound from the ring walk.  (1) BALL_SAMPLES points spread evenly over the cell-sorted array (i.e. over the cloud):
             // every lane keeps the nearest of its share; the K-th smallest of the 64 lane minima is the distance of K DISTINCT
-            // reference points, hence an upper bound of the K-th nearest distance -- but a loose one (the samples are ~0.06 of the
+            // reference points, hence an upper bound of the K-th nearest distance -- but a loose one (the samples are ~0.08 of the
             // cloud's extent apart: the ball it gives cuts thousands of points out of a surface).  (2) A descent from the nearest
             // sample: look at the 27 cells around the current best point, move to the nearest point found there, repeat until it
-            // stays in its cell; the K-th nearest of the LAST neighbourhood (no point counted twice) is a bound of the size of the
-            // answer itself when the descent ends near the global minimum (a far query's distance field over a bumpy surface has
-            // local minima: the bound of one is looser, the answer is the same).  Both are distances of K distinct points: the
-            // smaller one is used.  With fewer than K points in reach the bound stays infinite and the cover below is the whole
-            // grid: still exact.
-            const unsigned int Mtot = cell_start[(unsigned int)G * G * G];
-            float best = 3.402823466e+38f;
-            unsigned int best_j = 0u;
+            // stays in its cell; the K-th smallest of the lanes' nearest points in the LAST neighbourhood (distinct points again) is
+            // a bound of the size of the answer itself when the descent ends near the global minimum (a far query's distance field
+            // over a bumpy surface has local minima: the bound of one is looser, the answer is the same).  The smaller of the two
+            // is used.  With fewer than K points in reach the bound stays infinite and the cover below is the whole grid: exact.
+            float best = 3.402823466e+38f, bx = 0.f, by = 0.f, bz = 0.f;
 #pragma unroll 8
             for (unsigned int j = 0; j < BALL_SAMPLES / 64u; j++) {
                 const float4 p = s_samp[j * 64u + (unsigned int)lane];
                 const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
                 const float d = (EXCLUDE_SELF && __float_as_int(p.w) == q) ? 3.402823466e+38f : dx * dx + dy * dy + dz * dz;
-                if (d < best) { best = d; best_j = j * 64u + (unsigned int)lane; }
+                if (d < best) { best = d; bx = p.x; by = p.y; bz = p.z; }
             }
-            // the nearest sample of all (lowest lane on ties), then the K-th smallest lane minimum
             float nearest = best;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) nearest = fminf(nearest, __shfl_xor(nearest, o));
-            const unsigned long long holders = __ballot(best == nearest);
-            unsigned int cur_at = ball_sample_at((unsigned int)__shfl((int)best_j, holders ? (int)__builtin_ctzll(holders) : 0), Mtot);
-            float kth = 3.402823466e+38f;
-            for (int k = 0; k < K; k++) {   // K rounds: the smallest remaining lane minimum
-                float m = best;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
-                kth = m;
-                const unsigned long long eq = __ballot(best == m);
-                if (lane == (int)__builtin_ctzll(eq | (1ull << 63))) best = 3.402823466e+38f;  // retire ONE holder of the minimum
-            }
-            u2 = K <= 64 ? kth : 3.402823466e+38f;
+            u2 = wave_kth_smallest(best, lane, K - 1);
             if (nearest < 3.0e+38f) {
-                float cur_d = nearest;
-                // (the K best are only collected over the LAST neighbourhood; on the way there a lane keeps its nearest point and
-                // nothing else: maintaining K sorted candidates per lane in every step was most of this kernel's time)
-                unsigned int rb = 0u, re = 0u;
+                const int first = (int)__builtin_ctzll(__ballot(best == nearest) | (1ull << 63));
+                float cpx = __shfl(bx, first), cpy = __shfl(by, first), cpz = __shfl(bz, first), cur_d = nearest;
+                float lbest = 3.402823466e+38f;
                 for (int it = 0; it < 16; it++) {
-                    const float4 cp = sorted[cur_at];
-                    const int ccx = cell_coord(cp.x, g.ox, g), ccy = cell_coord(cp.y, g.oy, g), ccz = cell_coord(cp.z, g.oz, g);
+                    const int ccx = cell_coord(cpx, g.ox, g), ccy = cell_coord(cpy, g.oy, g), ccz = cell_coord(cpz, g.oz, g);
                     // lanes 0..8: the nine rows (z, y) of the neighbourhood; a row's three cells are one contiguous range of points
-                    rb = 0u; re = 0u;
+                    unsigned int rb = 0u, re = 0u;
                     if (lane < 9) {
                         const int z = ccz + lane / 3 - 1, y = ccy + lane % 3 - 1;
                         if (z >= 0 && z < G && y >= 0 && y < G) {
@@ -655,14 +692,12 @@ __global__ void __launch_bounds__(64 * BALL_WAVES) k_knn_ball(const float* __res
                             rb = cell_start[c0]; re = cell_start[c0 + (unsigned int)(x1 - x0) + 1u];
                         }
                     }
-                    float lbest = 3.402823466e+38f;
-                    unsigned int lat = cur_at;
-                    visit_rows(rb, re, lane, [&](unsigned int sidx) {
-                        const float4 p = sorted[sidx];
-                        if (EXCLUDE_SELF && __float_as_int(p.w) == q) return;
+                    lbest = 3.402823466e+38f;
+                    float lx = 0.f, ly = 0.f, lz = 0.f;
+                    visit_rows(sorted, rb, re, lane, [&](const float4 p, bool valid) {
                         const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
                         const float d = dx * dx + dy * dy + dz * dz;
-                        if (d < lbest) { lbest = d; lat = sidx; }
+                        if (valid && !(EXCLUDE_SELF && __float_as_int(p.w) == q) && d < lbest) { lbest = d; lx = p.x; ly = p.y; lz = p.z; }
                     });
                     float nb = lbest;
 #pragma unroll
@@ -671,43 +706,12 @@ __global__ void __launch_bounds__(64 * BALL_WAVES) k_knn_ball(const float* __res
                     n_desc++;
 #endif
                     if (!(nb < cur_d)) break;   // the neighbourhood holds nothing nearer than the point it was built around
-                    const unsigned long long hb = __ballot(lbest == nb);
-                    cur_at = (unsigned int)__shfl((int)lat, (int)__builtin_ctzll(hb | (1ull << 63)));
+                    const int win = (int)__builtin_ctzll(__ballot(lbest == nb) | (1ull << 63));
+                    cpx = __shfl(lx, win); cpy = __shfl(ly, win); cpz = __shfl(lz, win);
                     cur_d = nb;
                 }
-                // the K best of the neighbourhood the descent ended in (rb / re still describe its nine rows)
-#pragma unroll
-                for (int k = 0; k < K; k++) { bd[k] = 3.402823466e+38f; bi[k] = 0x7FFFFFFF; }
-                visit_rows(rb, re, lane, [&](unsigned int sidx) {
-                    const float4 p = sorted[sidx];
-                    int id = __float_as_int(p.w);
-                    if (EXCLUDE_SELF && id == q) return;
-                    const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
-                    float d = dx * dx + dy * dy + dz * dz;
-                    if (!(d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]))) return;
-#pragma unroll
-                    for (int k = 0; k < K; k++) {
-                        if (d < bd[k] || (d == bd[k] && id < bi[k])) {
-                            const float td = bd[k]; const int ti = bi[k];
-                            bd[k] = d; bi[k] = id; d = td; id = ti;
-                        }
-                    }
-                });
-                // K-th smallest of the last neighbourhood's points: K rounds over the heads of the 64 sorted lists
-                float kth2 = 3.402823466e+38f;
-                for (int k = 0; k < K; k++) {
-                    float m = bd[0];
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
-                    kth2 = m;
-                    const unsigned long long eq = __ballot(bd[0] == m);
-                    if (lane == (int)__builtin_ctzll(eq | (1ull << 63))) {
-#pragma unroll
-                        for (int j = 0; j + 1 < K; j++) { bd[j] = bd[j + 1]; bi[j] = bi[j + 1]; }
-                        bd[K - 1] = 3.402823466e+38f; bi[K - 1] = 0x7FFFFFFF;
-                    }
-                }
-                u2 = fminf(u2, kth2);
+                // (lbest: every lane's nearest point of the last neighbourhood visited -- no second pass over it)
+                u2 = fminf(u2, wave_kth_smallest(lbest, lane, K - 1));
             }
         }
 #ifdef SGR_KNN_STATS
@@ -716,7 +720,8 @@ __global__ void __launch_bounds__(64 * BALL_WAVES) k_knn_ball(const float* __res
         const bool unbounded = !(u2 < 3.0e+38f);
         const float U = unbounded ? 4.0f * (ext + fabsf(qx - g.ox) + fabsf(qy - g.oy) + fabsf(qz - g.oz))
                                   : sqrtf(u2) * (1.0f + 1e-5f) + 1e-5f * (ext + fabsf(qx) + fabsf(qy) + fabsf(qz));
-        const float U2 = U * U;
+        float U2 = U * U;    // (of the cover, fixed) ...
+        float keep2 = U2;    // ... and of the candidates kept: shrinks to the K-th best so far whenever the list is cut
         // cell rows the ball can touch.  The points live inside the grid, so along y (z) the ball only reaches as far as what the
         // query's distance to the grid along the two other axes leaves of U: for a query outside the cloud that is a small cap
         const float gx = fmaxf(fmaxf(g.ox - qx, qx - (g.ox + ext)), 0.0f) * (1.0f - 1e-5f);
@@ -726,16 +731,14 @@ __global__ void __launch_bounds__(64 * BALL_WAVES) k_knn_ball(const float* __res
         const int z0 = cell_coord(qz - Uz, g.oz, g), z1 = cell_coord(qz + Uz, g.oz, g);
         const int y0 = cell_coord(qy - Uy, g.oy, g), y1 = cell_coord(qy + Uy, g.oy, g);
         const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
-#pragma unroll
-        for (int k = 0; k < K; k++) { bd[k] = 3.402823466e+38f; bi[k] = 0x7FFFFFFF; }
         // The rows are enumerated 64 at a time without integer division (a slice z takes 8 / 16 / 32 / 64 lanes by how many rows y
-        // it has, several slices per step).  (round 5) Enumeration and scanning are decoupled: a row that the ball reaches and
-        // whose 4 x 4 x 4 groups hold anything -- LDS and arithmetic only -- is appended to a per-wave list, and the list is
-        // scanned 64 rows at a time.  A far query's ball has thousands of rows of which a tenth pass: before, each step of 64
-        // rows paid the latency of the cell_start look-up and of the points for the few that passed.
+        // it has, several slices per step).  Enumeration and scanning are decoupled: a row that the ball reaches and whose
+        // 4 x 4 x 4 groups hold anything -- LDS and arithmetic only -- is appended to a per-wave list, and the list is scanned 64
+        // rows at a time.  A far query's ball has thousands of rows of which a tenth pass: before, each step of 64 rows paid the
+        // latency of the cell_start look-up and of the points for the few that passed.
         const int sh = ny <= 8 ? 3 : (ny <= 16 ? 4 : (ny <= 32 ? 5 : 6));
         const int ly = lane & ((1 << sh) - 1), lz = lane >> sh, zstep = 64 >> sh;
-        unsigned int pending = 0u;
+        unsigned int pending = 0u, C = 0u;
         int zb = 0, yb = 0;
         for (;;) {
             const bool more = zb < nz;
@@ -765,7 +768,7 @@ __global__ void __launch_bounds__(64 * BALL_WAVES) k_knn_ball(const float* __res
                     }
                 }
                 const unsigned long long pm = __ballot(pass);
-                if (pass) s_rows[wv][pending + (unsigned int)__popcll(pm & ((1ull << lane) - 1ull))] = make_uint2(c0, ncell);
+                if (pass) s_rows[wv][pending + (unsigned int)__popcll(pm & lt)] = make_uint2(c0, ncell);
                 pending += (unsigned int)__popcll(pm);
                 yb += 1 << sh;
                 if (yb >= ny) { yb = 0; zb += zstep; }
@@ -787,25 +790,24 @@ __global__ void __launch_bounds__(64 * BALL_WAVES) k_knn_ball(const float* __res
                 wave_lds_fence();
                 if ((unsigned int)lane < pending) s_rows[wv][lane] = keep;
                 wave_lds_fence();
-                visit_rows(b, e, lane, [&](unsigned int sidx) {
-                    const float4 p = sorted[sidx];
-                    int id = __float_as_int(p.w);
-                    if (EXCLUDE_SELF && id == q) return;
+                visit_rows(sorted, b, e, lane, [&](const float4 p, bool valid) {
+                    const int id = __float_as_int(p.w);
                     const float dx = p.x - qx, ddy = p.y - qy, ddz = p.z - qz;
-                    float d = dx * dx + ddy * ddy + ddz * ddz;
-                    // U2 bounds the K-th nearest distance from above (with the margin taken on U): a point beyond it is not among
-                    // the answer -- the cells of the cover hold ~8 times the points of the ball itself on a surface
-                    if (d > U2) return;
-                    if (!(d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]))) return;
+                    const float d = dx * dx + ddy * ddy + ddz * ddz;
+                    // keep2 bounds the K-th nearest distance from above (U^2 with its margin, then the K-th best met so far): a
+                    // point beyond it is not among the answer -- the cells of the cover hold ~8 times the points of the ball
+                    const bool in = valid && !(EXCLUDE_SELF && id == q) && !(d > keep2);
+                    const unsigned long long im = __ballot(in);
+                    if (im == 0ull) return;
+                    if (in) cand[C + (unsigned int)__popcll(im & lt)] = make_uint2(__float_as_uint(d), (unsigned int)id);
+                    C += (unsigned int)__popcll(im);
 #ifdef SGR_KNN_STATS
-                    n_ins++;
+                    n_ins += in ? 1 : 0;
 #endif
-#pragma unroll
-                    for (int k = 0; k < K; k++) {
-                        if (d < bd[k] || (d == bd[k] && id < bi[k])) {
-                            const float td = bd[k]; const int ti = bi[k];
-                            bd[k] = d; bi[k] = id; d = td; id = ti;
-                        }
+                    wave_lds_fence();
+                    if (C > (unsigned int)(BALL_CAND - 64)) {
+                        C = ball_select<K>(cand, C, lane);
+                        if (C == (unsigned int)K) keep2 = fminf(keep2, __uint_as_float(cand[K - 1].x));
                     }
                 });
             } else if (!more) break;
@@ -820,26 +822,22 @@ __global__ void __launch_bounds__(64 * BALL_WAVES) k_knn_ball(const float* __res
             }
         }
 #endif
-        // the K best of the 64 sorted lists: K rounds of a wave-wide arg-min of the heads on (distance, index)
-        float sum3 = 0.f;
-        for (int k = 0; k < K; k++) {
-            float d = bd[0]; int id = bi[0]; int who = lane;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float od = __shfl_xor(d, o); const int oi = __shfl_xor(id, o); const int ow = __shfl_xor(who, o);
-                if (od < d || (od == d && oi < id) || (od == d && oi == id && ow < who)) { d = od; id = oi; who = ow; }
-            }
-            if (lane == who) {
-#pragma unroll
-                for (int j = 0; j + 1 < K; j++) { bd[j] = bd[j + 1]; bi[j] = bi[j + 1]; }
-                bd[K - 1] = 3.402823466e+38f; bi[K - 1] = 0x7FFFFFFF;
-            }
+        // the answer: the list's K best in order (fewer than K points in the whole set: the rest reads "none")
+        C = ball_select<K>(cand, C, lane);
+        if (out_mean) {
             if (lane == 0) {
-                if (out_mean) { if (k < 3) sum3 += d; }
-                else { out_d[(size_t)q * K + k] = d; out_i[(size_t)q * K + k] = (id == 0x7FFFFFFF) ? -1 : (int64_t)id; }
+                float sum3 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; k++) sum3 += (unsigned int)k < C ? __uint_as_float(cand[k].x) : 3.402823466e+38f;
+                out_mean[q] = sum3 / 3.0f;
             }
+        } else if (lane < K) {
+            const bool has = (unsigned int)lane < C;
+            const uint2 c = has ? cand[lane] : make_uint2(0u, 0u);
+            out_d[(size_t)q * K + lane] = has ? __uint_as_float(c.x) : 3.402823466e+38f;
+            out_i[(size_t)q * K + lane] = has ? (int64_t)(int)c.y : (int64_t)-1;
         }
-        if (lane == 0 && out_mean) out_mean[q] = sum3 / 3.0f;
+        wave_lds_fence();   // (the list is reused by the wave's next query)
     }
 }
 
