@@ -308,8 +308,9 @@ int sgr_knn(int N, const float* query, int M, const float* ref, int K, float* di
  * counting-sorted into ~6-point cells and each query walks rings of cells until its K-th best distance is covered.
  * `scratch`: sgr_knn_grid_scratch_bytes(M) bytes of device memory.  With M >= 50 000 the call reads ONE word back from the device
  * (how many cells of the default grid hold a point) and refines the grid when the set turns out to be a surface rather than a
- * volume (round 5: Gaussians bound to a mesh put ~110 points into every occupied cell of the volume-sized grid); smaller sets and
- * sgr_knn take no host round trip. */
+ * volume (round 5: Gaussians bound to a mesh put ~110 points into every occupied cell of the volume-sized grid); the choice is
+ * kept per calling thread for the next 63 reference sets of the same size, which take no round trip.  Smaller sets and sgr_knn
+ * never take one. */
 size_t sgr_knn_grid_scratch_bytes(int M);
 int sgr_knn_grid(int N, const float* query, int M, const float* ref, int K, float* dists, int64_t* idx, char* scratch,
                  void* stream);
