@@ -841,6 +841,20 @@ __global__ void __launch_bounds__(64 * BALL_WAVES) k_knn_ball(const float* __res
     }
 }
 
+__global__ void __launch_bounds__(256) k_ball_all(int N, int* __restrict__ ball_list, float* __restrict__ ball_u2, unsigned int* __restrict__ ball_count)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) *ball_count = (unsigned int)N;
+    if (t < N) { ball_list[t] = t; ball_u2[t] = 3.402823466e+38f; }
+}
+
+// query sets up to this size skip the lane-per-query ring walk (SGR_KNN_DIRECT_MAX overrides; 0: never)
+int grid_direct_max()
+{
+    static const int v = [] { const char* e = getenv("SGR_KNN_DIRECT_MAX"); return e ? atoi(e) : 262144; }();
+    return v;
+}
+
 int grid_max_ring()
 {
     static const int v = [] { const char* e = getenv("SGR_KNN_MAX_RING"); const int x = e ? atoi(e) : 0; return x > 0 ? x : GRID_MAX_RING; }();
@@ -1000,6 +1014,10 @@ void launch_grid_query(bool self, int N, const float* query, int M, const float*
         hipLaunchKernelGGL((k_grid_query<K, false, true>), dim3((N + 127) / 128), dim3(128), 0, s, N, query, gs.hdr, G, gs.cell_start,
                            gs.sorted, d, i, (float*)nullptr, &gs.hdr->far_count, gs.far_list, gs.far_cap, grid_max_ring(), &gs.hdr->ball_count,
                            gs.ball_list, gs.ball_u2);
+    else if ((unsigned int)N <= gs.far_cap && N <= grid_direct_max())
+        // a query set too small to fill the device one LANE per query (the level-set sampler's 124k pixels are 7 waves per CU, each
+        // as slow as its slowest lane's serial walk: 0.63 ms) goes to the wave-per-query kernel directly, every query without a bound
+        hipLaunchKernelGGL(k_ball_all, dim3((N + 255) / 256), dim3(256), 0, s, N, gs.ball_list, gs.ball_u2, &gs.hdr->ball_count);
     else
         hipLaunchKernelGGL((k_grid_query<K, false, false>), dim3((N + 127) / 128), dim3(128), 0, s, N, query, gs.hdr, G, gs.cell_start,
                            gs.sorted, d, i, (float*)nullptr, &gs.hdr->far_count, gs.far_list, gs.far_cap, grid_max_ring(), &gs.hdr->ball_count,

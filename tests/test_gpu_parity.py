@@ -300,6 +300,11 @@ def test_grid_knn_is_identical_to_exhaustive(dist):
     a = knn_points(q[None], p[None], K=8, method="brute")
     b = knn_points(q[None], p[None], K=8, method="grid")
     assert torch.equal(a.dists, b.dists) and torch.equal(a.idx, b.idx)
+    # (query sets up to 262144 go to the wave-per-query kernel directly; a larger one takes the lane-per-query ring walk first)
+    q = (torch.rand(300_000, 3, generator=g) * 3 - 1.5).to(dev)
+    a = knn_points(q[None], p[None], K=8, method="brute")
+    b = knn_points(q[None], p[None], K=8, method="grid")
+    assert torch.equal(a.dists, b.dists) and torch.equal(a.idx, b.idx)
     assert torch.equal(distCUDA2(p, method="brute"), distCUDA2(p, method="grid"))
     # queries far outside the cloud (the level-set sampler's silhouette pixels), along faces, edges and corners of the bounding
     # box, on its boundary planes and a hair outside them: the ring walk's stop bound uses the distance to the box there
