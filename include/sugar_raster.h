@@ -499,6 +499,18 @@ int sgr_level_set_points(int N, int K, const float* world_points, const int64_t*
                          const float* gaussian_std, int n_levels, const float* levels_host, int n_range, float range_size,
                          float density_factor, uint8_t* valid, float* points, float* normals, const float* packed, void* stream);
 
+/* The two per-view preparations of sgr_level_set_points, one launch each (as torch ops: ~40 and ~15 launches, and a host check
+ * inside the 4 x 4 inverse):
+ * sgr_view_std: gaussian_std[P] of sugar_model.py:1971-1972 = | scaling[P,3] (.) R(q)^T normalize(cam_center - centers) | for unit
+ *   quaternions[P,4] (real part first, 16-byte aligned); cam_center: 3 floats on the DEVICE.
+ * sgr_unproject_pixels: world[n,3] of the pixels picked[n] (int64 row-major indices into depth[H*W], the view-space depth image) through
+ *   the reference's NDC pixel tables (sugar_model.py:1934-1941) and the inverse of `viewmatrix` (the rasterizer's 16 floats, on the
+ *   DEVICE; inverted in the kernel) -- cameras.unproject_points(..., world_coordinates=True) of :1958-1959. */
+int sgr_view_std(int P, const float* centers, const float* quaternions, const float* scaling, const float* cam_center, float* out,
+                 void* stream);
+int sgr_unproject_pixels(int n, const int64_t* picked, const float* depth, int width, int height, float tanfovx, float tanfovy,
+                         const float* viewmatrix, float* world, void* stream);
+
 /* ---- SuGaR.get_points_rgb, sugar_scene/sugar_model.py:839-883 (with sugar_utils/spherical_harmonics.py:117-172) -----
  * colors[P,3] = clamp_min(eval_sh(D, sh, dir) + 0.5, 0),  dir = F.normalize(positions - camera_centers) when positions is
  * given (camera_centers[n_centers,3], n_centers = 1 or P), else directions[P,3] as they are.  sh is [P,M,3] (the

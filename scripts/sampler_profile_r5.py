@@ -39,8 +39,7 @@ for ci in (0, 3):
     d0 = (world - m[nbr[:, 0]]).norm(dim=-1)
     out[f"cam{ci}_dist_to_nearest_quantiles"] = [float(torch.quantile(d0, q)) for q in (0.5, 0.9, 0.99, 1.0)]
     B = timed(f"cam{ci}_scaled_rotation", lambda: scaled_rotation(ro, sc, inverse_scales=True))
-    to_cam = torch.nn.functional.normalize(cam.campos.reshape(1, 3) - m, dim=-1)
-    stds = (sc * sampler._rotate_inverse(ro, to_cam)).norm(dim=-1)
+    stds = timed(f"cam{ci}_view_std", lambda: sampler.view_std(m, ro, sc, cam.campos))
     res = timed(f"cam{ci}_level_sets", lambda: level_set_points(world, nbr, cam.campos.reshape(1, 3), m, B, op.reshape(-1, 1), stds))
     out[f"cam{ci}_points"] = {str(k): int(v["intersection_points"].shape[0]) for k, v in res.items()}
     timed(f"cam{ci}_whole_pass", lambda: sampler.sample_level_sets(m, sc, ro, op, cam))

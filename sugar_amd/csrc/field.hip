@@ -558,6 +558,69 @@ __device__ __forceinline__ void quat_M(float r, float i, float j, float k, float
     M[6] = i * k - j * r;    M[7] = j * k + i * r;     M[8] = -(i * i + j * j);
 }
 
+// ---- the two per-view preparations of the level-set sampler (sugar_model.py:1934-1972), one launch each ------------------------
+// gaussian_std of :1971-1972: | scales (.) R(q)^T normalize(cam_center - centre) | with the unit quaternions the model hands out
+// (`quaternion_apply(quaternion_invert(q), v)`; F.normalize: v / max(|v|, 1e-12)).  As torch ops this was ~40 launches over [P].
+__global__ void __launch_bounds__(256) k_view_std(int P, const float* __restrict__ centers, const float* __restrict__ quats,
+                                                  const float* __restrict__ scaling, const float* __restrict__ cam_center,
+                                                  float* __restrict__ out)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= P) return;
+    const float4 q = reinterpret_cast<const float4*>(quats)[g];
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    float vx = cam_center[0] - centers[3 * (size_t)g], vy = cam_center[1] - centers[3 * (size_t)g + 1],
+          vz = cam_center[2] - centers[3 * (size_t)g + 2];
+    const float inv = 1.0f / fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), 1e-12f);
+    vx *= inv; vy *= inv; vz *= inv;
+    // rows of R^T = columns of R
+    const float ox = (1 - 2 * (y * y + z * z)) * vx + 2 * (x * y + r * z) * vy + 2 * (x * z - r * y) * vz;
+    const float oy = 2 * (x * y - r * z) * vx + (1 - 2 * (x * x + z * z)) * vy + 2 * (y * z + r * x) * vz;
+    const float oz = 2 * (x * z + r * y) * vx + 2 * (y * z - r * x) * vy + (1 - 2 * (x * x + y * y)) * vz;
+    const float sx = scaling[3 * (size_t)g] * ox, sy = scaling[3 * (size_t)g + 1] * oy, sz = scaling[3 * (size_t)g + 2] * oz;
+    out[g] = sqrtf(sx * sx + sy * sy + sz * sz);
+}
+
+// World points of picked pixels (:1934-1959).  The reference lays an NDC grid over the image (x = W/m - 2 col / (m - 1), +x to the
+// LEFT, +y UP, m = min(W, H)) and un-projects through a camera whose focal length in NDC units is 2 fx / m; the rasterizer's camera
+// frame (+x right, +y down) is that frame with x and y negated.  `viewmatrix` is the rasterizer's (row vectors: p_view = [p 1] V);
+// its inverse is taken here, by cofactors, by every workgroup (a 4 x 4 torch.linalg.inv is a factorisation plus a host check).
+__global__ void __launch_bounds__(256) k_unproject_pixels(int n, const int64_t* __restrict__ picked, const float* __restrict__ depth,
+                                                          int W, int H, float f_ndc_x, float f_ndc_y,
+                                                          const float* __restrict__ viewmatrix, float* __restrict__ world)
+{
+    __shared__ float s_inv[16];
+    if (threadIdx.x < 16) {
+        float m[16];
+        for (int i = 0; i < 16; i++) m[i] = viewmatrix[i];
+        // cofactor C(r, c) of the 4 x 4; inverse(r, c) = C(c, r) / det
+        auto minor3 = [&](int r, int c) {
+            int rr[3], cc[3], a = 0, b = 0;
+            for (int i = 0; i < 4; i++) { if (i != r) rr[a++] = i; if (i != c) cc[b++] = i; }
+            const float a00 = m[rr[0] * 4 + cc[0]], a01 = m[rr[0] * 4 + cc[1]], a02 = m[rr[0] * 4 + cc[2]];
+            const float a10 = m[rr[1] * 4 + cc[0]], a11 = m[rr[1] * 4 + cc[1]], a12 = m[rr[1] * 4 + cc[2]];
+            const float a20 = m[rr[2] * 4 + cc[0]], a21 = m[rr[2] * 4 + cc[1]], a22 = m[rr[2] * 4 + cc[2]];
+            return a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
+        };
+        float det = 0.f;
+        for (int c = 0; c < 4; c++) det += ((c & 1) ? -1.f : 1.f) * m[c] * minor3(0, c);
+        const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
+        s_inv[threadIdx.x] = (((r + c) & 1) ? -1.f : 1.f) * minor3(c, r) / det;
+    }
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int64_t pix = picked[t];
+    const int row = (int)(pix / W), col = (int)(pix - (int64_t)row * W);
+    const int mm = W < H ? W : H;
+    const float ndc_x = (float)W / (float)mm - ((float)col / (float)(mm - 1)) * 2.0f;
+    const float ndc_y = (float)H / (float)mm - ((float)row / (float)(mm - 1)) * 2.0f;
+    const float z = depth[pix];
+    const float xc = -ndc_x * z / f_ndc_x, yc = -ndc_y * z / f_ndc_y;
+#pragma unroll
+    for (int a = 0; a < 3; a++) world[3 * (size_t)t + a] = xc * s_inv[a] + yc * s_inv[4 + a] + z * s_inv[8 + a] + s_inv[12 + a];
+}
+
 __global__ void __launch_bounds__(256) k_scaled_rotation_fwd(int P, const float* __restrict__ quats, const float* __restrict__ scaling,
                                                              int inverse, float* __restrict__ out)
 {
@@ -760,6 +823,28 @@ int sgr_scaled_rotation_backward(int P, const float* quaternions, const float* s
         return SGR_E_INVALID;
     hipLaunchKernelGGL(k_scaled_rotation_bwd, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, quaternions, scaling,
                        inverse_scales, dL_dout, dL_dquaternions, dL_dscaling);
+    return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
+}
+
+int sgr_view_std(int P, const float* centers, const float* quaternions, const float* scaling, const float* cam_center, float* out,
+                 void* stream)
+{
+    if (P <= 0) return 0;
+    if (!centers || !quaternions || !scaling || !cam_center || !out || ((uintptr_t)quaternions & 15)) return SGR_E_INVALID;
+    hipLaunchKernelGGL(k_view_std, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, centers, quaternions, scaling, cam_center,
+                       out);
+    return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
+}
+
+int sgr_unproject_pixels(int n, const int64_t* picked, const float* depth, int width, int height, float tanfovx, float tanfovy,
+                         const float* viewmatrix, float* world, void* stream)
+{
+    if (n <= 0) return 0;
+    if (!picked || !depth || !viewmatrix || !world || width < 2 || height < 2 || !(tanfovx > 0.f) || !(tanfovy > 0.f)) return SGR_E_INVALID;
+    const int m = width < height ? width : height;
+    const float f_ndc_x = ((float)width / (2.0f * tanfovx)) * 2.0f / (float)m, f_ndc_y = ((float)height / (2.0f * tanfovy)) * 2.0f / (float)m;
+    hipLaunchKernelGGL(k_unproject_pixels, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, picked, depth, width, height,
+                       f_ndc_x, f_ndc_y, viewmatrix, world);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 

@@ -16,8 +16,11 @@ The camera is a `sugar_amd.synthetic.Camera`-shaped tuple with DEVICE tensors (r
 them).  GPU tensors only; there is no CPU path."""
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
+from . import _lib
 from .field import level_set_points, scaled_rotation
 from .knn import knn_points
 
@@ -40,35 +43,47 @@ def render_depth(means3D, scales, rotations, opacities, cam, bg_value: float = -
     return img[0]
 
 
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
 def unproject_pixels(picked: torch.Tensor, depth_flat: torch.Tensor, cam) -> torch.Tensor:
-    """World points of the picked pixels.  The reference lays an NDC grid over the image (x = W/m - 2 col / (m - 1), +x to the LEFT,
-    +y UP, m = min(W, H); sugar_model.py:1934-1941) and un-projects through a pytorch3d camera whose focal length in NDC units is
-    2 fx / m; the camera frame of the rasterizer (COLMAP: +x right, +y down) is that frame with x and y negated."""
-    H, W = int(cam.image_height), int(cam.image_width)
-    m = min(W, H)
-    rows = torch.div(picked, W, rounding_mode="floor")
-    cols = picked - rows * W
-    ndc_x = W / m - (cols.to(torch.float32) / (m - 1)) * 2
-    ndc_y = H / m - (rows.to(torch.float32) / (m - 1)) * 2
-    z = depth_flat[picked]
-    f_ndc_x = (W / (2.0 * cam.tanfovx)) * 2.0 / m
-    f_ndc_y = (H / (2.0 * cam.tanfovy)) * 2.0 / m
-    xc = -ndc_x * z / f_ndc_x
-    yc = -ndc_y * z / f_ndc_y
-    c2w = torch.linalg.inv(cam.viewmatrix)  # row-vector convention: [x y z 1] @ inverse(W2C^T)
-    pts = torch.stack([xc, yc, z, torch.ones_like(z)], dim=-1) @ c2w
-    return pts[:, :3].contiguous()
+    """World points of the picked pixels, one launch (csrc/field.hip: k_unproject_pixels).  The reference lays an NDC grid over the
+    image (x = W/m - 2 col / (m - 1), +x to the LEFT, +y UP, m = min(W, H); sugar_model.py:1934-1941) and un-projects through a
+    pytorch3d camera whose focal length in NDC units is 2 fx / m; the camera frame of the rasterizer (COLMAP: +x right, +y down) is
+    that frame with x and y negated.  The view matrix is inverted inside the kernel (no `torch.linalg.inv`: that one checks its
+    factorisation on the host)."""
+    dev = depth_flat.device
+    picked = picked.to(torch.int64).contiguous()
+    depth_flat = depth_flat.to(torch.float32).contiguous()
+    vm = cam.viewmatrix.to(device=dev, dtype=torch.float32).contiguous()
+    out = torch.empty(picked.shape[0], 3, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().sgr_unproject_pixels(int(picked.shape[0]), _p(picked), _p(depth_flat), int(cam.image_width), int(cam.image_height),
+                                              float(cam.tanfovx), float(cam.tanfovy), _p(vm), _p(out), _stream(dev))
+    if rc < 0:
+        raise RuntimeError(f"sgr_unproject_pixels failed ({rc})")
+    return out
 
 
-def _rotate_inverse(q: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
-    """R(q)^T v for unit quaternions (real part first): `quaternion_apply(quaternion_invert(q), v)`"""
-    r, x, y, z = q.unbind(-1)
-    vx, vy, vz = v.unbind(-1)
-    # rows of R^T = columns of R
-    ox = (1 - 2 * (y * y + z * z)) * vx + 2 * (x * y + r * z) * vy + 2 * (x * z - r * y) * vz
-    oy = 2 * (x * y - r * z) * vx + (1 - 2 * (x * x + z * z)) * vy + 2 * (y * z + r * x) * vz
-    oz = 2 * (x * z + r * y) * vx + 2 * (y * z - r * x) * vy + (1 - 2 * (x * x + y * y)) * vz
-    return torch.stack([ox, oy, oz], dim=-1)
+def view_std(means3D: torch.Tensor, rotations: torch.Tensor, scales: torch.Tensor, campos: torch.Tensor) -> torch.Tensor:
+    """[P]: the extent of every Gaussian along its direction to the camera, | scales (.) R(q)^T normalize(campos - mean) |
+    (sugar_model.py:1971-1972; unit quaternions, real part first) -- one launch (csrc/field.hip: k_view_std)"""
+    dev = means3D.device
+    ce, q, sc = (t.to(torch.float32).contiguous() for t in (means3D, rotations, scales))
+    if q.data_ptr() % 16:
+        q = q.clone()
+    cc = campos.to(device=dev, dtype=torch.float32).reshape(3).contiguous()
+    out = torch.empty(ce.shape[0], dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().sgr_view_std(int(ce.shape[0]), _p(ce), _p(q), _p(sc), _p(cc), _p(out), _stream(dev))
+    if rc < 0:
+        raise RuntimeError(f"sgr_view_std failed ({rc})")
+    return out
 
 
 @torch.no_grad()
@@ -99,8 +114,7 @@ def sample_level_sets(means3D, scales, rotations, opacities, cam, *, n_surface_p
     nbr = knn_points(world[None], means3D[None], K=K).idx[0]
     gaussian_idx = nbr[:, 0]
     cam_center = cam.campos.reshape(1, 3)
-    to_cam = torch.nn.functional.normalize(cam_center - means3D, dim=-1)
-    stds = (scales * _rotate_inverse(rotations, to_cam)).norm(dim=-1)                                  # :1971-1972
+    stds = view_std(means3D, rotations, scales, cam.campos)                                            # :1971-1972
     B = scaled_rotation(rotations, scales, inverse_scales=True)                                        # :730-736
     res = level_set_points(world, nbr, cam_center, means3D, B, opacities.reshape(-1, 1), stds, surface_levels=tuple(surface_levels),
                            n_points_in_range=n_points_in_range, range_size=range_size, density_factor=density_factor,

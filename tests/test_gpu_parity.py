@@ -435,3 +435,42 @@ def test_grid_knn_on_a_surface_cloud_with_queries_off_the_surface():
         a = knn_points(q[None], small[None], K=16, method="brute")
         c = knn_points(q[None], small[None], K=16, method="grid")
         assert torch.equal(a.dists, c.dists) and torch.equal(a.idx, c.idx), M
+
+
+def test_the_samplers_two_per_view_kernels_equal_the_torch_formulas_they_replace():
+    """sgr_view_std / sgr_unproject_pixels (csrc/field.hip) against sugar_model.py:1934-1972 written out with torch ops"""
+    from sugar_amd import sampler, synthetic as syn
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    P = 20_000
+    means = torch.randn(P, 3, generator=g).to(dev)
+    q = torch.nn.functional.normalize(torch.randn(P, 4, generator=g), dim=-1).to(dev)
+    sc = torch.exp(torch.randn(P, 3, generator=g) - 3).to(dev)
+    c = syn.orbit_cameras(640, 360, 8)[2]
+    cam = c._replace(viewmatrix=c.viewmatrix.to(dev), projmatrix=c.projmatrix.to(dev), campos=c.campos.to(dev))
+    # gaussian_std
+    to_cam = torch.nn.functional.normalize(cam.campos.reshape(1, 3) - means, dim=-1)
+    r, x, y, z = q.unbind(-1)
+    vx, vy, vz = to_cam.unbind(-1)
+    ox = (1 - 2 * (y * y + z * z)) * vx + 2 * (x * y + r * z) * vy + 2 * (x * z - r * y) * vz
+    oy = 2 * (x * y - r * z) * vx + (1 - 2 * (x * x + z * z)) * vy + 2 * (y * z + r * x) * vz
+    oz = 2 * (x * z + r * y) * vx + 2 * (y * z - r * x) * vy + (1 - 2 * (x * x + y * y)) * vz
+    want = (sc * torch.stack([ox, oy, oz], dim=-1)).norm(dim=-1)
+    got = sampler.view_std(means, q, sc, cam.campos)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-9)
+    # back-projection
+    H, W = int(cam.image_height), int(cam.image_width)
+    depth = (torch.rand(H * W, generator=g) * 5 + 0.5).to(dev)
+    picked = torch.randperm(H * W, generator=g)[:5000].to(dev)
+    m = min(W, H)
+    rows = torch.div(picked, W, rounding_mode="floor")
+    cols = picked - rows * W
+    ndc_x = W / m - (cols.to(torch.float32) / (m - 1)) * 2
+    ndc_y = H / m - (rows.to(torch.float32) / (m - 1)) * 2
+    zz = depth[picked]
+    xc = -ndc_x * zz / ((W / (2.0 * cam.tanfovx)) * 2.0 / m)
+    yc = -ndc_y * zz / ((H / (2.0 * cam.tanfovy)) * 2.0 / m)
+    c2w = torch.linalg.inv(cam.viewmatrix.double())
+    want = (torch.stack([xc, yc, zz, torch.ones_like(zz)], dim=-1).double() @ c2w)[:, :3]
+    got = sampler.unproject_pixels(picked, depth, cam)
+    assert (got.double() - want).abs().max() < 1e-5 * float(want.abs().max())
