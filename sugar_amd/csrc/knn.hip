@@ -564,6 +564,15 @@ __device__ __forceinline__ float wave_kth_smallest(float v, int lane, int k)
     return __shfl(v, (int)__builtin_ctzll(m | (1ull << 63)));
 }
 
+// The kernel is bound by dependent look-ups (cell range -> points, and the cross-lane steps between them): what it needs is waves
+// to switch to.  52 KB of LDS per workgroup let three of them share a CU; six waves per SIMD need <= 80 VGPRs (no spills at that,
+// scripts/kernel_meta.py).  Same box, 124k queries over config 4's cloud: 1.80 ms at two workgroups per CU / 104 VGPRs, 1.60 at three.
+#ifndef BALL_OCCUPANCY
+#define BALL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(6, 6)))
+#endif
+#ifndef BALL_GRID_MAX
+#define BALL_GRID_MAX 768u   // three workgroups per CU
+#endif
 #define BALL_WAVES 8           // waves of a k_knn_ball workgroup: they share the staged samples and the occupancy mask
 #define BALL_ROW_LIST 128      // per-wave list of cell rows waiting to be scanned (a flush takes 64)
 #define BALL_CAND 128          // per-wave list of candidates (distance, index) within the bound; reduced to the K best when it fills
@@ -623,7 +632,7 @@ __device__ __forceinline__ unsigned int ball_select(uint2* __restrict__ cand, un
 // only costs time.  (round 5, third form of this kernel: per-lane sorted lists in registers and a K-round cross-lane merge before;
 // 2 x K sorted (distance, index) registers per lane, an insertion network per visited batch and 18 K dependent ds_bpermute at the end.)
 template <int K, bool EXCLUDE_SELF>
-__global__ void __launch_bounds__(64 * BALL_WAVES) k_knn_ball(const float* __restrict__ query, const GridHdr* __restrict__ hdr, int G,
+__global__ void __launch_bounds__(64 * BALL_WAVES) BALL_OCCUPANCY k_knn_ball(const float* __restrict__ query, const GridHdr* __restrict__ hdr, int G,
                                                   const unsigned int* __restrict__ cell_start, const float4* __restrict__ sorted,
                                                   float* __restrict__ out_d, int64_t* __restrict__ out_i, float* __restrict__ out_mean,
                                                   const int* __restrict__ qlist, const float* __restrict__ qu2,
@@ -995,7 +1004,7 @@ void launch_far(int N, const float* query, int M, const float* ref, const GridSc
     const unsigned int cap = gs.far_cap < (unsigned int)N ? gs.far_cap : (unsigned int)N;
     // one wave per query, BALL_WAVES per workgroup, grid-stride over the (device-side) count: two workgroups per CU hold their 76 KB of LDS
     const unsigned int ball_groups = (cap + BALL_WAVES - 1) / BALL_WAVES;
-    hipLaunchKernelGGL((k_knn_ball<K, EXCLUDE_SELF>), dim3(ball_groups < 512u ? ball_groups : 512u), dim3(64 * BALL_WAVES), 0, s, query,
+    hipLaunchKernelGGL((k_knn_ball<K, EXCLUDE_SELF>), dim3(ball_groups < BALL_GRID_MAX ? ball_groups : BALL_GRID_MAX), dim3(64 * BALL_WAVES), 0, s, query,
                        gs.hdr, G, gs.cell_start, gs.sorted, d, i, mean, gs.ball_list, gs.ball_u2, &gs.hdr->ball_count, cap, gs.coarse,
                        gs.samples);
     constexpr int Q = K <= 4 ? 8 : (K <= 16 ? 4 : 2);  // queries per workgroup: Q * K (distance, index) pairs per thread in registers
