@@ -30,6 +30,8 @@ python scripts/kernel_meta.py > "$OUT/kernel_meta.txt" 2>&1
 python scripts/sampler_profile_r5.py config4 > "$OUT/sampler_profile_config4.json" 2> /dev/null
 python scripts/sampler_profile_r5.py metric > "$OUT/sampler_profile_metric_scene.json" 2> /dev/null
 python scripts/knn_far_bench.py > "$OUT/knn_far_bench.json" 2> /dev/null
+python scripts/knn_offset_probe.py > "$OUT/knn_offset_probe.json" 2> /dev/null
+SGR_KNN_DIRECT_MAX=0 python scripts/knn_offset_probe.py > "$OUT/knn_offset_probe_ring_walk_first.json" 2> /dev/null
 python scripts/reference_loop_profile.py --all-patches > "$OUT/reference_loop_torch_profile_all_patches.txt" 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_kt

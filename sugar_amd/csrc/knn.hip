@@ -1023,9 +1023,12 @@ void launch_grid_query(bool self, int N, const float* query, int M, const float*
         hipLaunchKernelGGL((k_grid_query<K, false, true>), dim3((N + 127) / 128), dim3(128), 0, s, N, query, gs.hdr, G, gs.cell_start,
                            gs.sorted, d, i, (float*)nullptr, &gs.hdr->far_count, gs.far_list, gs.far_cap, grid_max_ring(), &gs.hdr->ball_count,
                            gs.ball_list, gs.ball_u2);
-    else if ((unsigned int)N <= gs.far_cap && N <= grid_direct_max())
-        // a query set too small to fill the device one LANE per query (the level-set sampler's 124k pixels are 7 waves per CU, each
-        // as slow as its slowest lane's serial walk: 0.63 ms) goes to the wave-per-query kernel directly, every query without a bound
+    else if ((unsigned int)N <= gs.far_cap && N <= grid_direct_max() && G > grid_res(M))
+        // A query set too small to fill the device one LANE per query (the level-set sampler's 124k pixels are 7 waves per CU, each
+        // as slow as its slowest lane's serial walk) goes to the wave-per-query kernel directly, every query without a bound --
+        // when the reference set is a SURFACE (build_grid refined the grid: G > grid_res(M)).  Same box, 124k queries: config 4's
+        // cloud 1.50 -> 1.09 ms on the surface, 3.26 -> 2.77 at distance 1; over a VOLUME (the metric scene, 0 / 10 / 30 % of the
+        // queries outside it) the ring walk finishes most queries itself and stays ahead: 0.74 / 0.64 / 0.69 against 1.02 / 0.93 / 1.00.
         hipLaunchKernelGGL(k_ball_all, dim3((N + 255) / 256), dim3(256), 0, s, N, gs.ball_list, gs.ball_u2, &gs.hdr->ball_count);
     else
         hipLaunchKernelGGL((k_grid_query<K, false, false>), dim3((N + 127) / 128), dim3(128), 0, s, N, query, gs.hdr, G, gs.cell_start,
