@@ -210,8 +210,12 @@ def compute_level_surface_points_from_camera_fast(
         gaussian_idx = fragments.pix_to_face[0, ..., 0].reshape(-1)[picked] // self.n_triangles_per_gaussian
         closest_gaussians_idx = self.knn_idx[gaussian_idx]
     cam_center = p3d_cameras.get_camera_center()
-    gaussian_to_camera = torch.nn.functional.normalize(cam_center - self.points, dim=-1)               # :1971-1972
-    gaussian_standard_deviations = (self.scaling * quaternion_apply(quaternion_invert(self.quaternions), gaussian_to_camera)).norm(dim=-1)
+    if self.points.is_cuda:                                                                            # :1971-1972, one launch
+        from .sampler import view_std
+        gaussian_standard_deviations = view_std(self.points.detach(), self.quaternions.detach(), self.scaling.detach(), cam_center.detach())
+    else:
+        gaussian_to_camera = torch.nn.functional.normalize(cam_center - self.points, dim=-1)
+        gaussian_standard_deviations = (self.scaling * quaternion_apply(quaternion_invert(self.quaternions), gaussian_to_camera)).norm(dim=-1)
     B = self.get_covariance(return_full_matrix=True, return_sqrt=True, inverse_scales=True)
     with torch.no_grad():
         res = _level_set_points(all_world_points.detach(), closest_gaussians_idx, cam_center.detach(), self.points.detach(),
