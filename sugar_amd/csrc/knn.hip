@@ -520,10 +520,13 @@ __global__ void __launch_bounds__(128) k_grid_query(int N, const float* __restri
 // The points of up to 64 cell rows -- lane r holds row r as the contiguous range [b, e) of the cell-sorted array -- visited by the
 // WHOLE wave: the ranges are concatenated (exclusive scan of their lengths) and lane l takes elements l, l + 64, ... of the
 // concatenation (a 6-step search over the scanned offsets through ds_bpermute finds the row an element belongs to).  Every lane
-// works whatever the rows' lengths are; a step is two batches of 64 independent loads, both in flight before either is used.
+// works whatever the rows' lengths are; a step is VISIT_WIDTH batches of 64 independent loads, all in flight before any is used.
 // (round 5: before, a lane walked its own row serially -- one dependent load per point, and a surface cloud puts the points of a
 // ball into ~15 of the 64 lanes: 355k cycles per query by the cycle counter of a development build, -DSGR_KNN_STATS, almost all
 // of it waiting.)  `f(point, valid)` is called by ALL lanes (it may ballot); call visit_rows wave-uniformly.
+#ifndef VISIT_WIDTH
+#define VISIT_WIDTH 2
+#endif
 template <class F>
 __device__ __forceinline__ void visit_rows(const float4* __restrict__ sorted, unsigned int b, unsigned int e, int lane, F&& f)
 {
@@ -532,21 +535,25 @@ __device__ __forceinline__ void visit_rows(const float4* __restrict__ sorted, un
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
     const unsigned int total = __shfl(inc, 63), excl = inc - cnt;
-    for (unsigned int base = 0; base < total; base += 128u) {
-        const unsigned int s0 = base + (unsigned int)lane, s1 = s0 + 64u;
-        int r0 = 0, r1 = 0;   // the last row whose offset is <= s (empty rows share their successor's offset and are stepped over)
+    for (unsigned int base = 0; base < total; base += 64u * VISIT_WIDTH) {
+        unsigned int sl[VISIT_WIDTH], at[VISIT_WIDTH];
+        int r[VISIT_WIDTH];   // the last row whose offset is <= sl (empty rows share their successor's offset and are stepped over)
+#pragma unroll
+        for (int u = 0; u < VISIT_WIDTH; u++) { sl[u] = base + 64u * u + (unsigned int)lane; r[u] = 0; }
 #pragma unroll
         for (int step = 32; step > 0; step >>= 1) {
-            const unsigned int o0 = __shfl(excl, r0 + step), o1 = __shfl(excl, r1 + step);
-            if (o0 <= s0) r0 += step;
-            if (o1 <= s1) r1 += step;
+#pragma unroll
+            for (int u = 0; u < VISIT_WIDTH; u++) { const unsigned int o = __shfl(excl, r[u] + step); if (o <= sl[u]) r[u] += step; }
         }
-        const unsigned int at0 = __shfl(b, r0) + (s0 - __shfl(excl, r0)), at1 = __shfl(b, r1) + (s1 - __shfl(excl, r1));
-        const bool v0 = s0 < total, v1 = s1 < total;
+#pragma unroll
+        for (int u = 0; u < VISIT_WIDTH; u++) at[u] = __shfl(b, r[u]) + (sl[u] - __shfl(excl, r[u]));
         const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 p0 = v0 ? sorted[at0] : none, p1 = v1 ? sorted[at1] : none;
-        f(p0, v0);
-        if (base + 64u < total) f(p1, v1);   // (uniform)
+        float4 p[VISIT_WIDTH];
+#pragma unroll
+        for (int u = 0; u < VISIT_WIDTH; u++) p[u] = sl[u] < total ? sorted[at[u]] : none;
+#pragma unroll
+        for (int u = 0; u < VISIT_WIDTH; u++)
+            if (base + 64u * u < total) f(p[u], sl[u] < total);   // (uniform)
     }
 }
 
