@@ -1,4 +1,5 @@
-// knn.hip -- exact k-nearest-neighbour kernels for gfx950 (v1: LDS-tiled exhaustive search).
+// knn.hip -- exact k-nearest-neighbour kernels for gfx950: the LDS-tiled exhaustive search (below: the parity anchor and
+// `method="brute"`) and the uniform-grid search built on the same arithmetic (k_grid_*, k_knn_ball: further down).
 //
 //   sgr_dist2 : distCUDA2 of simple-knn (simple-knn/simple_knn.cu:147-221): mean of the three smallest squared
 //               distances to the OTHER points.  The reference gets there with a Morton sort + box pruning; the
@@ -493,9 +494,9 @@ __global__ void __launch_bounds__(128) k_grid_query(int N, const float* __restri
         // walking hundreds of cells, two dependent loads each, while the other lanes of its wave idle: 10 % such queries cost 13
         // of the sampler's 14.3 ms (and 6.6 ms still with the tighter bound above).  After `max_ring` rings the lane stops: once
         // it holds K candidates its K-th best distance U bounds the answer -- the K nearest lie in the ball (q, U) -- and the query
-        // goes to k_knn_ball, where a whole wave scans exactly the cells that ball touches.  A query that has not met K points
-        // after GRID_GIVEUP_RING rings (a far outlier of a tiny set) goes to the exhaustive kernels.  Same distances, same
-        // (distance, index) order everywhere: same result.
+        // goes to k_knn_ball, where a whole wave scans exactly the cells that ball touches.  Same distances, same (distance, index)
+        // order everywhere: same result.  (Only when the hand-over list is full does a lane walk on; the exhaustive kernels behind
+        // this one take what the grid scratch's far list holds -- nothing since round 5.)
         if (r >= max_ring && far_list) {
             // (round 5) a lane WITHOUT K candidates hands its query over too, with "no bound yet": k_knn_ball then takes the bound
             // from a spread sample of the reference set.  It used to walk on, alone, for up to 12 rings (~15 000 cells, two dependent
