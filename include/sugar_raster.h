@@ -508,6 +508,9 @@ int sgr_level_set_points(int N, int K, const float* world_points, const int64_t*
  *   DEVICE; inverted in the kernel) -- cameras.unproject_points(..., world_coordinates=True) of :1958-1959. */
 int sgr_view_std(int P, const float* centers, const float* quaternions, const float* scaling, const float* cam_center, float* out,
                  void* stream);
+/* out[P,3] = the view-space depth of every centre, three times: the colours of the sampler's depth render (sugar_model.py:1901-1911,
+ * `depth.expand(-1, 3)`); viewmatrix: the rasterizer's 16 floats on the DEVICE. */
+int sgr_view_depth_rgb(int P, const float* centers, const float* viewmatrix, float* out, void* stream);
 int sgr_unproject_pixels(int n, const int64_t* picked, const float* depth, int width, int height, float tanfovx, float tanfovy,
                          const float* viewmatrix, float* world, void* stream);
 

@@ -74,6 +74,7 @@ SIGNATURES = {
     "sgr_scaled_rotation_backward": (_i, [_i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "sgr_pack_gaussians": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "sgr_view_std": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sgr_view_depth_rgb": (_i, [_i, _vp, _vp, _vp, _vp]),
     "sgr_unproject_pixels": (_i, [_i, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "sgr_level_set_points": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "sgr_sh_to_rgb_forward": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

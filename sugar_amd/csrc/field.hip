@@ -558,6 +558,18 @@ __device__ __forceinline__ void quat_M(float r, float i, float j, float k, float
     M[6] = i * k - j * r;    M[7] = j * k + i * r;     M[8] = -(i * i + j * j);
 }
 
+// the depth render's colours (sugar_model.py:1901-1911): every Gaussian's view-space z three times (`depth.expand(-1, 3)`), from the
+// rasterizer's row-vector view matrix -- as torch ops a [P,3] x [3,1] GEMM, an add and an expanding copy
+__global__ void __launch_bounds__(256) k_view_depth_rgb(int P, const float* __restrict__ centers, const float* __restrict__ viewmatrix,
+                                                        float* __restrict__ out)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= P) return;
+    const float x = centers[3 * (size_t)g], y = centers[3 * (size_t)g + 1], z = centers[3 * (size_t)g + 2];
+    const float d = x * viewmatrix[2] + y * viewmatrix[6] + z * viewmatrix[10] + viewmatrix[14];
+    out[3 * (size_t)g] = d; out[3 * (size_t)g + 1] = d; out[3 * (size_t)g + 2] = d;
+}
+
 // ---- the two per-view preparations of the level-set sampler (sugar_model.py:1934-1972), one launch each ------------------------
 // gaussian_std of :1971-1972: | scales (.) R(q)^T normalize(cam_center - centre) | with the unit quaternions the model hands out
 // (`quaternion_apply(quaternion_invert(q), v)`; F.normalize: v / max(|v|, 1e-12)).  As torch ops this was ~40 launches over [P].
@@ -823,6 +835,14 @@ int sgr_scaled_rotation_backward(int P, const float* quaternions, const float* s
         return SGR_E_INVALID;
     hipLaunchKernelGGL(k_scaled_rotation_bwd, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, quaternions, scaling,
                        inverse_scales, dL_dout, dL_dquaternions, dL_dscaling);
+    return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
+}
+
+int sgr_view_depth_rgb(int P, const float* centers, const float* viewmatrix, float* out, void* stream)
+{
+    if (P <= 0) return 0;
+    if (!centers || !viewmatrix || !out) return SGR_E_INVALID;
+    hipLaunchKernelGGL(k_view_depth_rgb, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, centers, viewmatrix, out);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 

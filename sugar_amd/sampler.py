@@ -34,7 +34,13 @@ def render_depth(means3D, scales, rotations, opacities, cam, bg_value: float = -
     """[H,W] depth image: the Gaussian rasterizer with depth as the colour of every Gaussian (sugar_model.py:1901-1911)"""
     from .diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     dev = means3D.device
-    depth_rgb = view_depth(means3D, cam.viewmatrix).expand(-1, 3).contiguous()
+    ce = means3D.to(torch.float32).contiguous()
+    vm = cam.viewmatrix.to(device=dev, dtype=torch.float32).contiguous()
+    depth_rgb = torch.empty(ce.shape[0], 3, dtype=torch.float32, device=dev)   # (one launch: csrc/field.hip, k_view_depth_rgb)
+    with torch.cuda.device(dev):
+        rc = _lib.load().sgr_view_depth_rgb(int(ce.shape[0]), _p(ce), _p(vm), _p(depth_rgb), _stream(dev))
+    if rc < 0:
+        raise RuntimeError(f"sgr_view_depth_rgb failed ({rc})")
     st = GaussianRasterizationSettings(int(cam.image_height), int(cam.image_width), cam.tanfovx, cam.tanfovy,
                                        torch.full((3,), float(bg_value), device=dev), 1.0, cam.viewmatrix, cam.projmatrix, 0,
                                        cam.campos, False, False)

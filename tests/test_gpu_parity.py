@@ -458,6 +458,14 @@ def test_the_samplers_two_per_view_kernels_equal_the_torch_formulas_they_replace
     want = (sc * torch.stack([ox, oy, oz], dim=-1)).norm(dim=-1)
     got = sampler.view_std(means, q, sc, cam.campos)
     assert torch.allclose(got, want, rtol=1e-5, atol=1e-9)
+    # the depth render's colours
+    from sugar_amd import _lib
+    import ctypes as C
+    rgb = torch.empty(P, 3, device=dev)
+    rc = _lib.load().sgr_view_depth_rgb(P, C.c_void_p(means.data_ptr()), C.c_void_p(cam.viewmatrix.contiguous().data_ptr()),
+                                        C.c_void_p(rgb.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.allclose(rgb, sampler.view_depth(means, cam.viewmatrix).expand(-1, 3), rtol=1e-5, atol=1e-6)
     # back-projection
     H, W = int(cam.image_height), int(cam.image_width)
     depth = (torch.rand(H * W, generator=g) * 5 + 0.5).to(dev)
