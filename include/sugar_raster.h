@@ -344,6 +344,13 @@ int sgr_adam_step(long long n, float* params, const float* grads, float* exp_avg
                   const long long* seg_begin, const long long* seg_end, const float* seg_lr_a, const float* seg_lr_b,
                   const int* seg_period, const int* seg_split, float beta1, float beta2, float eps, int step,
                   float grad_scale, void* stream);
+/* The same update for up to 8 SEPARATE tensors in one launch (a drop-in `torch.optim.Adam` over the reference's six parameter
+ * tensors: gaussian_model.py:152-166, sugar_optimizer.py:60-85): tensor t has n[t] floats in params[t] / grads[t] / exp_avg[t] /
+ * exp_avg_sq[t] (16-byte aligned device pointers; the pointer tables and the per-tensor lr / beta1 / beta2 / eps / 1-based step are
+ * HOST arrays).  Bit-identical to one sgr_adam_step per tensor with a single segment of that learning rate. */
+int sgr_adam_step_multi(int n_tensors, const long long* n, float* const* params, const float* const* grads, float* const* exp_avg,
+                        float* const* exp_avg_sq, const float* lr, const float* beta1, const float* beta2, const float* eps,
+                        const int* step, void* stream);
 /* The same step with a second gradient term: the gradient of element i < extra_n is grads[i] + extra[i] (both scaled by
  * grad_scale).  Used for the position gradient of sgr_sh_adam_from_views_ex (positions first in the flat buffer). */
 int sgr_adam_step_ex(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n_seg,

@@ -63,6 +63,7 @@ SIGNATURES = {
     "sgr_l1_ssim_backward": (_i, [_i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "sgr_l1_ssim_backward_ex": (_i, [_i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "sgr_adam_step": (_i, [C.c_longlong, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _i, _f, _vp]),
+    "sgr_adam_step_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgr_adam_step_ex": (_i, [C.c_longlong, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _i, _f, _vp, C.c_longlong, _vp]),
     "sgr_density_field_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "sgr_density_field_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -118,6 +118,63 @@ __global__ void __launch_bounds__(256) k_adam(long long n4, f4* __restrict__ p, 
     }
 }
 
+// ---- several tensors, one launch (a drop-in torch.optim.Adam: six parameter tensors of their own) ------------------------------
+#define ADAM_MAX_TENSORS 8
+struct AdamMulti {
+    int n_t;
+    float* p[ADAM_MAX_TENSORS]; const float* g[ADAM_MAX_TENSORS]; float* m[ADAM_MAX_TENSORS]; float* v[ADAM_MAX_TENSORS];
+    long long n[ADAM_MAX_TENSORS];
+    float lr_bc1[ADAM_MAX_TENSORS] /* lr / (1 - b1^t) */, bc2_sqrt[ADAM_MAX_TENSORS], b1[ADAM_MAX_TENSORS], b2[ADAM_MAX_TENSORS],
+          omb1[ADAM_MAX_TENSORS], omb2[ADAM_MAX_TENSORS], eps[ADAM_MAX_TENSORS];
+    unsigned int blk_begin[ADAM_MAX_TENSORS + 1];   // workgroups [blk_begin[t], blk_begin[t + 1]) stream tensor t
+};
+
+// the update of k_adam (same operations in the same order: bit-identical to one launch per tensor), the tensor chosen per workgroup
+__global__ void __launch_bounds__(256) k_adam_multi(AdamMulti a)
+{
+    int t = 0;
+#pragma unroll
+    for (int j = 1; j < ADAM_MAX_TENSORS; j++)
+        if (j < a.n_t && blockIdx.x >= a.blk_begin[j]) t = j;
+    float *pp_ = nullptr, *mm_ = nullptr, *vv_ = nullptr; const float* gg_ = nullptr;
+    long long n = 0; float step_size = 0.f, bc2_sqrt = 1.f, b1 = 0.f, b2 = 0.f, omb1 = 0.f, omb2 = 0.f, eps = 0.f;
+    unsigned int first = 0u, last = 0u;
+#pragma unroll
+    for (int j = 0; j < ADAM_MAX_TENSORS; j++)   // (selects instead of dynamic indexing of the by-value argument: no scratch)
+        if (j == t) { pp_ = a.p[j]; gg_ = a.g[j]; mm_ = a.m[j]; vv_ = a.v[j]; n = a.n[j]; step_size = a.lr_bc1[j]; bc2_sqrt = a.bc2_sqrt[j];
+                      b1 = a.b1[j]; b2 = a.b2[j]; omb1 = a.omb1[j]; omb2 = a.omb2[j]; eps = a.eps[j]; first = a.blk_begin[j]; last = a.blk_begin[j + 1]; }
+    const long long n4 = n / 4;
+    f4* p = reinterpret_cast<f4*>(pp_); const f4* g = reinterpret_cast<const f4*>(gg_);
+    f4* m = reinterpret_cast<f4*>(mm_); f4* v = reinterpret_cast<f4*>(vv_);
+    const unsigned int lb = blockIdx.x - first, nb = last - first;
+    for (long long i = (long long)lb * 256 + threadIdx.x; i < n4; i += (long long)nb * 256) {
+        const f4 gg = __builtin_nontemporal_load(&g[i]);
+        f4 pp = p[i], mm = __builtin_nontemporal_load(&m[i]), vv = __builtin_nontemporal_load(&v[i]);
+        float* pf = reinterpret_cast<float*>(&pp);
+        float* mf = reinterpret_cast<float*>(&mm);
+        float* vf = reinterpret_cast<float*>(&vv);
+        const float* gf = reinterpret_cast<const float*>(&gg);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            mf[c] = b1 * mf[c] + omb1 * gf[c];
+            vf[c] = b2 * vf[c] + omb2 * gf[c] * gf[c];
+            const float denom = sqrtf(vf[c]) / bc2_sqrt + eps;
+            pf[c] -= step_size * (mf[c] / denom);
+        }
+        p[i] = pp;
+        __builtin_nontemporal_store(mm, &m[i]);
+        __builtin_nontemporal_store(vv, &v[i]);
+    }
+    if (lb == 0 && (long long)threadIdx.x < n - 4 * n4) {   // the last n % 4 elements
+        const long long e = 4 * n4 + threadIdx.x;
+        const float gg = gg_[e];
+        const float mm = b1 * mm_[e] + omb1 * gg, vv = b2 * vv_[e] + omb2 * gg * gg;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        pp_[e] -= step_size * (mm / denom);
+        mm_[e] = mm; vv_[e] = vv;
+    }
+}
+
 }  // namespace
 
 int sgr_adam_launch(long long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n_seg,
@@ -165,4 +222,43 @@ extern "C" int sgr_adam_step(long long n, float* params, const float* grads, flo
 {
     return sgr_adam_step_ex(n, params, grads, exp_avg, exp_avg_sq, n_seg, seg_begin, seg_end, seg_lr_a, seg_lr_b, seg_period, seg_split,
                             beta1, beta2, eps, step, grad_scale, nullptr, 0, stream);
+}
+
+extern "C" int sgr_adam_step_multi(int n_tensors, const long long* n, float* const* params, const float* const* grads,
+                                   float* const* exp_avg, float* const* exp_avg_sq, const float* lr, const float* beta1,
+                                   const float* beta2, const float* eps, const int* step, void* stream)
+{
+    if (n_tensors <= 0) return 0;
+    if (n_tensors > ADAM_MAX_TENSORS || !n || !params || !grads || !exp_avg || !exp_avg_sq || !lr || !beta1 || !beta2 || !eps || !step)
+        return SGR_E_INVALID;
+    AdamMulti a;
+    a.n_t = n_tensors;
+    unsigned int blk = 0;
+    for (int t = 0; t < ADAM_MAX_TENSORS; t++) {
+        const bool on = t < n_tensors;
+        if (on) {
+            if (n[t] < 0 || step[t] < 1 || !params[t] || !grads[t] || !exp_avg[t] || !exp_avg_sq[t]) return SGR_E_INVALID;
+            if (((uintptr_t)params[t] | (uintptr_t)grads[t] | (uintptr_t)exp_avg[t] | (uintptr_t)exp_avg_sq[t]) & 15) return SGR_E_INVALID;
+        }
+        a.p[t] = on ? params[t] : nullptr; a.g[t] = on ? grads[t] : nullptr; a.m[t] = on ? exp_avg[t] : nullptr; a.v[t] = on ? exp_avg_sq[t] : nullptr;
+        a.n[t] = on ? n[t] : 0;
+        float bc1 = 1.f, bc2s = 1.f;
+        if (on) sgr_bias_corrections(beta1[t], beta2[t], step[t], &bc1, &bc2s);
+        // (k_adam forms lr / bc1 per element; the same float division here, once)
+        a.lr_bc1[t] = on ? lr[t] / bc1 : 0.f; a.bc2_sqrt[t] = bc2s;
+        a.b1[t] = on ? beta1[t] : 0.f; a.b2[t] = on ? beta2[t] : 0.f;
+        a.omb1[t] = on ? sgr_one_minus(beta1[t]) : 0.f; a.omb2[t] = on ? sgr_one_minus(beta2[t]) : 0.f; a.eps[t] = on ? eps[t] : 0.f;
+        a.blk_begin[t] = blk;
+        if (on) {
+            const long long n4 = n[t] / 4;
+            long long b = (n4 + 255) / 256;
+            if (b > 4096) b = 4096;
+            if (b < 1) b = 1;
+            blk += (unsigned int)b;
+        }
+    }
+    a.blk_begin[ADAM_MAX_TENSORS] = blk;
+    for (int t = n_tensors; t < ADAM_MAX_TENSORS; t++) a.blk_begin[t] = blk;
+    hipLaunchKernelGGL(k_adam_multi, dim3(blk), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }

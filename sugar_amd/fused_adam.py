@@ -1,7 +1,8 @@
 """`torch.optim.Adam` with its `step()` on the one-launch HIP kernel (csrc/adam.hip: k_adam) -- for the optimisers the reference
 builds itself: `GaussianModel.training_setup` (gaussian_splatting/scene/gaussian_model.py:152-166) and `SuGaROptimizer`
 (sugar_scene/sugar_optimizer.py:60-85), both `torch.optim.Adam(l, lr=0.0, eps=1e-15)` over six parameter tensors.  Stock PyTorch
-runs that step as ~50 multi-tensor kernels (1.5 ms at 1M Gaussians on an MI355X); here it is one launch per parameter tensor.
+runs that step as ~50 multi-tensor kernels (1.5 ms at 1M Gaussians on an MI355X); here it is ONE launch for up to eight parameter
+tensors (sgr_adam_step_multi).
 
 `FusedAdam` IS a `torch.optim.Adam`: same constructor, same `param_groups`, same per-parameter state (`step`, `exp_avg`,
 `exp_avg_sq` -- what the reference's densifier cuts, concatenates and resets: gaussian_model.py:258-316, sugar_densifier.py), same
@@ -52,7 +53,6 @@ class FusedAdam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
-        one = (C.c_longlong * 1)
         # Everything a launch can reject is prepared BEFORE any state changes (a step that failed half way would leave some
         # parameters updated and some step counters advanced): dense, 16-byte aligned storage for parameter, gradient and moments.
         # `.contiguous()` returns the SAME storage for a contiguous tensor at an odd offset (a `[1:]` slice): those get a real copy.
@@ -79,16 +79,25 @@ class FusedAdam(torch.optim.Adam):
         for group, p, state, dense, grad, m, v in plan:
             state["step"] += 1
             state["exp_avg"], state["exp_avg_sq"] = m, v
-            lr = float(group["lr"])
-            b1, b2 = group["betas"]
-            n = p.numel()
-            with torch.cuda.device(p.device):
-                rc = lib.sgr_adam_step(n, C.c_void_p(dense.data_ptr()), C.c_void_p(grad.data_ptr()), C.c_void_p(m.data_ptr()),
-                                       C.c_void_p(v.data_ptr()), 1, one(0), one(n), (C.c_float * 1)(lr), (C.c_float * 1)(lr),
-                                       (C.c_int * 1)(1), (C.c_int * 1)(1), float(b1), float(b2), float(group["eps"]),
-                                       int(state["step"]), 1.0, C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream))
-            if rc < 0:
-                raise RuntimeError(f"sgr_adam_step failed ({rc})")
+        # one launch per 8 tensors of a device (sgr_adam_step_multi: the six tensors of the reference's optimisers are ONE launch)
+        by_dev = {}
+        for item in plan:
+            by_dev.setdefault(item[1].device, []).append(item)
+        for dev, items in by_dev.items():
+            for k0 in range(0, len(items), 8):
+                chunk = items[k0:k0 + 8]
+                T = len(chunk)
+                ptrs = lambda sel: (C.c_void_p * T)(*[sel(it).data_ptr() for it in chunk])
+                with torch.cuda.device(dev):
+                    rc = lib.sgr_adam_step_multi(
+                        T, (C.c_longlong * T)(*[it[1].numel() for it in chunk]), ptrs(lambda it: it[3]), ptrs(lambda it: it[4]),
+                        ptrs(lambda it: it[5]), ptrs(lambda it: it[6]), (C.c_float * T)(*[float(it[0]["lr"]) for it in chunk]),
+                        (C.c_float * T)(*[float(it[0]["betas"][0]) for it in chunk]), (C.c_float * T)(*[float(it[0]["betas"][1]) for it in chunk]),
+                        (C.c_float * T)(*[float(it[0]["eps"]) for it in chunk]), (C.c_int * T)(*[int(it[2]["step"]) for it in chunk]),
+                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+                if rc < 0:
+                    raise RuntimeError(f"sgr_adam_step_multi failed ({rc})")
+        for group, p, state, dense, grad, m, v in plan:
             if dense is not p:
                 p.copy_(dense)
         return loss
