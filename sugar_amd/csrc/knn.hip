@@ -12,7 +12,6 @@
 // (dx*dx + dy*dy) + dz*dz with individually rounded ops (-ffp-contract=off), identical to the oracle.
 #include "../../include/sugar_raster.h"
 #include "sgr_common.h"
-#include <cstdio>
 #include <cstdlib>
 #include <string>
 
@@ -130,9 +129,6 @@ namespace {
 
 // order-preserving uint encodings of the bbox; far_count: queries handed to the exhaustive kernels, ball_count: to the ball scan
 struct GridHdr { unsigned int minb[3], maxb[3], far_count, ball_count, occupied, pad;
-#ifdef SGR_KNN_STATS
-                 unsigned long long st[8];  // development build: unbounded queries, descent steps, rows, rows past the mask, points scanned, insertions, cycles (sample / descent / cover)
-#endif
 };  // occupied: non-empty cells (k_grid_count)
 // Rings a lane walks on its own before it hands its query to k_knn_ball (with K candidates in hand) -- measured, 124k queries
 // against 1M points, 0 / 10 / 30 % of them outside the cloud: cap 1: 1.06 / 1.39 / 2.02 ms, 2: 1.12 / 1.85 / 2.46, 3: 1.13 / 2.57 /
@@ -160,9 +156,6 @@ __global__ void k_grid_init(GridHdr* h)
 {
     if (threadIdx.x < 3) { h->minb[threadIdx.x] = 0xFFFFFFFFu; h->maxb[threadIdx.x] = 0u; }
     if (threadIdx.x == 3) { h->far_count = 0u; h->ball_count = 0u; h->occupied = 0u; h->pad = 0u; }
-#ifdef SGR_KNN_STATS
-    if (threadIdx.x < 8) h->st[threadIdx.x] = 0ull;
-#endif
 }
 
 // Far queries, Q per workgroup (grid-stride over the fallback list): the 256 threads split the reference set -- every point is
@@ -523,7 +516,7 @@ __global__ void __launch_bounds__(128) k_grid_query(int N, const float* __restri
 // concatenation (a 6-step search over the scanned offsets through ds_bpermute finds the row an element belongs to).  Every lane
 // works whatever the rows' lengths are; a step is VISIT_WIDTH batches of 64 independent loads, all in flight before any is used.
 // (round 5: before, a lane walked its own row serially -- one dependent load per point, and a surface cloud puts the points of a
-// ball into ~15 of the 64 lanes: 355k cycles per query by the cycle counter of a development build, -DSGR_KNN_STATS, almost all
+// ball into ~15 of the 64 lanes: 355k cycles per query by the cycle counter of a development build (profiles/r05_knn_ball_counters.txt), almost all
 // of it waiting.)  `f(point, valid)` is called by ALL lanes (it may ballot); call visit_rows wave-uniformly.
 #ifndef VISIT_WIDTH
 #define VISIT_WIDTH 2
@@ -666,11 +659,6 @@ __global__ void __launch_bounds__(64 * BALL_WAVES) BALL_OCCUPANCY k_knn_ball(con
         const float qx = query[3 * (size_t)q], qy = query[3 * (size_t)q + 1], qz = query[3 * (size_t)q + 2];
         const float ext = (float)G * g.h;
         float u2 = qu2[w];
-#ifdef SGR_KNN_STATS
-        unsigned long long* st = const_cast<GridHdr*>(hdr)->st;
-        unsigned long long c_t0 = __builtin_readcyclecounter(), n_desc = 0, n_rows = 0, n_pass = 0, n_pts = 0, n_ins = 0;
-        if (lane == 0 && !(u2 < 3.0e+38f)) atomicAdd(&st[0], 1ull);
-#endif
         if (!(u2 < 3.0e+38f)) {
             // No bound from the ring walk.  (1) BALL_SAMPLES points spread evenly over the cell-sorted array (i.e. over the cloud):
             // every lane keeps the nearest of its share; the K-th smallest of the 64 lane minima is the distance of K DISTINCT
@@ -719,9 +707,6 @@ __global__ void __launch_bounds__(64 * BALL_WAVES) BALL_OCCUPANCY k_knn_ball(con
                     float nb = lbest;
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) nb = fminf(nb, __shfl_xor(nb, o));
-#ifdef SGR_KNN_STATS
-                    n_desc++;
-#endif
                     if (!(nb < cur_d)) break;   // the neighbourhood holds nothing nearer than the point it was built around
                     const int win = (int)__builtin_ctzll(__ballot(lbest == nb) | (1ull << 63));
                     cpx = __shfl(lx, win); cpy = __shfl(ly, win); cpz = __shfl(lz, win);
@@ -731,9 +716,6 @@ __global__ void __launch_bounds__(64 * BALL_WAVES) BALL_OCCUPANCY k_knn_ball(con
                 u2 = fminf(u2, wave_kth_smallest(lbest, lane, K - 1));
             }
         }
-#ifdef SGR_KNN_STATS
-        const unsigned long long c_t1 = __builtin_readcyclecounter();
-#endif
         const bool unbounded = !(u2 < 3.0e+38f);
         const float U = unbounded ? 4.0f * (ext + fabsf(qx - g.ox) + fabsf(qy - g.oy) + fabsf(qz - g.oz))
                                   : sqrtf(u2) * (1.0f + 1e-5f) + 1e-5f * (ext + fabsf(qx) + fabsf(qy) + fabsf(qz));
@@ -764,9 +746,6 @@ __global__ void __launch_bounds__(64 * BALL_WAVES) BALL_OCCUPANCY k_knn_ball(con
                 bool pass = false;
                 unsigned int c0 = 0u, ncell = 0u;
                 if (z <= z1 && y <= y1) {
-#ifdef SGR_KNN_STATS
-                    n_rows++;
-#endif
                     // distance of the query to the slab of cell row (z, y) along each axis (zero inside the slab)
                     const float zl = g.oz + (float)z * g.h, yl = g.oy + (float)y * g.h;
                     const float dz = fmaxf(fmaxf(zl - qz, qz - (zl + g.h)), 0.0f), dy = fmaxf(fmaxf(yl - qy, qy - (yl + g.h)), 0.0f);
@@ -797,9 +776,6 @@ __global__ void __launch_bounds__(64 * BALL_WAVES) BALL_OCCUPANCY k_knn_ball(con
                 if ((unsigned int)lane < take) {
                     const uint2 r = s_rows[wv][lane];
                     b = cell_start[r.x]; e = cell_start[r.x + r.y];
-#ifdef SGR_KNN_STATS
-                    n_pass++; n_pts += e - b;
-#endif
                 }
                 pending -= take;
                 uint2 keep = make_uint2(0u, 0u);
@@ -818,9 +794,6 @@ __global__ void __launch_bounds__(64 * BALL_WAVES) BALL_OCCUPANCY k_knn_ball(con
                     if (im == 0ull) return;
                     if (in) cand[C + (unsigned int)__popcll(im & lt)] = make_uint2(__float_as_uint(d), (unsigned int)id);
                     C += (unsigned int)__popcll(im);
-#ifdef SGR_KNN_STATS
-                    n_ins += in ? 1 : 0;
-#endif
                     wave_lds_fence();
                     if (C > (unsigned int)(BALL_CAND - 64)) {
                         C = ball_select<K>(cand, C, lane);
@@ -829,16 +802,6 @@ __global__ void __launch_bounds__(64 * BALL_WAVES) BALL_OCCUPANCY k_knn_ball(con
                 });
             } else if (!more) break;
         }
-#ifdef SGR_KNN_STATS
-        {
-            const unsigned long long c_t2 = __builtin_readcyclecounter();
-            for (int o = 32; o > 0; o >>= 1) { n_rows += __shfl_xor(n_rows, o); n_pass += __shfl_xor(n_pass, o); n_pts += __shfl_xor(n_pts, o); n_ins += __shfl_xor(n_ins, o); }
-            if (lane == 0) {
-                atomicAdd(&st[1], n_desc); atomicAdd(&st[2], n_rows); atomicAdd(&st[3], n_pass); atomicAdd(&st[4], n_pts); atomicAdd(&st[5], n_ins);
-                atomicAdd(&st[6], c_t1 - c_t0); atomicAdd(&st[7], c_t2 - c_t1);
-            }
-        }
-#endif
         // the answer: the list's K best in order (fewer than K points in the whole set: the rest reads "none")
         C = ball_select<K>(cand, C, lane);
         if (out_mean) {
@@ -1070,16 +1033,6 @@ int sgr_knn_grid(int N, const float* query, int M, const float* ref, int K, floa
         case 32: launch_grid_query<32>(self, N, query, M, ref, gs, G, dists, idx, s); break;
         default: return SGR_E_INVALID;
     }
-#ifdef SGR_KNN_STATS
-    {
-        unsigned long long st[8]; unsigned int bc = 0;
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(st, gs.hdr->st, sizeof(st), hipMemcpyDeviceToHost);
-        (void)hipMemcpy(&bc, &gs.hdr->ball_count, 4, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[knn stats] N %d G %d ball %u unbounded %llu descent_steps %llu rows %llu past_mask %llu points %llu insertions %llu cyc_bound %llu cyc_cover %llu\n",
-                N, G, bc, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
-    }
-#endif
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 
