@@ -285,9 +285,10 @@ size_t sgr_binning_point_list_offset(int64_t R);        /* uint32[R]: Gaussian i
 
 /* ---- optional per-stage timing (HIP events recorded on the caller's stream, process-wide) --
  * Stages: 0 preprocess, 1 ordered tile count + scans, 2 ordered scatter into the tile lists, 3 global depth sort of
- * the Gaussians, 4 blend forward, 5 blend backward, 6 preprocess backward.  sgr_profile_read synchronises the recorded events, returns the summed
+ * the Gaussians, 4 blend forward (k_blend_fwd_w alone), 5 blend backward, 6 preprocess backward, 7 the two launches behind the blend that
+ * repair a walk hint (empty when every hint held).  sgr_profile_read synchronises the recorded events, returns the summed
  * milliseconds and launch counts per stage since the last read, and clears the record. */
-#define SGR_N_STAGES 7
+#define SGR_N_STAGES 8
 void sgr_profile_enable(int stage_mask); /* bit s set: record events around stage s (0 disables; each event pair costs
                                             several microseconds of GPU pipeline, so time only what is being measured) */
 int sgr_profile_read(double* ms_sum, int64_t* count, int n_stages);

@@ -8,7 +8,7 @@ from sugar_amd import _lib, synthetic as syn
 from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, grad_sink
 from sugar_amd.train_step import GaussianParams, FlatAdam
 
-STAGES = ["preprocess", "bin_count_scan", "bin_scatter", "depth_sort", "blend_fwd", "blend_bwd", "preprocess_bwd"]
+STAGES = ["preprocess", "bin_count_scan", "bin_scatter", "depth_sort", "blend_fwd", "blend_bwd", "preprocess_bwd", "hint_repair"]
 lib = _lib.load()
 dev = torch.device("cuda:0")
 scene, cams, bg = syn.make_config("metric")

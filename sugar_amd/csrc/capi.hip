@@ -309,6 +309,9 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
             sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
                                  tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, (uint32_t)R_, opts->tile_need,
                                  opts->tile_order, s, hint_repair ? repair_flag : nullptr, repair_list);
+        }   // (that stage timer -- bench.py's roofline.launch_ms -- brackets k_blend_fwd_w alone; the two gated launches are a stage of their own)
+        {
+            StageTimer t(s, SGR_STAGE_HINT_REPAIR);
             if (opts->tile_need && two_level && R_ > 0 && hint_repair) {
                 // Walk-hint repair: tiles that outran their hint are on the device's repair list now.  The list-write pass once more
                 // with the repair flags as ITS hint (0: nothing needed; 0xFFFFFFFF: the whole list) and the blend once more over the

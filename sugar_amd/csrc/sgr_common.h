@@ -113,7 +113,7 @@ static inline BinLayout sgr_bin_layout(int64_t R, int T)
 
 // stage ids of the optional event profile (sgr_profile_read)
 enum { SGR_STAGE_PREPROCESS = 0, SGR_STAGE_SCAN /* bin_count + scans */, SGR_STAGE_SCATTER, SGR_STAGE_SORT /* depth sort */, SGR_STAGE_BLEND_FWD,
-       SGR_STAGE_BLEND_BWD, SGR_STAGE_PREPROCESS_BWD, SGR_STAGE_COUNT };
+       SGR_STAGE_BLEND_BWD, SGR_STAGE_PREPROCESS_BWD, SGR_STAGE_HINT_REPAIR /* the two gated launches behind the blend */, SGR_STAGE_COUNT };
 
 // ---- kernel launchers (defined in the .hip translation units) --------------------------------
 struct PreprocessArgs {
