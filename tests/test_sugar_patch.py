@@ -258,3 +258,14 @@ def test_random_prefix_of_permutation_is_a_sample_without_replacement():
     assert chi2_first < 400 + 5 * (2 * 400) ** 0.5, chi2_first
     s = rp(100, 60, "cpu")
     assert len(set(s.tolist())) == 60
+
+
+def test_the_standalone_sampler_has_no_cpu_path():
+    """sugar_amd.sampler is device code behind a thin wrapper: CPU tensors are refused loudly, nothing falls back"""
+    import pytest
+    from sugar_amd import sampler, synthetic as syn
+    cam = syn.orbit_cameras(64, 48, 2)[0]
+    m = torch.zeros(10, 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sampler.sample_level_sets(m, torch.ones(10, 3), torch.tensor([[1.0, 0, 0, 0]]).repeat(10, 1), torch.ones(10, 1), cam)
+
