@@ -596,30 +596,26 @@ __global__ void __launch_bounds__(256) k_view_std(int P, const float* __restrict
 // World points of picked pixels (:1934-1959).  The reference lays an NDC grid over the image (x = W/m - 2 col / (m - 1), +x to the
 // LEFT, +y UP, m = min(W, H)) and un-projects through a camera whose focal length in NDC units is 2 fx / m; the rasterizer's camera
 // frame (+x right, +y down) is that frame with x and y negated.  `viewmatrix` is the rasterizer's (row vectors: p_view = [p 1] V);
-// its inverse is taken here, by cofactors, by every workgroup (a 4 x 4 torch.linalg.inv is a factorisation plus a host check).
+// its inverse is taken here, in closed form, by every thread (a 4 x 4 torch.linalg.inv is a factorisation plus a host check).
 __global__ void __launch_bounds__(256) k_unproject_pixels(int n, const int64_t* __restrict__ picked, const float* __restrict__ depth,
                                                           int W, int H, float f_ndc_x, float f_ndc_y,
                                                           const float* __restrict__ viewmatrix, float* __restrict__ world)
 {
-    __shared__ float s_inv[16];
-    if (threadIdx.x < 16) {
-        float m[16];
-        for (int i = 0; i < 16; i++) m[i] = viewmatrix[i];
-        // cofactor C(r, c) of the 4 x 4; inverse(r, c) = C(c, r) / det
-        auto minor3 = [&](int r, int c) {
-            int rr[3], cc[3], a = 0, b = 0;
-            for (int i = 0; i < 4; i++) { if (i != r) rr[a++] = i; if (i != c) cc[b++] = i; }
-            const float a00 = m[rr[0] * 4 + cc[0]], a01 = m[rr[0] * 4 + cc[1]], a02 = m[rr[0] * 4 + cc[2]];
-            const float a10 = m[rr[1] * 4 + cc[0]], a11 = m[rr[1] * 4 + cc[1]], a12 = m[rr[1] * 4 + cc[2]];
-            const float a20 = m[rr[2] * 4 + cc[0]], a21 = m[rr[2] * 4 + cc[1]], a22 = m[rr[2] * 4 + cc[2]];
-            return a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
-        };
-        float det = 0.f;
-        for (int c = 0; c < 4; c++) det += ((c & 1) ? -1.f : 1.f) * m[c] * minor3(0, c);
-        const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
-        s_inv[threadIdx.x] = (((r + c) & 1) ? -1.f : 1.f) * minor3(c, r) / det;
-    }
-    __syncthreads();
+    // the inverse's first three columns (all the back-projection reads), by 2 x 2 sub-determinants; every thread the same few dozen
+    // operations on the same 16 scalars
+    const float m00 = viewmatrix[0], m01 = viewmatrix[1], m02 = viewmatrix[2], m03 = viewmatrix[3];
+    const float m10 = viewmatrix[4], m11 = viewmatrix[5], m12 = viewmatrix[6], m13 = viewmatrix[7];
+    const float m20 = viewmatrix[8], m21 = viewmatrix[9], m22 = viewmatrix[10], m23 = viewmatrix[11];
+    const float m30 = viewmatrix[12], m31 = viewmatrix[13], m32 = viewmatrix[14], m33 = viewmatrix[15];
+    const float s0 = m00 * m11 - m10 * m01, s1 = m00 * m12 - m10 * m02, s2 = m00 * m13 - m10 * m03;
+    const float s3 = m01 * m12 - m11 * m02, s4 = m01 * m13 - m11 * m03, s5 = m02 * m13 - m12 * m03;
+    const float c5 = m22 * m33 - m32 * m23, c4 = m21 * m33 - m31 * m23, c3 = m21 * m32 - m31 * m22;
+    const float c2 = m20 * m33 - m30 * m23, c1 = m20 * m32 - m30 * m22, c0 = m20 * m31 - m30 * m21;
+    const float idet = 1.0f / (s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0);
+    const float i00 = (m11 * c5 - m12 * c4 + m13 * c3) * idet, i01 = (-m01 * c5 + m02 * c4 - m03 * c3) * idet, i02 = (m31 * s5 - m32 * s4 + m33 * s3) * idet;
+    const float i10 = (-m10 * c5 + m12 * c2 - m13 * c1) * idet, i11 = (m00 * c5 - m02 * c2 + m03 * c1) * idet, i12 = (-m30 * s5 + m32 * s2 - m33 * s1) * idet;
+    const float i20 = (m10 * c4 - m11 * c2 + m13 * c0) * idet, i21 = (-m00 * c4 + m01 * c2 - m03 * c0) * idet, i22 = (m30 * s4 - m31 * s2 + m33 * s0) * idet;
+    const float i30 = (-m10 * c3 + m11 * c1 - m12 * c0) * idet, i31 = (m00 * c3 - m01 * c1 + m02 * c0) * idet, i32 = (-m30 * s3 + m31 * s1 - m32 * s0) * idet;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
     const int64_t pix = picked[t];
@@ -629,8 +625,9 @@ __global__ void __launch_bounds__(256) k_unproject_pixels(int n, const int64_t* 
     const float ndc_y = (float)H / (float)mm - ((float)row / (float)(mm - 1)) * 2.0f;
     const float z = depth[pix];
     const float xc = -ndc_x * z / f_ndc_x, yc = -ndc_y * z / f_ndc_y;
-#pragma unroll
-    for (int a = 0; a < 3; a++) world[3 * (size_t)t + a] = xc * s_inv[a] + yc * s_inv[4 + a] + z * s_inv[8 + a] + s_inv[12 + a];
+    world[3 * (size_t)t] = xc * i00 + yc * i10 + z * i20 + i30;
+    world[3 * (size_t)t + 1] = xc * i01 + yc * i11 + z * i21 + i31;
+    world[3 * (size_t)t + 2] = xc * i02 + yc * i12 + z * i22 + i32;
 }
 
 __global__ void __launch_bounds__(256) k_scaled_rotation_fwd(int P, const float* __restrict__ quats, const float* __restrict__ scaling,
