@@ -37,7 +37,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-STAGES = ["preprocess", "bin_count_scan", "bin_scatter", "depth_sort", "blend_fwd", "blend_bwd", "preprocess_bwd", "hint_repair"]
+STAGES = ["preprocess", "bin_count_scan", "bin_scatter", "depth_sort", "blend_fwd", "blend_bwd", "preprocess_bwd", "hint_repair",
+          "fwd_post", "loss_fwd", "loss_bwd", "fill", "sh_adam", "adam", "masked_colors"]  # (include/sugar_raster.h: stage ids)
+RASTER_STAGES = STAGES[:8]  # the rasterizer's own stages: `ms_fwd_bwd` is their sum, as on every earlier round's line
 
 
 def main():
@@ -68,7 +70,16 @@ def main():
     ap.add_argument("--reference-loop-steps", type=int, default=24)
     ap.add_argument("--plain-3dgs-step", action="store_true", help="config3 / config4: time the vanilla 3DGS step on the config's scene (what rounds 1-4 printed) instead of the step the config defines")
     ap.add_argument("--no-eight-thread-baseline", action="store_true", help="skip the extra 8-thread run of the CPU baseline (BASELINE.md section 2's planned core count)")
+    ap.add_argument("--spawn-check", action="store_true", help="only bring the process group up, all-reduce one word and print {n_gpus: world size as seen after init} (tests/test_bench_spawn.py; needs no GPU with SGR_BENCH_BACKEND=gloo)")
     args = ap.parse_args()
+
+    # `--gpus N` without a launcher's environment: this process becomes the launcher (one rank per GPU under torch.distributed.run,
+    # exactly the command line of the docstring), so a bare `python bench.py --gpus 8` can never run one rank and call it eight
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks; refusing to "
+                         "report one as the other")
 
     wd = args.watchdog_sec or (900 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 0)
     if wd > 0:
@@ -83,6 +94,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.spawn_check:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group(os.environ.get("SGR_BENCH_BACKEND", "nccl"))
+        one = torch.ones(1, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(one)
+        if dist.get_rank() == 0:
+            os.write(json_fd, (json.dumps({"spawn_check": True, "n_gpus": dist.get_world_size(), "ranks_summed": int(one.item()),
+                                           "backend": dist.get_backend()}) + "\n").encode())
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP rasterizer has no CPU path")
     # one rank per GPU; SGR_BENCH_BACKEND=gloo with fewer GPUs than ranks is a functional rehearsal only (ranks share a GPU)
@@ -102,8 +125,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if use_group and dist.get_world_size() != args.gpus and not (args.force_collectives and args.gpus == 1):
+        raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+    world = dist.get_world_size() if use_group else 1  # (as seen after init: what `n_gpus` on the line reports)
 
     from sugar_amd import build, _lib, synthetic as syn
     if rank == 0:
@@ -481,12 +505,17 @@ def main():
                                 else f"view-sharded dp{world}, single process, no collective"),
                 "instances_per_view": R, "instances_walked_fwd": R_f, "instances_walked_bwd": R_b,
             },
-            "ms_fwd_bwd": sum(stages.values()),
+            "ms_fwd_bwd": sum(stages[n] for n in RASTER_STAGES),
             # wall time of the host loop; the native trainer spends most of it WAITING for the previous step's header (it runs one
             # step ahead of the GPU by design): host_work_ms_per_step is what it actually computes and enqueues
             "host_enqueue_ms_per_step": 1e3 * (t_enq - t0) / K,
             "host_work_ms_per_step": (1e3 * (hw1 - hw0) / K) if isinstance(trainer, NativeTrainer) else None,
             "stages_ms": stages,
+            # every launch of the native step sits inside one stage: their sum against the step time of the timed region
+            # (the stage times come from the untimed pass with an event pair around every stage; the pairs themselves cost
+            # pipeline time, the step in the timed region carries one pair only)
+            "stages_sum_ms": sum(stages.values()),
+            "stages_cover_frac": sum(stages.values()) / (1e3 * elapsed / K) if native and world == 1 else None,
             "roofline": {
                 "kernel": "k_blend_fwd_w", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -507,6 +536,11 @@ def main():
             out["coarse_sdf_step"] = trainer.report(args.steps)
         if refine_cfg:
             out["refine_step"] = trainer.report()
+        if out["stages_cover_frac"] is not None:
+            out["stages_cover_ok"] = abs(out["stages_cover_frac"] - 1.0) <= 0.05
+            if not out["stages_cover_ok"]:
+                print(f"[bench] the stages sum to {out['stages_cover_frac']:.3f} of the step: something in the step is not inside a stage "
+                      "(or the GPU idles between launches)", file=sys.stderr)
         out.update(extras)
         if forward_only:
             # (a sync-free forward that outgrew its capacity returns at once and would be timed as an abnormally fast step)
@@ -520,6 +554,12 @@ def main():
                 out["list_write_pass"] = list_write
         if comm is not None:
             out.update(comm)
+            n_small = int(getattr(params, "n_small", 11 * P))
+            out["comm_bytes_per_rank"] = {
+                "all_gather_send": 12 * (P + 1), "all_gather_recv": 12 * (P + 1) * world, "all_reduce_buffer": 4 * n_small,
+                "all_reduce_ring_wire": int(2 * 4 * n_small * (world - 1) / max(world, 1)),
+                "what": "per step: masked colour gradients + camera centre row of every view (all-gather), the 11 non-SH floats per "
+                        "Gaussian (all-reduce; ring wire bytes = 2 (N-1)/N x buffer)"}
             out["config"]["collectives"] = ("forced on a one-rank RCCL group" if world == 1 else "RCCL") + \
                 (", enqueued by the library (sgr_trainer_step_exchange)" if getattr(trainer, "native_collectives", False) else ", torch.distributed between four phase calls")
         if world == 1 and not args.no_cpu_baseline:
@@ -531,6 +571,30 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
 
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher environment: re-run this command line under torch.distributed.run with N ranks
+    on this node (rendezvous on 127.0.0.1, a free port) and hand its output and exit code through.  With the RCCL backend N may not
+    exceed the GPUs present: ranks sharing a GPU would be reported as a scaling point (SGR_BENCH_BACKEND=gloo allows it as a
+    functional rehearsal and says so on the line)."""
+    import socket
+    import subprocess
+    backend = os.environ.get("SGR_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n > n_dev:
+            print(f"bench.py: --gpus {n} but {n_dev} GPU(s) on this node; RCCL needs one GPU per rank", file=sys.stderr)
+            return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print("[bench] no launcher environment: " + " ".join(cmd), file=sys.stderr)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def make_target_renderer(scene, bg, dev, rasterizer_cls, settings_cls, seed=1234):

@@ -98,6 +98,8 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user,
 #define SGR_HDR_HINT_MISS 3  /* != 0: a tile needed more entries than its walk hint allowed */
 #define SGR_HDR_CHUNKS 5      /* 512-entry chunks of the super-tile lists (two-level binning) */
 #define SGR_HDR_L1_OVERFLOW 6 /* != 0: the level-1 (super-tile) list overflowed its capacity */
+#define SGR_HDR_LAYOUT_CAP 8  /* the instance capacity the binning buffer of this forward was laid out for (written by the forward
+                                 blend kernel, read by the backward blend kernel: the binning buffer may be cloned or moved between them) */
 #define SGR_HDR_REPAIR 7      /* tiles that outran their walk hint and were rendered again inside the same forward (round 5): a hint
                                  that is too short costs those tiles a second pass, not the forward; SGR_HDR_HINT_MISS is only raised
                                  when more than 1024 tiles did */
@@ -286,9 +288,12 @@ size_t sgr_binning_point_list_offset(int64_t R);        /* uint32[R]: Gaussian i
 /* ---- optional per-stage timing (HIP events recorded on the caller's stream, process-wide) --
  * Stages: 0 preprocess, 1 ordered tile count + scans, 2 ordered scatter into the tile lists, 3 global depth sort of
  * the Gaussians, 4 blend forward (k_blend_fwd_w alone), 5 blend backward, 6 preprocess backward, 7 the two launches behind the blend that
- * repair a walk hint (empty when every hint held).  sgr_profile_read synchronises the recorded events, returns the summed
- * milliseconds and launch counts per stage since the last read, and clears the record. */
-#define SGR_N_STAGES 8
+ * repair a walk hint (empty when every hint held); and the rest of sgr_trainer_step, so that the stages cover every launch of the
+ * native train step: 8 post-blend bookkeeping when it is a launch of its own (it rides in the loss kernel otherwise), 9 loss
+ * forward, 10 loss backward, 11 reset of the backward's accumulator table, 12 SH-Adam from the colour gradients, 13 flat Adam,
+ * 14 the masked-colour kernel of the two-phase (exchange) backward.  sgr_profile_read synchronises the recorded events, returns
+ * the summed milliseconds and launch counts per stage since the last read, and clears the record. */
+#define SGR_N_STAGES 15
 void sgr_profile_enable(int stage_mask); /* bit s set: record events around stage s (0 disables; each event pair costs
                                             several microseconds of GPU pipeline, so time only what is being measured) */
 int sgr_profile_read(double* ms_sum, int64_t* count, int n_stages);

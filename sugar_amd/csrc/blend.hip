@@ -174,6 +174,7 @@ __device__ __forceinline__ void blend_fwd_body(int W, int H, int gx, int T_tiles
 {
     // sync-free forward: the list did not fit the caller's capacity (or the level-1 binning overflowed) -> leave everything
     // untouched; the caller repeats the forward and every later kernel of the step reads the same header
+    if (!REPAIR && blockIdx.x == 0 && threadIdx.x == 0) header[SGR_HDR_LAYOUT_CAP] = list_cap;  // the layout of THIS forward's binning buffer, for its backward
     if (header[SGR_HDR_R] > list_cap || header[4 + SGR_B2_HDR_OVERFLOW]) return;
     // entry k: {x, y, -0.5*conic.x*log2e, -conic.y*log2e | -0.5*conic.z*log2e, opacity, r, g | b, bitcast(1-based list position), -, -}
     // (one spare entry: the walk's look-ahead reads one entry past the last)
@@ -452,7 +453,7 @@ __device__ __forceinline__ void bwd_phase_a(uint32_t e_addr, uint32_t w_addr, in
 
 __global__ void __launch_bounds__(64)
 k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ point_list,
-              const unsigned long long* __restrict__ blk_mask, const uint32_t* __restrict__ blk_nb, const GeomRec* __restrict__ rec,
+              const char* __restrict__ binning, const uint32_t* __restrict__ blk_nb, const GeomRec* __restrict__ rec,
               const float* __restrict__ bg, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
               const float* __restrict__ dL_dpix, float* __restrict__ acc, const uint32_t* __restrict__ tile_order,
               const uint32_t* __restrict__ header, uint32_t list_cap)
@@ -476,6 +477,8 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
     const float pixfx = (float)px, pixfy = (float)py;
     const uint32_t r0 = tile_start[tile];
     const int total = (int)(tile_start[tile + 1] - r0);
+    // (the survivor masks sit behind the point list as the FORWARD laid it out: its capacity is in the header, not the caller's R)
+    const unsigned long long* blk_mask = reinterpret_cast<const unsigned long long*>(binning + SGR_BIN_MASK_OFFSET(header[SGR_HDR_LAYOUT_CAP]));
     const unsigned long long* my_mask = blk_mask + 4 * ((size_t)(r0 >> 6) + (size_t)tile) + sub;
     const size_t pix_id = (size_t)W * py + px;
     const size_t HW = (size_t)H * W;
@@ -704,7 +707,7 @@ void sgr_launch_blend_fwd_post(int gx, int gy, const uint32_t* tile_maxc, const 
 }
 
 void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
-                          const unsigned long long* blk_mask, const uint32_t* blk_nb, const GeomRec* rec, const float* bg,
+                          const char* binning, const uint32_t* blk_nb, const GeomRec* rec, const float* bg,
                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* acc,
                           const uint32_t* tile_maxc, const uint32_t* header, uint32_t list_cap, uint32_t* tile_order, int order_ready,
                           hipStream_t s)
@@ -716,6 +719,6 @@ void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
         SgrTileOrderJob job = {T, list_cap, tile_maxc, nullptr, header, tile_order, nullptr, nullptr, nullptr, 0.f, gx, gy};
         hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, job);
     }
-    hipLaunchKernelGGL(k_blend_bwd_w, dim3(sgr_blend_grid(T)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, blk_mask, blk_nb, rec,
+    hipLaunchKernelGGL(k_blend_bwd_w, dim3(sgr_blend_grid(T)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, binning, blk_nb, rec,
                        bg, final_T, n_contrib, dL_dpix, acc, tile_order, header, list_cap);
 }

@@ -8,7 +8,6 @@
 
 #include <cstdlib>
 #include <mutex>
-#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -45,22 +44,11 @@ struct Pinned {
 thread_local Pinned g_pinned;
 
 // Speculative forward (SGR_FLAG_SPECULATIVE): the instance list is laid out for the caller's guess of the capacity, while the call
-// returns the true instance count.  The backward is handed that count (rasterizer.h:57-84: "R = the value forward returned") and
-// must find the forward's layout: the library remembers, per binning buffer, the capacity it was laid out for.  Every forward sets or
-// clears the entry of the buffer it was given, so a recycled address can never carry a stale layout.
-std::mutex g_layout_mu;
-std::unordered_map<const void*, int64_t> g_layout_R;
-void layout_set(const void* binning, int64_t cap)
-{
-    std::lock_guard<std::mutex> lk(g_layout_mu);
-    if (cap > 0) g_layout_R[binning] = cap; else g_layout_R.erase(binning);
-}
-int64_t layout_get(const void* binning, int64_t R)
-{
-    std::lock_guard<std::mutex> lk(g_layout_mu);
-    auto it = g_layout_R.find(binning);
-    return it == g_layout_R.end() ? R : it->second;
-}
+// returns the true instance count, and the backward is handed that count (rasterizer.h:57-84: "R = the value forward returned").
+// The layout is SELF-DESCRIBING: the forward blend kernel leaves the capacity its list was laid out for in the image scratch's
+// device header (word SGR_HDR_LAYOUT_CAP) and the backward blend kernel finds the survivor masks from there -- the point list
+// itself starts at offset 0 of the binning buffer for every capacity.  (Until round 5 a process-global map keyed by the binning
+// buffer's ADDRESS remembered the capacity: a caller that cloned or moved the opaque buffer got silently wrong gradients.)
 struct ScanEvent {
     hipEvent_t e = nullptr;
     ~ScanEvent() { /* leaked on purpose, like the pinned slot */ }
@@ -84,32 +72,29 @@ struct Prof {
 Prof g_prof;            // process-wide: autograd runs the backward on its own thread
 std::mutex g_prof_mu;
 
-struct StageTimer {
-    hipStream_t s; int stage; hipEvent_t a = nullptr, b = nullptr; bool live = false;
-    StageTimer(hipStream_t s_, int stage_) : s(s_), stage(stage_)
-    {
-        if (g_prof.mask & (1u << stage_)) {
-            std::lock_guard<std::mutex> lk(g_prof_mu);
-            if (g_prof.recs.size() < 65536) {
-                a = g_prof.get(); b = g_prof.get();
-                live = a && b;
-            }
-            if (live) (void)hipEventRecord(a, s);
-        }
-    }
-    void stop()
-    {
-        if (live) {
-            (void)hipEventRecord(b, s);
-            std::lock_guard<std::mutex> lk(g_prof_mu);
-            g_prof.recs.push_back({stage, a, b});
-            live = false;
-        }
-    }
-    ~StageTimer() { stop(); }
-};
-
 }  // namespace
+
+// the per-stage event timer of sgr_common.h (used by capi.hip and train.hip)
+SgrStageTimer::SgrStageTimer(hipStream_t s_, int stage_) : s(s_), stage(stage_)
+{
+    if (g_prof.mask & (1u << stage_)) {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (g_prof.recs.size() < 65536) {
+            a = g_prof.get(); b = g_prof.get();
+            live = a && b;
+        }
+        if (live) (void)hipEventRecord(a, s);
+    }
+}
+void SgrStageTimer::stop()
+{
+    if (live) {
+        (void)hipEventRecord(b, s);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.recs.push_back({stage, a, b});
+        live = false;
+    }
+}
 
 // error reporting for the other translation units (mesh_raster.hip): same thread-local message as sgr_last_error()
 int sgr_fail(int code, const char* msg) { return fail(code, msg ? msg : ""); }
@@ -240,11 +225,11 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     pa.key_minmax = reinterpret_cast<uint2*>(sort_scratch + sgr_sort_minmax_offset(P));
     pa.sort_counters = reinterpret_cast<uint32_t*>(sort_scratch + sgr_sort_counters_offset(P)); pa.n_sort_counters = sgr_sort_counter_words();
     if (opts->tile_need && hint_repair) { pa.zero_words = repair_flag; pa.n_zero_words = IL.T; }  // (the walk hint's repair flags start from zero)
-    { StageTimer t(s, SGR_STAGE_PREPROCESS); sgr_launch_preprocess_fwd(pa, s); }
+    { SgrStageTimer t(s, SGR_STAGE_PREPROCESS); sgr_launch_preprocess_fwd(pa, s); }
     STAGE_CHECK("preprocess");
 
     const uint32_t* order = nullptr;
-    { StageTimer t(s, SGR_STAGE_SORT); sgr_launch_gaussian_sort(P, sort_scratch, &order, pa.rect_by_id, rects, s); }
+    { SgrStageTimer t(s, SGR_STAGE_SORT); sgr_launch_gaussian_sort(P, sort_scratch, &order, pa.rect_by_id, rects, s); }
     STAGE_CHECK("gaussian_sort");
 
     // speculative: sync-free launches with the caller's capacity, then ONE wait for the tile scan's header at the END of the call,
@@ -260,7 +245,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     char* bin2 = img + IL.total;
     bool two_level = binning_mode == 0;
     {
-        StageTimer t(s, SGR_STAGE_SCAN);
+        SgrStageTimer t(s, SGR_STAGE_SCAN);
         if (two_level) {
             sgr_launch_bin2_count(P, IL.gx, IL.gy, B2, bin2, header + 4, rects, order, tile_cursor,
                                   binning_capacity > 0 ? opts->chunk_grid : 0u, s);
@@ -296,7 +281,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
         uint32_t* point_list = reinterpret_cast<uint32_t*>(binning + BL.point_list);
         unsigned long long* blk_mask = reinterpret_cast<unsigned long long*>(binning + BL.blk_mask);
         if (R_ > 0) {
-            StageTimer t(s, SGR_STAGE_SCATTER);
+            SgrStageTimer t(s, SGR_STAGE_SCATTER);
             if (two_level)
                 sgr_launch_bin2_write(IL.gx, IL.gy, B2, bin2, header + 4, n_chunks_, rects, order, tile_start, point_list,
                                       nosync_ ? (uint32_t)R_ : 0xFFFFFFFFu, opts->tile_need, s);
@@ -305,13 +290,13 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
         }
         STAGE_CHECK("bin_scatter");
         {
-            StageTimer t(s, SGR_STAGE_BLEND_FWD);
+            SgrStageTimer t(s, SGR_STAGE_BLEND_FWD);
             sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
                                  tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, (uint32_t)R_, opts->tile_need,
                                  opts->tile_order, s, hint_repair ? repair_flag : nullptr, repair_list);
         }   // (that stage timer -- bench.py's roofline.launch_ms -- brackets k_blend_fwd_w alone; the two gated launches are a stage of their own)
         {
-            StageTimer t(s, SGR_STAGE_HINT_REPAIR);
+            SgrStageTimer t(s, SGR_STAGE_HINT_REPAIR);
             if (opts->tile_need && two_level && R_ > 0 && hint_repair) {
                 // Walk-hint repair: tiles that outran their hint are on the device's repair list now.  The list-write pass once more
                 // with the repair flags as ITS hint (0: nothing needed; 0xFFFFFFFF: the whole list) and the blend once more over the
@@ -327,8 +312,11 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
             STAGE_CHECK("blend_fwd");
             return 0;
         }
-        sgr_launch_blend_fwd_post(IL.gx, IL.gy, tile_maxc, tile_walked, header, (uint32_t)R_, opts->tile_need_out, opts->hint_margin, hh_dev,
-                                  tile_cursor, opts->tile_order_out, s);
+        {
+            SgrStageTimer t(s, SGR_STAGE_FWD_POST);
+            sgr_launch_blend_fwd_post(IL.gx, IL.gy, tile_maxc, tile_walked, header, (uint32_t)R_, opts->tile_need_out, opts->hint_margin, hh_dev,
+                                      tile_cursor, opts->tile_order_out, s);
+        }
         STAGE_CHECK("blend_fwd");
         // ... and once more behind the blend: word 3 (hint miss) is final only now
         if (opts->header_host && !hh_dev) HIP_TRY(hipMemcpyAsync(opts->header_host + 8, header, 32, hipMemcpyDeviceToHost, s));
@@ -376,16 +364,12 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
         const int rc = tail(R, nosync, n_chunks);
         if (rc < 0) return rc;
     }
-    if (!speculative) {
-        layout_set(binning, 0);
-        return R;
-    }
+    if (!speculative) return R;
     // ---- speculative: the tile scan's header has long arrived (list-write pass and blend are queued behind it)
     HIP_TRY(hipEventSynchronize(g_scan_ev.e));
     const bool overflow = g_pinned.p[4 + SGR_B2_HDR_OVERFLOW] != 0u;
     const int64_t R_true = (int64_t)g_pinned.p[SGR_HDR_R];
     if (!overflow && R_true <= binning_capacity) {
-        layout_set(binning, binning_capacity);
         if (opts->info) opts->info->speculation = 1;
         return R_true;
     }
@@ -398,7 +382,6 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
         rc = tail(R, false, n_chunks);
         if (rc < 0) return rc;
     }
-    layout_set(binning, 0);
     return R;
 }
 
@@ -465,23 +448,22 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
     if (phase != 0 && !compact) return fail(SGR_E_INVALID, "the two-phase backward is for the compact SH mode");
 
     const ImgLayout IL = sgr_img_layout(width, height);
-    const BinLayout BL = sgr_bin_layout(layout_get(binning_buffer, R), IL.T);  // (a speculative forward laid the list out for its capacity)
+    const BinLayout BL = sgr_bin_layout(R, IL.T);  // (only point_list, at offset 0 for every R; the masks' offset is read on the device)
     const GeomRec* rec = reinterpret_cast<const GeomRec*>(geom_buffer);
     const float* final_T = reinterpret_cast<const float*>(img_buffer + IL.final_T);
     const uint32_t* n_contrib = reinterpret_cast<const uint32_t*>(img_buffer + IL.n_contrib);
     const uint32_t* tile_start = reinterpret_cast<const uint32_t*>(img_buffer + IL.tile_start);
     const uint32_t* blk_nb = reinterpret_cast<const uint32_t*>(img_buffer + IL.blk_nb);
     const uint32_t* point_list = reinterpret_cast<const uint32_t*>(binning_buffer + BL.point_list);
-    const unsigned long long* blk_mask = reinterpret_cast<const unsigned long long*>(binning_buffer + BL.blk_mask);
 
     // the blend backward accumulates nine sums per Gaussian with atomics into the private acc[P][12] table
     float* acc = reinterpret_cast<float*>(geom_buffer + sgr_geom_acc_offset(P));
     if (phase != 2) {
-        HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * SGR_ACC_STRIDE * 4, s));
+        { SgrStageTimer t(s, SGR_STAGE_FILL); HIP_TRY(hipMemsetAsync(acc, 0, (size_t)P * SGR_ACC_STRIDE * 4, s)); }
         if (R > 0) {
-            StageTimer t(s, SGR_STAGE_BLEND_BWD);
+            SgrStageTimer t(s, SGR_STAGE_BLEND_BWD);
             // (the forward's per-tile counters are dead by now: their array holds the backward's launch order)
-            sgr_launch_blend_bwd(width, height, IL.gx, IL.gy, tile_start, point_list, blk_mask, blk_nb, rec, background, final_T,
+            sgr_launch_blend_bwd(width, height, IL.gx, IL.gy, tile_start, point_list, binning_buffer, blk_nb, rec, background, final_T,
                                  n_contrib, dL_dpix, acc, reinterpret_cast<const uint32_t*>(img_buffer + IL.tile_maxc),
                                  reinterpret_cast<const uint32_t*>(img_buffer + IL.header), (uint32_t)(R > 0xFFFFFFFFll ? 0xFFFFFFFFll : R),
                                  reinterpret_cast<uint32_t*>(img_buffer + IL.tile_cursor),
@@ -489,7 +471,7 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
         }
         STAGE_CHECK("blend_bwd");
         if (phase == 1) {
-            sgr_launch_masked_colors(P, rec, acc, dL_dcolor, cam_pos, opts ? opts->campos_row : nullptr, s);
+            { SgrStageTimer t(s, SGR_STAGE_MASKED_COLORS); sgr_launch_masked_colors(P, rec, acc, dL_dcolor, cam_pos, opts ? opts->campos_row : nullptr, s); }
             STAGE_CHECK("masked_colors");
             return 0;
         }
@@ -517,7 +499,7 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
     pb.dL_dcolor = phase == 2 ? nullptr : dL_dcolor;  // phase 2: already written (and possibly being sent) by phase 1
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_dsh = use_sh ? dL_dsh : nullptr;
     pb.dL_dscale = cov3D_precomp ? nullptr : dL_dscale; pb.dL_drot = cov3D_precomp ? nullptr : dL_drot;
-    { StageTimer t(s, SGR_STAGE_PREPROCESS_BWD); sgr_launch_preprocess_bwd(pb, s); }
+    { SgrStageTimer t(s, SGR_STAGE_PREPROCESS_BWD); sgr_launch_preprocess_bwd(pb, s); }
     STAGE_CHECK("preprocess_bwd");
     return 0;
 }

@@ -901,10 +901,17 @@ __global__ void __launch_bounds__(256) k_grid_coarse(int G, const unsigned int* 
     if (cell_start[base + xb] > cell_start[base + xa]) atomicOr(&coarse[(z >> 2) * 32 + (y >> 2)], 1u << xc);
 }
 
-#define GRID_PROBE_REUSE 63   // sets of the same size that reuse a probed resolution before the next probe
+#define GRID_PROBE_REUSE 63   // sets of the same size that reuse a resolution before the occupancy is looked at again
+// The occupancy probe is ASYNCHRONOUS (round 6; it used to synchronise the caller's stream on every 64th call): a call copies the
+// occupied-cell count of the grid it built into pinned memory behind its kernels and records an event; a LATER call for a set of the
+// same size reads the value once the event has completed (hipEventQuery, never a wait) and picks its resolution from it.  The
+// resolution is a matter of speed only -- any G gives the same neighbours -- so a set's first query simply runs on the default grid.
 struct ProbeSlot {
     unsigned int* p = nullptr;
+    hipEvent_t ev = nullptr;
     int last_M = 0, last_G = 0, reused = 0;
+    bool pending = false;
+    int pending_M = 0, pending_G = 0;
     ~ProbeSlot() { /* leaked on purpose: the HIP runtime may be gone at thread exit */ }
 };
 thread_local ProbeSlot g_probe;
@@ -929,31 +936,40 @@ int build_grid(int M, const float* ref, const GridScratch& gs, hipStream_t s)
     // again (the level-set sampler: all Gaussians, once per view): the choice made for a set of M points is reused for the next
     // GRID_PROBE_REUSE sets of that size -- no second counting pass (0.13 ms at 1M) and no host round trip -- and probed again then.
     const bool probe = M >= GRID_PROBE_MIN_POINTS && Gmax > G;
-    if (probe && g_probe.last_M == M && g_probe.last_G > 0 && g_probe.reused < GRID_PROBE_REUSE) {
-        g_probe.reused++;
-        G = g_probe.last_G;
+    if (probe) {
+        ProbeSlot& pr = g_probe;
+        if (pr.pending && hipEventQuery(pr.ev) == hipSuccess) {
+            pr.pending = false;
+            if (pr.pending_M == M) {
+                // how full was that grid?  ~6 points per occupied cell: the set fills its box, keep it.  Many more: the set is a
+                // surface (or a few clusters): refine until an occupied cell holds ~6 again -- occupied cells of a surface grow with G^2
+                const double per_cell = (double)M / (double)(pr.p[0] ? pr.p[0] : 1u);
+                int Gn = pr.pending_G;
+                if (per_cell > 24.0 || (per_cell < 2.0 && Gn > G)) {
+                    Gn = (int)ceil((double)pr.pending_G * sqrt(per_cell / 6.0));
+                    if (Gn > Gmax) Gn = Gmax;
+                    if (Gn < G) Gn = G;
+                }
+                pr.last_M = M; pr.last_G = Gn; pr.reused = 0;
+            }
+        } else if (pr.pending) {
+            (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+        }
+        if (pr.last_M == M && pr.last_G > 0) G = pr.last_G;
+    }
+    {
         const int rc = count_cells(M, ref, gs, G, s);
         if (rc < 0) return rc;
-    } else {
-        int rc = count_cells(M, ref, gs, G, s);
-        if (rc < 0) return rc;
-        if (probe) {
-            // how full is the coarse grid?  ~6 points per occupied cell: the set fills its box, keep it.  Many more: the set is a
-            // surface (or a few clusters): refine until an occupied cell holds ~6 again -- occupied cells of a surface grow with G^2
-            if (!g_probe.p && hipHostMalloc(reinterpret_cast<void**>(&g_probe.p), 64, hipHostMallocDefault) != hipSuccess) return SGR_E_HIP;
-            if (hipMemcpyAsync(g_probe.p, &gs.hdr->occupied, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return SGR_E_HIP;
-            if (hipStreamSynchronize(s) != hipSuccess) return SGR_E_HIP;
-            const double per_cell = (double)M / (double)(g_probe.p[0] ? g_probe.p[0] : 1u);
-            if (per_cell > 24.0) {
-                int G2 = (int)ceil((double)G * sqrt(per_cell / 6.0));
-                if (G2 > Gmax) G2 = Gmax;
-                if (G2 > G) {
-                    G = G2;
-                    rc = count_cells(M, ref, gs, G, s);
-                    if (rc < 0) return rc;
-                }
-            }
-            g_probe.last_M = M; g_probe.last_G = G; g_probe.reused = 0;
+    }
+    if (probe) {
+        ProbeSlot& pr = g_probe;
+        const bool due = !(pr.last_M == M && pr.last_G > 0) || ++pr.reused > GRID_PROBE_REUSE;
+        if (due && !pr.pending) {
+            if (!pr.p && hipHostMalloc(reinterpret_cast<void**>(&pr.p), 64, hipHostMallocDefault) != hipSuccess) return SGR_E_HIP;
+            if (!pr.ev && hipEventCreateWithFlags(&pr.ev, hipEventDisableTiming) != hipSuccess) return SGR_E_HIP;
+            if (hipMemcpyAsync(pr.p, &gs.hdr->occupied, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return SGR_E_HIP;
+            if (hipEventRecord(pr.ev, s) != hipSuccess) return SGR_E_HIP;
+            pr.pending = true; pr.pending_M = M; pr.pending_G = G;
         }
     }
     const size_t cells = (size_t)G * G * G;

@@ -98,6 +98,7 @@ void sgr_launch_bin2_write(int gx, int gy, const Bin2Layout& L, char* scratch, c
 //           8x8 block of the tile, the lanes (entries) that survive the block's exact cull -- written by the forward blend
 //           for the backward; batch b of tile t (list start r0) sits in slot (r0 >> 6) + t + b
 struct BinLayout { size_t point_list, blk_mask, total; };
+#define SGR_BIN_MASK_OFFSET(cap) ((((size_t)(cap) * 4 + 255) / 256) * 256)  /* = sgr_bin_layout(cap, .).blk_mask, usable on the device */
 static inline BinLayout sgr_bin_layout(int64_t R, int T)
 {
     BinLayout L;
@@ -113,7 +114,17 @@ static inline BinLayout sgr_bin_layout(int64_t R, int T)
 
 // stage ids of the optional event profile (sgr_profile_read)
 enum { SGR_STAGE_PREPROCESS = 0, SGR_STAGE_SCAN /* bin_count + scans */, SGR_STAGE_SCATTER, SGR_STAGE_SORT /* depth sort */, SGR_STAGE_BLEND_FWD,
-       SGR_STAGE_BLEND_BWD, SGR_STAGE_PREPROCESS_BWD, SGR_STAGE_HINT_REPAIR /* the two gated launches behind the blend */, SGR_STAGE_COUNT };
+       SGR_STAGE_BLEND_BWD, SGR_STAGE_PREPROCESS_BWD, SGR_STAGE_HINT_REPAIR /* the two gated launches behind the blend */,
+       // the rest of the native train step (train.hip): with these the stages cover every launch of sgr_trainer_step
+       SGR_STAGE_FWD_POST /* post-blend bookkeeping when it is a launch of its own */, SGR_STAGE_LOSS_FWD, SGR_STAGE_LOSS_BWD,
+       SGR_STAGE_FILL /* the backward's accumulator reset */, SGR_STAGE_SH_ADAM, SGR_STAGE_ADAM, SGR_STAGE_MASKED_COLORS, SGR_STAGE_COUNT };
+// HIP events around a stage on the caller's stream when sgr_profile_enable() selected it (capi.hip); a no-op otherwise
+struct SgrStageTimer {
+    hipStream_t s; int stage; hipEvent_t a = nullptr, b = nullptr; bool live = false;
+    SgrStageTimer(hipStream_t s_, int stage_);
+    void stop();
+    ~SgrStageTimer() { stop(); }
+};
 
 // ---- kernel launchers (defined in the .hip translation units) --------------------------------
 struct PreprocessArgs {
@@ -222,8 +233,9 @@ void sgr_launch_blend_fwd_repair(int W, int H, int gx, int gy, const uint32_t* t
 void sgr_launch_blend_fwd_post(int gx, int gy, const uint32_t* tile_maxc, const uint32_t* tile_walked, uint32_t* header, uint32_t list_cap,
                                uint32_t* tile_need_out, float hint_margin, uint32_t* header_host_dev, uint32_t* order_scratch,
                                uint32_t* order_out, hipStream_t s);
+// binning: the binning buffer's base; the survivor masks sit at sgr_bin_layout(header[SGR_HDR_LAYOUT_CAP]).blk_mask (device-side)
 void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
-                          const unsigned long long* blk_mask, const uint32_t* blk_nb, const GeomRec* rec, const float* bg,
+                          const char* binning, const uint32_t* blk_nb, const GeomRec* rec, const float* bg,
                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* acc,
                           const uint32_t* tile_maxc, const uint32_t* header, uint32_t list_cap, uint32_t* tile_order, int order_ready,
                           hipStream_t s);

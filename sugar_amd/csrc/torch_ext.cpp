@@ -142,10 +142,26 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
     const int M = sh.dim() == 3 ? (int)sh.size(1) : 0;
     auto f32 = torch::TensorOptions().dtype(torch::kFloat32).device(dev);
     const bool use_cov = cov3D_precomp.numel() != 0;
-    // every row of these is written by sgr_backward (rows of culled Gaussians are set to zero): no zero-fill
+    TORCH_CHECK(means3D.is_cuda(), "the HIP rasterizer needs tensors on a ROCm device (got CPU tensors); there is no CPU fallback");
+    // the scratch the forward returned and its radii: same device, the dtypes the forward produced, dense (the C ABI takes raw pointers)
+    if (P != 0) {
+        TORCH_CHECK(radii.device() == dev && radii.scalar_type() == torch::kInt32 && radii.is_contiguous() && radii.numel() == P,
+                    "radii must be the forward's int32[P] tensor on ", dev);
+        const torch::Tensor* bufs[3] = {&geomBuffer, &binningBuffer, &imageBuffer};
+        const char* names[3] = {"geomBuffer", "binningBuffer", "imageBuffer"};
+        for (int k = 0; k < 3; k++)
+            TORCH_CHECK(bufs[k]->device() == dev && bufs[k]->scalar_type() == torch::kByte && bufs[k]->is_contiguous() && bufs[k]->numel() > 0,
+                        names[k], " must be the forward's uint8 scratch tensor on ", dev, " (contiguous)");
+        TORCH_CHECK((size_t)geomBuffer.numel() >= sgr_geom_bytes(P), "geomBuffer is smaller than the forward's geometry scratch for ", P, " Gaussians");
+        TORCH_CHECK((size_t)imageBuffer.numel() >= sgr_img_bytes(W, H), "imageBuffer is smaller than the forward's image scratch for ", W, "x", H);
+        TORCH_CHECK(dL_dout_color.dim() == 3 && dL_dout_color.size(0) == 3, "dL_dout_color must be [3, H, W]");
+    }
+    // every row of these is written by sgr_backward (rows of culled Gaussians are set to zero): no zero-fill -- except dL_dsh when
+    // the colours were precomputed: the kernels then never touch it, and the reference hands back zeros (rasterize_points.cu:151-159)
+    const bool sh_written = M != 0 && colors.numel() == 0;
     torch::Tensor dL_dmeans3D = torch::empty({P, 3}, f32), dL_dmeans2D = torch::empty({P, 3}, f32), dL_dcolors = torch::empty({P, 3}, f32),
                   dL_dconic = torch::empty({P, 2, 2}, f32), dL_dopacity = torch::empty({P, 1}, f32), dL_dcov3D = torch::empty({P, 6}, f32),
-                  dL_dsh = torch::empty({P, M, 3}, f32);
+                  dL_dsh = sh_written ? torch::empty({P, M, 3}, f32) : torch::zeros({P, M, 3}, f32);
     torch::Tensor dL_dscales = use_cov ? torch::zeros({P, 3}, f32) : torch::empty({P, 3}, f32);
     torch::Tensor dL_drotations = use_cov ? torch::zeros({P, 4}, f32) : torch::empty({P, 4}, f32);
     if (P != 0) {

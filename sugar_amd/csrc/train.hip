@@ -204,10 +204,10 @@ int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* v, int phases, const 
         int rc = t->defer_post ? sgr_forward_post_job(W, H, c.img, R, &fo, &job) : 0;
         if (rc < 0) return tfail(rc, "sgr_forward_post_job failed");
         // (the loss value comes out of a spare workgroup of the backward kernel)
-        rc = sgr_l1_ssim_forward_job(3, W, H, c.image, v->gt_image, c.lambda_dssim, c.loss_scratch, nullptr, t->defer_post ? &job : nullptr, stream);
+        { SgrStageTimer tm(s, SGR_STAGE_LOSS_FWD); rc = sgr_l1_ssim_forward_job(3, W, H, c.image, v->gt_image, c.lambda_dssim, c.loss_scratch, nullptr, t->defer_post ? &job : nullptr, stream); }
         if (rc < 0) return tfail(rc, "l1_ssim_forward failed");
         if (t->defer_post && hipEventRecord(t->hdr_event, s) != hipSuccess) return tfail(SGR_E_HIP, "hipEventRecord failed");
-        rc = sgr_l1_ssim_backward_ex(3, W, H, c.image, v->gt_image, c.lambda_dssim, c.loss_scratch, nullptr, c.grad_image, c.loss_out, stream);
+        { SgrStageTimer tm(s, SGR_STAGE_LOSS_BWD); rc = sgr_l1_ssim_backward_ex(3, W, H, c.image, v->gt_image, c.lambda_dssim, c.loss_scratch, nullptr, c.grad_image, c.loss_out, stream); }
         if (rc < 0) return tfail(rc, "l1_ssim_backward failed");
     }
     if (phases & 3) {
@@ -239,15 +239,19 @@ int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* v, int phases, const 
             const float* cams = ex->all_campos ? ex->all_campos : (ex->all_colors ? nullptr : c.colors + 3 * (size_t)P);
             if (!cams) return tfail(SGR_E_INVALID, "sgr_trainer_step: all_campos missing");
             const size_t stride = (size_t)(ex->view_stride ? ex->view_stride : (ex->all_colors ? P : P + 1));
+            SgrStageTimer tm(s, SGR_STAGE_SH_ADAM);
             sgr_launch_sh_adam_from_views(P, ex->n_views, c.D, c.M, stride, means3D, cams, cols, flat + c.off_features,
                                           c.exp_avg + c.off_features, c.exp_avg_sq + c.off_features, c.lr_features_dc,
                                           c.lr_features_rest, c.beta1, c.beta2, c.eps, bc1, bc2_sqrt, ex->grad_scale, nullptr, s, header, cap);
+            tm.stop();
             if (hipGetLastError() != hipSuccess) return tfail(SGR_E_HIP, "sh_adam launch failed");
         }
         if (phases & 8) {
+            SgrStageTimer tm(s, SGR_STAGE_ADAM);
             const int rc = sgr_adam_launch(c.n_small, flat, grad, c.exp_avg, c.exp_avg_sq, 4, t->seg_begin, t->seg_end, t->seg_lr, t->seg_lr,
                                            t->seg_one, t->seg_one, c.beta1, c.beta2, c.eps, ex->step, ex->grad_scale, nullptr, 0, header,
                                            cap, s);
+            tm.stop();
             if (rc < 0) return tfail(rc, "adam launch failed");
         }
     }

@@ -303,6 +303,8 @@ class _CModule:
         dL_dcov3D = None if lean else torch.empty(P, 6, **f)
         compact_sh = bool(grad_out and grad_out.get("compact_sh")) and M > 0
         dL_dsh = None if compact_sh else _sink_or_empty(grad_out, "shs", (P, M, 3), **f)
+        if dL_dsh is not None and colors.numel() != 0 and dL_dsh.numel() != 0:
+            dL_dsh.zero_()  # SHs AND precomputed colours: the kernels take the colours and never touch dL_dsh (reference: zeros)
         dL_dscales = torch.zeros(P, 3, **f) if use_cov else _sink_or_empty(grad_out, "scales", (P, 3), **f)
         dL_drotations = torch.zeros(P, 4, **f) if use_cov else _sink_or_empty(grad_out, "rotations", (P, 4), **f)
         raw_mode = 4 if (grad_out and grad_out.get("raw_params")) else 0  # SGR_MODE_RAW_PARAMS

@@ -38,6 +38,17 @@ def _unsupported_reason(group, p):
     return None
 
 
+def _parent_step(opt, closure):
+    """torch.optim.Adam.step WITHOUT its hook wrapper: `FusedAdam.step` is itself the hooked entry point (Optimizer.__init__ /
+    `adopt` wrap the class's `step` with `profile_hook_step`), so the fallback must not run the step pre/post hooks a second time --
+    a gradient-exchange pre-hook (sugar_amd.view_parallel.attach) would all-reduce twice, and with average=False scale the
+    gradients by the world size."""
+    f = torch.optim.Adam.step
+    if getattr(f, "hooked", False) and hasattr(f, "__wrapped__"):
+        f = f.__wrapped__
+    return f(opt, closure)
+
+
 class FusedAdam(torch.optim.Adam):
     @torch.no_grad()
     def step(self, closure=None):
@@ -46,7 +57,7 @@ class FusedAdam(torch.optim.Adam):
         if reason is not None:
             STATS["fallback_steps"] += 1
             STATS["last_fallback_reason"] = reason
-            return super().step(closure)
+            return _parent_step(self, closure)
         STATS["fused_steps"] += 1
         loss = None
         if closure is not None:
@@ -73,7 +84,7 @@ class FusedAdam(torch.optim.Adam):
                 STATS["fallback_steps"] += 1
                 STATS["last_fallback_reason"] = "allocator returned storage that is not 16-byte aligned"
                 STATS["fused_steps"] -= 1
-                super().step(None)
+                _parent_step(self, None)
                 return loss
             plan.append((group, p, state, dense, grad, m, v))
         for group, p, state, dense, grad, m, v in plan:

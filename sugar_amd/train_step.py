@@ -680,15 +680,19 @@ class NativeTrainer:
         from .view_parallel import all_reduce_densification_stats
         all_reduce_densification_stats(self, group=group)
 
-    def densify_and_prune(self, max_grad=0.0002, min_opacity=0.005, extent=1.0, max_screen_size=None, seed=0, group=None):
+    def densify_and_prune(self, max_grad=0.0002, min_opacity=0.005, extent=1.0, max_screen_size=None, seed=None, group=None):
         """gaussian_model.py:390-403 on the trainer's own buffers: statistics exchanged over the ranks, clone / split / prune with a
-        generator every rank seeds identically, then `resize`.  Returns (cloned, split, pruned)."""
+        generator every rank seeds identically, then `resize`.  Returns (cloned, split, pruned).
+        The split offsets come from ONE generator per trainer that advances from event to event (the reference draws from the
+        advancing global RNG, gaussian_model.py:352-356): seeded once (0) and identically on every rank; an explicit `seed` reseeds it."""
         from . import densify
         if self.world > 1 or (dist.is_available() and dist.is_initialized()):
             self.all_reduce_densification_stats(group)
         else:
             self.synchronize()
-        g = torch.Generator(device=self.dev).manual_seed(int(seed))
+        if seed is not None or getattr(self, "_densify_gen", None) is None:
+            self._densify_gen = torch.Generator(device=self.dev).manual_seed(int(seed or 0))
+        g = self._densify_gen
         p = self.params
         stats = dict(xyz_gradient_accum=self.xyz_gradient_accum, denom=self.denom, max_radii2D=self.max_radii2D)
         t, m1, m2, nc, ns, npr = densify.densify_and_prune(p.raw(), p.split_flat(self.exp_avg), p.split_flat(self.exp_avg_sq), stats,

@@ -40,14 +40,24 @@ def _params_of(optimizer):
 
 @torch.no_grad()
 def all_reduce_gradients(params, group=None, average=True, bucket_bytes=BUCKET_BYTES):
-    """sum (mean) of `.grad` over the ranks, in place, in flat buckets.  Missing gradients count as zeros and stay materialised."""
+    """sum (mean) of `.grad` over the ranks, in place, in flat buckets.  A gradient missing on this rank but present on another counts as zeros; one missing on every rank
+    stays None."""
     world = _world(group)
     if world == 1:
         return 0
     # (a tensor that neither asks for a gradient nor carries one is frozen on every rank alike; one that carries a hand-assigned
     # `.grad` -- views of a flat gradient buffer, sugar_amd.train_step._torch_adam -- takes part)
     params = [p for p in params if p.requires_grad or p.grad is not None]
-    n_coll = 0
+    if not params:
+        return 0
+    # A parameter without a gradient on EVERY rank stays without one (torch.optim.Adam skips it: no step count, no momentum update --
+    # what the single-GPU loop does for a tensor that is not in this iteration's graph); one that has a gradient on SOME rank gets
+    # zeros on the others.  One small MAX all-reduce of the per-parameter flags decides.
+    flags = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=torch.float32, device=params[0].device)
+    dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+    has = flags.cpu().tolist()
+    params = [p for p, h in zip(params, has) if h > 0.0]
+    n_coll = 1
     i = 0
     while i < len(params):
         bucket, nbytes = [], 0

@@ -133,3 +133,40 @@ def test_the_torch_extension_path_equals_the_ctypes_path(use_sh, use_cov):
         dgr._EXT, dgr._EXT_TRIED = saved
     _same(b, a)
     assert set(a["grads"]) == set(b["grads"])
+
+
+def test_the_backward_finds_the_forwards_layout_in_cloned_scratch_buffers():
+    """The three scratch tensors are opaque but ordinary tensors: a caller may clone, checkpoint or move them between forward and
+    backward (the reference's own debug path copies them: DGR/__init__.py:105-118).  After a speculative HIT the instance list is
+    laid out for the guessed capacity while the call returns the true count; the backward must find that layout in the buffers
+    themselves (device header word SGR_HDR_LAYOUT_CAP), not in a side table keyed by the original buffer's address."""
+    from sugar_amd import diff_gaussian_rasterization as dgr
+    from sugar_amd.diff_gaussian_rasterization import _C
+    dev = torch.device(DEV)
+    W, H, P = 560, 336, 60_011
+    scene = syn.make_scene(P, 17, 0.004, 0.05)
+    cam = syn.orbit_cameras(W, H)[3]
+    bg = torch.tensor([0.3, 0.2, 0.1], device=dev)
+    t = {k: getattr(scene, k).to(dev) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    empty = torch.empty(0, device=dev)
+    fwd = (bg, t["means3D"], empty, t["opacities"], t["scales"], t["rotations"], 1.0, empty, cam.viewmatrix.to(dev), cam.projmatrix.to(dev),
+           cam.tanfovx, cam.tanfovy, H, W, t["shs"], 3, cam.campos.to(dev), False, False)
+    dgr._SPEC_CAP.pop((0, P, W, H), None)
+    _C.rasterize_gaussians(*fwd)                                   # learns the count
+    R, color, radii, geom, binning, img = _C.rasterize_gaussians(*fwd)
+    lf = _C.last_forward
+    assert lf["speculative"] and not lf["speculation_missed"] and lf["list_capacity"] > R   # laid out for MORE than R
+    g = torch.randn(3, H, W, generator=torch.Generator().manual_seed(5)).to(dev)
+
+    def bwd(geom_, binning_, img_):
+        return _C.rasterize_gaussians_backward(bg, t["means3D"], radii, empty, t["scales"], t["rotations"], 1.0, empty, cam.viewmatrix.to(dev),
+                                               cam.projmatrix.to(dev), cam.tanfovx, cam.tanfovy, g, t["shs"], 3, cam.campos.to(dev), geom_, R,
+                                               binning_, img_, False)
+    want = [x.clone() for x in bwd(geom, binning, img)]
+    g2, b2, i2 = geom.clone(), binning.clone(), img.clone()
+    geom.fill_(0xEE); binning.fill_(0xEE); img.fill_(0xEE)         # the originals are gone
+    del geom, binning, img
+    got = bwd(g2, b2, i2)
+    for a, b in zip(want, got):
+        if a.numel():
+            assert float((a - b).norm() / a.norm().clamp_min(1e-30)) < 2e-5   # (float atomics: same sums, another order)

@@ -228,3 +228,48 @@ def test_gradient_exchange_counts_missing_gradients_as_zeros_and_buckets():
     h.remove()
     with pytest.raises(TypeError):
         vp.attach(object())
+
+
+def _none_grad_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a, b = torch.nn.Parameter(torch.ones(5)), torch.nn.Parameter(torch.ones(3))
+    opt = torch.optim.Adam([a, b], lr=0.1)
+    vp.attach(opt)
+    # step 1: b has a gradient on rank 0 only -> zeros on rank 1, both step it with the mean
+    a.grad = torch.full((5,), float(rank + 1))
+    b.grad = torch.ones(3) if rank == 0 else None
+    opt.step()
+    b1 = b.detach().clone()
+    # step 2: b has no gradient on ANY rank -> it stays None and Adam skips b (no momentum step), as on one GPU
+    a.grad = torch.ones(5); b.grad = None
+    opt.step()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), a=a.detach().numpy(), b1=b1.numpy(), b2=b.detach().numpy(),
+             b_grad_none=np.array(b.grad is None), b_steps=np.array(float(opt.state[b]["step"])))
+    dist.destroy_process_group()
+
+
+def test_a_gradient_missing_on_every_rank_stays_missing_and_the_parameter_is_not_stepped(tmp_path):
+    world = 2
+    mp.spawn(_none_grad_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
+    for k in r[0].files:
+        assert np.array_equal(r[0][k], r[1][k]), k
+    assert bool(r[0]["b_grad_none"]) and float(r[0]["b_steps"]) == 1.0
+    assert np.all(r[0]["b1"] < 1.0) and np.array_equal(r[0]["b1"], r[0]["b2"])   # moved in step 1, untouched in step 2
+
+
+def test_the_fallback_of_fused_adam_runs_the_step_hooks_once():
+    """a CPU parameter makes FusedAdam fall back to torch's own step; the pre-hook (where the gradient exchange lives) must fire
+    once per step, for a constructed FusedAdam and for a torch.optim.Adam converted in place (`adopt`)"""
+    from sugar_amd import fused_adam
+    for make in (lambda ps: fused_adam.FusedAdam(ps, lr=0.1), lambda ps: fused_adam.adopt(torch.optim.Adam(ps, lr=0.1))):
+        p = torch.nn.Parameter(torch.ones(4))
+        opt = make([p])
+        calls = []
+        opt.register_step_pre_hook(lambda o, a, k: calls.append("pre"))
+        opt.register_step_post_hook(lambda o, a, k: calls.append("post"))
+        p.grad = torch.ones(4)
+        opt.step()
+        assert calls == ["pre", "post"], calls
+        assert float(p.detach()[0]) < 1.0
