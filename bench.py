@@ -387,6 +387,34 @@ def main():
                                            "delta_ms": ms_d - ms_plain,
                                            "what": "dL/dmeans2D written + radii kept + max_radii2D / xyz_gradient_accum / denom updated in the backward preprocess kernel"}
         del dtr, snap
+    if world == 1 and native and not args.no_densify_variant:
+        # the same step in exact-alpha mode (include/sugar_raster.h: SGR_FLAG_EXACT_ALPHA: alpha as the reference rounds it, gradients
+        # within the reference's own float-atomic noise): what bit-level parity of the transmittance costs
+        snap = snapshot(trainer)
+        ms_fast = time_steps(trainer, base)
+        restore(trainer, snap)
+        lib.sgr_set_exact_alpha(1)
+        try:
+            for s in range(len(cams)):
+                do_step(trainer, s)
+            restore(trainer, snap)
+            lib.sgr_profile_enable((1 << STAGES.index("blend_fwd")) | (1 << STAGES.index("blend_bwd")))
+            ms_exact = time_steps(trainer, base)
+            lib.sgr_profile_enable(0)
+            lib.sgr_profile_read(ms, cnt, len(STAGES))
+            xs = {n: (ms[i] / cnt[i] if cnt[i] else 0.0) for i, n in enumerate(STAGES) if n in ("blend_fwd", "blend_bwd")}
+        finally:
+            lib.sgr_set_exact_alpha(0)
+        restore(trainer, snap)
+        for s in range(len(cams)):   # (walk hints of the default mode again)
+            do_step(trainer, s)
+        restore(trainer, snap)
+        extras["exact_alpha_variant"] = {"ms_per_step": ms_exact, "ms_per_step_default_same_moment": ms_fast, "delta_ms": ms_exact - ms_fast,
+                                         "blend_fwd_ms": xs.get("blend_fwd"), "blend_bwd_ms": xs.get("blend_bwd"),
+                                         "what": "sgr_set_exact_alpha(1): power / expf / test_T rounded exactly as forward.cu:333-347 and "
+                                                 "backward.cu:492-499 (final_T, n_contrib bit-identical to the reference; gradients <= 1e-5 "
+                                                 "norm-wise at BASELINE sizes, tests/test_gpu_fullsize.py)"}
+        del snap
     if world == 1 and not forward_only and args.drift_steps > 0:
         # the headline is the scene as defined (parameters restored after the pre-roll); this is the same step after the
         # optimiser has moved the scene towards the (random) target images for a while: R shrinks, the walked depth grows

@@ -161,6 +161,18 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user,
  * finds that layout through the binning buffer's address, so the caller passes the returned count as usual.  Ignored with
  * SGR_FLAG_DEFER_POST.  sgr_forward_info.speculation reports hit / miss. */
 #define SGR_FLAG_SPECULATIVE 8
+/* SGR_FLAG_EXACT_ALPHA / SGR_BWD_EXACT_ALPHA / sgr_set_exact_alpha (round 6): the blend kernels evaluate alpha exactly as the
+ * reference does -- `power` rounded operation by operation in the order of forward.cu:333 / backward.cu:492, G = expf(power)
+ * by the device library's own two-term algorithm, test_T = T (1 - alpha) -- instead of the pre-scaled-conic + v_exp_f32 form.
+ * alpha, T, final_T and n_contrib are then bit-identical to the reference's kernels (compiled without FP contraction) and every
+ * gradient tensor agrees with them to the reference's own float-atomic noise (about 4e-6 norm-wise at BASELINE sizes, against
+ * 5e-5 .. 8e-5 in the default mode, where alpha differs by ~1e-7 relative and the sums over a splat's pixels cancel heavily).
+ * Price: 12 more vector instructions per (list entry, 8x8 block) in both blend kernels.  The default (off) meets the 1e-4 bar;
+ * the mode is process-wide (sgr_set_exact_alpha, or SGR_EXACT_ALPHA=1 in the environment) or per call (the two flags).  Forward
+ * and backward of one view should run in the same mode. */
+#define SGR_FLAG_EXACT_ALPHA 16
+void sgr_set_exact_alpha(int on);
+int sgr_get_exact_alpha(void);
 #define SGR_MODE_RAW_PARAMS 4 /* or-ed into the `phase` argument of sgr_backward_phase (phases 0, 1, 2 as before) */
 /* Compact SH mode only (dL_dsh == NULL): the backward skips the SH block altogether -- no read of shs, and dL_dmean3D
  * comes out WITHOUT the term through the view direction; sgr_sh_adam_from_views_ex forms that term. */
@@ -220,6 +232,7 @@ typedef struct sgr_backward_opts {
                             buffer), written by the kernel that writes dL_dcolor; NULL = not wanted */
     int flags;           /* SGR_BWD_* */
 } sgr_backward_opts;
+#define SGR_BWD_EXACT_ALPHA 2      /* see SGR_FLAG_EXACT_ALPHA */
 #define SGR_BWD_TILE_ORDER_READY 1 /* the forward of this view was given tile_order_out: its launch order is in the image scratch */
 int sgr_backward_ex(int phase, int P, int D, int M, int64_t R,
                     const float* background, int width, int height,

@@ -18,6 +18,8 @@ _vp, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 SIGNATURES = {
     "sgr_abi_version": (_i, []),
     "sgr_last_error": (C.c_char_p, []),
+    "sgr_set_exact_alpha": (None, [_i]),
+    "sgr_get_exact_alpha": (_i, []),
     "sgr_forward": (_i64, [ALLOC_FN, _vp, ALLOC_FN, _vp, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp,
                            _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp]),
     "sgr_forward_ex": (_i64, [ALLOC_FN, _vp, ALLOC_FN, _vp, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp,

@@ -117,51 +117,185 @@ __device__ __forceinline__ bool block_hit(float gxc, float gyc, float cx, float 
     "v_mov_b32 %[last], " POS "\n"                                                                  \
     "s_mov_b64 exec, %[live]\n"
 
+// EXACT-ALPHA variant (round 6; sgr_set_exact_alpha / SGR_FLAG_EXACT_ALPHA).  tests/test_gpu_fullsize.py's gradient differences from
+// the reference (5e-5 .. 8e-5 norm-wise on rotations, against a bar of 1e-4) were traced switch by switch
+// (profiles/r06_grad_switch_table.txt) to ONE place: alpha.  Both sides evaluate it to ~1 ulp, but with different roundings -- the
+// pre-scaled conic and the folded log2(e) above against `power` rounded operation by operation and the two-term expf of the
+// device library -- and the sums over a splat's pixels cancel so heavily that 1e-7 relative in alpha is 5e-5 in dL/drotation (the
+// reference's own float-atomic order alone is 2e-6 there).  This body follows forward.cu:333-347 operation for operation:
+//   power = -0.5 (cx dx dx + cz dy dy) - cy dx dy    individually rounded, in that order (the entry carries -0.5 cx and -0.5 cz: exact scalings)
+//   G     = expf(power)                              the device library's algorithm: ph = x c, e = rint(ph), a = (ph - e) + (fma(x, c, -ph)
+//                                                    + x c_lo), G = ldexp(exp2(a), e); its range checks are dead here (power <= 0 survives,
+//                                                    an underflowing G fails the 1/255 test either way)
+//   test_T = T (1 - alpha)
+// With it alpha, T, final_T and n_contrib are bit-identical to the reference's (compiled without contraction) and every gradient
+// tensor is within the reference's own run-to-run spread; 12 more VALU instructions per entry (33 against 21).
+#define SGR_FWD_BODY_X(X, Y, A, B, CZ, OP, R, G, BL, POS)                                           \
+    "v_sub_f32 v60, " X ", %[px]\n"                                                                 \
+    "v_sub_f32 v61, " Y ", %[py]\n"                                                                 \
+    "v_mul_f32 v62, " A ", v60\n"                                                                   \
+    "v_mul_f32 v63, " CZ ", v61\n"                                                                  \
+    "v_mul_f32 v62, v62, v60\n"                                                                     \
+    "v_mul_f32 v63, v63, v61\n"                                                                     \
+    "v_mul_f32 v60, " B ", v60\n"                                                                   \
+    "v_add_f32 v62, v62, v63\n"                                                                     \
+    "v_mul_f32 v60, v60, v61\n"                                                                     \
+    "v_sub_f32 v63, v62, v60\n"         /* power */                                                 \
+    "v_mul_f32 v60, 0x3fb8aa3b, v63\n"  /* ph = power * log2(e) */                                  \
+    "v_rndne_f32 v61, v60\n"            /* e */                                                     \
+    "v_fma_f32 v62, v63, %[chi], -v60\n" /* the product's rounding error */                         \
+    "v_fmac_f32 v62, 0x32a5705f, v63\n" /* + power * (log2(e) - float(log2(e))) */                  \
+    "v_sub_f32 v60, v60, v61\n"                                                                     \
+    "v_add_f32 v60, v60, v62\n"         /* a */                                                     \
+    "v_exp_f32 v60, v60\n"                                                                          \
+    "v_cvt_i32_f32 v61, v61\n"                                                                      \
+    "s_mov_b64 %[live], exec\n"                                                                     \
+    "v_cmp_nlt_f32 vcc, 0, v63\n"       /* !(power > 0) */                                          \
+    "v_ldexp_f32 v62, v60, v61\n"       /* G = expf(power) */                                       \
+    "v_mul_f32 v62, " OP ", v62\n"                                                                  \
+    "v_min_f32 v62, 0x3f7d70a4, v62\n"  /* alpha = min(0.99, opacity * G) */                        \
+    "s_and_b64 exec, exec, vcc\n"                                                                   \
+    "v_cmp_ngt_f32 vcc, 0x3b808081, v62\n" /* !(alpha < 1/255) */                                   \
+    "v_sub_f32 v60, 1.0, v62\n"         /* 1 - alpha */                                             \
+    "v_mul_f32 v61, v62, %[T]\n"        /* alpha * T */                                             \
+    "v_mul_f32 v60, %[T], v60\n"        /* test_T = T (1 - alpha), forward.cu:347 */                \
+    "s_and_b64 exec, exec, vcc\n"                                                                   \
+    "v_cmp_gt_f32 vcc, 0x38d1b717, v60\n" /* test_T < 0.0001: this lane is finished */              \
+    "s_andn2_b64 %[live], %[live], vcc\n"                                                           \
+    "s_andn2_b64 exec, exec, vcc\n"                                                                 \
+    "v_mov_b32 %[T], v60\n"                                                                         \
+    "v_fmac_f32 %[C0], " R ", v61\n"                                                                \
+    "v_fmac_f32 %[C1], " G ", v61\n"                                                                \
+    "v_fmac_f32 %[C2], " BL ", v61\n"                                                               \
+    "v_mov_b32 %[last], " POS "\n"                                                                  \
+    "s_mov_b64 exec, %[live]\n"
+
 #define SGR_FWD_ENTRY_BYTES 48
 
 
+#ifndef SGR_BLEND_CXX
+#define SGR_FWD_WALK_ASM(BODY)                                                                                                 \
+        "s_mov_b64 %[full], exec\n"                                                                                            \
+        "s_and_b64 exec, exec, %[live]\n"                                                                                      \
+        "s_waitcnt lgkmcnt(0)\n"  /* scalar loads return out of order: none may be pending while LDS reads are counted */      \
+        "ds_read_b128 v[40:43], %[addr]\n"                                                                                     \
+        "ds_read_b128 v[44:47], %[addr] offset:16\n"                                                                           \
+        "ds_read_b64 v[48:49], %[addr] offset:32\n"                                                                            \
+        "1:\n"                                                                                                                 \
+        "ds_read_b128 v[50:53], %[addr] offset:48\n"                                                                           \
+        "ds_read_b128 v[54:57], %[addr] offset:64\n"                                                                           \
+        "ds_read_b64 v[58:59], %[addr] offset:80\n"                                                                            \
+        "s_waitcnt lgkmcnt(3)\n"                                                                                               \
+        BODY("v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49")                                             \
+        "s_cbranch_execz 3f\n"                                                                                                 \
+        "s_add_i32 %[n], %[n], -1\n"                                                                                           \
+        "s_cmp_eq_u32 %[n], 0\n"                                                                                               \
+        "s_cbranch_scc1 3f\n"                                                                                                  \
+        "ds_read_b128 v[40:43], %[addr] offset:96\n"                                                                           \
+        "ds_read_b128 v[44:47], %[addr] offset:112\n"                                                                          \
+        "ds_read_b64 v[48:49], %[addr] offset:128\n"                                                                           \
+        "v_add_u32 %[addr], 96, %[addr]\n"                                                                                     \
+        "s_waitcnt lgkmcnt(3)\n"                                                                                               \
+        BODY("v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59")                                             \
+        "s_cbranch_execz 3f\n"                                                                                                 \
+        "s_add_i32 %[n], %[n], -1\n"                                                                                           \
+        "s_cmp_eq_u32 %[n], 0\n"                                                                                               \
+        "s_cbranch_scc0 1b\n"                                                                                                  \
+        "3:\n"                                                                                                                 \
+        "s_waitcnt lgkmcnt(0)\n"                                                                                               \
+        "s_mov_b64 exec, %[full]\n"
+#define SGR_FWD_WALK_OPERANDS                                                                                                  \
+        : [T] "+v"(T), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [last] "+v"(last), [addr] "+v"(addr), [n] "+s"(n),          \
+          [live] "+s"(live), [full] "=&s"(full)                                                                                \
+        : [px] "v"(pixfx), [py] "v"(pixfy), [chi] "s"(LOG2E)                                                                   \
+        : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", \
+          "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc", "memory"
+template <bool EXACT>
 __device__ __forceinline__ void fwd_walk(uint32_t addr, int& n, unsigned long long& live, float pixfx, float pixfy, float& T,
                                          float& C0, float& C1, float& C2, uint32_t& last)
 {
     unsigned long long full;
-    asm volatile(
-        "s_mov_b64 %[full], exec\n"
-        "s_and_b64 exec, exec, %[live]\n"
-        "s_waitcnt lgkmcnt(0)\n"  /* scalar loads return out of order: none may be pending while LDS reads are counted */
-        "ds_read_b128 v[40:43], %[addr]\n"
-        "ds_read_b128 v[44:47], %[addr] offset:16\n"
-        "ds_read_b64 v[48:49], %[addr] offset:32\n"
-        "1:\n"
-        "ds_read_b128 v[50:53], %[addr] offset:48\n"
-        "ds_read_b128 v[54:57], %[addr] offset:64\n"
-        "ds_read_b64 v[58:59], %[addr] offset:80\n"
-        "s_waitcnt lgkmcnt(3)\n"
-        SGR_FWD_BODY("v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49")
-        "s_cbranch_execz 3f\n"
-        "s_add_i32 %[n], %[n], -1\n"
-        "s_cmp_eq_u32 %[n], 0\n"
-        "s_cbranch_scc1 3f\n"
-        "ds_read_b128 v[40:43], %[addr] offset:96\n"
-        "ds_read_b128 v[44:47], %[addr] offset:112\n"
-        "ds_read_b64 v[48:49], %[addr] offset:128\n"
-        "v_add_u32 %[addr], 96, %[addr]\n"
-        "s_waitcnt lgkmcnt(3)\n"
-        SGR_FWD_BODY("v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59")
-        "s_cbranch_execz 3f\n"
-        "s_add_i32 %[n], %[n], -1\n"
-        "s_cmp_eq_u32 %[n], 0\n"
-        "s_cbranch_scc0 1b\n"
-        "3:\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "s_mov_b64 exec, %[full]\n"
-        : [T] "+v"(T), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [last] "+v"(last), [addr] "+v"(addr), [n] "+s"(n),
-          [live] "+s"(live), [full] "=&s"(full)
-        : [px] "v"(pixfx), [py] "v"(pixfy)
-        : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56",
-          "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc", "memory");
+    if constexpr (EXACT) asm volatile(SGR_FWD_WALK_ASM(SGR_FWD_BODY_X) SGR_FWD_WALK_OPERANDS);
+    else asm volatile(SGR_FWD_WALK_ASM(SGR_FWD_BODY) SGR_FWD_WALK_OPERANDS);
 }
+#endif
 
-template <bool REPAIR>
+#ifdef SGR_BLEND_CXX
+// ---- ANALYSIS BUILD (SGR_BLEND_DEFS="-DSGR_BLEND_CXX=<mask>", scripts/r06_grad_switches.sh): the two hand-scheduled walks as plain
+// C++, with the places where their arithmetic departs from the reference's (forward.cu:330-366, backward.cu:486-554, compiled without
+// contraction) switchable one by one, to find which departure carries the gradient error of tests/test_gpu_fullsize.py.  Mask 0
+// reproduces the assembly bit for bit.  Not a product path: slower, and never built by default.
+//   1  power from the raw conic in the reference's operation order (ours: conic pre-scaled by log2 e, two FMAs)
+//   2  G = expf(power) (needs 1; ours: v_exp_f32 of the pre-scaled power)
+//   4  test_T = T * (1 - alpha)  (ours: T - alpha * T)
+//   8  C += (c * alpha) * T, unfused  (ours: fma(c, alpha * T, C))
+//  16  T = T / (1 - alpha)  (ours: T * v_rcp_f32(1 - alpha))
+//  32  accum_rec per channel and the background term as in backward.cu:514-534 (ours: the scalar recurrence on colour . g)
+//  64  phase B's moment sums in double
+#define SGR_X(bit) ((SGR_BLEND_CXX) & (bit))
+#pragma clang fp contract(off)
+__device__ __forceinline__ float x_power_G(const float* e, float dx, float dy, float& power_sign)
+{
+#if SGR_X(1)
+    const float power = -0.5f * (e[2] * dx * dx + e[4] * dy * dy) - e[3] * dx * dy;
+    power_sign = power;
+#if SGR_X(2)
+    return expf(power);
+#else
+    return __builtin_amdgcn_exp2f(power * LOG2E);
+#endif
+#else
+    const float t = __builtin_fmaf(e[2], dx, e[3] * dy);
+    const float p2 = __builtin_fmaf(dx, t, (e[4] * dy) * dy);
+    power_sign = p2;
+    return __builtin_amdgcn_exp2f(p2);
+#endif
+}
+__device__ __forceinline__ void fwd_walk_cxx(const float* s_e, int& n, unsigned long long& live, float pixfx, float pixfy, float& T,
+                                             float& C0, float& C1, float& C2, uint32_t& last)
+{
+    const int lane = threadIdx.x;
+    const int n0 = n;
+    for (int k = 0; k < n0; k++) {
+        const float* e = s_e + k * (SGR_FWD_ENTRY_BYTES / 4);
+        const bool act = (live >> lane) & 1ull;
+        bool fin = false;
+        if (act) {
+            const float dx = e[0] - pixfx, dy = e[1] - pixfy;
+            float ps;
+            const float G = x_power_G(e, dx, dy, ps);
+            if (!(ps > 0.f)) {
+                const float alpha = fminf(0.99f, e[5] * G);
+                if (!(alpha < 1.0f / 255.0f)) {
+#if SGR_X(4)
+                    const float test_T = T * (1.f - alpha);
+                    const float aT = alpha * T;
+#else
+                    const float aT = alpha * T;
+                    const float test_T = T - aT;
+#endif
+                    if (test_T < 0.0001f) fin = true;
+                    else {
+#if SGR_X(8)
+                        C0 += e[6] * alpha * T; C1 += e[7] * alpha * T; C2 += e[8] * alpha * T;
+#else
+                        C0 = __builtin_fmaf(e[6], aT, C0); C1 = __builtin_fmaf(e[7], aT, C1); C2 = __builtin_fmaf(e[8], aT, C2);
+#endif
+                        T = test_T;
+                        last = __float_as_uint(e[9]);
+                    }
+                }
+            }
+        }
+        live &= ~__ballot(fin);
+        if (live == 0ull) { n = n0 - k; return; }
+    }
+    n = 0;
+}
+#pragma clang fp contract(fast)
+#endif  // SGR_BLEND_CXX
+
+template <bool REPAIR, bool EXACT>
 __device__ __forceinline__ void blend_fwd_body(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_start,
                                                     const uint32_t* __restrict__ point_list, const GeomRec* __restrict__ rec,
                                                     const float* __restrict__ bg, float* __restrict__ final_T,
@@ -265,8 +399,18 @@ __device__ __forceinline__ void blend_fwd_body(int W, int H, int gx, int T_tiles
         if (hit) {
             const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             float4* e = reinterpret_cast<float4*>(s_e + pos * (SGR_FWD_ENTRY_BYTES / 4));
-            e[0] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
-            e[1] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v2.x, v2.y);
+#if defined(SGR_BLEND_CXX) && ((SGR_BLEND_CXX) & 1)
+            e[0] = make_float4(v0.x, v0.y, v0.z, v0.w);   // (analysis build: the raw conic)
+            e[1] = make_float4(v1.x, v1.y, v2.x, v2.y);
+#else
+            if (EXACT) {  // the raw conic, the two halvings applied (exact): SGR_FWD_BODY_X
+                e[0] = make_float4(v0.x, v0.y, -0.5f * v0.z, v0.w);
+                e[1] = make_float4(-0.5f * v1.x, v1.y, v2.x, v2.y);
+            } else {
+                e[0] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
+                e[1] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v2.x, v2.y);
+            }
+#endif
             *reinterpret_cast<float2*>(e + 2) = make_float2(v2.z, __uint_as_float((uint32_t)(base + lane + 1)));
         }
         if (lane == 0) my_mask[4 * (size_t)n_batches] = m;
@@ -275,7 +419,11 @@ __device__ __forceinline__ void blend_fwd_body(int W, int H, int gx, int T_tiles
         __builtin_amdgcn_wave_barrier();
         if (n > 0) {
             const int n0 = n;
-            fwd_walk(lds0, n, live, pixfx, pixfy, T, C0, C1, C2, last_contributor);
+#ifdef SGR_BLEND_CXX
+            fwd_walk_cxx(s_e, n, live, pixfx, pixfy, T, C0, C1, C2, last_contributor);
+#else
+            fwd_walk<EXACT>(lds0, n, live, pixfx, pixfy, T, C0, C1, C2, last_contributor);
+#endif
             if (live == 0ull) {  // every pixel finished at compacted entry n0 - n: its list position is the furthest examined
                 walked = __float_as_uint(s_e[(n0 - n) * (SGR_FWD_ENTRY_BYTES / 4) + 9]);
                 break;
@@ -299,9 +447,15 @@ __device__ __forceinline__ void blend_fwd_body(int W, int H, int gx, int T_tiles
         const size_t HW = (size_t)H * W;
         final_T[pix_id] = T;
         n_contrib[pix_id] = last_contributor;
+#if defined(SGR_BLEND_CXX) && ((SGR_BLEND_CXX) & 8)
+        out_color[pix_id] = __fadd_rn(C0, __fmul_rn(T, bg[0]));
+        out_color[HW + pix_id] = __fadd_rn(C1, __fmul_rn(T, bg[1]));
+        out_color[2 * HW + pix_id] = __fadd_rn(C2, __fmul_rn(T, bg[2]));
+#else
         out_color[pix_id] = C0 + T * bg[0];
         out_color[HW + pix_id] = C1 + T * bg[1];
         out_color[2 * HW + pix_id] = C2 + T * bg[2];
+#endif
     }
     // deepest contributor / furthest examined position of the TILE (zeroed by the launcher): maximum over its four blocks
     uint32_t mc = inside ? last_contributor : 0u;
@@ -313,32 +467,32 @@ __device__ __forceinline__ void blend_fwd_body(int W, int H, int gx, int T_tiles
     }
 }
 
-__global__ void __launch_bounds__(64) k_blend_fwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_start,
-                                                    const uint32_t* __restrict__ point_list, const GeomRec* __restrict__ rec,
-                                                    const float* __restrict__ bg, float* __restrict__ final_T,
-                                                    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_maxc,
-                                                    uint32_t* __restrict__ tile_walked, float* __restrict__ out_color,
-                                                    unsigned long long* __restrict__ blk_mask, uint32_t* __restrict__ blk_nb,
-                                                    uint32_t* __restrict__ header, uint32_t list_cap,
-                                                    const uint32_t* __restrict__ tile_need, const uint32_t* __restrict__ launch_order,
+#define SGR_FWD_PARAMS                                                                                                         \
+    int W, int H, int gx, int T_tiles, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,               \
+        const GeomRec *__restrict__ rec, const float *__restrict__ bg, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, \
+        uint32_t *__restrict__ tile_maxc, uint32_t *__restrict__ tile_walked, float *__restrict__ out_color,                         \
+        unsigned long long *__restrict__ blk_mask, uint32_t *__restrict__ blk_nb, uint32_t *__restrict__ header, uint32_t list_cap
+#define SGR_FWD_ARGS W, H, gx, T_tiles, tile_start, point_list, rec, bg, final_T, n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap
+__global__ void __launch_bounds__(64) k_blend_fwd_w(SGR_FWD_PARAMS, const uint32_t* __restrict__ tile_need, const uint32_t* __restrict__ launch_order,
                                                     uint32_t* __restrict__ repair_flag, uint32_t* __restrict__ repair_list)
 {
-    blend_fwd_body<false>(W, H, gx, T_tiles, tile_start, point_list, rec, bg, final_T, n_contrib, tile_maxc, tile_walked, out_color, blk_mask,
-                          blk_nb, header, list_cap, tile_need, launch_order, repair_flag, repair_list);
+    blend_fwd_body<false, false>(SGR_FWD_ARGS, tile_need, launch_order, repair_flag, repair_list);
+}
+// (the exact-alpha variant: SGR_FWD_BODY_X)
+__global__ void __launch_bounds__(64) k_blend_fwd_wx(SGR_FWD_PARAMS, const uint32_t* __restrict__ tile_need, const uint32_t* __restrict__ launch_order,
+                                                     uint32_t* __restrict__ repair_flag, uint32_t* __restrict__ repair_list)
+{
+    blend_fwd_body<false, true>(SGR_FWD_ARGS, tile_need, launch_order, repair_flag, repair_list);
 }
 
 // the repair pass of the walk hint (a kernel name of its own, so that a trace tells the gated, usually empty launch from the blend)
-__global__ void __launch_bounds__(64) k_blend_fwd_repair(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_start,
-                                                         const uint32_t* __restrict__ point_list, const GeomRec* __restrict__ rec,
-                                                         const float* __restrict__ bg, float* __restrict__ final_T,
-                                                         uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_maxc,
-                                                         uint32_t* __restrict__ tile_walked, float* __restrict__ out_color,
-                                                         unsigned long long* __restrict__ blk_mask, uint32_t* __restrict__ blk_nb,
-                                                         uint32_t* __restrict__ header, uint32_t list_cap,
-                                                         const uint32_t* __restrict__ repair_list)
+__global__ void __launch_bounds__(64) k_blend_fwd_repair(SGR_FWD_PARAMS, const uint32_t* __restrict__ repair_list)
 {
-    blend_fwd_body<true>(W, H, gx, T_tiles, tile_start, point_list, rec, bg, final_T, n_contrib, tile_maxc, tile_walked, out_color, blk_mask,
-                         blk_nb, header, list_cap, nullptr, repair_list, nullptr, nullptr);
+    blend_fwd_body<true, false>(SGR_FWD_ARGS, nullptr, repair_list, nullptr, nullptr);
+}
+__global__ void __launch_bounds__(64) k_blend_fwd_repairx(SGR_FWD_PARAMS, const uint32_t* __restrict__ repair_list)
+{
+    blend_fwd_body<true, true>(SGR_FWD_ARGS, nullptr, repair_list, nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -376,7 +530,7 @@ __global__ void __launch_bounds__(64) k_blend_fwd_repair(int W, int H, int gx, i
 // (Measured, same box: the walk is bound by the latency of this dependent chain at the 3 waves per SIMD the LDS footprint allows,
 // not by instruction issue -- removing 2.5 of 30 instructions that sit beside the chain changed the kernel by < 1 %, zeroing the
 // panel row with a second LDS write instead of the two v_mov cost 1.5 % there and 5 % at the 5 waves per SIMD of the 8-row groups.)
-#define SGR_BWD_BODY(X, Y, A, B, CZ, OP, R, G_, BL, POS, XY, OFF)                                 \
+#define SGR_BWD_HEAD(X, Y, A, B, CZ, OP, POS)                                                     \
     "v_sub_f32 " X ", " X ", %[px]\n"                                                             \
     "v_sub_f32 " Y ", " Y ", %[py]\n"                                                             \
     "v_mul_f32 " B ", " B ", " Y "\n"                                                             \
@@ -388,7 +542,35 @@ __global__ void __launch_bounds__(64) k_blend_fwd_repair(int W, int H, int gx, i
     "v_mov_b32 " X ", 0\n"                                                                        \
     "v_mov_b32 " Y ", 0\n"                                                                        \
     "v_cmp_nlt_f32 %[m0], 0, " CZ "\n"   /* !(power > 0) */                                       \
+    "v_cmp_le_u32 %[m1], " POS ", %[lastc]\n" /* at or before this pixel's last contributor */
+// the exact-alpha head (see SGR_FWD_BODY_X: backward.cu:492-499 operation for operation; A = -0.5 cx, B = cy, CZ = -0.5 cz on entry,
+// A = G and CZ = power on exit, like the head above)
+#define SGR_BWD_HEAD_X(X, Y, A, B, CZ, OP, POS)                                                   \
+    "v_sub_f32 " X ", " X ", %[px]\n"                                                             \
+    "v_sub_f32 " Y ", " Y ", %[py]\n"                                                             \
+    "v_mul_f32 " A ", " A ", " X "\n"                                                             \
+    "v_mul_f32 " CZ ", " CZ ", " Y "\n"                                                           \
+    "v_mul_f32 " A ", " A ", " X "\n"                                                             \
+    "v_mul_f32 " CZ ", " CZ ", " Y "\n"                                                           \
+    "v_mul_f32 " B ", " B ", " X "\n"                                                             \
+    "v_add_f32 " A ", " A ", " CZ "\n"                                                            \
+    "v_mul_f32 " B ", " B ", " Y "\n"                                                             \
+    "v_sub_f32 " CZ ", " A ", " B "\n"   /* power */                                              \
+    "v_mul_f32 " A ", 0x3fb8aa3b, " CZ "\n"                                                       \
+    "v_rndne_f32 " B ", " A "\n"                                                                  \
+    "v_fma_f32 " X ", " CZ ", %[chi], -" A "\n"                                                   \
+    "v_fmac_f32 " X ", 0x32a5705f, " CZ "\n"                                                      \
+    "v_sub_f32 " A ", " A ", " B "\n"                                                             \
+    "v_add_f32 " A ", " A ", " X "\n"                                                             \
+    "v_exp_f32 " A ", " A "\n"                                                                    \
+    "v_cvt_i32_f32 " B ", " B "\n"                                                                \
+    "v_mov_b32 " X ", 0\n"                                                                        \
+    "v_mov_b32 " Y ", 0\n"                                                                        \
+    "v_cmp_nlt_f32 %[m0], 0, " CZ "\n"   /* !(power > 0) */                                       \
     "v_cmp_le_u32 %[m1], " POS ", %[lastc]\n" /* at or before this pixel's last contributor */    \
+    "v_ldexp_f32 " A ", " A ", " B "\n"  /* G = expf(power) */
+#define SGR_BWD_BODY(HEAD, X, Y, A, B, CZ, OP, R, G_, BL, POS, XY, OFF)                           \
+    HEAD(X, Y, A, B, CZ, OP, POS)                                                                 \
     "v_mul_f32 " OP ", " OP ", " A "\n"                                                           \
     "v_min_f32 " OP ", 0x3f7d70a4, " OP "\n" /* alpha */                                          \
     "s_and_b64 %[m0], %[m0], %[m1]\n"                                                             \
@@ -411,48 +593,110 @@ __global__ void __launch_bounds__(64) k_blend_fwd_repair(int W, int H, int gx, i
     "ds_write_b64 %[waddr], " XY OFF "\n"
 
 // rows (1..BW_SUB) queue entries starting at LDS address e_addr -> panel rows 0..rows-1 at w_addr (+ 8 * lane already added)
+#ifndef SGR_BLEND_CXX
+#define SGR_BWD_WALK_ASM(HEAD)                                                                                                  \
+        "s_mov_b64 %[full], exec\n"                                                                                             \
+        "s_waitcnt lgkmcnt(0)\n"                                                                                                \
+        "ds_read_b128 v[64:67], %[eaddr]\n"                                                                                     \
+        "ds_read_b128 v[68:71], %[eaddr] offset:16\n"                                                                           \
+        "ds_read_b64 v[72:73], %[eaddr] offset:32\n"                                                                            \
+        "1:\n"                                                                                                                  \
+        "ds_read_b128 v[74:77], %[eaddr] offset:48\n"                                                                           \
+        "ds_read_b128 v[78:81], %[eaddr] offset:64\n"                                                                           \
+        "ds_read_b64 v[82:83], %[eaddr] offset:80\n"                                                                            \
+        "s_waitcnt lgkmcnt(3)\n"                                                                                                \
+        SGR_BWD_BODY(HEAD, "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v[64:65]", "")                \
+        "s_add_i32 %[n], %[n], -1\n"                                                                                            \
+        "s_cmp_eq_u32 %[n], 0\n"                                                                                                \
+        "s_cbranch_scc1 3f\n"                                                                                                   \
+        "ds_read_b128 v[64:67], %[eaddr] offset:96\n"                                                                           \
+        "ds_read_b128 v[68:71], %[eaddr] offset:112\n"                                                                          \
+        "ds_read_b64 v[72:73], %[eaddr] offset:128\n"                                                                           \
+        "v_add_u32 %[eaddr], 96, %[eaddr]\n"                                                                                    \
+        "s_waitcnt lgkmcnt(4)\n"  /* the panel write of the previous entry may still be counted */                              \
+        SGR_BWD_BODY(HEAD, "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v[74:75]", " offset:520")      \
+        "v_add_u32 %[waddr], 1040, %[waddr]\n"                                                                                  \
+        "s_add_i32 %[n], %[n], -1\n"                                                                                            \
+        "s_cmp_eq_u32 %[n], 0\n"                                                                                                \
+        "s_cbranch_scc0 1b\n"                                                                                                   \
+        "3:\n"                                                                                                                  \
+        "s_waitcnt lgkmcnt(0)\n"
+#define SGR_BWD_WALK_OPERANDS                                                                                                   \
+        : [T] "+v"(T), [acc] "+v"(acc_g), [eaddr] "+v"(e_addr), [waddr] "+v"(w_addr), [n] "+s"(rows), [full] "=&s"(full),        \
+          [m0] "=&s"(m0), [m1] "=&s"(m1)                                                                                        \
+        : [px] "v"(pixfx), [py] "v"(pixfy), [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [ntb] "v"(ntb), [lastc] "v"(lastc),        \
+          [inside] "s"(inside_mask), [chi] "s"(LOG2E)                                                                           \
+        : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78",              \
+          "v79", "v80", "v81", "v82", "v83", "vcc", "scc", "memory"
+template <bool EXACT>
 __device__ __forceinline__ void bwd_phase_a(uint32_t e_addr, uint32_t w_addr, int rows, unsigned long long inside_mask, float pixfx,
                                             float pixfy, float g0, float g1, float g2, float ntb, uint32_t lastc, float& T,
                                             float& acc_g)
 {
     unsigned long long full, m0, m1;
-    asm volatile(
-        "s_mov_b64 %[full], exec\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "ds_read_b128 v[64:67], %[eaddr]\n"
-        "ds_read_b128 v[68:71], %[eaddr] offset:16\n"
-        "ds_read_b64 v[72:73], %[eaddr] offset:32\n"
-        "1:\n"
-        "ds_read_b128 v[74:77], %[eaddr] offset:48\n"
-        "ds_read_b128 v[78:81], %[eaddr] offset:64\n"
-        "ds_read_b64 v[82:83], %[eaddr] offset:80\n"
-        "s_waitcnt lgkmcnt(3)\n"
-        SGR_BWD_BODY("v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v[64:65]", "")
-        "s_add_i32 %[n], %[n], -1\n"
-        "s_cmp_eq_u32 %[n], 0\n"
-        "s_cbranch_scc1 3f\n"
-        "ds_read_b128 v[64:67], %[eaddr] offset:96\n"
-        "ds_read_b128 v[68:71], %[eaddr] offset:112\n"
-        "ds_read_b64 v[72:73], %[eaddr] offset:128\n"
-        "v_add_u32 %[eaddr], 96, %[eaddr]\n"
-        "s_waitcnt lgkmcnt(4)\n"  /* the panel write of the previous entry may still be counted */
-        SGR_BWD_BODY("v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v[74:75]", " offset:520")
-        "v_add_u32 %[waddr], 1040, %[waddr]\n"
-        "s_add_i32 %[n], %[n], -1\n"
-        "s_cmp_eq_u32 %[n], 0\n"
-        "s_cbranch_scc0 1b\n"
-        "3:\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        : [T] "+v"(T), [acc] "+v"(acc_g), [eaddr] "+v"(e_addr), [waddr] "+v"(w_addr), [n] "+s"(rows), [full] "=&s"(full),
-          [m0] "=&s"(m0), [m1] "=&s"(m1)
-        : [px] "v"(pixfx), [py] "v"(pixfy), [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [ntb] "v"(ntb), [lastc] "v"(lastc),
-          [inside] "s"(inside_mask)
-        : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78",
-          "v79", "v80", "v81", "v82", "v83", "vcc", "scc", "memory");
+    if constexpr (EXACT) asm volatile(SGR_BWD_WALK_ASM(SGR_BWD_HEAD_X) SGR_BWD_WALK_OPERANDS);
+    else asm volatile(SGR_BWD_WALK_ASM(SGR_BWD_HEAD) SGR_BWD_WALK_OPERANDS);
 }
+#endif
 
-__global__ void __launch_bounds__(64)
-k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ point_list,
+#ifdef SGR_BLEND_CXX
+struct XBwd { float accum_rec[3] = {0.f, 0.f, 0.f}, last_alpha = 0.f, last_color[3] = {0.f, 0.f, 0.f}; };
+#pragma clang fp contract(off)
+__device__ __forceinline__ void bwd_phase_a_cxx(const float* q, float2* zw, int rows, unsigned long long inside_mask, float pixfx, float pixfy,
+                                                float g0, float g1, float g2, float ntb, uint32_t lastc, float& T, float& acc_g, XBwd& st,
+                                                const float* bg, float T_final)
+{
+    const int lane = threadIdx.x;
+    const bool inside = (inside_mask >> lane) & 1ull;
+    for (int r = 0; r < rows; r++) {
+        const float* e = q + r * BW_ENTRY_DW;
+        const float dx = e[0] - pixfx, dy = e[1] - pixfy;
+        float ps;
+        const float G = x_power_G(e, dx, dy, ps);
+        const float alpha = fminf(0.99f, e[5] * G);
+        float Z = 0.f, Wt = 0.f;
+        if (!(ps > 0.f) && __float_as_uint(e[9]) <= lastc && inside && !(alpha < 1.0f / 255.0f)) {
+#if SGR_X(16)
+            T = T / (1.f - alpha);
+            const float B = 1.f / (1.f - alpha);
+#else
+            const float B = __builtin_amdgcn_rcpf(1.f - alpha);
+            T = T * B;
+#endif
+            Wt = alpha * T;
+            float dLda;
+#if SGR_X(32)
+            const float c[3] = {e[6], e[7], e[8]}, g[3] = {g0, g1, g2};
+            dLda = 0.f;
+            for (int ch = 0; ch < 3; ch++) {
+                st.accum_rec[ch] = st.last_alpha * st.last_color[ch] + (1.f - st.last_alpha) * st.accum_rec[ch];
+                st.last_color[ch] = c[ch];
+                dLda += (c[ch] - st.accum_rec[ch]) * g[ch];
+            }
+            dLda *= T;
+            st.last_alpha = alpha;
+            float bg_dot = 0.f;
+            for (int i = 0; i < 3; i++) bg_dot += bg[i] * g[i];
+            dLda += (-T_final / (1.f - alpha)) * bg_dot;
+            (void)B; (void)ntb;
+#else
+            const float cg = __builtin_fmaf(e[8], g2, __builtin_fmaf(e[7], g1, e[6] * g0));
+            float d = cg - acc_g;
+            acc_g = __builtin_fmaf(alpha, d, acc_g);
+            d = d * T;
+            dLda = __builtin_fmaf(ntb, B, d);
+#endif
+            Z = G * dLda;
+        }
+        zw[r * BW_ZW_STRIDE] = make_float2(Z, Wt);
+    }
+}
+#pragma clang fp contract(fast)
+#endif
+
+template <bool EXACT>
+__device__ __forceinline__ void
+blend_bwd_body(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ point_list,
               const char* __restrict__ binning, const uint32_t* __restrict__ blk_nb, const GeomRec* __restrict__ rec,
               const float* __restrict__ bg, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
               const float* __restrict__ dL_dpix, float* __restrict__ acc, const uint32_t* __restrict__ tile_order,
@@ -510,14 +754,24 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
     const uint32_t q_lds = (uint32_t)(uintptr_t)s_q;
     const uint32_t zw_lds = (uint32_t)(uintptr_t)s_zw + 8u * (uint32_t)lane;
 
+#ifdef SGR_BLEND_CXX
+    XBwd xst;
+#endif
     int qn = 0;  // entries waiting in the queue (they sit at its front)
     // the queued entries in groups of BW_SUB (all of them at the end, full groups only before), the rest moves to the front
     auto drain = [&](const bool last_batch) {
         int qs = 0;
         while (qn - qs >= BW_SUB || (last_batch && qn > qs)) {
             const int rows = min(BW_SUB, qn - qs);
-            bwd_phase_a(q_lds + (uint32_t)qs * (BW_ENTRY_DW * 4), zw_lds, rows, inside_mask, pixfx, pixfy, g0, g1, g2, ntb,
-                        last_contributor, T, acc_g);
+#ifdef SGR_BLEND_CXX
+            bwd_phase_a_cxx(s_q + qs * BW_ENTRY_DW, s_zw + lane, rows, inside_mask, pixfx, pixfy, g0, g1, g2, ntb, last_contributor, T, acc_g,
+                            xst, bg, T_final);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#else
+            bwd_phase_a<EXACT>(q_lds + (uint32_t)qs * (BW_ENTRY_DW * 4), zw_lds, rows, inside_mask, pixfx, pixfy, g0, g1, g2, ntb,
+                               last_contributor, T, acc_g);
+#endif
             // ---------------- phase B: lane = (panel row bg_, pixel rows 2 bq and 2 bq + 1)
             if (bg_ < rows) {
                 const float* e = s_q + (qs + bg_) * BW_ENTRY_DW;
@@ -529,26 +783,39 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
                 // 5e-8).  xb - xc is exact, and every product below is of the size of the moment it contributes to.
                 const float xb = e[0] - (float)bx0, yb = e[1] - (float)by0;
                 const float xc = rintf(xb), yc = rintf(yb);
+#if defined(SGR_BLEND_CXX) && ((SGR_BLEND_CXX) & 64)
+                double s0 = 0., sx = 0., sxx = 0., k0 = 0., k1 = 0., k2 = 0.;   // (analysis build)
+#else
                 float s0 = 0.f, sx = 0.f, sxx = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
+#endif
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const float2 v = row[i];
                     const float t = (float)i - xc;
+#if defined(SGR_BLEND_CXX) && ((SGR_BLEND_CXX) & 64)
+                    const double u = (double)v.x * t;
+#else
                     const float u = v.x * t;
+#endif
                     s0 += v.x; sx += u; sxx += u * t;
                     k0 += v.y * rg0[i]; k1 += v.y * rg1[i]; k2 += v.y * rg2[i];
                 }
                 // this lane's share of the moments (its pixels all have y = bq), shifted from (xc, yc) to the Gaussian's centre,
                 // d = centre - pixel = (xb - x, yb - y) -- the shift is linear in the moments, so it is applied to the shares and the
                 // shifted shares are summed over the eight lanes of the Gaussian
-                const float y0 = (float)bq - yc;
-                const float sy = y0 * s0, sxy = y0 * sx, syy = y0 * sy;
-                const float xr = xb - xc, yr = yb - yc;
-                const float dxs = xr * s0 - sx, dys = yr * s0 - sy;
-                const float dxx = xr * (xr * s0 - 2.f * sx) + sxx;
-                const float dyy = yr * (yr * s0 - 2.f * sy) + syy;
-                const float dxy = xr * dys - yr * sx + sxy;  // xr yr S0 - xr Sy - yr Sx + Sxy
-                float o[9] = {k0, k1, k2, s0, dxs, dys, dxx, dxy, dyy};
+#if defined(SGR_BLEND_CXX) && ((SGR_BLEND_CXX) & 64)
+                typedef double mom_t;
+#else
+                typedef float mom_t;
+#endif
+                const mom_t y0 = (float)bq - yc;
+                const mom_t sy = y0 * s0, sxy = y0 * sx, syy = y0 * sy;
+                const mom_t xr = xb - xc, yr = yb - yc;
+                const mom_t dxs = xr * s0 - sx, dys = yr * s0 - sy;
+                const mom_t dxx = xr * (xr * s0 - 2.f * sx) + sxx;
+                const mom_t dyy = yr * (yr * s0 - 2.f * sy) + syy;
+                const mom_t dxy = xr * dys - yr * sx + sxy;  // xr yr S0 - xr Sy - yr Sx + Sxy
+                float o[9] = {(float)k0, (float)k1, (float)k2, (float)s0, (float)dxs, (float)dys, (float)dxx, (float)dxy, (float)dyy};
 #pragma unroll
                 for (int v = 0; v < 9; v++) o[v] += pair_in_row(o[v]);  // lanes bq and bq ^ 1
                 // ... and over the four 16-lane rows, two values per lane swap: row r of q0 ends up with the total of o[r], row r
@@ -631,8 +898,18 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
             // back to front: rank = taken lanes ABOVE this one
             const uint32_t slot = (uint32_t)qn + (uint32_t)__popcll(lane == 63 ? 0ull : (m >> (lane + 1)));
             float4* e = reinterpret_cast<float4*>(s_q + slot * BW_ENTRY_DW);
-            e[0] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
-            e[1] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v2.x, v2.y);
+#if defined(SGR_BLEND_CXX) && ((SGR_BLEND_CXX) & 1)
+            e[0] = make_float4(v0.x, v0.y, v0.z, v0.w);
+            e[1] = make_float4(v1.x, v1.y, v2.x, v2.y);
+#else
+            if (EXACT) {
+                e[0] = make_float4(v0.x, v0.y, -0.5f * v0.z, v0.w);
+                e[1] = make_float4(-0.5f * v1.x, v1.y, v2.x, v2.y);
+            } else {
+                e[0] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
+                e[1] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v2.x, v2.y);
+            }
+#endif
             e[2] = make_float4(v2.z, __uint_as_float(pos), __uint_as_float(id_cur), 0.f);
         }
         qn += __popcll(m);
@@ -641,6 +918,15 @@ k_blend_bwd_w(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ ti
     }
     drain(true);
 }
+
+#define SGR_BWD_PARAMS                                                                                                              \
+    int W, int H, int gx, int T_tiles, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,                    \
+        const char *__restrict__ binning, const uint32_t *__restrict__ blk_nb, const GeomRec *__restrict__ rec, const float *__restrict__ bg, \
+        const float *__restrict__ final_Ts, const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,                      \
+        float *__restrict__ acc, const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ header, uint32_t list_cap
+#define SGR_BWD_ARGS W, H, gx, T_tiles, tile_start, point_list, binning, blk_nb, rec, bg, final_Ts, n_contrib, dL_dpix, acc, tile_order, header, list_cap
+__global__ void __launch_bounds__(64) k_blend_bwd_w(SGR_BWD_PARAMS) { blend_bwd_body<false>(SGR_BWD_ARGS); }
+__global__ void __launch_bounds__(64) k_blend_bwd_wx(SGR_BWD_PARAMS) { blend_bwd_body<true>(SGR_BWD_ARGS); }  // exact alpha (SGR_BWD_HEAD_X)
 
 // Launch order of the backward: tiles by how deep the forward walked them (tile_maxc), deepest first, so that the waves still
 // running when the grid drains are the short ones.  (Workgroups start in index order; with ~2.5 dispatch rounds of waves whose
@@ -668,10 +954,10 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
                           uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
                           uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, const uint32_t* launch_order, hipStream_t s,
-                          uint32_t* repair_flag, uint32_t* repair_list)
+                          uint32_t* repair_flag, uint32_t* repair_list, int exact)
 {
     const int T = gx * gy;  // (tile_maxc and tile_walked were zeroed by the tile scan: the blocks of a tile combine with atomicMax)
-    hipLaunchKernelGGL(k_blend_fwd_w, dim3(sgr_blend_grid(T)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg, final_T,
+    hipLaunchKernelGGL(exact ? k_blend_fwd_wx : k_blend_fwd_w, dim3(sgr_blend_grid(T)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg, final_T,
                        n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap, tile_need, launch_order,
                        tile_need ? repair_flag : nullptr, repair_list);
 }
@@ -679,12 +965,12 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
 void sgr_launch_blend_fwd_repair(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                                  const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
                                  uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
-                                 uint32_t* header, uint32_t list_cap, const uint32_t* repair_list, hipStream_t s)
+                                 uint32_t* header, uint32_t list_cap, const uint32_t* repair_list, hipStream_t s, int exact)
 {
     const int T = gx * gy;
     const int cover = T < SGR_REPAIR_TILES ? T : SGR_REPAIR_TILES;
     // (T_tiles stays the tile count: it clamps the list's entries; the slots beyond the listed tiles leave at once)
-    hipLaunchKernelGGL(k_blend_fwd_repair, dim3(sgr_blend_grid(cover)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg,
+    hipLaunchKernelGGL(exact ? k_blend_fwd_repairx : k_blend_fwd_repair, dim3(sgr_blend_grid(cover)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg,
                        final_T, n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap, repair_list);
 }
 
@@ -710,7 +996,7 @@ void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
                           const char* binning, const uint32_t* blk_nb, const GeomRec* rec, const float* bg,
                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* acc,
                           const uint32_t* tile_maxc, const uint32_t* header, uint32_t list_cap, uint32_t* tile_order, int order_ready,
-                          hipStream_t s)
+                          hipStream_t s, int exact)
 {
     const int T = gx * gy;
     if (order_ready) {}                           // (the forward sorted: sgr_forward_opts.tile_order_out)
@@ -719,6 +1005,6 @@ void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
         SgrTileOrderJob job = {T, list_cap, tile_maxc, nullptr, header, tile_order, nullptr, nullptr, nullptr, 0.f, gx, gy};
         hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, job);
     }
-    hipLaunchKernelGGL(k_blend_bwd_w, dim3(sgr_blend_grid(T)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, binning, blk_nb, rec,
+    hipLaunchKernelGGL(exact ? k_blend_bwd_wx : k_blend_bwd_w, dim3(sgr_blend_grid(T)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, binning, blk_nb, rec,
                        bg, final_T, n_contrib, dL_dpix, acc, tile_order, header, list_cap);
 }

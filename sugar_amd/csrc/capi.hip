@@ -99,9 +99,19 @@ void SgrStageTimer::stop()
 // error reporting for the other translation units (mesh_raster.hip): same thread-local message as sgr_last_error()
 int sgr_fail(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 
+// process-wide default of the exact-alpha mode (include/sugar_raster.h: sgr_set_exact_alpha); SGR_EXACT_ALPHA=1 in the environment sets it
+static int g_exact_alpha = -1;
+int sgr_exact_alpha()
+{
+    if (g_exact_alpha < 0) { const char* e = getenv("SGR_EXACT_ALPHA"); g_exact_alpha = (e && e[0] && e[0] != '0') ? 1 : 0; }
+    return g_exact_alpha;
+}
+
 extern "C" {
 
 int sgr_abi_version(void) { return SGR_ABI_VERSION; }
+void sgr_set_exact_alpha(int on) { g_exact_alpha = on ? 1 : 0; }
+int sgr_get_exact_alpha(void) { return sgr_exact_alpha(); }
 
 const char* sgr_last_error(void) { return g_err.c_str(); }
 
@@ -163,6 +173,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     int64_t binning_capacity = opts->binning_capacity;
     const int flags = opts->flags;
     const int binning_mode = (flags & SGR_FLAG_SINGLE_LEVEL_BINNING) ? 1 : 0;
+    const int exact = (sgr_exact_alpha() || (flags & SGR_FLAG_EXACT_ALPHA)) ? 1 : 0;
     if (opts->tile_need && binning_mode == 1) return fail(SGR_E_INVALID, "the walk hint needs the two-level binning");
     if (P <= 0 || width <= 0 || height <= 0) return fail(SGR_E_INVALID, "P, width and height must be positive");
     if (!means3D || !opacities || !viewmatrix || !projmatrix || !background || !out_color)
@@ -293,7 +304,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
             SgrStageTimer t(s, SGR_STAGE_BLEND_FWD);
             sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
                                  tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, (uint32_t)R_, opts->tile_need,
-                                 opts->tile_order, s, hint_repair ? repair_flag : nullptr, repair_list);
+                                 opts->tile_order, s, hint_repair ? repair_flag : nullptr, repair_list, exact);
         }   // (that stage timer -- bench.py's roofline.launch_ms -- brackets k_blend_fwd_w alone; the two gated launches are a stage of their own)
         {
             SgrStageTimer t(s, SGR_STAGE_HINT_REPAIR);
@@ -305,7 +316,7 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
                 sgr_launch_bin2_write(IL.gx, IL.gy, B2, bin2, header + 4, n_chunks_, rects, order, tile_start, point_list,
                                       nosync_ ? (uint32_t)R_ : 0xFFFFFFFFu, repair_flag, s, header + SGR_HDR_REPAIR, 512u);
                 sgr_launch_blend_fwd_repair(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
-                                            tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, (uint32_t)R_, repair_list, s);
+                                            tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, (uint32_t)R_, repair_list, s, exact);
             }
         }
         if (flags & SGR_FLAG_DEFER_POST) {  // (the caller's next kernel carries the post-blend job: sgr_forward_post_job)
@@ -467,7 +478,8 @@ static int backward_impl(int phase, int P, int D, int M, int64_t R, const float*
                                  n_contrib, dL_dpix, acc, reinterpret_cast<const uint32_t*>(img_buffer + IL.tile_maxc),
                                  reinterpret_cast<const uint32_t*>(img_buffer + IL.header), (uint32_t)(R > 0xFFFFFFFFll ? 0xFFFFFFFFll : R),
                                  reinterpret_cast<uint32_t*>(img_buffer + IL.tile_cursor),
-                                 (opts && (opts->flags & SGR_BWD_TILE_ORDER_READY)) ? 1 : 0, s);
+                                 (opts && (opts->flags & SGR_BWD_TILE_ORDER_READY)) ? 1 : 0, s,
+                                 (sgr_exact_alpha() || (opts && (opts->flags & SGR_BWD_EXACT_ALPHA))) ? 1 : 0);
         }
         STAGE_CHECK("blend_bwd");
         if (phase == 1) {

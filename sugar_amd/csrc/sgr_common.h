@@ -222,14 +222,16 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
                           uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
                           uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, const uint32_t* launch_order, hipStream_t s,
-                          uint32_t* repair_flag = nullptr, uint32_t* repair_list = nullptr);
+                          uint32_t* repair_flag = nullptr, uint32_t* repair_list = nullptr, int exact = 0);
+// exact: the exact-alpha kernels (blend.hip: SGR_FWD_BODY_X); process-wide default sgr_exact_alpha() (capi.hip)
+int sgr_exact_alpha();
 // Walk-hint repair: the tiles the first pass listed (they outran their hint) once more, over their full lists (written meanwhile
 // by a list-write pass gated on the same count).  A no-op launch when the list is empty.
 #define SGR_REPAIR_TILES 1024
 void sgr_launch_blend_fwd_repair(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,
                                  const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
                                  uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
-                                 uint32_t* header, uint32_t list_cap, const uint32_t* repair_list, hipStream_t s);
+                                 uint32_t* header, uint32_t list_cap, const uint32_t* repair_list, hipStream_t s, int exact = 0);
 void sgr_launch_blend_fwd_post(int gx, int gy, const uint32_t* tile_maxc, const uint32_t* tile_walked, uint32_t* header, uint32_t list_cap,
                                uint32_t* tile_need_out, float hint_margin, uint32_t* header_host_dev, uint32_t* order_scratch,
                                uint32_t* order_out, hipStream_t s);
@@ -238,7 +240,7 @@ void sgr_launch_blend_bwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
                           const char* binning, const uint32_t* blk_nb, const GeomRec* rec, const float* bg,
                           const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, float* acc,
                           const uint32_t* tile_maxc, const uint32_t* header, uint32_t list_cap, uint32_t* tile_order, int order_ready,
-                          hipStream_t s);
+                          hipStream_t s, int exact = 0);
 // the post-blend bookkeeping as a job another kernel can carry (tile_order.h); capi.hip fills it for a forward that was run with
 // SGR_FLAG_DEFER_POST, loss.hip's forward kernel executes it in a spare workgroup
 struct SgrTileOrderJob;

@@ -146,21 +146,55 @@ def _product(scene, cam, bg, g, mode="sh"):
     return out
 
 
+_SCENES = {}
+
+
+def _config(config):
+    """(scene generation takes seconds at these sizes: every config is made once per session)"""
+    if config not in _SCENES:
+        _SCENES.clear()   # one at a time: config 5 alone is 6M Gaussians
+        _SCENES[config] = syn.make_config(config)
+    return _SCENES[config]
+
+
+# round 6: three cameras per backward config (one camera per case left the margin to the 1e-4 bar unprobed)
 @pytest.mark.parametrize("config,cam_id,backward,mode", [
-    ("config2", 0, True, "sh"), ("metric", 0, True, "sh"), ("metric", 5, True, "sh"), ("config3", 2, True, "sh"),
-    ("config5", 1, False, "sh"),
-    ("config4", 1, True, "sh"), ("config4", 6, True, "precomp"), ("config3", 4, True, "precomp"), ("config3", 6, True, "depth"),
-    ("metric", 3, True, "cov"), ("metric", 6, True, "scalemod")])
+    ("config2", 0, True, "sh"), ("config2", 3, True, "sh"), ("config2", 6, True, "sh"),
+    ("metric", 0, True, "sh"), ("metric", 5, True, "sh"), ("metric", 2, True, "sh"), ("metric", 7, True, "sh"),
+    ("metric", 3, True, "cov"), ("metric", 6, True, "scalemod"),
+    ("config3", 2, True, "sh"), ("config3", 0, True, "sh"), ("config3", 5, True, "sh"),
+    ("config3", 4, True, "precomp"), ("config3", 1, True, "precomp"), ("config3", 7, True, "precomp"), ("config3", 6, True, "depth"),
+    ("config4", 1, True, "sh"), ("config4", 4, True, "sh"), ("config4", 7, True, "sh"), ("config4", 6, True, "precomp"),
+    ("config5", 1, False, "sh")])
 def test_full_size_parity_with_the_reference(config, cam_id, backward, mode):
-    scene, cams, bg = syn.make_config(config)
+    _parity_case(config, cam_id, backward, mode, exact=False)
+
+
+@pytest.mark.parametrize("config,cam_id,mode", [
+    ("config2", 0, "sh"), ("metric", 5, "sh"), ("metric", 3, "cov"), ("config3", 2, "sh"), ("config3", 4, "precomp"), ("config3", 6, "depth"),
+    ("config4", 1, "sh")])
+def test_full_size_parity_in_exact_alpha_mode(config, cam_id, mode):
+    """sugar_amd.set_exact_alpha(True) (include/sugar_raster.h: SGR_FLAG_EXACT_ALPHA): alpha evaluated operation for operation as
+    forward.cu:333-347 / backward.cu:492-499 do -> transmittance, final_T and n_contrib BIT-IDENTICAL to the reference's kernels,
+    image to the last fused multiply-add, every gradient tensor <= 1e-5 norm-wise (the reference against itself: ~2e-6)."""
+    import sugar_amd
+    sugar_amd.set_exact_alpha(True)
+    try:
+        _parity_case(config, cam_id, True, mode, exact=True)
+    finally:
+        sugar_amd.set_exact_alpha(False)
+
+
+def _parity_case(config, cam_id, backward, mode, exact):
+    scene, cams, bg = _config(config)
     cam = cams[cam_id]
     H, W = cam.image_height, cam.image_width
     g = torch.randn(3, H, W, generator=torch.Generator().manual_seed(0)).to(DEV) if backward else None
     st, rg = _ref(scene, cam, bg, g, mode)
     rv = _ref_views(st)
     hp = _product(scene, cam, bg, g, mode)
-    rep = REPORT.setdefault(f"{config}/cam{cam_id}" + ("" if mode == "sh" else "/" + mode),
-                            dict(P=st["P"], W=W, H=H, num_rendered=st["R"], mode=mode))
+    rep = REPORT.setdefault(f"{config}/cam{cam_id}" + ("" if mode == "sh" else "/" + mode) + ("/exact_alpha" if exact else ""),
+                            dict(P=st["P"], W=W, H=H, num_rendered=st["R"], mode=mode, exact_alpha=exact))
     # ---- bit-exact part: tile assignment and depth order
     assert hp["R"] == st["R"]
     assert torch.equal(hp["radii"], st["radii"])
@@ -178,6 +212,9 @@ def test_full_size_parity_with_the_reference(config, cam_id, backward, mode):
     assert flips <= 1e-4, flips
     assert e["norm_rel"] <= 1e-5 and e["frac_gt_1e4"] <= 1e-3, e
     assert eT["norm_rel"] <= 1e-5 and eT["frac_gt_1e4"] <= 1e-3, eT
+    if exact:
+        assert torch.equal(hp["n_contrib"], rv["n_contrib"]) and torch.equal(hp["final_T"], rv["final_T"])   # bit for bit
+        assert e["norm_rel"] <= 5e-7, e   # (colours: fma(c, alpha T, C) here, (c alpha) T + C there -- the only difference left)
     if not backward:
         return
     # ---- gradients; the reference's own run-to-run spread (float atomics in an undefined order) beside them
@@ -190,7 +227,8 @@ def test_full_size_parity_with_the_reference(config, cam_id, backward, mode):
         e = stats(hp["grads"][k].reshape(ref.shape), ref)
         own = stats(rg2[n], ref)
         rep["grads"][k] = dict(product_vs_reference=e, reference_vs_itself=own)
-        if not (e["norm_rel"] <= 1e-4 and e["frac_gt_1e4"] <= 1e-3):
+        bar = 1e-5 if exact else 1e-4
+        if not (e["norm_rel"] <= bar and e["frac_gt_1e4"] <= 1e-3):
             bad.append((k, e, own))
     assert not bad, bad
 
