@@ -161,15 +161,16 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user,
  * finds that layout through the binning buffer's address, so the caller passes the returned count as usual.  Ignored with
  * SGR_FLAG_DEFER_POST.  sgr_forward_info.speculation reports hit / miss. */
 #define SGR_FLAG_SPECULATIVE 8
-/* SGR_FLAG_EXACT_ALPHA / SGR_BWD_EXACT_ALPHA / sgr_set_exact_alpha (round 6): the blend kernels evaluate alpha exactly as the
- * reference does -- `power` rounded operation by operation in the order of forward.cu:333 / backward.cu:492, G = expf(power)
- * by the device library's own two-term algorithm, test_T = T (1 - alpha) -- instead of the pre-scaled-conic + v_exp_f32 form.
- * alpha, T, final_T and n_contrib are then bit-identical to the reference's kernels (compiled without FP contraction) and every
- * gradient tensor agrees with them to the reference's own float-atomic noise (about 4e-6 norm-wise at BASELINE sizes, against
- * 5e-5 .. 8e-5 in the default mode, where alpha differs by ~1e-7 relative and the sums over a splat's pixels cancel heavily).
- * Price: 12 more vector instructions per (list entry, 8x8 block) in both blend kernels.  The default (off) meets the 1e-4 bar;
- * the mode is process-wide (sgr_set_exact_alpha, or SGR_EXACT_ALPHA=1 in the environment) or per call (the two flags).  Forward
- * and backward of one view should run in the same mode. */
+/* Exact alpha (round 6; THE DEFAULT): the blend kernels evaluate alpha exactly as the reference does -- `power` rounded
+ * operation by operation in the order of forward.cu:333 / backward.cu:492, G = expf(power) by the device library's own two-term
+ * algorithm, test_T = T (1 - alpha).  alpha, T, final_T and n_contrib are then bit-identical to the reference's kernels (compiled
+ * without FP contraction) and every gradient tensor agrees with them to the reference's own float-atomic noise (about 4e-6
+ * norm-wise at BASELINE sizes).  The alternative, sgr_set_exact_alpha(0) or SGR_EXACT_ALPHA=0 in the environment ("fast alpha"):
+ * conic pre-scaled by log2(e), two FMAs and one v_exp_f32 -- 12 fewer vector instructions per (list entry, 8x8 block), ~6 % of a
+ * train step -- evaluates alpha just as accurately but with other roundings (~1e-7 relative apart), and the sums over a splat's
+ * pixels cancel so heavily that this is 3e-5 .. 1.4e-4 norm-wise in dL/dscale and dL/drotation: around north_star's 1e-4 bar, over
+ * it for some cameras (profiles/r06_grad_switch_table.txt, profiles/r06_fullsize_parity_fast_alpha.json).  The mode is process-wide;
+ * SGR_FLAG_EXACT_ALPHA / SGR_BWD_EXACT_ALPHA force it on for one call.  Forward and backward of a view must run in the same mode. */
 #define SGR_FLAG_EXACT_ALPHA 16
 void sgr_set_exact_alpha(int on);
 int sgr_get_exact_alpha(void);
@@ -435,12 +436,22 @@ typedef struct sgr_train_exchange { /* phases 4 and 8 */
     const float* all_campos;     /* [n_views][3]; NULL: this view's campos */
     float grad_scale;            /* 1 / n_views: the mean over the views is folded into the Adam kernels */
     int step;                    /* 1-based Adam step (bias correction) */
+    /* round 6 -- the exchange in CHUNKS (each chunk's Adam launch starts as soon as ITS collective has landed):
+     * phase 4 over the Gaussians [g_begin, g_end) only (both 0: all P); all_colors / view_stride then describe the chunk's own
+     * block [n_views][view_stride][3] with row 0 = Gaussian g_begin.  g_begin must be a multiple of 64.
+     * phase 8 over the floats [f_begin, f_end) of the flat small-parameter range only (both 0: all n_small); multiples of 4. */
+    int64_t g_begin, g_end;
+    int64_t f_begin, f_end;
 } sgr_train_exchange;
 typedef struct sgr_trainer sgr_trainer;
 sgr_trainer* sgr_trainer_create(const sgr_train_config* cfg); /* copies cfg; NULL on a bad configuration (sgr_last_error) */
 void sgr_trainer_destroy(sgr_trainer* t);
 int sgr_trainer_set_binning(sgr_trainer* t, char* binning, size_t bytes, int64_t capacity); /* after a capacity overflow */
 int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* view, int phases, const sgr_train_exchange* ex, void* stream);
+/* chunks of the in-library exchange (sgr_trainer_step_exchange): the colour all-gather and the small all-reduce are cut into
+ * `n` pieces (1 <= n <= 16; default 1 -- sugar_amd.train_step.NativeTrainer sets 1 / 2 / 4 for 1 / 2 / more ranks), each followed
+ * by its own Adam launch.  Results are bit-identical for every n on one or two ranks. */
+int sgr_trainer_set_exchange_chunks(sgr_trainer* t, int n);
 /* Waits for the header copy of the most recent phase-1 call (the copy sits behind the forward's blend kernel) and returns
  * 1 if that forward was valid, 0 if the step was a no-op on the device and has to be repeated; header_out[16] (may be NULL)
  * receives the two header copies (word 0: the real num_rendered, word 3: hint miss, word 6: level-1 overflow). */

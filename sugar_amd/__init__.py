@@ -2,9 +2,10 @@
 
 
 def set_exact_alpha(on: bool = True) -> None:
-    """Exact-alpha mode of the blend kernels (include/sugar_raster.h: SGR_FLAG_EXACT_ALPHA): alpha, T, final_T and n_contrib
-    bit-identical to the reference's kernels, gradients within the reference's own float-atomic noise; ~12 more vector
-    instructions per (list entry, 8x8 block).  Off by default (the default meets north_star's 1e-4 bar); also SGR_EXACT_ALPHA=1."""
+    """Exact-alpha mode of the blend kernels (include/sugar_raster.h): alpha, T, final_T and n_contrib bit-identical to the
+    reference's kernels, gradients within the reference's own float-atomic noise.  ON by default.  `set_exact_alpha(False)` (or
+    SGR_EXACT_ALPHA=0 in the environment) selects the fast evaluation: ~6 % of a train step faster, gradients 3e-5 .. 1.4e-4
+    norm-wise from the reference's -- around north_star's 1e-4 bar, not safely inside it."""
     from . import _lib
     _lib.load().sgr_set_exact_alpha(1 if on else 0)
 

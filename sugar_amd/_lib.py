@@ -42,6 +42,7 @@ SIGNATURES = {
     "sgr_trainer_comm_destroy": (_i, [_vp]),
     "sgr_trainer_comm_abort": (_i, [_vp]),
     "sgr_trainer_step_exchange": (_i, [_vp, _vp, _i, _vp]),
+    "sgr_trainer_set_exchange_chunks": (_i, [_vp, _i]),
     "sgr_trainer_last_exchange_wait_ms": (C.c_double, [_vp]),
     "sgr_bin2_bytes": (_sz, [_i, _i, _i]),
     "sgr_sh_grad_from_views": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp]),
@@ -132,7 +133,8 @@ class TrainView(C.Structure):
 
 
 class TrainExchange(C.Structure):
-    _fields_ = [("n_views", _i), ("all_colors", _vp), ("view_stride", _i64), ("all_campos", _vp), ("grad_scale", _f), ("step", _i)]
+    _fields_ = [("n_views", _i), ("all_colors", _vp), ("view_stride", _i64), ("all_campos", _vp), ("grad_scale", _f), ("step", _i),
+                ("g_begin", _i64), ("g_end", _i64), ("f_begin", _i64), ("f_end", _i64)]
 
 
 SGR_FLAG_RAW_PARAMS, SGR_FLAG_SINGLE_LEVEL_BINNING, SGR_FLAG_SPECULATIVE = 1, 2, 8

@@ -99,11 +99,11 @@ void SgrStageTimer::stop()
 // error reporting for the other translation units (mesh_raster.hip): same thread-local message as sgr_last_error()
 int sgr_fail(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 
-// process-wide default of the exact-alpha mode (include/sugar_raster.h: sgr_set_exact_alpha); SGR_EXACT_ALPHA=1 in the environment sets it
+// process-wide exact-alpha mode (include/sugar_raster.h: sgr_set_exact_alpha): ON unless SGR_EXACT_ALPHA=0 is in the environment
 static int g_exact_alpha = -1;
 int sgr_exact_alpha()
 {
-    if (g_exact_alpha < 0) { const char* e = getenv("SGR_EXACT_ALPHA"); g_exact_alpha = (e && e[0] && e[0] != '0') ? 1 : 0; }
+    if (g_exact_alpha < 0) { const char* e = getenv("SGR_EXACT_ALPHA"); g_exact_alpha = (e && e[0] == '0') ? 0 : 1; }
     return g_exact_alpha;
 }
 

@@ -67,13 +67,6 @@ Rccl& rccl()
     return r;
 }
 
-// the camera centres of all views, row P of every rank's block of the gathered buffer, as one [world, 3] array
-__global__ void k_gather_campos(int world, size_t block_floats, size_t row_offset, const float* __restrict__ recv, float* __restrict__ out)
-{
-    const int i = threadIdx.x;
-    if (i < 3 * world) out[i] = recv[(size_t)(i / 3) * block_floats + row_offset + (size_t)(i % 3)];
-}
-
 }  // namespace
 
 struct sgr_trainer {
@@ -82,7 +75,9 @@ struct sgr_trainer {
     RcclComm comm = nullptr;
     int world = 1, rank = 0;
     hipStream_t comm_stream = nullptr;
-    hipEvent_t ev_colors = nullptr, ev_gathered = nullptr, ev_small = nullptr, ev_reduced = nullptr;
+    hipEvent_t ev_colors = nullptr, ev_small = nullptr;
+    int chunks = 1;                                   // pieces of the colour all-gather / the small all-reduce (sgr_trainer_set_exchange_chunks)
+    hipEvent_t ev_gathered[16] = {}, ev_reduced[16] = {};  // piece k has landed
     float* recv = nullptr;        // caller's buffer: world x (P + 1) x 3 floats
     float* campos_all = nullptr;  // world x 3 floats (owned)
     double last_wait_ms = 0.0;    // what the last sgr_trainer_step_exchange spent waiting for the forward's header
@@ -239,16 +234,28 @@ int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* v, int phases, const 
             const float* cams = ex->all_campos ? ex->all_campos : (ex->all_colors ? nullptr : c.colors + 3 * (size_t)P);
             if (!cams) return tfail(SGR_E_INVALID, "sgr_trainer_step: all_campos missing");
             const size_t stride = (size_t)(ex->view_stride ? ex->view_stride : (ex->all_colors ? P : P + 1));
+            // a chunk of the Gaussians (the exchange in pieces): the colour block starts at the chunk's first Gaussian
+            const bool part = ex->g_end > ex->g_begin;
+            const long long g0 = part ? ex->g_begin : 0, g1 = part ? ex->g_end : P;
+            if (g0 < 0 || g1 > P || (g0 & 63)) return tfail(SGR_E_INVALID, "sgr_trainer_step: bad Gaussian range (g_begin must be a multiple of 64)");
+            if (part && !ex->all_colors) cols += 3 * (size_t)g0;
+            const size_t fo = (size_t)g0 * 3 * (size_t)c.M;
             SgrStageTimer tm(s, SGR_STAGE_SH_ADAM);
-            sgr_launch_sh_adam_from_views(P, ex->n_views, c.D, c.M, stride, means3D, cams, cols, flat + c.off_features,
-                                          c.exp_avg + c.off_features, c.exp_avg_sq + c.off_features, c.lr_features_dc,
-                                          c.lr_features_rest, c.beta1, c.beta2, c.eps, bc1, bc2_sqrt, ex->grad_scale, nullptr, s, header, cap);
+            sgr_launch_sh_adam_from_views((int)(g1 - g0), ex->n_views, c.D, c.M, stride, means3D + 3 * (size_t)g0, cams, cols,
+                                          flat + c.off_features + fo, c.exp_avg + c.off_features + fo, c.exp_avg_sq + c.off_features + fo,
+                                          c.lr_features_dc, c.lr_features_rest, c.beta1, c.beta2, c.eps, bc1, bc2_sqrt, ex->grad_scale, nullptr, s,
+                                          header, cap);
             tm.stop();
             if (hipGetLastError() != hipSuccess) return tfail(SGR_E_HIP, "sh_adam launch failed");
         }
         if (phases & 8) {
+            const bool part = ex->f_end > ex->f_begin;
+            const long long f0 = part ? ex->f_begin : 0, f1 = part ? ex->f_end : c.n_small;
+            if (f0 < 0 || f1 > c.n_small || (f0 & 3)) return tfail(SGR_E_INVALID, "sgr_trainer_step: bad float range (f_begin must be a multiple of 4)");
+            long long sb[4], se[4];
+            for (int k = 0; k < 4; k++) { sb[k] = t->seg_begin[k] - f0; se[k] = t->seg_end[k] - f0; }  // (the launch indexes from its own base)
             SgrStageTimer tm(s, SGR_STAGE_ADAM);
-            const int rc = sgr_adam_launch(c.n_small, flat, grad, c.exp_avg, c.exp_avg_sq, 4, t->seg_begin, t->seg_end, t->seg_lr, t->seg_lr,
+            const int rc = sgr_adam_launch(f1 - f0, flat + f0, grad + f0, c.exp_avg + f0, c.exp_avg_sq + f0, 4, sb, se, t->seg_lr, t->seg_lr,
                                            t->seg_one, t->seg_one, c.beta1, c.beta2, c.eps, ex->step, ex->grad_scale, nullptr, 0, header,
                                            cap, s);
             tm.stop();
@@ -278,7 +285,6 @@ int sgr_trainer_comm_init(sgr_trainer* t, const char* id128, int world, int rank
     if (recv_bytes < (size_t)world * ((size_t)t->c.P + 1) * 3 * sizeof(float))
         return tfail(SGR_E_INVALID, "sgr_trainer_comm_init: receive buffer smaller than world x (P + 1) x 3 floats");
     if (t->comm) return tfail(SGR_E_INVALID, "sgr_trainer_comm_init: already initialised");
-    if (world > 85) return tfail(SGR_E_INVALID, "sgr_trainer_comm_init: at most 85 ranks (k_gather_campos gathers 3 x world floats in one workgroup)");
     Rccl& r = rccl();
     if (!r.ok()) return tfail(SGR_E_INVALID, "RCCL could not be loaded (librccl.so)");
     RcclUniqueId id;
@@ -287,8 +293,11 @@ int sgr_trainer_comm_init(sgr_trainer* t, const char* id128, int world, int rank
     if (rc != 0) { t->comm = nullptr; return tfail(SGR_E_HIP, std::string("ncclCommInitRank: ") + (r.GetErrorString ? r.GetErrorString(rc) : "failed")); }
     t->world = world; t->rank = rank; t->recv = recv;
     bool ok = hipStreamCreateWithFlags(&t->comm_stream, hipStreamNonBlocking) == hipSuccess;
-    for (hipEvent_t* e : {&t->ev_colors, &t->ev_gathered, &t->ev_small, &t->ev_reduced})
+    for (hipEvent_t* e : {&t->ev_colors, &t->ev_small})
         ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < 16; k++)
+        ok = ok && hipEventCreateWithFlags(&t->ev_gathered[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&t->ev_reduced[k], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&t->campos_all), (size_t)world * 3 * sizeof(float)) == hipSuccess;
     if (!ok) { (void)sgr_trainer_comm_destroy(t); return tfail(SGR_E_HIP, "sgr_trainer_comm_init: stream / event / buffer creation failed"); }
     return 0;
@@ -307,13 +316,23 @@ int sgr_trainer_comm_abort(sgr_trainer* t)
 
 double sgr_trainer_last_exchange_wait_ms(sgr_trainer* t) { return t ? t->last_wait_ms : 0.0; }
 
+int sgr_trainer_set_exchange_chunks(sgr_trainer* t, int n)
+{
+    if (!t || n < 1 || n > 16) return tfail(SGR_E_INVALID, "sgr_trainer_set_exchange_chunks: 1 <= n <= 16");
+    t->chunks = n;
+    return 0;
+}
+
 int sgr_trainer_comm_destroy(sgr_trainer* t)
 {
     if (!t) return 0;
     if (t->comm_stream) (void)hipStreamSynchronize(t->comm_stream);
     if (t->comm) { (void)rccl().CommDestroy(t->comm); t->comm = nullptr; }
-    for (hipEvent_t* e : {&t->ev_colors, &t->ev_gathered, &t->ev_small, &t->ev_reduced})
+    for (hipEvent_t* e : {&t->ev_colors, &t->ev_small})
         if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+    for (int k = 0; k < 16; k++)
+        for (hipEvent_t* e : {&t->ev_gathered[k], &t->ev_reduced[k]})
+            if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
     if (t->comm_stream) { (void)hipStreamDestroy(t->comm_stream); t->comm_stream = nullptr; }
     if (t->campos_all) { (void)hipFree(t->campos_all); t->campos_all = nullptr; }
     t->world = 1; t->rank = 0; t->recv = nullptr;
@@ -333,7 +352,7 @@ int sgr_trainer_step_exchange(sgr_trainer* t, const sgr_train_view* v, int step,
     Rccl& r = rccl();
     hipStream_t s = (hipStream_t)stream;
     const sgr_train_config& c = t->c;
-    const size_t P = (size_t)c.P, block = (P + 1) * 3;
+    const size_t P = (size_t)c.P;
     int rc = sgr_trainer_step(t, v, 1, nullptr, stream);
     if (rc < 0) return rc;
     uint32_t hdr[16];
@@ -346,29 +365,61 @@ int sgr_trainer_step_exchange(sgr_trainer* t, const sgr_train_view* v, int step,
     do {                                                                                       \
         if ((expr) != hipSuccess) return tfail(SGR_E_HIP, std::string(what) + ": HIP call failed"); \
     } while (0)
+    // The exchange in `chunks` pieces (round 6).  Communication stream, in order: the camera centres (3 floats per rank), the colour
+    // gradients of Gaussian chunk 0 .. C-1 (each rank's piece lands in the chunk's own [world][len][3] block of `recv`), then -- once
+    // the preprocess half has produced them -- the 11 small floats per Gaussian as C slices of the flat gradient buffer (in place).
+    // Compute stream: preprocess half, then SH-Adam of chunk k behind ITS gather, then flat Adam of slice j behind ITS reduction.
+    // Only the first piece of each collective and whatever the wire cannot hide is exposed (DESIGN.md section 6 has the model).
+    const int C = t->chunks;
+    auto g_at = [&](int k) { return k >= C ? P : (k <= 0 ? (size_t)0 : (P * (size_t)k / (size_t)C) & ~(size_t)255); };
+    const size_t NS = (size_t)c.n_small;
+    auto f_at = [&](int k) { return k >= C ? NS : (k <= 0 ? (size_t)0 : (NS * (size_t)k / (size_t)C) & ~(size_t)1023); };
+#define NCCL_TRY(expr, what)                                                                                            \
+    do {                                                                                                                \
+        const int nrc_ = (expr);                                                                                        \
+        if (nrc_ != 0) return tfail(SGR_E_HIP, std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(nrc_) : "failed")); \
+    } while (0)
     EX_TRY(hipEventRecord(t->ev_colors, s), "record colours");
     EX_TRY(hipStreamWaitEvent(t->comm_stream, t->ev_colors, 0), "wait colours");
-    int nrc = r.AllGather(c.colors, t->recv, block, RCCL_FLOAT, t->comm, t->comm_stream);
-    if (nrc != 0) return tfail(SGR_E_HIP, std::string("ncclAllGather: ") + (r.GetErrorString ? r.GetErrorString(nrc) : "failed"));
-    EX_TRY(hipEventRecord(t->ev_gathered, t->comm_stream), "record gathered");
+    NCCL_TRY(r.AllGather(c.colors + 3 * P, t->campos_all, 3, RCCL_FLOAT, t->comm, t->comm_stream), "ncclAllGather (camera centres)");
+    for (int k = 0; k < C; k++) {
+        const size_t g0 = g_at(k), g1 = g_at(k + 1);
+        if (g1 > g0)
+            NCCL_TRY(r.AllGather(c.colors + 3 * g0, t->recv + 3 * (size_t)t->world * g0, 3 * (g1 - g0), RCCL_FLOAT, t->comm, t->comm_stream),
+                     "ncclAllGather (colour gradients)");
+        EX_TRY(hipEventRecord(t->ev_gathered[k], t->comm_stream), "record gathered");
+    }
     rc = sgr_trainer_step(t, v, 2, nullptr, stream);
     if (rc < 0) return rc;
     EX_TRY(hipEventRecord(t->ev_small, s), "record small gradients");
     EX_TRY(hipStreamWaitEvent(t->comm_stream, t->ev_small, 0), "wait small gradients");
-    nrc = r.AllReduce(c.flat_grad, c.flat_grad, (size_t)c.n_small, RCCL_FLOAT, RCCL_SUM, t->comm, t->comm_stream);
-    if (nrc != 0) return tfail(SGR_E_HIP, std::string("ncclAllReduce: ") + (r.GetErrorString ? r.GetErrorString(nrc) : "failed"));
-    EX_TRY(hipEventRecord(t->ev_reduced, t->comm_stream), "record reduced");
-    EX_TRY(hipStreamWaitEvent(s, t->ev_gathered, 0), "wait gathered");
-    hipLaunchKernelGGL(k_gather_campos, dim3(1), dim3(256), 0, s, t->world, block, 3 * P, t->recv, t->campos_all);
+    for (int k = 0; k < C; k++) {
+        const size_t f0 = f_at(k), f1 = f_at(k + 1);
+        if (f1 > f0)
+            NCCL_TRY(r.AllReduce(c.flat_grad + f0, c.flat_grad + f0, f1 - f0, RCCL_FLOAT, RCCL_SUM, t->comm, t->comm_stream), "ncclAllReduce");
+        EX_TRY(hipEventRecord(t->ev_reduced[k], t->comm_stream), "record reduced");
+    }
     sgr_train_exchange ex;
     std::memset(&ex, 0, sizeof(ex));
-    ex.n_views = t->world; ex.all_colors = t->recv; ex.view_stride = (int64_t)(P + 1); ex.all_campos = t->campos_all;
-    ex.grad_scale = 1.0f / (float)t->world; ex.step = step;
-    rc = sgr_trainer_step(t, v, 4, &ex, stream);
-    if (rc < 0) return rc;
-    EX_TRY(hipStreamWaitEvent(s, t->ev_reduced, 0), "wait reduced");
-    rc = sgr_trainer_step(t, v, 8, &ex, stream);
-    if (rc < 0) return rc;
+    ex.n_views = t->world; ex.all_campos = t->campos_all; ex.grad_scale = 1.0f / (float)t->world; ex.step = step;
+    for (int k = 0; k < C; k++) {
+        const size_t g0 = g_at(k), g1 = g_at(k + 1);
+        EX_TRY(hipStreamWaitEvent(s, t->ev_gathered[k], 0), "wait gathered");
+        if (g1 <= g0) continue;
+        ex.all_colors = t->recv + 3 * (size_t)t->world * g0; ex.view_stride = (int64_t)(g1 - g0);
+        ex.g_begin = (int64_t)g0; ex.g_end = (int64_t)g1;
+        rc = sgr_trainer_step(t, v, 4, &ex, stream);
+        if (rc < 0) return rc;
+    }
+    for (int k = 0; k < C; k++) {
+        const size_t f0 = f_at(k), f1 = f_at(k + 1);
+        EX_TRY(hipStreamWaitEvent(s, t->ev_reduced[k], 0), "wait reduced");
+        if (f1 <= f0) continue;
+        ex.f_begin = (int64_t)f0; ex.f_end = (int64_t)f1;
+        rc = sgr_trainer_step(t, v, 8, &ex, stream);
+        if (rc < 0) return rc;
+    }
+#undef NCCL_TRY
 #undef EX_TRY
     return 0;
 }

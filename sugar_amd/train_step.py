@@ -588,6 +588,9 @@ class NativeTrainer:
         P, M = params.P, params.M
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.exchange = self.world > 1 or (bool(force_collectives) and dist.is_available() and dist.is_initialized())
+        # pieces of the colour all-gather / small all-reduce (`set_exchange_chunks`; any value gives the same bits): every piece costs
+        # two launches and an event wait, and on one or two ranks there is next to nothing on the wire to hide behind them
+        self.exchange_chunks = 1 if self.world <= 1 else (2 if self.world == 2 else 4)
         self.walk_hint = bool(walk_hint)
         self.launch_order = bool(launch_order)  # sgr_forward_opts.tile_order: the blend kernels start with the deepest tiles
         import os as _os
@@ -615,11 +618,14 @@ class NativeTrainer:
         self._h = None
         self._allocate()
         # The gradient exchange inside the library (sgr_trainer_step_exchange: RCCL bound at run time, collectives on the library's own
-        # stream, ONE call per step, no interpreter between the phases).  Opt-in (`native_collectives=True` or SGR_NATIVE_COLLECTIVES=1)
-        # and only with the RCCL backend: it could be exercised with one rank only on the one-GPU test boxes, so the torch.distributed
-        # path -- tested with two ranks over gloo -- stays the default for the driver's multi-GPU runs.
+        # stream, ONE call per step, no interpreter between the phases).  Round 6: the DEFAULT with the RCCL backend on several ranks
+        # (measured on one rank with forced collectives: 0.10 ms of exchange overhead per step against 0.28 ms for the
+        # torch.distributed path, whose ten phase calls per step the host cannot enqueue inside the 0.27 ms the GPU still has queued
+        # when the forward's header arrives); `native_collectives=False` or SGR_NATIVE_COLLECTIVES=0 selects the torch.distributed
+        # path (the one the two-rank gloo tests exercise; same plan, same kernels, same bits).
         if native_collectives is None:
-            native_collectives = _os.environ.get("SGR_NATIVE_COLLECTIVES", "0") == "1"
+            env = _os.environ.get("SGR_NATIVE_COLLECTIVES")
+            native_collectives = (env == "1") if env is not None else (self.exchange and self.world > 1 and dist.get_backend() == "nccl")
         self.native_collectives = False
         if native_collectives and self.exchange:
             if dist.get_backend() != "nccl":
@@ -634,6 +640,16 @@ class NativeTrainer:
             if rc < 0:
                 raise RuntimeError("sgr_trainer_comm_init failed: " + lib.sgr_trainer_last_error().decode(errors="replace"))
             self.native_collectives = True
+            lib.sgr_trainer_set_exchange_chunks(self._h, self.exchange_chunks)
+
+    def set_exchange_chunks(self, n: int):
+        """pieces of the gradient exchange (1 .. 16); the results do not depend on it (on one or two ranks: bit for bit)"""
+        n = int(n)
+        if not 1 <= n <= 16:
+            raise ValueError("exchange chunks: 1 .. 16")
+        self.exchange_chunks = n
+        if getattr(self, "native_collectives", False) and self._lib.sgr_trainer_set_exchange_chunks(self._h, n) < 0:
+            raise RuntimeError("sgr_trainer_set_exchange_chunks failed")
 
     def _allocate(self):
         """everything sized by the Gaussian count, and the library handle over it (construction, and again after `resize`)"""
@@ -648,7 +664,8 @@ class NativeTrainer:
         self._grad_image = torch.empty(3, self.H, self.W, device=dev)
         self.loss_out = torch.zeros(3, device=dev)
         self._send = torch.zeros(P + 1, 3, device=dev)
-        self._recv = torch.empty(self.world * (P + 1), 3, device=dev) if self.exchange else None
+        self._recv = torch.empty(self.world * (P + 1), 3, device=dev) if self.exchange else None   # chunk k: its own [world][len_k][3] block
+        self._cams_all = torch.empty(self.world, 3, device=dev) if self.exchange else None          # every view's camera centre
         self.radii = torch.zeros(P, dtype=torch.int32, device=dev)
         if self.densify_stats:  # gaussian_model.py:125-127 / sugar_densifier.py:152-154
             self.viewspace_grad = torch.zeros(P, 3, device=dev)
@@ -885,15 +902,44 @@ class NativeTrainer:
             if not (R or missed):
                 raise RuntimeError("level-1 binning overflow: this view needs the single-level binning (use ViewShardedTrainer)")
             self._repair(key, R, missed)
-        work = dist.all_gather_into_tensor(self._recv, self._send, async_op=True)  # colours + camera centre: one collective
+        # The exchange in `exchange_chunks` pieces (round 6; the same plan as sgr_trainer_step_exchange, csrc/train.hip): the camera
+        # centres, then the colour gradients of Gaussian chunk 0 .. C-1 -- each into the chunk's own [world][len][3] block of the
+        # receive buffer -- beside the preprocess half; then the 11 small floats per Gaussian as C slices of the flat gradient
+        # buffer beside the SH half of Adam.  SH-Adam of chunk k is enqueued behind ITS gather, flat Adam of slice j behind ITS
+        # reduction: only the first piece of each collective (and whatever the wire cannot hide) is exposed.
+        C = self.exchange_chunks
+        n_small = self.params.n_small
+        g_at = lambda k: P if k >= C else (0 if k <= 0 else (P * k // C) & ~255)
+        f_at = lambda k: n_small if k >= C else (0 if k <= 0 else (n_small * k // C) & ~1023)
+        send, recv = self._send.view(-1), self._recv.view(-1)
+        w_cam = dist.all_gather_into_tensor(self._cams_all.view(-1), send[3 * P: 3 * P + 3], async_op=True)
+        gathers = []
+        for k in range(C):
+            g0, g1 = g_at(k), g_at(k + 1)
+            gathers.append(dist.all_gather_into_tensor(recv[3 * world * g0: 3 * world * g1], send[3 * g0: 3 * g1], async_op=True)
+                           if g1 > g0 else None)
         self._call(cam, gt_image, key, 2, None)
-        small = dist.all_reduce(self.params.flat_grad[: self.params.n_small], op=dist.ReduceOp.SUM, async_op=True)
-        work.wait()
-        cams = self._recv.view(world, P + 1, 3)[:, P].contiguous()
-        ex = self._L.TrainExchange(world, self._recv.data_ptr(), P + 1, cams.data_ptr(), 1.0 / world, self.t)
-        self._call(cam, gt_image, key, 4, ex)
-        small.wait()
-        self._call(cam, gt_image, key, 8, ex)
+        fg = self.params.flat_grad
+        reduces = []
+        for k in range(C):
+            f0, f1 = f_at(k), f_at(k + 1)
+            reduces.append(dist.all_reduce(fg[f0:f1], op=dist.ReduceOp.SUM, async_op=True) if f1 > f0 else None)
+        w_cam.wait()
+        for k in range(C):
+            g0, g1 = g_at(k), g_at(k + 1)
+            if gathers[k] is None:
+                continue
+            gathers[k].wait()
+            ex = self._L.TrainExchange(world, self._recv.data_ptr() + 12 * world * g0, g1 - g0, self._cams_all.data_ptr(), 1.0 / world, self.t,
+                                       g0, g1, 0, 0)
+            self._call(cam, gt_image, key, 4, ex)
+        for k in range(C):
+            f0, f1 = f_at(k), f_at(k + 1)
+            if reduces[k] is None:
+                continue
+            reduces[k].wait()
+            ex = self._L.TrainExchange(world, None, 0, self._cams_all.data_ptr(), 1.0 / world, self.t, 0, 0, f0, f1)
+            self._call(cam, gt_image, key, 8, ex)
         return self.loss_out[0]
 
     def synchronize(self):

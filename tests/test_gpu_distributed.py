@@ -67,7 +67,7 @@ def test_two_ranks_densify_identically(tmp_path):
     assert np.array_equal(r[0]["flat"], r[1]["flat"]) and np.array_equal(r[0]["m1"], r[1]["m1"]), "replicas diverged across the densification"
 
 
-def _worker(rank, world, port, out_dir, native=False):
+def _worker(rank, world, port, out_dir, native=False, chunks=None):
     from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     from sugar_amd.train_step import GaussianParams, NativeTrainer, ViewShardedTrainer
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -78,6 +78,8 @@ def _worker(rank, world, port, out_dir, native=False):
     if native:
         tr = NativeTrainer(params, torch.zeros(3), W, H, capacity=50000 if rank == 1 else None)  # rank 1 starts too small
         assert tr.exchange and tr.world == world
+        if chunks:
+            tr.set_exchange_chunks(chunks)   # (default 4: SH-Adam / Adam of a piece start behind that piece's collective)
         for s in range(STEPS):
             k = (s * world + rank) % len(cams)
             tr.step(cams[k], gts[k], cam_key=k)
@@ -98,14 +100,15 @@ def _worker(rank, world, port, out_dir, native=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("native", [False, True])
+@pytest.mark.parametrize("native", [False, True, 1, 7])
 def test_two_ranks_match_sequential_accumulation(tmp_path, native):
     """native=True: the same exchange driven by NativeTrainer (sgr_trainer_step in its four phases, the collectives between
     them); rank 1 starts with a list capacity that is too small and must repair it BEFORE anything is sent."""
     from sugar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     from sugar_amd.train_step import GaussianParams, render, train_loss
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), native), nprocs=world, join=True)
+    chunks = native if (native is not True and native is not False) else None   # (1: one collective each; 7: ragged pieces)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), bool(native), chunks), nprocs=world, join=True)
     flats = [np.load(tmp_path / f"flat_{r}.npy") for r in range(world)]
     assert np.array_equal(flats[0], flats[1]), "replicas diverged"
     # single-process reference: plain autograd accumulation of the same views, mean gradient, one flat Adam step per batch
@@ -190,6 +193,15 @@ def _rccl_worker(rank, world, port, out_dir):
     assert nl.redone >= 1
     np.save(os.path.join(out_dir, "rccl_native_in_library.npy"), pl.flat.detach().cpu().numpy())
     del nl
+    # ... the same with ONE piece per collective (the default is four)
+    p1 = GaussianParams(scene, dev)
+    n1 = NativeTrainer(p1, torch.zeros(3), W, H, force_collectives=True, native_collectives=True)
+    n1.set_exchange_chunks(1)
+    for s in range(3):
+        n1.step(cams[s % len(cams)], gts[s % len(cams)], cam_key=s)
+    n1.synchronize()
+    np.save(os.path.join(out_dir, "rccl_native_in_library_one_piece.npy"), p1.flat.detach().cpu().numpy())
+    del n1
     np.save(os.path.join(out_dir, "rccl_forced.npy"), flats[True])
     np.save(os.path.join(out_dir, "rccl_plain.npy"), flats[False])
     np.save(os.path.join(out_dir, "rccl_flat_exchange.npy"), params.flat.detach().cpu().numpy())
@@ -199,12 +211,50 @@ def _rccl_worker(rank, world, port, out_dir):
 def test_single_rank_rccl_group_runs_the_collective_path(tmp_path):
     scene = syn.make_scene(P, 17, 0.01, 0.08)
     mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
-    a, b, c, d, e = (np.load(tmp_path / f"rccl_{n}.npy") for n in ("forced", "plain", "flat_exchange", "native", "native_in_library"))
+    a, b, c, d, e, f = (np.load(tmp_path / f"rccl_{n}.npy") for n in ("forced", "plain", "flat_exchange", "native", "native_in_library",
+                                                                      "native_in_library_one_piece"))
     from sugar_amd.train_step import GaussianParams
     start = GaussianParams(scene, torch.device("cuda:0")).flat.detach().cpu().numpy()
     upd = np.abs(b - start).max()
     assert upd > 1e-4
-    for other in (a, c, d, e):
+    for other in (a, c, d, e, f):
         # (float atomics in the blend backward: the sign of a near-zero gradient may flip a +-lr Adam step)
         assert float((np.abs(other - b) > 1e-2 * upd).mean()) < 1e-4
         assert float(np.linalg.norm(other - b) / np.linalg.norm(b - start)) < 1e-3
+
+
+def test_the_optimiser_phases_in_pieces_equal_the_whole_bit_for_bit():
+    """The exchange runs in pieces (sgr_train_exchange.g_begin/g_end, f_begin/f_end): SH-Adam over a Gaussian range, flat Adam over
+    a float range.  On the SAME gradients the pieces must reproduce the whole bit for bit (the kernels are per-element; the blend
+    backward's float atomics are kept out of the comparison by running both from one snapshot)."""
+    from sugar_amd import _lib
+    from sugar_amd.train_step import GaussianParams, NativeTrainer
+    dev = torch.device("cuda:0")
+    scene, cams, gts = _setup(dev)
+    params = GaussianParams(scene, dev)
+    tr = NativeTrainer(params, torch.zeros(3), W, H)
+    for s in range(2):
+        tr.step(cams[s], gts[s], cam_key=s)
+    tr.synchronize()                      # gradients and colour gradients of the last step are in the trainer's buffers
+    snap = (params.flat.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone())
+    n_small, Pn = params.n_small, params.P
+
+    def run(pieces):
+        with torch.no_grad():
+            params.flat.copy_(snap[0]); tr.exp_avg.copy_(snap[1]); tr.exp_avg_sq.copy_(snap[2])
+        g_at = lambda k: Pn if k >= pieces else (Pn * k // pieces) & ~255
+        f_at = lambda k: n_small if k >= pieces else (n_small * k // pieces) & ~1023
+        for k in range(pieces):
+            if g_at(k + 1) > g_at(k):
+                tr._call(cams[1], gts[1], 1, 4, _lib.TrainExchange(1, None, 0, None, 1.0, 3, g_at(k), g_at(k + 1), 0, 0))
+        for k in range(pieces):
+            if f_at(k + 1) > f_at(k):
+                tr._call(cams[1], gts[1], 1, 8, _lib.TrainExchange(1, None, 0, None, 1.0, 3, 0, 0, f_at(k), f_at(k + 1)))
+        torch.cuda.synchronize()
+        return params.flat.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone()
+    whole = run(1)
+    assert not torch.equal(whole[0], snap[0])
+    for pieces in (4, 7, 16):
+        got = run(pieces)
+        for a, b in zip(whole, got):
+            assert torch.equal(a, b), pieces

@@ -167,22 +167,27 @@ def _config(config):
     ("config4", 1, True, "sh"), ("config4", 4, True, "sh"), ("config4", 7, True, "sh"), ("config4", 6, True, "precomp"),
     ("config5", 1, False, "sh")])
 def test_full_size_parity_with_the_reference(config, cam_id, backward, mode):
-    _parity_case(config, cam_id, backward, mode, exact=False)
+    """The product's default: alpha evaluated operation for operation as forward.cu:333-347 / backward.cu:492-499 do (exact-alpha
+    mode, include/sugar_raster.h) -> transmittance, final_T and n_contrib BIT-IDENTICAL to the reference's kernels, the image to the
+    last fused multiply-add, every gradient tensor <= 1e-5 norm-wise (the reference against itself: ~2e-6)."""
+    import sugar_amd
+    assert sugar_amd.exact_alpha()
+    _parity_case(config, cam_id, backward, mode, exact=True)
 
 
 @pytest.mark.parametrize("config,cam_id,mode", [
-    ("config2", 0, "sh"), ("metric", 5, "sh"), ("metric", 3, "cov"), ("config3", 2, "sh"), ("config3", 4, "precomp"), ("config3", 6, "depth"),
+    ("config2", 0, "sh"), ("metric", 5, "sh"), ("metric", 3, "cov"), ("config3", 2, "sh"), ("config3", 5, "sh"), ("config3", 4, "precomp"),
     ("config4", 1, "sh")])
-def test_full_size_parity_in_exact_alpha_mode(config, cam_id, mode):
-    """sugar_amd.set_exact_alpha(True) (include/sugar_raster.h: SGR_FLAG_EXACT_ALPHA): alpha evaluated operation for operation as
-    forward.cu:333-347 / backward.cu:492-499 do -> transmittance, final_T and n_contrib BIT-IDENTICAL to the reference's kernels,
-    image to the last fused multiply-add, every gradient tensor <= 1e-5 norm-wise (the reference against itself: ~2e-6)."""
+def test_full_size_parity_in_fast_alpha_mode(config, cam_id, mode):
+    """sugar_amd.set_exact_alpha(False): the pre-scaled-conic + v_exp_f32 evaluation of alpha (rounds 1-5).  Same lists, image within
+    1e-5 -- but dL/dscale and dL/drotation 3e-5 .. 1.4e-4 norm-wise from the reference's (config 3, camera 5: 1.39e-4): the sums over
+    a splat's pixels amplify alpha's last bit.  That is why it is no longer the default; the bar here is 2e-4."""
     import sugar_amd
-    sugar_amd.set_exact_alpha(True)
+    sugar_amd.set_exact_alpha(False)
     try:
-        _parity_case(config, cam_id, True, mode, exact=True)
+        _parity_case(config, cam_id, True, mode, exact=False)
     finally:
-        sugar_amd.set_exact_alpha(False)
+        sugar_amd.set_exact_alpha(True)
 
 
 def _parity_case(config, cam_id, backward, mode, exact):
@@ -193,7 +198,7 @@ def _parity_case(config, cam_id, backward, mode, exact):
     st, rg = _ref(scene, cam, bg, g, mode)
     rv = _ref_views(st)
     hp = _product(scene, cam, bg, g, mode)
-    rep = REPORT.setdefault(f"{config}/cam{cam_id}" + ("" if mode == "sh" else "/" + mode) + ("/exact_alpha" if exact else ""),
+    rep = REPORT.setdefault(f"{config}/cam{cam_id}" + ("" if mode == "sh" else "/" + mode) + ("" if exact else "/fast_alpha"),
                             dict(P=st["P"], W=W, H=H, num_rendered=st["R"], mode=mode, exact_alpha=exact))
     # ---- bit-exact part: tile assignment and depth order
     assert hp["R"] == st["R"]
@@ -227,8 +232,8 @@ def _parity_case(config, cam_id, backward, mode, exact):
         e = stats(hp["grads"][k].reshape(ref.shape), ref)
         own = stats(rg2[n], ref)
         rep["grads"][k] = dict(product_vs_reference=e, reference_vs_itself=own)
-        bar = 1e-5 if exact else 1e-4
-        if not (e["norm_rel"] <= bar and e["frac_gt_1e4"] <= 1e-3):
+        bar = 1e-5 if exact else 2e-4
+        if not (e["norm_rel"] <= bar and e["frac_gt_1e4"] <= (1e-3 if exact else 3e-3)):
             bad.append((k, e, own))
     assert not bad, bad
 
