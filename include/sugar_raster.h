@@ -551,6 +551,24 @@ int sgr_view_depth_rgb(int P, const float* centers, const float* viewmatrix, flo
 int sgr_unproject_pixels(int n, const int64_t* picked, const float* depth, int width, int height, float tanfovx, float tanfovy,
                          const float* viewmatrix, float* world, void* stream);
 
+/* ---- the sampling pass without host round trips (round 6; csrc/pick.hip) -----------------------------------------------------------
+ * sgr_pick_pixels: sugar_model.py:1929-1957 -- of the n_pix pixels of `depth` (the view-space depth image, "no depth" < 0) those with a
+ *   depth are the candidates, and a uniformly random subset of min(k, n_valid) of them is written to picked[k] (int64 row-major pixel
+ *   indices, in RASTER order; the reference keeps `torch.randperm(n_valid)[:k]` of them: the same distribution of the SET, another order
+ *   of the rows, which nothing behind it depends on).  *count = min(k, n_valid) and *n_valid stay on the device (either may be NULL);
+ *   rows behind the count repeat picked[0] (pixel 0 when nothing is valid), so that everything computed from them stays finite.
+ *   The subset is a function of (seed, which pixels are valid).  scratch: sgr_pick_pixels_scratch_bytes(n_pix) bytes.  No host wait.
+ * sgr_compact_level_rows: behind sgr_level_set_points (valid[L,N], points[L,N,3], normals[L,N,3] or NULL): per level the rows with
+ *   valid != 0 among the first *n_rows (device word, or NULL: all N) move to the front of rows_out[L,N] (their row numbers),
+ *   points_out[L,N,3], normals_out[L,N,3] and -- for two per-row int64 tags such as the pixel and the front Gaussian of every row --
+ *   tag_*_out[L,N]; counts[L] (device) receives how many.  Rows behind the count are left untouched. */
+size_t sgr_pick_pixels_scratch_bytes(int n_pix);
+int sgr_pick_pixels(int n_pix, const float* depth, int k, uint32_t seed, int64_t* picked, uint32_t* count, uint32_t* n_valid, char* scratch,
+                    void* stream);
+int sgr_compact_level_rows(int N, int L, const uint8_t* valid, const uint32_t* n_rows, const float* points, const float* normals,
+                           const int64_t* tag_a, const int64_t* tag_b, int64_t* rows_out, float* points_out, float* normals_out,
+                           int64_t* tag_a_out, int64_t* tag_b_out, uint32_t* counts, void* stream);
+
 /* ---- SuGaR.get_points_rgb, sugar_scene/sugar_model.py:839-883 (with sugar_utils/spherical_harmonics.py:117-172) -----
  * colors[P,3] = clamp_min(eval_sh(D, sh, dir) + 0.5, 0),  dir = F.normalize(positions - camera_centers) when positions is
  * given (camera_centers[n_centers,3], n_centers = 1 or P), else directions[P,3] as they are.  sh is [P,M,3] (the

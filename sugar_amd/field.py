@@ -137,9 +137,11 @@ def density_field(x, nbr_idx, centers, inv_scaled_rot, strengths, density_factor
 
 def level_set_points(world_points, nbr_idx, cam_center, centers, inv_scaled_rot, strengths, gaussian_std,
                      surface_levels=(0.1, 0.3, 0.5), n_points_in_range: int = 21, range_size: float = 3.0,
-                     density_factor: float = 1.0, return_normals: bool = True):
+                     density_factor: float = 1.0, return_normals: bool = True, raw: bool = False):
     """Per level: dict(valid=bool[N], valid_idx=int64[n_valid], intersection_points=[n_valid,3], normals=[n_valid,3]) -- the `outputs` of
-    sugar_model.py:2013-2081 (rows where the reference's empty_pixels is False)."""
+    sugar_model.py:2013-2081 (rows where the reference's empty_pixels is False).
+    `raw=True`: no gathering (and no host round trip): returns (valid uint8[L,N], points[L,N,3], normals[L,N,3] or None) as the kernel
+    wrote them -- sugar_amd.sampler compacts them on the device."""
     lib = _lib.load()
     wp, nb, ce, Bm, st = _prep(world_points, nbr_idx, centers, inv_scaled_rot, strengths)
     dev = wp.device
@@ -158,6 +160,8 @@ def level_set_points(world_points, nbr_idx, cam_center, centers, inv_scaled_rot,
                                       _p(nrm), _p(packed), _stream(dev))
     if rc < 0:
         raise RuntimeError(f"sgr_level_set_points failed ({rc})")
+    if raw:
+        return valid, pts, nrm
     out = {}
     for i, level in enumerate(surface_levels):
         m = valid[i].bool()

@@ -96,10 +96,16 @@ def view_std(means3D: torch.Tensor, rotations: torch.Tensor, scales: torch.Tenso
 def sample_level_sets(means3D, scales, rotations, opacities, cam, *, n_surface_points: int = 124_000,
                       surface_levels=(0.1, 0.3, 0.5), n_points_in_range: int = 21, range_size: float = 3.0,
                       density_factor: float = 1.0, K: int = 16, return_normals: bool = True, cpu_randperm: bool = False,
-                      depth: torch.Tensor | None = None):
+                      depth: torch.Tensor | None = None, sync_free: bool = False, seed: int | None = None):
     """One sampling pass for one view.  Returns {level: dict(intersection_points[n,3], pixel_idx[n], gaussian_idx[n], normals[n,3])}.
     `scales` / `rotations` / `opacities` are the ACTIVATED values ([P,3], unit [P,4], [P,1]); `cpu_randperm` draws the pixel subset on
-    the CPU as the reference does (:1955), so that a seeded run picks the reference's pixels."""
+    the CPU as the reference does (:1955), so that a seeded run picks the reference's pixels.
+
+    `sync_free=True` (round 6): nothing in the pass waits for the GPU.  The pixel subset is chosen on the device into
+    `n_surface_points` rows (sgr_pick_pixels: a uniformly random subset of the valid pixels, in raster order), every stage runs on
+    that fixed size, and the valid rows of every level are moved to the front on the device (sgr_compact_level_rows).  The tensors of
+    a level then have `n_surface_points` rows of which the first `count` -- a 0-d int32 DEVICE tensor in the level's dict -- are
+    meaningful; `trim(result)` slices them (one host wait for all levels)."""
     if not means3D.is_cuda:
         raise RuntimeError("sample_level_sets needs tensors on a ROCm device; there is no CPU fallback")
     from .sugar_patch import random_prefix_of_permutation
@@ -108,6 +114,11 @@ def sample_level_sets(means3D, scales, rotations, opacities, cam, *, n_surface_p
     if depth is None:
         depth = render_depth(means3D, scales, rotations, opacities, cam)
     depth_flat = depth.reshape(-1)
+    if sync_free:
+        if n_surface_points <= 0 or cpu_randperm:
+            raise ValueError("sync_free needs a positive n_surface_points and the device-side pixel subset")
+        return _sample_sync_free(means3D, scales, rotations, opacities, cam, depth_flat.to(torch.float32).contiguous(), int(n_surface_points),
+                                 tuple(surface_levels), n_points_in_range, range_size, density_factor, K, return_normals, seed)
     valid_pix = torch.logical_not(depth_flat < 0.).nonzero(as_tuple=True)[0]
     n_valid = valid_pix.shape[0]
     if n_surface_points == -1:
@@ -131,4 +142,58 @@ def sample_level_sets(means3D, scales, rotations, opacities, cam, *, n_surface_p
         rows = r["valid_idx"]
         out[lv] = dict(intersection_points=r["intersection_points"], pixel_idx=picked[rows], gaussian_idx=gaussian_idx[rows],
                        normals=r["normals"])
+    return out
+
+
+def _sample_sync_free(means3D, scales, rotations, opacities, cam, depth_flat, n, surface_levels, n_points_in_range, range_size,
+                      density_factor, K, return_normals, seed):
+    lib = _lib.load()
+    dev = means3D.device
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())   # (the CPU generator: seeded by torch.manual_seed, no device wait)
+    picked = torch.empty(n, dtype=torch.int64, device=dev)
+    words = torch.empty(2, dtype=torch.int32, device=dev)        # [count, n_valid]
+    scratch = torch.empty(int(lib.sgr_pick_pixels_scratch_bytes(depth_flat.numel())), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.sgr_pick_pixels(int(depth_flat.numel()), _p(depth_flat), n, C.c_uint32(seed & 0xFFFFFFFF), _p(picked), _p(words),
+                                 C.c_void_p(words.data_ptr() + 4), _p(scratch), _stream(dev))
+    if rc < 0:
+        raise RuntimeError(f"sgr_pick_pixels failed ({rc})")
+    world = unproject_pixels(picked, depth_flat, cam)
+    nbr = knn_points(world[None], means3D[None], K=K).idx[0]
+    gaussian_idx = nbr[:, 0].contiguous()
+    stds = view_std(means3D, rotations, scales, cam.campos)
+    B = scaled_rotation(rotations, scales, inverse_scales=True)
+    valid, pts, nrm = level_set_points(world, nbr, cam.campos.reshape(1, 3), means3D, B, opacities.reshape(-1, 1), stds,
+                                       surface_levels=surface_levels, n_points_in_range=n_points_in_range, range_size=range_size,
+                                       density_factor=density_factor, return_normals=return_normals, raw=True)
+    L = len(surface_levels)
+    rows = torch.empty(L, n, dtype=torch.int64, device=dev)
+    pts_c = torch.empty(L, n, 3, device=dev)
+    nrm_c = torch.empty(L, n, 3, device=dev) if return_normals else None
+    pix_c = torch.empty(L, n, dtype=torch.int64, device=dev)
+    gid_c = torch.empty(L, n, dtype=torch.int64, device=dev)
+    counts = torch.empty(L, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.sgr_compact_level_rows(n, L, _p(valid), _p(words), _p(pts), _p(nrm) if nrm is not None else None, _p(picked),
+                                        _p(gaussian_idx), _p(rows), _p(pts_c), _p(nrm_c) if nrm_c is not None else None, _p(pix_c),
+                                        _p(gid_c), _p(counts), _stream(dev))
+    if rc < 0:
+        raise RuntimeError(f"sgr_compact_level_rows failed ({rc})")
+    out = {}
+    for i, lv in enumerate(surface_levels):
+        out[lv] = dict(intersection_points=pts_c[i], pixel_idx=pix_c[i], gaussian_idx=gid_c[i], normals=nrm_c[i] if return_normals else None,
+                       count=counts[i], n_picked=words[0], n_valid_pixels=words[1], picked=picked)
+    return out
+
+
+def trim(result):
+    """a `sync_free` result with every level's tensors cut to their counts (ONE host wait for all levels)"""
+    levels = list(result)
+    counts = torch.stack([result[lv]["count"] for lv in levels]).cpu().tolist()
+    out = {}
+    for lv, c in zip(levels, counts):
+        r = result[lv]
+        out[lv] = dict(intersection_points=r["intersection_points"][:c], pixel_idx=r["pixel_idx"][:c], gaussian_idx=r["gaussian_idx"][:c],
+                       normals=(r["normals"][:c] if r["normals"] is not None else None))
     return out

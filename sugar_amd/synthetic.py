@@ -45,6 +45,11 @@ CONFIGS = {
     # config 4 (refine mode): s_lo / s_hi are unused -- the in-plane scales come from the triangles, the third one is the
     # mesh thickness (make_bound_scene)
     "config4": (1_000_000, 1920, 1080, 4, None, None, None, 0.0),
+    # the same mesh-bound scene as a FRESHLY BOUND refined model has it (round 6): opacities 0.9999 (sugar_model.py:281-283: a model
+    # bound to a surface mesh starts from inverse_sigmoid(0.9999)), in-plane scales = the reference's initial value exactly
+    # (:323-326: the triangles are covered), no in-plane rotation (:337-339) -- an opaque surface, where config 4 above is a
+    # half-transparent, mid-refinement state whose depth render floats off the surface
+    "config4_opaque": (1_000_000, 1920, 1080, 4, None, None, None, 0.0),
 }
 
 
@@ -224,7 +229,7 @@ def bound_gaussians(verts, faces, plane_scales, complex_rot, thickness: float, n
     return means.contiguous(), scales.contiguous(), quats.contiguous()
 
 
-def make_bound_scene(P: int, seed: int, n_per_triangle: int = 1, extent: float = 3.3, sh_degree: int = 3) -> BoundScene:
+def make_bound_scene(P: int, seed: int, n_per_triangle: int = 1, extent: float = 3.3, sh_degree: int = 3, opaque: bool = False) -> BoundScene:
     """~P flat Gaussians on a grid surface mesh, in a mid-refinement state: in-plane scales = the reference's initial value
     (shortest edge x the inscribed-circle factor, sugar_model.py:323-326) times a log-uniform factor per axis in [0.5, 2],
     a uniformly random in-plane rotation, opacities and SH as in the other configs.  The Gaussian count is 2*n_u*n_v*n."""
@@ -242,8 +247,12 @@ def make_bound_scene(P: int, seed: int, n_per_triangle: int = 1, extent: float =
     z = torch.randn(Pn, 2, generator=g)
     z = z / z.norm(dim=-1, keepdim=True)
     thickness = extent / 1_000_000.0
-    means, scales, quats = bound_gaussians(verts, faces, plane, z, thickness, n)
     opacities = torch.sigmoid(torch.randn(Pn, 1, generator=g) * 2.0)
+    if opaque:   # a freshly bound model (sugar_model.py:281-283, 323-339); the draws above keep the generator's state aligned
+        plane = s0.clone()
+        z = torch.zeros(Pn, 2); z[:, 0] = 1.0
+        opacities = torch.full((Pn, 1), 0.9999)
+    means, scales, quats = bound_gaussians(verts, faces, plane, z, thickness, n)
     M = (sh_degree + 1) ** 2
     dc = (torch.rand(Pn, 1, 3, generator=g) - 0.5) / SH_C0
     rest = torch.randn(Pn, M - 1, 3, generator=g) * 0.1
@@ -290,8 +299,8 @@ def depth_as_colour(means3D: torch.Tensor, viewmatrix: torch.Tensor):
 def make_config(name: str, P: int | None = None):
     """Returns (scene, cameras, bg[3]) for a BASELINE config name; P may override the Gaussian count."""
     P0, W, H, seed, s_lo, s_hi, max_norm, bg = CONFIGS[name]
-    if name == "config4":
-        scene = make_bound_scene(P0 if P is None else P, seed).scene
+    if name in ("config4", "config4_opaque"):
+        scene = make_bound_scene(P0 if P is None else P, seed, opaque=name == "config4_opaque").scene
     else:
         scene = make_scene(P0 if P is None else P, seed, s_lo, s_hi, max_norm)
     return scene, orbit_cameras(W, H), torch.full((3,), bg)
