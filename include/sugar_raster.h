@@ -100,6 +100,7 @@ int64_t sgr_forward(sgr_alloc_fn geom_alloc, void* geom_user,
 #define SGR_HDR_L1_OVERFLOW 6 /* != 0: the level-1 (super-tile) list overflowed its capacity */
 #define SGR_HDR_LAYOUT_CAP 8  /* the instance capacity the binning buffer of this forward was laid out for (written by the forward
                                  blend kernel, read by the backward blend kernel: the binning buffer may be cloned or moved between them) */
+#define SGR_HDR_DEEP 9        /* tiles of this view whose blocks were blended by the eight-wave kernel for long lists (round 6) */
 #define SGR_HDR_REPAIR 7      /* tiles that outran their walk hint and were rendered again inside the same forward (round 5): a hint
                                  that is too short costs those tiles a second pass, not the forward; SGR_HDR_HINT_MISS is only raised
                                  when more than 1024 tiles did */
@@ -172,6 +173,15 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user,
  * it for some cameras (profiles/r06_grad_switch_table.txt, profiles/r06_fullsize_parity_fast_alpha.json).  The mode is process-wide;
  * SGR_FLAG_EXACT_ALPHA / SGR_BWD_EXACT_ALPHA force it on for one call.  Forward and backward of a view must run in the same mode. */
 #define SGR_FLAG_EXACT_ALPHA 16
+/* Long lists (round 6).  With a walk hint (sgr_forward_opts.tile_need) the 8x8 blocks of a tile whose hinted list is longer than
+ * `entries` are blended by an eight-wave kernel -- alpha for eight 64-entry batches in parallel, then the cheap sequential
+ * transmittance chain -- beside the one-wave kernel, on a stream of the library's own; bit-identical results.  Default 1024
+ * (SGR_DEEP_MIN in the environment); 0 disables.  Header word SGR_HDR_DEEP reports how many tiles took that path. */
+#define SGR_FLAG_NO_DEEP 32   /* this call: one wave per block whatever the hint says (a caller that knows its lists are short saves the
+                                 side stream's fork and join: sgr_trainer_step sets it unless the camera's last visit left a hint
+                                 above the threshold -- host header word 9, second copy, carries the largest hint written) */
+void sgr_set_deep_min(int entries);
+int sgr_get_deep_min(void);
 void sgr_set_exact_alpha(int on);
 int sgr_get_exact_alpha(void);
 #define SGR_MODE_RAW_PARAMS 4 /* or-ed into the `phase` argument of sgr_backward_phase (phases 0, 1, 2 as before) */
@@ -428,7 +438,9 @@ typedef struct sgr_train_view {
     uint32_t chunk_grid;         /* see sgr_forward_opts */
     const uint32_t* tile_order;  /* launch order of this camera's previous visit (device, [tiles]) or NULL */
     uint32_t* tile_order_out;    /* receives this visit's order (also used by this step's backward), or NULL */
+    uint32_t flags;              /* SGR_VIEW_* */
 } sgr_train_view;
+#define SGR_VIEW_DEEP_LISTS 1    /* this camera's hint has tiles above sgr_get_deep_min(): use the eight-wave kernel for them */
 typedef struct sgr_train_exchange { /* phases 4 and 8 */
     int n_views;                 /* views whose colour gradients are summed (1: this rank's own) */
     const float* all_colors;     /* [n_views][view_stride][3]; NULL: cfg.colors */
@@ -561,13 +573,15 @@ int sgr_unproject_pixels(int n, const int64_t* picked, const float* depth, int w
  * sgr_compact_level_rows: behind sgr_level_set_points (valid[L,N], points[L,N,3], normals[L,N,3] or NULL): per level the rows with
  *   valid != 0 among the first *n_rows (device word, or NULL: all N) move to the front of rows_out[L,N] (their row numbers),
  *   points_out[L,N,3], normals_out[L,N,3] and -- for two per-row int64 tags such as the pixel and the front Gaussian of every row --
- *   tag_*_out[L,N]; counts[L] (device) receives how many.  Rows behind the count are left untouched. */
+ *   tag_*_out[L,N]; counts[L] (device) receives how many.  Rows behind the count are left untouched.  scratch:
+ *   sgr_compact_level_rows_scratch_bytes(N, L) bytes. */
 size_t sgr_pick_pixels_scratch_bytes(int n_pix);
 int sgr_pick_pixels(int n_pix, const float* depth, int k, uint32_t seed, int64_t* picked, uint32_t* count, uint32_t* n_valid, char* scratch,
                     void* stream);
 int sgr_compact_level_rows(int N, int L, const uint8_t* valid, const uint32_t* n_rows, const float* points, const float* normals,
                            const int64_t* tag_a, const int64_t* tag_b, int64_t* rows_out, float* points_out, float* normals_out,
-                           int64_t* tag_a_out, int64_t* tag_b_out, uint32_t* counts, void* stream);
+                           int64_t* tag_a_out, int64_t* tag_b_out, uint32_t* counts, char* scratch, void* stream);
+size_t sgr_compact_level_rows_scratch_bytes(int N, int L);
 
 /* ---- SuGaR.get_points_rgb, sugar_scene/sugar_model.py:839-883 (with sugar_utils/spherical_harmonics.py:117-172) -----
  * colors[P,3] = clamp_min(eval_sh(D, sh, dir) + 0.5, 0),  dir = F.normalize(positions - camera_centers) when positions is

@@ -13,3 +13,10 @@ def set_exact_alpha(on: bool = True) -> None:
 def exact_alpha() -> bool:
     from . import _lib
     return bool(_lib.load().sgr_get_exact_alpha())
+
+
+def set_deep_min(entries: int = 1024) -> None:
+    """Hinted list length above which a tile's 8x8 blocks are blended by the eight-wave kernel for long lists
+    (include/sugar_raster.h: sgr_set_deep_min); 0 disables.  Results are bit-identical either way."""
+    from . import _lib
+    _lib.load().sgr_set_deep_min(int(entries))

@@ -18,6 +18,8 @@ _vp, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 SIGNATURES = {
     "sgr_abi_version": (_i, []),
     "sgr_last_error": (C.c_char_p, []),
+    "sgr_set_deep_min": (None, [_i]),
+    "sgr_get_deep_min": (_i, []),
     "sgr_set_exact_alpha": (None, [_i]),
     "sgr_get_exact_alpha": (_i, []),
     "sgr_forward": (_i64, [ALLOC_FN, _vp, ALLOC_FN, _vp, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp,
@@ -82,7 +84,8 @@ SIGNATURES = {
     "sgr_unproject_pixels": (_i, [_i, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "sgr_pick_pixels_scratch_bytes": (_sz, [_i]),
     "sgr_pick_pixels": (_i, [_i, _vp, _i, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
-    "sgr_compact_level_rows": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sgr_compact_level_rows": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sgr_compact_level_rows_scratch_bytes": (_sz, [_i, _i]),
     "sgr_level_set_points": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "sgr_sh_to_rgb_forward": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "sgr_sh_to_rgb_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -132,7 +135,7 @@ class TrainConfig(C.Structure):
 class TrainView(C.Structure):
     _fields_ = [("viewmatrix", _vp), ("projmatrix", _vp), ("campos", _vp), ("tan_fovx", _f), ("tan_fovy", _f), ("gt_image", _vp),
                 ("tile_need", _vp), ("tile_need_out", _vp), ("hint_margin", _f), ("chunk_grid", C.c_uint32),
-                ("tile_order", _vp), ("tile_order_out", _vp)]
+                ("tile_order", _vp), ("tile_order_out", _vp), ("flags", C.c_uint32)]
 
 
 class TrainExchange(C.Structure):

@@ -498,6 +498,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int T, const uint32_t* __res
         header[SGR_HDR_HINT_MISS] = 0;
         if (clear_b2_words) { header[4] = 0; header[5] = 0; header[6] = 0; }  // single-level path: k_sup_scan did not run
         header[7] = 0;
+        header[SGR_HDR_DEEP] = 0;
         // the header for the host, written straight into its pinned memory (a 32-byte copy command of its own cost the stream
         // 8 us, twice per forward); words 4-6 were left by k_sup_scan, an earlier kernel on this stream
         const uint32_t w4 = clear_b2_words ? 0u : header[4], w5 = clear_b2_words ? 0u : header[5], w6 = clear_b2_words ? 0u : header[6];
@@ -563,7 +564,7 @@ int sgr_sort_counter_words() { return RS_COUNTER_WORDS; }
 // kernel, which also zeroes the counters; on return *order_out points at the sorted Gaussian ids (inside sort_scratch).
 // Buffers: pass 0 a -> b, pass 1 b -> c, pass 2 c -> b (or -> a when it is the last one), pass 3 b -> a.
 void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_out, const uint2* rect_by_id, uint2* rects_sorted,
-                              hipStream_t s)
+                              hipStream_t s, int part)
 {
     const size_t n = (size_t)P;
     const size_t arr = sgr_align(n * 4);
@@ -584,8 +585,9 @@ void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_
     uint32_t* kout[4] = {keys_b, keys_c, keys_b, keys_a};
     uint32_t* vout[4] = {vals_b, vals_c, vals_b, vals_a};
     static const int allow_skip = getenv("SGR_SORT_FOUR_PASSES") ? 0 : 1;  // (development: always run the fourth pass)
-    hipLaunchKernelGGL(k_rs_prepare, dim3(chunks), dim3(256), 0, s, P, keys_a, chunks, status, minmax, n_minmax, params, counters, allow_skip);
-    for (int pass = 0; pass < 4; pass++)
+    if (part != 2)
+        hipLaunchKernelGGL(k_rs_prepare, dim3(chunks), dim3(256), 0, s, P, keys_a, chunks, status, minmax, n_minmax, params, counters, allow_skip);
+    for (int pass = (part == 2 ? 2 : 0); pass < (part == 1 ? 2 : 4); pass++)
         hipLaunchKernelGGL(k_rs_pass, dim3(chunks), dim3(RS_THREADS), 0, s, P, kin[pass], vin[pass], kout[pass], vout[pass], 8 * pass, chunks,
                            status, counters, rect_by_id, pass >= 2 ? rects_sorted : (uint2*)nullptr, params, pass, keys_a, vals_a);
     *order_out = vals_a;

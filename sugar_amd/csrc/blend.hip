@@ -304,7 +304,7 @@ __device__ __forceinline__ void blend_fwd_body(int W, int H, int gx, int T_tiles
                                                     unsigned long long* __restrict__ blk_mask, uint32_t* __restrict__ blk_nb,
                                                     uint32_t* __restrict__ header, uint32_t list_cap,
                                                     const uint32_t* __restrict__ tile_need, const uint32_t* __restrict__ launch_order,
-                                                    uint32_t* __restrict__ repair_flag, uint32_t* __restrict__ repair_list)
+                                                    uint32_t* __restrict__ repair_flag, uint32_t* __restrict__ repair_list, uint32_t deep_min = 0u)
 {
     // sync-free forward: the list did not fit the caller's capacity (or the level-1 binning overflowed) -> leave everything
     // untouched; the caller repeats the forward and every later kernel of the step reads the same header
@@ -339,6 +339,8 @@ __device__ __forceinline__ void blend_fwd_body(int W, int H, int gx, int T_tiles
     const int total_all = (int)(tile_start[tile + 1] - r0);
     // walk hint: only the first tile_need[tile] entries of the list are guaranteed to have been written
     const int total = tile_need ? (int)min((uint32_t)total_all, tile_need[tile]) : total_all;
+    // a block whose hinted list is longer than deep_min entries belongs to k_blend_fwd_deep (eight waves per block, below)
+    if (!REPAIR && deep_min && tile_need && (uint32_t)total > deep_min) return;
 
     float T = 1.0f;
     uint32_t last_contributor = 0;
@@ -474,15 +476,15 @@ __device__ __forceinline__ void blend_fwd_body(int W, int H, int gx, int T_tiles
         unsigned long long *__restrict__ blk_mask, uint32_t *__restrict__ blk_nb, uint32_t *__restrict__ header, uint32_t list_cap
 #define SGR_FWD_ARGS W, H, gx, T_tiles, tile_start, point_list, rec, bg, final_T, n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap
 __global__ void __launch_bounds__(64) k_blend_fwd_w(SGR_FWD_PARAMS, const uint32_t* __restrict__ tile_need, const uint32_t* __restrict__ launch_order,
-                                                    uint32_t* __restrict__ repair_flag, uint32_t* __restrict__ repair_list)
+                                                    uint32_t* __restrict__ repair_flag, uint32_t* __restrict__ repair_list, uint32_t deep_min)
 {
-    blend_fwd_body<false, false>(SGR_FWD_ARGS, tile_need, launch_order, repair_flag, repair_list);
+    blend_fwd_body<false, false>(SGR_FWD_ARGS, tile_need, launch_order, repair_flag, repair_list, deep_min);
 }
 // (the exact-alpha variant: SGR_FWD_BODY_X)
 __global__ void __launch_bounds__(64) k_blend_fwd_wx(SGR_FWD_PARAMS, const uint32_t* __restrict__ tile_need, const uint32_t* __restrict__ launch_order,
-                                                     uint32_t* __restrict__ repair_flag, uint32_t* __restrict__ repair_list)
+                                                     uint32_t* __restrict__ repair_flag, uint32_t* __restrict__ repair_list, uint32_t deep_min)
 {
-    blend_fwd_body<false, true>(SGR_FWD_ARGS, tile_need, launch_order, repair_flag, repair_list);
+    blend_fwd_body<false, true>(SGR_FWD_ARGS, tile_need, launch_order, repair_flag, repair_list, deep_min);
 }
 
 // the repair pass of the walk hint (a kernel name of its own, so that a trace tells the gated, usually empty launch from the blend)
@@ -493,6 +495,176 @@ __global__ void __launch_bounds__(64) k_blend_fwd_repair(SGR_FWD_PARAMS, const u
 __global__ void __launch_bounds__(64) k_blend_fwd_repairx(SGR_FWD_PARAMS, const uint32_t* __restrict__ repair_list)
 {
     blend_fwd_body<true, true>(SGR_FWD_ARGS, nullptr, repair_list, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Long lists (round 6): EIGHT waves per 8 x 8 block.
+//
+// A block whose (hinted) list runs to thousands of entries -- the silhouette tiles of BASELINE config 4's flat, mesh-bound splats walk
+// 4 500 -- is a serial chain for its one wave while the rest of the chip has long finished.  Splitting the LIST between waves and
+// composing (C1 + T1 C2, T1 T2) was built in round 5 and was slower: pixels stop all along such a list, nearly every run had to be
+// walked twice.  What parallelises without that problem is the EXPENSIVE part of an entry, alpha (cull, gather, power, exp: 25 of
+// the walk's 33 instructions), which does not depend on the state of the pixel; what stays sequential is the cheap part, the
+// transmittance chain T <- T (1 - alpha) with its stop rule and the colour sums (same operations in the same order as the one-wave
+// walk, so the result is bit-identical to it -- and with exact alpha to the reference):
+//   phase A  every wave takes one 64-entry batch of the next eight: ids and records gathered (lane = entry), the exact block cull,
+//            the survivor mask for the backward, then per survivor (wave-uniform, broadcast with v_readlane) one alpha per pixel lane
+//            into the wave's LDS panel (0 = "skipped": power > 0 or alpha < 1/255);
+//   phase B  wave 0 walks the eight panels in list order: per survivor a load, the three transmittance operations, the stop test,
+//            three FMAs.
+// The blocks are listed by k_deep_list (tiles whose hinted length exceeds deep_min); k_blend_fwd_w(x) skips exactly those, and the
+// two kernels run side by side on two streams (capi.hip).  136 KB of LDS: one workgroup per CU, which is all a handful of blocks need.
+#define DEEP_WAVES 8
+#define DEEP_ROWS 64
+template <bool EXACT>
+__device__ __forceinline__ float deep_alpha(float x, float y, float cx, float cy, float cz, float op, float px, float py)
+{
+#pragma clang fp contract(off)
+    const float dx = x - px, dy = y - py;
+    if (EXACT) {   // SGR_FWD_BODY_X, operation for operation
+        const float t1 = ((-0.5f * cx) * dx) * dx, t2 = ((-0.5f * cz) * dy) * dy;
+        const float power = (t1 + t2) - (cy * dx) * dy;
+        if (power > 0.f) return 0.f;
+        const float alpha = fminf(0.99f, op * expf(power));
+        return alpha < 1.0f / 255.0f ? 0.f : alpha;
+    } else {       // SGR_FWD_BODY
+        const float A = -0.5f * LOG2E * cx, B = -LOG2E * cy, CZ = -0.5f * LOG2E * cz;
+        const float t = __builtin_fmaf(A, dx, B * dy);
+        const float p2 = __builtin_fmaf(dx, t, (CZ * dy) * dy);
+        if (p2 > 0.f) return 0.f;
+        const float alpha = fminf(0.99f, op * __builtin_amdgcn_exp2f(p2));
+        return alpha < 1.0f / 255.0f ? 0.f : alpha;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_deep_list(int T, const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_need,
+                                                   uint32_t deep_min, uint32_t* __restrict__ header, uint32_t list_cap,
+                                                   uint32_t* __restrict__ deep_list)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T || header[SGR_HDR_R] > list_cap || header[4 + SGR_B2_HDR_OVERFLOW]) return;
+    const uint32_t total = min(tile_start[t + 1] - tile_start[t], tile_need[t]);
+    if (total > deep_min) deep_list[atomicAdd(&header[SGR_HDR_DEEP], 1u)] = (uint32_t)t;
+}
+
+template <bool EXACT>
+__global__ void __launch_bounds__(64 * DEEP_WAVES)
+k_blend_fwd_deep(SGR_FWD_PARAMS, const uint32_t* __restrict__ tile_need, const uint32_t* __restrict__ deep_list,
+                 uint32_t* __restrict__ repair_flag, uint32_t* __restrict__ repair_list)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_deep[];
+    float* s_alpha = s_deep;                                                              // [DEEP_WAVES][DEEP_ROWS][64]
+    float4* s_ent = reinterpret_cast<float4*>(s_deep + DEEP_WAVES * DEEP_ROWS * 64);      // [DEEP_WAVES][DEEP_ROWS] {r, g, b, position}
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_ent + DEEP_WAVES * DEEP_ROWS);        // [DEEP_WAVES] survivors of the wave's batch, [8] stop
+    if (header[SGR_HDR_R] > list_cap || header[4 + SGR_B2_HDR_OVERFLOW]) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n_deep = header[SGR_HDR_DEEP];
+    for (uint32_t slot = blockIdx.x; slot < 4u * n_deep; slot += gridDim.x) {
+        const int tile = (int)min(deep_list[slot >> 2], (uint32_t)(T_tiles - 1)), sub = (int)(slot & 3u);
+        const int tx = tile % gx, ty = tile / gx;
+        const int bx0 = tx * SGR_TILE_X + 8 * (sub & 1), by0 = ty * SGR_TILE_Y + 8 * (sub >> 1);
+        const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
+        const bool inside = px < W && py < H;
+        const float pixfx = (float)px, pixfy = (float)py;
+        const uint32_t r0 = tile_start[tile];
+        const int total_all = (int)(tile_start[tile + 1] - r0);
+        const int total = (int)min((uint32_t)total_all, tile_need[tile]);
+        const int n_b = (total + 63) / 64;
+        unsigned long long* my_mask = blk_mask + 4 * ((size_t)(r0 >> 6) + (size_t)tile) + sub;
+        // the pixel state lives in wave 0
+        float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+        uint32_t last_contributor = 0, walked = (uint32_t)total;
+        unsigned long long live = __ballot(inside);
+        int batches_seen = 0;
+        for (int seg = 0; seg < n_b; seg += DEEP_WAVES) {
+            // ---------------- phase A: one batch per wave
+            const int b = seg + wave;
+            uint32_t cnt = 0;
+            if (b < n_b) {   // (wave-uniform)
+                const uint32_t id = point_list[r0 + (uint32_t)min(64 * b + lane, total - 1)];
+                const float4* rp = reinterpret_cast<const float4*>(rec + id);
+                const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
+                const bool hit = (64 * b + lane < total) && block_hit(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, (float)bx0, (float)by0);
+                unsigned long long m = __ballot(hit);
+                if (lane == 0) my_mask[4 * (size_t)b] = m;
+                float* arow = s_alpha + ((size_t)wave * DEEP_ROWS) * 64 + lane;
+                while (m) {
+                    const int j = (int)__builtin_ctzll(m);
+                    m &= m - 1;
+#define RL(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j))
+                    const float ex = RL(v0.x), ey = RL(v0.y), ecx = RL(v0.z), ecy = RL(v0.w), ecz = RL(v1.x), eop = RL(v1.y);
+                    arow[(size_t)cnt * 64] = deep_alpha<EXACT>(ex, ey, ecx, ecy, ecz, eop, pixfx, pixfy);
+                    if (lane == 0) s_ent[wave * DEEP_ROWS + cnt] = make_float4(RL(v2.x), RL(v2.y), RL(v2.z), __uint_as_float((uint32_t)(64 * b + j + 1)));
+#undef RL
+                    cnt++;
+                }
+            }
+            if (lane == 0) s_cnt[wave] = cnt;
+            __syncthreads();
+            // ---------------- phase B: wave 0, in list order
+            if (wave == 0) {
+                bool stop = false;
+                for (int w = 0; w < DEEP_WAVES && !stop; w++) {
+                    if (seg + w >= n_b) break;
+                    batches_seen = seg + w + 1;
+                    const int n = (int)s_cnt[w];
+                    const float* arow = s_alpha + ((size_t)w * DEEP_ROWS) * 64 + lane;
+                    for (int r = 0; r < n; r++) {
+                        const float a = arow[(size_t)r * 64];
+                        const float4 e = s_ent[w * DEEP_ROWS + r];
+                        bool fin = false;
+                        if (((live >> lane) & 1ull) && a != 0.f) {
+                            float test_T, aT;
+                            {
+#pragma clang fp contract(off)
+                                aT = a * T;
+                                test_T = EXACT ? T * (1.0f - a) : T - aT;
+                            }
+                            if (test_T < 0.0001f) fin = true;
+                            else {
+                                C0 = __builtin_fmaf(e.x, aT, C0); C1 = __builtin_fmaf(e.y, aT, C1); C2 = __builtin_fmaf(e.z, aT, C2);
+                                T = test_T;
+                                last_contributor = __float_as_uint(e.w);
+                            }
+                        }
+                        live &= ~__ballot(fin);
+                        if (live == 0ull) { walked = __float_as_uint(e.w); stop = true; break; }
+                    }
+                }
+                if (lane == 0) s_cnt[DEEP_WAVES] = stop ? 1u : 0u;
+            }
+            __syncthreads();
+            if (s_cnt[DEEP_WAVES]) break;
+        }
+        if (wave == 0) {
+            if (total < total_all && live != 0ull && lane == 0) {   // the hint was too short (see blend_fwd_body)
+                if (repair_flag) {
+                    if (atomicExch(&repair_flag[tile], 0xFFFFFFFFu) == 0u) repair_list[atomicAdd(&header[SGR_HDR_REPAIR], 1u)] = (uint32_t)tile;
+                } else {
+                    atomicOr(&header[SGR_HDR_HINT_MISS], 1u);
+                }
+            }
+            if (inside) {
+                const size_t pix_id = (size_t)W * py + px;
+                const size_t HW = (size_t)H * W;
+                final_T[pix_id] = T;
+                n_contrib[pix_id] = last_contributor;
+                out_color[pix_id] = C0 + T * bg[0];
+                out_color[HW + pix_id] = C1 + T * bg[1];
+                out_color[2 * HW + pix_id] = C2 + T * bg[2];
+            }
+            uint32_t mc = inside ? last_contributor : 0u;
+            for (int o = 32; o > 0; o >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, o));
+            if (lane == 0) {
+                atomicMax(&tile_maxc[tile], mc);
+                atomicMax(&tile_walked[tile], __ballot(inside) ? walked : 0u);
+                // batches with a mask: every batch of the segments phase A touched (the backward drops what lies behind the deepest contributor)
+                const int masked = min(n_b, ((batches_seen + DEEP_WAVES - 1) / DEEP_WAVES) * DEEP_WAVES);
+                blk_nb[4 * tile + sub] = mc ? (uint32_t)masked : 0u;
+            }
+        }
+        __syncthreads();   // (the panels are rewritten by the next block of this workgroup)
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -954,12 +1126,38 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
                           uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
                           uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, const uint32_t* launch_order, hipStream_t s,
-                          uint32_t* repair_flag, uint32_t* repair_list, int exact)
+                          uint32_t* repair_flag, uint32_t* repair_list, int exact, uint32_t deep_min)
 {
     const int T = gx * gy;  // (tile_maxc and tile_walked were zeroed by the tile scan: the blocks of a tile combine with atomicMax)
     hipLaunchKernelGGL(exact ? k_blend_fwd_wx : k_blend_fwd_w, dim3(sgr_blend_grid(T)), dim3(64), 0, s, W, H, gx, T, tile_start, point_list, rec, bg, final_T,
                        n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap, tile_need, launch_order,
-                       tile_need ? repair_flag : nullptr, repair_list);
+                       tile_need ? repair_flag : nullptr, repair_list, tile_need ? deep_min : 0u);
+}
+
+// the blocks of tiles whose hinted list is longer than deep_min, eight waves per block (the kernel above skips exactly those)
+void sgr_launch_blend_fwd_deep(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list, const GeomRec* rec,
+                               const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc, uint32_t* tile_walked,
+                               float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb, uint32_t* header, uint32_t list_cap,
+                               const uint32_t* tile_need, uint32_t* deep_list, uint32_t deep_min, hipStream_t s, uint32_t* repair_flag,
+                               uint32_t* repair_list, int exact)
+{
+    const int T = gx * gy;
+    const size_t lds = (size_t)DEEP_WAVES * DEEP_ROWS * 64 * 4 + (size_t)DEEP_WAVES * DEEP_ROWS * 16 + 64;
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_blend_fwd_deep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_blend_fwd_deep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
+    hipLaunchKernelGGL(k_deep_list, dim3((T + 255) / 256), dim3(256), 0, s, T, tile_start, tile_need, deep_min, header, list_cap, deep_list);
+    if (exact)
+        hipLaunchKernelGGL(k_blend_fwd_deep<true>, dim3(256), dim3(64 * DEEP_WAVES), lds, s, W, H, gx, T, tile_start, point_list, rec, bg, final_T,
+                           n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap, tile_need, deep_list, repair_flag,
+                           repair_list);
+    else
+        hipLaunchKernelGGL(k_blend_fwd_deep<false>, dim3(256), dim3(64 * DEEP_WAVES), lds, s, W, H, gx, T, tile_start, point_list, rec, bg, final_T,
+                           n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap, tile_need, deep_list, repair_flag,
+                           repair_list);
 }
 
 void sgr_launch_blend_fwd_repair(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list,

@@ -55,6 +55,27 @@ struct ScanEvent {
 };
 thread_local ScanEvent g_scan_ev;
 
+// the side stream of the forward (depth keys + the first half of the depth sort beside the preprocess kernel), one per calling
+// thread and device; leaked on purpose like the pinned slot
+struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr; int device = -1; };
+thread_local SideStream g_side[16];
+SideStream* side_stream()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SideStream& sd = g_side[dev];
+    if (!sd.st) {
+        // (highest priority: the sort's few, latency-bound workgroups should get their slots ahead of the preprocess kernel's thousands)
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&sd.st, hipStreamNonBlocking, hi) != hipSuccess) { sd.st = nullptr; (void)hipGetLastError(); return nullptr; }
+        if (hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        sd.device = dev;
+    }
+    return (sd.fork && sd.join) ? &sd : nullptr;
+}
+
 // ---- optional per-stage timing with HIP events on the caller's stream (bench.py's roofline leg) ----------
 struct Prof {
     unsigned mask = 0;  // bit s set: time stage s
@@ -107,9 +128,19 @@ int sgr_exact_alpha()
     return g_exact_alpha;
 }
 
+// hinted list length above which a tile's blocks go to the eight-wave blend kernel (0: never); SGR_DEEP_MIN in the environment
+static int g_deep_min = -1;
+uint32_t sgr_deep_min()
+{
+    if (g_deep_min < 0) { const char* e = getenv("SGR_DEEP_MIN"); g_deep_min = e ? atoi(e) : 1024; if (g_deep_min < 0) g_deep_min = 0; }
+    return (uint32_t)g_deep_min;
+}
+
 extern "C" {
 
 int sgr_abi_version(void) { return SGR_ABI_VERSION; }
+void sgr_set_deep_min(int entries) { g_deep_min = entries > 0 ? entries : 0; }
+int sgr_get_deep_min(void) { return (int)sgr_deep_min(); }
 void sgr_set_exact_alpha(int on) { g_exact_alpha = on ? 1 : 0; }
 int sgr_get_exact_alpha(void) { return sgr_exact_alpha(); }
 
@@ -236,11 +267,30 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
     pa.key_minmax = reinterpret_cast<uint2*>(sort_scratch + sgr_sort_minmax_offset(P));
     pa.sort_counters = reinterpret_cast<uint32_t*>(sort_scratch + sgr_sort_counters_offset(P)); pa.n_sort_counters = sgr_sort_counter_words();
     if (opts->tile_need && hint_repair) { pa.zero_words = repair_flag; pa.n_zero_words = IL.T; }  // (the walk hint's repair flags start from zero)
+    // Sort beside preprocess (round 6): the depth keys come from a 12-byte-per-Gaussian kernel of their own on a side stream, which
+    // also runs the sort's histogram kernel and its first two passes while the HBM-bound preprocess kernel streams on the caller's;
+    // the caller's stream joins before the sort's last pass (it carries the rectangles the preprocess kernel writes).
+    // (OFF by default: measured on one box over 3 x 100 steps each, the sort stage shrinks from 77 to 40 us but the step does not --
+    // 1.083 ms with the overlap against 1.074 without: the two cross-stream event waits and the contention on the preprocess
+    // kernel eat what the overlap hides; profiles/r06_sort_overlap_ab.txt.  SGR_SORT_OVERLAP=1 enables it.)
+    static const bool overlap_ok = getenv("SGR_SORT_OVERLAP") != nullptr && getenv("SGR_SORT_OVERLAP")[0] == '1';
+    SideStream* side = (overlap_ok && !debug && P >= 65536) ? side_stream() : nullptr;
+    const uint32_t* order = nullptr;
+    if (side) {
+        HIP_TRY(hipEventRecord(side->fork, s));
+        HIP_TRY(hipStreamWaitEvent(side->st, side->fork, 0));
+        sgr_launch_depth_keys(pa, side->st);
+        sgr_launch_gaussian_sort(P, sort_scratch, &order, pa.rect_by_id, rects, side->st, 1);
+        HIP_TRY(hipEventRecord(side->join, side->st));
+        pa.keys_elsewhere = 1;
+    }
     { SgrStageTimer t(s, SGR_STAGE_PREPROCESS); sgr_launch_preprocess_fwd(pa, s); }
     STAGE_CHECK("preprocess");
-
-    const uint32_t* order = nullptr;
-    { SgrStageTimer t(s, SGR_STAGE_SORT); sgr_launch_gaussian_sort(P, sort_scratch, &order, pa.rect_by_id, rects, s); }
+    {
+        SgrStageTimer t(s, SGR_STAGE_SORT);
+        if (side) HIP_TRY(hipStreamWaitEvent(s, side->join, 0));
+        sgr_launch_gaussian_sort(P, sort_scratch, &order, pa.rect_by_id, rects, s, side ? 2 : 0);
+    }
     STAGE_CHECK("gaussian_sort");
 
     // speculative: sync-free launches with the caller's capacity, then ONE wait for the tile scan's header at the END of the call,
@@ -302,9 +352,24 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
         STAGE_CHECK("bin_scatter");
         {
             SgrStageTimer t(s, SGR_STAGE_BLEND_FWD);
+            // Long lists: the blocks of tiles whose hinted list exceeds deep_min go to the eight-wave kernel on the side stream, beside
+            // the one-wave kernel (which skips exactly those).  Only with a walk hint: without one every tile's full list counts.
+            const uint32_t deep_cfg = sgr_deep_min();
+            SideStream* dside = (deep_cfg && opts->tile_need && two_level && !debug && !(flags & SGR_FLAG_NO_DEEP)) ? side_stream() : nullptr;
+            const uint32_t deep_min = dside ? deep_cfg : 0u;
+            if (dside) {
+                HIP_TRY(hipEventRecord(dside->fork, s));
+                HIP_TRY(hipStreamWaitEvent(dside->st, dside->fork, 0));
+                sgr_launch_blend_fwd_deep(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib, tile_maxc,
+                                          tile_walked, out_color, blk_mask, blk_nb, header, (uint32_t)R_, opts->tile_need,
+                                          reinterpret_cast<uint32_t*>(img + IL.deep_list), deep_min, dside->st,
+                                          hint_repair ? repair_flag : nullptr, repair_list, exact);
+                HIP_TRY(hipEventRecord(dside->join, dside->st));
+            }
             sgr_launch_blend_fwd(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib,
                                  tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, (uint32_t)R_, opts->tile_need,
-                                 opts->tile_order, s, hint_repair ? repair_flag : nullptr, repair_list, exact);
+                                 opts->tile_order, s, hint_repair ? repair_flag : nullptr, repair_list, exact, deep_min);
+            if (dside) HIP_TRY(hipStreamWaitEvent(s, dside->join, 0));
         }   // (that stage timer -- bench.py's roofline.launch_ms -- brackets k_blend_fwd_w alone; the two gated launches are a stage of their own)
         {
             SgrStageTimer t(s, SGR_STAGE_HINT_REPAIR);

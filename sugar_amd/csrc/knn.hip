@@ -272,17 +272,42 @@ __device__ __forceinline__ int cell_coord(float v, float o, const GridGeom& g)
     return min(max(c, 0), g.G - 1);
 }
 
+// lane-run detection inside a wave: `head` = this lane's cell differs from the previous lane's (or it is lane 0); len = lanes from this
+// head up to the next head (or the end of the live lanes).  Dead lanes carry the key 0xFFFFFFFF and are never heads.
+__device__ __forceinline__ bool grid_run_head(unsigned int c, bool live, unsigned int& len)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned int prev = (unsigned int)__shfl_up((int)c, 1);
+    const bool head = live && (lane == 0 || prev != c);
+    const unsigned long long hm = __ballot(head), lm = __ballot(live);
+    // lanes after this one that start a run, or are dead: the nearest ends this run
+    const unsigned long long stop = (hm | ~lm) & ~((2ull << lane) - 1ull);
+    const int end = stop ? (int)__builtin_ctzll(stop) : 64;
+    len = (unsigned int)(end - lane);
+    return head;
+}
+
 __global__ void __launch_bounds__(256) k_grid_count(int M, const float* __restrict__ pts, GridHdr* __restrict__ hdr, int G,
                                                     unsigned int* __restrict__ cell_count, unsigned int* __restrict__ cell_of)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
+    const bool live = i < M;
     const GridGeom g = grid_geom(hdr, G);
-    const int cx = cell_coord(pts[3 * (size_t)i], g.ox, g), cy = cell_coord(pts[3 * (size_t)i + 1], g.oy, g),
-              cz = cell_coord(pts[3 * (size_t)i + 2], g.oz, g);
-    const unsigned int c = ((unsigned int)cz * G + cy) * G + cx;
-    cell_of[i] = c;
-    if (atomicAdd(&cell_count[c], 1u) == 0u) atomicAdd(&hdr->occupied, 1u);
+    unsigned int c = 0xFFFFFFFFu;
+    if (live) {
+        const int cx = cell_coord(pts[3 * (size_t)i], g.ox, g), cy = cell_coord(pts[3 * (size_t)i + 1], g.oy, g),
+                  cz = cell_coord(pts[3 * (size_t)i + 2], g.oz, g);
+        c = ((unsigned int)cz * G + cy) * G + cx;
+        cell_of[i] = c;
+    }
+    // Runs of neighbouring lanes in the same cell (points of a mesh or of a scan come in spatial order) take ONE atomic: the run's
+    // first lane adds the run's length (1M returning atomics, many on the same address within a wave, made this kernel 0.15 ms);
+    // and the occupied-cell count takes one atomic per wave instead of one per first touch of a cell.
+    unsigned int len;
+    const bool head = grid_run_head(c, live, len);
+    const bool fresh = head && atomicAdd(&cell_count[c], len) == 0u;
+    const unsigned long long fm = __ballot(fresh);
+    if (fm && (threadIdx.x & 63) == (unsigned int)__builtin_ctzll(fm)) atomicAdd(&hdr->occupied, (unsigned int)__popcll(fm));
 }
 
 // exclusive scan of the cell counts (G^3 <= 2M cells), two launches: sums of 4096-cell blocks, then every block adds up the sums
@@ -370,9 +395,18 @@ __global__ void __launch_bounds__(256) k_grid_scatter(int M, const float* __rest
                                                       float4* __restrict__ sorted)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
-    const unsigned int c = cell_of[i];
-    const unsigned int pos = cell_start[c] + atomicAdd(&cursor[c], 1u);
+    const bool live = i < M;
+    const unsigned int c = live ? cell_of[i] : 0xFFFFFFFFu;
+    // (as in k_grid_count: one returning atomic per run of lanes in the same cell; the run's lanes take consecutive slots)
+    unsigned int len;
+    const bool head = grid_run_head(c, live, len);
+    unsigned int base = 0u;
+    if (head) base = cell_start[c] + atomicAdd(&cursor[c], len);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long hm = __ballot(head);
+    if (!live) return;
+    const int my_head = 63 - (int)__builtin_clzll(hm & ((2ull << lane) - 1ull));   // the nearest head at or before this lane
+    const unsigned int pos = (unsigned int)__shfl((int)base, my_head) + (unsigned int)(lane - my_head);
     sorted[pos] = make_float4(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], __int_as_float(i));
 }
 

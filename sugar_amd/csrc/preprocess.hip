@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreprocessArgs a)
     const int li = valid ? idx : a.P - 1;
     const size_t i3 = 3 * (size_t)li;
 
-    if (blockIdx.x == 0)  // the depth sort's histograms and chunk tickets start from zero (binning.hip)
+    if (blockIdx.x == 0 && !a.keys_elsewhere)  // the depth sort's histograms and chunk tickets start from zero (binning.hip)
         for (int i = threadIdx.x; i < a.n_sort_counters; i += 256) a.sort_counters[i] = 0u;
     if (a.zero_words && blockIdx.x == gridDim.x - 1)
         for (int i = threadIdx.x; i < a.n_zero_words; i += 256) a.zero_words[i] = 0u;
@@ -420,11 +420,46 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(PreprocessArgs a)
         const float4* srcv = reinterpret_cast<const float4*>(&rec);
         dst[0] = srcv[0]; dst[1] = srcv[1]; dst[2] = srcv[2];
         if (a.radii) a.radii[idx] = out_radius;
-        a.sort_keys[idx] = key;
+        if (!a.keys_elsewhere) a.sort_keys[idx] = key;
         a.rect_by_id[idx] = rect;
     }
+    if (a.keys_elsewhere) return;   // (uniform: k_depth_keys wrote the keys and their ranges, the sort is already under way)
     // smallest and largest depth key of the workgroup's visible Gaussians: the depth sort works on key - min and drops its
     // fourth pass when the range fits 24 bits (binning.hip)
+    uint32_t kmin = key, kmax = key == 0xFFFFFFFFu ? 0u : key;
+    for (int o = 32; o > 0; o >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o));
+    }
+    if ((threadIdx.x & 63) == 0) { s_mm[0][threadIdx.x >> 6] = kmin; s_mm[1][threadIdx.x >> 6] = kmax; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        a.key_minmax[blockIdx.x] = make_uint2(min(min(s_mm[0][0], s_mm[0][1]), min(s_mm[0][2], s_mm[0][3])),
+                                              max(max(s_mm[1][0], s_mm[1][1]), max(s_mm[1][2], s_mm[1][3])));
+}
+
+// The depth-sort keys on their own (round 6).  The sort needs nothing of a Gaussian but its view-space depth, 12 bytes in and 4 out,
+// while k_preprocess_fwd is a 59 us HBM-bound stream of 350 bytes per Gaussian: sgr_forward_ex runs this kernel, the sort's histogram
+// kernel and its first two passes on a stream of its own BESIDE the preprocess kernel and joins before the last pass (which carries
+// the tile rectangles the preprocess kernel writes).  Same arithmetic as above (xform4x3 on the same camera words), so the key of a
+// rendered Gaussian is bit-identical to rec.depth.  A Gaussian the preprocess kernel culls for another reason than its depth (zero
+// radius, empty tile rectangle) keeps its depth key here -- it is sorted among the others and skipped by the binning passes (its
+// rectangle has zero width), so the order of the rendered ones, and with it every tile list, is unchanged.
+__global__ void __launch_bounds__(256) k_depth_keys(PreprocessArgs a)
+{
+    __shared__ uint32_t s_mm[2][4];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = idx < a.P;
+    const size_t i3 = 3 * (size_t)(valid ? idx : a.P - 1);
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < a.n_sort_counters; i += 256) a.sort_counters[i] = 0u;
+    const float cam_raw = cam_request(a.viewmatrix, a.projmatrix, a.cam_pos);
+    const V3 p_orig = {a.means3D[i3], a.means3D[i3 + 1], a.means3D[i3 + 2]};
+    Cam cam;
+    cam_unpack(cam_raw, cam);
+    const V3 p_view = xform4x3(p_orig, cam.vm);
+    const uint32_t key = (valid && !(p_view.z <= 0.2f)) ? __float_as_uint(p_view.z) : 0xFFFFFFFFu;
+    if (valid) a.sort_keys[idx] = key;
     uint32_t kmin = key, kmax = key == 0xFFFFFFFFu ? 0u : key;
     for (int o = 32; o > 0; o >>= 1) {
         kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o));
@@ -1119,6 +1154,12 @@ void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatri
 {
     if (P <= 0) return;
     hipLaunchKernelGGL(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, viewmatrix, present);
+}
+
+void sgr_launch_depth_keys(const PreprocessArgs& a, hipStream_t s)
+{
+    if (a.P <= 0) return;
+    hipLaunchKernelGGL(k_depth_keys, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
 }
 
 void sgr_launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s)

@@ -41,7 +41,7 @@ size_t sgr_sort_rects_offset(int P);    // binning.hip: offset of the packed rec
 static inline size_t sgr_geom_total(int P) { return sgr_geom_sort_offset(P) + sgr_sort_scratch_bytes(P); }
 
 struct ImgLayout {
-    size_t final_T, n_contrib, tile_start, tile_cursor, tile_maxc, tile_walked, blk_nb, header, repair_flag, repair_list, blk_hist, total;
+    size_t final_T, n_contrib, tile_start, tile_cursor, tile_maxc, tile_walked, blk_nb, header, repair_flag, repair_list, deep_list, blk_hist, total;
     int n_blocks;      // slices of the depth order in the ordered binning
     int gx, gy, T;
 };
@@ -64,6 +64,7 @@ static inline ImgLayout sgr_img_layout(int W, int H)
     // walk hint) and the list of those tiles (the second blend pass's launch order); their count is header word SGR_HDR_REPAIR
     L.repair_flag = off; off = sgr_align(off + (size_t)L.T * 4);
     L.repair_list = off; off = sgr_align(off + (size_t)L.T * 4);
+    L.deep_list = off;   off = sgr_align(off + (size_t)L.T * 4);   // tiles whose blocks k_blend_fwd_deep takes (count: header word SGR_HDR_DEEP)
     // the single-level fallback keeps one LDS counter per tile: beyond ~38 000 tiles (8K images) only the two-level path exists
     L.n_blocks = ((size_t)L.T * 4 <= SGR_LEGACY_LDS_BYTES) ? SGR_BIN_SLICES : 0;
     L.blk_hist = off;    off = sgr_align(off + (size_t)L.n_blocks * L.T * 4);
@@ -140,11 +141,13 @@ struct PreprocessArgs {
     uint2* rect_by_id;    // [P] packed tile rectangle of every Gaussian (w == 0: culled)
     uint2* key_minmax;    // [ceil(P / 256)] smallest / largest depth key of every workgroup's visible Gaussians
     uint32_t* sort_counters; int n_sort_counters;  // zeroed by workgroup 0 (histograms and tickets of the depth sort)
+    int keys_elsewhere = 0;  // 1: sgr_launch_depth_keys writes sort_keys / key_minmax and zeroes the counters (the sort overlaps this kernel)
     uint32_t* zero_words = nullptr; int n_zero_words = 0;  // more words to zero, by the last workgroup (the walk hint's repair flags:
                                                            // as a store stream of the single-workgroup tile scan they cost it 9 us)
 };
 void sgr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 void sgr_launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
+void sgr_launch_depth_keys(const PreprocessArgs& a, hipStream_t s);  // sort keys + key ranges + counter reset only (preprocess.hip)
 
 struct PreprocessBwdArgs {
     int P, D, M;
@@ -201,8 +204,9 @@ int sgr_adam_launch(long long n, float* params, const float* grads, float* exp_a
                     const int* seg_period, const int* seg_split, float beta1, float beta2, float eps, int step, float grad_scale,
                     const float* extra, long long extra_n, const uint32_t* guard, uint32_t guard_cap, hipStream_t s);
 
+// part: 0 the whole sort; 1 histogram kernel + passes 0 and 1 (keys only); 2 passes 2 and 3 (the last one carries the rectangles)
 void sgr_launch_gaussian_sort(int P, char* sort_scratch, const uint32_t** order_out, const uint2* rect_by_id, uint2* rects_sorted,
-                              hipStream_t s);
+                              hipStream_t s, int part = 0);
 size_t sgr_sort_rect_by_id_offset(int P);  // binning.hip: the by-id rectangles written by the preprocess kernel
 size_t sgr_sort_minmax_offset(int P);      // binning.hip: the per-workgroup key ranges written by the preprocess kernel
 size_t sgr_sort_counters_offset(int P);    // binning.hip: the counters the preprocess kernel zeroes for the sort
@@ -222,9 +226,16 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
                           const GeomRec* rec, const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc,
                           uint32_t* tile_walked, float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb,
                           uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, const uint32_t* launch_order, hipStream_t s,
-                          uint32_t* repair_flag = nullptr, uint32_t* repair_list = nullptr, int exact = 0);
+                          uint32_t* repair_flag = nullptr, uint32_t* repair_list = nullptr, int exact = 0, uint32_t deep_min = 0u);
+// blocks of tiles whose hinted list is longer than deep_min entries: eight waves per block (blend.hip); deep_list: [T] words of scratch
+void sgr_launch_blend_fwd_deep(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list, const GeomRec* rec,
+                               const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc, uint32_t* tile_walked,
+                               float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb, uint32_t* header, uint32_t list_cap,
+                               const uint32_t* tile_need, uint32_t* deep_list, uint32_t deep_min, hipStream_t s, uint32_t* repair_flag,
+                               uint32_t* repair_list, int exact);
 // exact: the exact-alpha kernels (blend.hip: SGR_FWD_BODY_X); process-wide default sgr_exact_alpha() (capi.hip)
 int sgr_exact_alpha();
+uint32_t sgr_deep_min();   // capi.hip: process-wide threshold of the eight-wave kernel (sgr_set_deep_min)
 // Walk-hint repair: the tiles the first pass listed (they outran their hint) once more, over their full lists (written meanwhile
 // by a list-write pass gated on the same count).  A no-op launch when the list is empty.
 #define SGR_REPAIR_TILES 1024

@@ -68,11 +68,24 @@ __device__ __forceinline__ void sgr_tile_order_block(const SgrTileOrderJob& j)
     // the second header copy for the host (word 3, the hint-miss flag, is final now that the blend kernel is done)
     if (j.header_host && tid < 8) j.header_host[8 + tid] = j.header[tid];
     if (SGR_FORWARD_INVALID(j.header, j.list_cap)) return;  // (an invalid forward leaves the previous order and hint in place)
-    if (j.need_out)  // what the tile walked now, plus a margin, plus one batch
+    if (j.need_out) {  // what the tile walked now, plus a margin, plus one batch
+        uint32_t mx = 0u;
         for (int i = tid; i < T; i += NT) {
             const uint32_t w = j.tile_walked[i];
-            j.need_out[i] = w + (uint32_t)((float)w * j.margin) + 64u;
+            const uint32_t need = w + (uint32_t)((float)w * j.margin) + 64u;
+            j.need_out[i] = need;
+            mx = max(mx, need);
         }
+        // the largest hint written, for the host (second header copy, word 9 -- the slot of the duplicate of the largest tile
+        // count): a caller decides from it whether the camera's next visit needs the kernel for long lists (SGR_FLAG_NO_DEEP)
+        if (j.header_host) {
+            for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+            if (lane == 0) s_w[wave] = mx;
+            __syncthreads();
+            if (tid == 0) { uint32_t m = 0u; for (int w = 0; w < NT / 64; w++) m = max(m, s_w[w]); j.header_host[8 + SGR_HDR_MAXCOUNT] = m; }
+            __syncthreads();
+        }
+    }
 #ifdef SGR_ORDER_SUPER_TILE
     // ---- order at SUPER-TILE granularity: the 8x8-tile super-tiles by the depth of their deepest tile, deepest first, the tiles
     // of a super-tile in raster order behind one another (consecutive slots: one XCD, see sgr_slot_of_workgroup).  Depth is

@@ -177,7 +177,7 @@ int sgr_trainer_step(sgr_trainer* t, const sgr_train_view* v, int phases, const 
         sgr_forward_opts fo;
         std::memset(&fo, 0, sizeof(fo));
         fo.binning_capacity = c.binning_capacity;
-        fo.flags = SGR_FLAG_RAW_PARAMS;
+        fo.flags = SGR_FLAG_RAW_PARAMS | ((v->flags & SGR_VIEW_DEEP_LISTS) ? 0 : SGR_FLAG_NO_DEEP);
         fo.header_host = c.header_host;
         // the post-blend bookkeeping (launch order, walk hint, second header copy) rides in the loss forward kernel, which is what
         // follows the blend here; the event for the host is recorded behind it

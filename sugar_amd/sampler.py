@@ -174,10 +174,11 @@ def _sample_sync_free(means3D, scales, rotations, opacities, cam, depth_flat, n,
     pix_c = torch.empty(L, n, dtype=torch.int64, device=dev)
     gid_c = torch.empty(L, n, dtype=torch.int64, device=dev)
     counts = torch.empty(L, dtype=torch.int32, device=dev)
+    scr2 = torch.empty(int(lib.sgr_compact_level_rows_scratch_bytes(n, L)), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = lib.sgr_compact_level_rows(n, L, _p(valid), _p(words), _p(pts), _p(nrm) if nrm is not None else None, _p(picked),
                                         _p(gaussian_idx), _p(rows), _p(pts_c), _p(nrm_c) if nrm_c is not None else None, _p(pix_c),
-                                        _p(gid_c), _p(counts), _stream(dev))
+                                        _p(gid_c), _p(counts), _p(scr2), _stream(dev))
     if rc < 0:
         raise RuntimeError(f"sgr_compact_level_rows failed ({rc})")
     out = {}

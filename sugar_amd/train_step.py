@@ -609,6 +609,8 @@ class NativeTrainer:
         self.densify_stats = bool(densify_stats)
         self._betas, self._eps, self._lambda_dssim = betas, eps, lambda_dssim
         self._hdr = torch.zeros(16, dtype=torch.int32).pin_memory()
+        self._deep_min = int(lib.sgr_get_deep_min()) or (1 << 31)   # (0 = the long-list kernel is off)
+        self._last_max_need = 0
         self._hints = {}       # camera key -> int32[T] walk hint
         self._pending = None   # (cam, gt, key) of the step whose forward has not been validated yet
         self.redone = 0
@@ -763,7 +765,7 @@ class NativeTrainer:
             ent = self._hints.get(key)
             if ent is None:  # per camera: [walk hint, hint usable, level-2 chunks of the last validated visit, launch order, order usable]
                 ent = self._hints[key] = [torch.zeros(self.T, dtype=torch.int32, device=self.dev), False, 0,
-                                          torch.zeros(self.T, dtype=torch.int32, device=self.dev), False]
+                                          torch.zeros(self.T, dtype=torch.int32, device=self.dev), False, 0]   # [5]: largest hint written
             if self.walk_hint:
                 # (usable once a forward that wrote it was validated, and not while the hints are paused)
                 need = ent[0].data_ptr() if (ent[1] and use_hint and self._calls >= self._hint_pause_until) else None
@@ -775,8 +777,12 @@ class NativeTrainer:
                 order_out = ent[3].data_ptr()
             self._last_hinted = need is not None
             self._calls += 1
+        # long lists: the eight-wave blend kernel (and the side stream it runs on) only for a camera whose hint has a tile above the
+        # library's threshold -- the largest hint of its last validated visit came back in the host header
+        ent5 = self._hints.get(key)
+        deep = 1 if (need is not None and ent5 is not None and ent5[5] > self._deep_min) else 0
         view = L.TrainView(cam.viewmatrix.data_ptr(), cam.projmatrix.data_ptr(), cam.campos.data_ptr(), cam.tanfovx, cam.tanfovy,
-                           gt.data_ptr(), need, need_out, self.hint_margin, self._chunk_grid(key), order, order_out)
+                           gt.data_ptr(), need, need_out, self.hint_margin, self._chunk_grid(key), order, order_out, deep)
         with torch.cuda.device(self.dev):
             stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
             if exchange_step is not None:
@@ -812,6 +818,7 @@ class NativeTrainer:
         self.last_num_rendered = int(hdr[0])
         self._last_chunks = int(hdr[5])
         self.last_repaired_tiles = int(hdr[8 + 7])   # tiles that outran their walk hint and were rendered again in place
+        self._last_max_need = int(hdr[8 + 1])        # the largest walk hint this forward wrote (tile_order.h)
         if ok:
             self.repaired_tiles += self.last_repaired_tiles
         return bool(ok), (int(hdr[0]) if int(hdr[0]) > self.capacity else 0), bool(hdr[8 + 3])
@@ -843,6 +850,7 @@ class NativeTrainer:
                     self._hints[key][1] = True
                     self._hints[key][2] = self._last_chunks
                     self._hints[key][4] = True
+                    self._hints[key][5] = self._last_max_need
                 self._hint_feedback(False)
                 self._pending = None
                 return
@@ -880,6 +888,7 @@ class NativeTrainer:
                         self._hints[key][1] = True
                         self._hints[key][2] = self._last_chunks
                         self._hints[key][4] = True
+                        self._hints[key][5] = self._last_max_need
                     self._hint_feedback(False)
                     return self.loss_out[0]
                 if not (R or missed):
@@ -897,6 +906,7 @@ class NativeTrainer:
                     self._hints[key][1] = True
                     self._hints[key][2] = self._last_chunks
                     self._hints[key][4] = True
+                    self._hints[key][5] = self._last_max_need
                 self._hint_feedback(False)
                 break
             if not (R or missed):
