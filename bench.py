@@ -487,9 +487,11 @@ def main():
                     if pj.get("valu_wave_insts_per_launch") and blend_ms > 0:
                         n_inst, dt_ns, simds = float(pj["valu_wave_insts_per_launch"]), float(pj["simd_issue_interval_ns"]), 1024
                         issue_ms = n_inst * dt_ns * 1e-6 / simds
-                        valu = {"kernel": "k_blend_fwd_w", "bound": "valu_issue", "wave_insts_per_launch": n_inst,
+                        guide_ns = 2.0 / 2.4   # MI355X_MICROARCH.md: 2 cycles per wave64 VALU instruction at 2.4 GHz
+                        valu = {"kernel": pj.get("kernel", "k_blend_fwd_w"), "bound": "valu_issue", "wave_insts_per_launch": n_inst,
                                 "simd_issue_interval_ns": dt_ns, "simds": simds, "issue_ms": issue_ms, "launch_ms": blend_ms,
                                 "frac": issue_ms / blend_ms,
+                                "simd_issue_interval_ns_guide": guide_ns, "frac_at_guide_rate": n_inst * guide_ns * 1e-6 / simds / blend_ms,
                                 "what": "SQ_INSTS_VALU per launch (committed PMC pass) x the measured interval at which one SIMD "
                                         "retires wave64 vector instructions (scripts/microbench/valu_rate.hip) / 1024 SIMDs, over "
                                         "the launch time measured in THIS run: the share of the kernel its vector ALUs are busy",
@@ -562,6 +564,23 @@ def main():
         }
         if valu is not None:
             out["roofline_valu"] = valu
+        out["roofline"]["kernel"] = "k_blend_fwd_wx" if lib.sgr_get_exact_alpha() else "k_blend_fwd_w"
+        if not forward_only and stages.get("blend_bwd", 0) > 0:
+            # the two other large kernels of the step against the same roofline (112 B per walked instance
+            # + 20 B per pixel + 8 B per tile for the backward blend; parameters, two moments in and out plus the views' colour
+            # gradients and the centre for the SH-Adam kernel)
+            bb = 112.0 * R_b + 20.0 * W * H + 8.0 * T
+            others = [{"kernel": "k_blend_bwd_wx" if lib.sgr_get_exact_alpha() else "k_blend_bwd_w", "bound": "hbm", "algorithmic_bytes_per_launch": bb,
+                       "launch_ms": stages["blend_bwd"], "achieved": bb / (stages["blend_bwd"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": bb / (stages["blend_bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                       "what": "latency-bound: a dependent chain per (entry, block) at 5 waves per SIMD (DESIGN.md section 5)"}]
+            if stages.get("sh_adam", 0) > 0:
+                M_ = int(getattr(params, "M", 16))
+                sb = float(P) * (6.0 * 12.0 * M_ + 12.0 * world + 12.0)
+                others.append({"kernel": "k_sh_adam_from_views", "bound": "hbm", "algorithmic_bytes_per_launch": sb, "launch_ms": stages["sh_adam"],
+                               "achieved": sb / (stages["sh_adam"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": sb / (stages["sh_adam"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None})
+            out["roofline_other_kernels"] = others
         out["parity_bar"] = ("tests/test_gpu_fullsize.py vs the reference's kernels on the same GPU (exact-alpha mode, the default): tile lists / "
                              "ranges / radii / num_rendered / final_T / n_contrib bit-exact; image <= 5e-7 norm-wise; every gradient tensor <= 1e-5 "
                              "norm-wise AND >= 99.9 % of its elements within 1e-4 relative (floor 1e-3 of the tensor's largest magnitude), next "

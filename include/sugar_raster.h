@@ -175,8 +175,9 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user,
 #define SGR_FLAG_EXACT_ALPHA 16
 /* Long lists (round 6).  With a walk hint (sgr_forward_opts.tile_need) the 8x8 blocks of a tile whose hinted list is longer than
  * `entries` are blended by an eight-wave kernel -- alpha for eight 64-entry batches in parallel, then the cheap sequential
- * transmittance chain -- beside the one-wave kernel, on a stream of the library's own; bit-identical results.  Default 1024
- * (SGR_DEEP_MIN in the environment); 0 disables.  Header word SGR_HDR_DEEP reports how many tiles took that path. */
+ * transmittance chain -- beside the one-wave kernel, on a stream of the library's own; bit-identical results.  Default 0 = off
+ * (SGR_DEEP_MIN in the environment sets it): measured on BASELINE config 4 the kernel is bit-exact but not yet faster than the
+ * one-wave walk (profiles/r06_blend_fwd_deep_lists_ab.txt).  Header word SGR_HDR_DEEP reports how many tiles took that path. */
 #define SGR_FLAG_NO_DEEP 32   /* this call: one wave per block whatever the hint says (a caller that knows its lists are short saves the
                                  side stream's fork and join: sgr_trainer_step sets it unless the camera's last visit left a hint
                                  above the threshold -- host header word 9, second copy, carries the largest hint written) */

@@ -89,7 +89,7 @@ __device__ __forceinline__ bool block_hit(float gxc, float gyc, float cx, float 
 //   out: live updated, n = entries not yet started when every lane had finished (0: the batch was walked to its end)
 // gfx950 hazards observed by hand (the compiler does not look inside): one independent instruction between v_exp_f32 and the
 // use of its result; EXEC is only ever written by SALU instructions before VALU instructions depend on it.
-#define SGR_FWD_BODY(X, Y, A, B, CZ, OP, R, G, BL, POS)                                             \
+#define SGR_FWD_BODY(X, Y, A, B, CZ, OP, R, G, BL, POS, XY, AB)                                     \
     "v_sub_f32 v60, " X ", %[px]\n"                                                                 \
     "v_sub_f32 v61, " Y ", %[py]\n"                                                                 \
     "v_mul_f32 v62, " B ", v61\n"                                                                   \
@@ -130,7 +130,7 @@ __device__ __forceinline__ bool block_hit(float gxc, float gyc, float cx, float 
 //   test_T = T (1 - alpha)
 // With it alpha, T, final_T and n_contrib are bit-identical to the reference's (compiled without contraction) and every gradient
 // tensor is within the reference's own run-to-run spread; 12 more VALU instructions per entry (33 against 21).
-#define SGR_FWD_BODY_X(X, Y, A, B, CZ, OP, R, G, BL, POS)                                           \
+#define SGR_FWD_BODY_X(X, Y, A, B, CZ, OP, R, G, BL, POS, XY, AB)                                   \
     "v_sub_f32 v60, " X ", %[px]\n"                                                                 \
     "v_sub_f32 v61, " Y ", %[py]\n"                                                                 \
     "v_mul_f32 v62, " A ", v60\n"                                                                   \
@@ -170,6 +170,47 @@ __device__ __forceinline__ bool block_hit(float gxc, float gyc, float cx, float 
     "v_mov_b32 %[last], " POS "\n"                                                                  \
     "s_mov_b64 exec, %[live]\n"
 
+// A/B build option -DSGR_FWD_PK (round-5 verdict item 5, "build one instruction-diet variant"): the exact body with `power` on
+// packed arithmetic -- (dx, dy), (cx' dx, cz' dy) and their squares as three v_pk_*_f32 instead of six scalar operations; the entry
+// then carries (-0.5 cx, -0.5 cz) as a register pair and cy behind them.  Same operations on the same values: bit-identical.
+// 30 instead of 33 vector instructions per entry; profiles/r06_fwd_pk_ab.txt has what that bought.
+#define SGR_FWD_BODY_XPK(X, Y, A, B, CZ, OP, R, G, BL, POS, XY, AB)                                  \
+    "v_pk_add_f32 v[60:61], " XY ", %[pxy] neg_lo:[0,1] neg_hi:[0,1]\n"                              \
+    "v_pk_mul_f32 v[62:63], " AB ", v[60:61]\n"                                                      \
+    "v_pk_mul_f32 v[62:63], v[62:63], v[60:61]\n"                                                    \
+    "v_mul_f32 v60, " CZ ", v60\n"      /* cy dx  (CZ holds cy in this layout) */                   \
+    "v_add_f32 v62, v62, v63\n"                                                                     \
+    "v_mul_f32 v60, v60, v61\n"                                                                     \
+    "v_sub_f32 v63, v62, v60\n"         /* power */                                                 \
+    "v_mul_f32 v60, 0x3fb8aa3b, v63\n"                                                              \
+    "v_rndne_f32 v61, v60\n"                                                                        \
+    "v_fma_f32 v62, v63, %[chi], -v60\n"                                                            \
+    "v_fmac_f32 v62, 0x32a5705f, v63\n"                                                             \
+    "v_sub_f32 v60, v60, v61\n"                                                                     \
+    "v_add_f32 v60, v60, v62\n"                                                                     \
+    "v_exp_f32 v60, v60\n"                                                                          \
+    "v_cvt_i32_f32 v61, v61\n"                                                                      \
+    "s_mov_b64 %[live], exec\n"                                                                     \
+    "v_cmp_nlt_f32 vcc, 0, v63\n"                                                                   \
+    "v_ldexp_f32 v62, v60, v61\n"                                                                   \
+    "v_mul_f32 v62, " OP ", v62\n"                                                                  \
+    "v_min_f32 v62, 0x3f7d70a4, v62\n"                                                              \
+    "s_and_b64 exec, exec, vcc\n"                                                                   \
+    "v_cmp_ngt_f32 vcc, 0x3b808081, v62\n"                                                          \
+    "v_sub_f32 v60, 1.0, v62\n"                                                                     \
+    "v_mul_f32 v61, v62, %[T]\n"                                                                    \
+    "v_mul_f32 v60, %[T], v60\n"                                                                    \
+    "s_and_b64 exec, exec, vcc\n"                                                                   \
+    "v_cmp_gt_f32 vcc, 0x38d1b717, v60\n"                                                           \
+    "s_andn2_b64 %[live], %[live], vcc\n"                                                           \
+    "s_andn2_b64 exec, exec, vcc\n"                                                                 \
+    "v_mov_b32 %[T], v60\n"                                                                         \
+    "v_fmac_f32 %[C0], " R ", v61\n"                                                                \
+    "v_fmac_f32 %[C1], " G ", v61\n"                                                                \
+    "v_fmac_f32 %[C2], " BL ", v61\n"                                                               \
+    "v_mov_b32 %[last], " POS "\n"                                                                  \
+    "s_mov_b64 exec, %[live]\n"
+
 #define SGR_FWD_ENTRY_BYTES 48
 
 
@@ -186,7 +227,7 @@ __device__ __forceinline__ bool block_hit(float gxc, float gyc, float cx, float 
         "ds_read_b128 v[54:57], %[addr] offset:64\n"                                                                           \
         "ds_read_b64 v[58:59], %[addr] offset:80\n"                                                                            \
         "s_waitcnt lgkmcnt(3)\n"                                                                                               \
-        BODY("v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49")                                             \
+        BODY("v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v[40:41]", "v[42:43]")                      \
         "s_cbranch_execz 3f\n"                                                                                                 \
         "s_add_i32 %[n], %[n], -1\n"                                                                                           \
         "s_cmp_eq_u32 %[n], 0\n"                                                                                               \
@@ -196,7 +237,7 @@ __device__ __forceinline__ bool block_hit(float gxc, float gyc, float cx, float 
         "ds_read_b64 v[48:49], %[addr] offset:128\n"                                                                           \
         "v_add_u32 %[addr], 96, %[addr]\n"                                                                                     \
         "s_waitcnt lgkmcnt(3)\n"                                                                                               \
-        BODY("v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59")                                             \
+        BODY("v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v[50:51]", "v[52:53]")                      \
         "s_cbranch_execz 3f\n"                                                                                                 \
         "s_add_i32 %[n], %[n], -1\n"                                                                                           \
         "s_cmp_eq_u32 %[n], 0\n"                                                                                               \
@@ -207,7 +248,7 @@ __device__ __forceinline__ bool block_hit(float gxc, float gyc, float cx, float 
 #define SGR_FWD_WALK_OPERANDS                                                                                                  \
         : [T] "+v"(T), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [last] "+v"(last), [addr] "+v"(addr), [n] "+s"(n),          \
           [live] "+s"(live), [full] "=&s"(full)                                                                                \
-        : [px] "v"(pixfx), [py] "v"(pixfy), [chi] "s"(LOG2E)                                                                   \
+        : [px] "v"(pixfx), [py] "v"(pixfy), [chi] "s"(LOG2E), [pxy] "v"(pixxy)                                                 \
         : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", \
           "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc", "memory"
 template <bool EXACT>
@@ -215,7 +256,12 @@ __device__ __forceinline__ void fwd_walk(uint32_t addr, int& n, unsigned long lo
                                          float& C0, float& C1, float& C2, uint32_t& last)
 {
     unsigned long long full;
+    const unsigned long long pixxy = ((unsigned long long)__float_as_uint(pixfy) << 32) | (unsigned long long)__float_as_uint(pixfx);  // (px, py) as a register pair
+#ifdef SGR_FWD_PK
+    if constexpr (EXACT) asm volatile(SGR_FWD_WALK_ASM(SGR_FWD_BODY_XPK) SGR_FWD_WALK_OPERANDS);
+#else
     if constexpr (EXACT) asm volatile(SGR_FWD_WALK_ASM(SGR_FWD_BODY_X) SGR_FWD_WALK_OPERANDS);
+#endif
     else asm volatile(SGR_FWD_WALK_ASM(SGR_FWD_BODY) SGR_FWD_WALK_OPERANDS);
 }
 #endif
@@ -406,8 +452,13 @@ __device__ __forceinline__ void blend_fwd_body(int W, int H, int gx, int T_tiles
             e[1] = make_float4(v1.x, v1.y, v2.x, v2.y);
 #else
             if (EXACT) {  // the raw conic, the two halvings applied (exact): SGR_FWD_BODY_X
+#ifdef SGR_FWD_PK
+                e[0] = make_float4(v0.x, v0.y, -0.5f * v0.z, -0.5f * v1.x);   // (-0.5 cx, -0.5 cz) as a pair, cy behind them
+                e[1] = make_float4(v0.w, v1.y, v2.x, v2.y);
+#else
                 e[0] = make_float4(v0.x, v0.y, -0.5f * v0.z, v0.w);
                 e[1] = make_float4(-0.5f * v1.x, v1.y, v2.x, v2.y);
+#endif
             } else {
                 e[0] = make_float4(v0.x, v0.y, -0.5f * LOG2E * v0.z, -LOG2E * v0.w);
                 e[1] = make_float4(-0.5f * LOG2E * v1.x, v1.y, v2.x, v2.y);
@@ -516,6 +567,69 @@ __global__ void __launch_bounds__(64) k_blend_fwd_repairx(SGR_FWD_PARAMS, const 
 // two kernels run side by side on two streams (capi.hip).  136 KB of LDS: one workgroup per CU, which is all a handful of blocks need.
 #define DEEP_WAVES 8
 #define DEEP_ROWS 64
+// Phase B of k_blend_fwd_deep as a hand-scheduled loop (the compiler's version of it -- a dependent LDS read, a 64-bit shift and a
+// ballot per row -- ran at ~350 cycles per row, which made the eight-wave kernel no faster than the one-wave walk it replaces):
+// the tail of SGR_FWD_BODY(_X) behind the alpha it reads from the panel, rows double-buffered like the entries of fwd_walk.
+//   aaddr: LDS byte address of this lane's alpha in row 0 (row stride 256 B); eaddr: of row 0's {r, g, b, position} (16 B per row)
+//   n rows (> 0); on return n = rows not yet started when every lane had finished (0: walked to the end), live updated
+#define SGR_DEEP_TAIL(EXACT_OPS, A, R, G, BL, POS)                                                  \
+    "s_mov_b64 %[live], exec\n"                                                                     \
+    "v_cmp_neq_f32 vcc, 0, " A "\n"     /* 0 = skipped in phase A (power > 0 or alpha < 1/255) */   \
+    "s_and_b64 exec, exec, vcc\n"                                                                   \
+    EXACT_OPS(A)                                                                                    \
+    "v_cmp_gt_f32 vcc, 0x38d1b717, v60\n" /* test_T < 0.0001: this lane is finished */              \
+    "s_andn2_b64 %[live], %[live], vcc\n"                                                           \
+    "s_andn2_b64 exec, exec, vcc\n"                                                                 \
+    "v_mov_b32 %[T], v60\n"                                                                         \
+    "v_fmac_f32 %[C0], " R ", v61\n"                                                                \
+    "v_fmac_f32 %[C1], " G ", v61\n"                                                                \
+    "v_fmac_f32 %[C2], " BL ", v61\n"                                                               \
+    "v_mov_b32 %[last], " POS "\n"                                                                  \
+    "s_mov_b64 exec, %[live]\n"
+#define SGR_DEEP_T_EXACT(A) "v_sub_f32 v60, 1.0, " A "\n" "v_mul_f32 v61, " A ", %[T]\n" "v_mul_f32 v60, %[T], v60\n"
+#define SGR_DEEP_T_FAST(A) "v_mul_f32 v61, " A ", %[T]\n" "v_sub_f32 v60, %[T], v61\n"
+#define SGR_DEEP_WALK_ASM(OPS)                                                                      \
+        "s_mov_b64 %[full], exec\n"                                                                 \
+        "s_and_b64 exec, exec, %[live]\n"                                                           \
+        "s_waitcnt lgkmcnt(0)\n"                                                                    \
+        "ds_read_b32 v40, %[aaddr]\n"                                                               \
+        "ds_read_b128 v[44:47], %[eaddr]\n"                                                         \
+        "1:\n"                                                                                      \
+        "ds_read_b32 v50, %[aaddr] offset:256\n"                                                    \
+        "ds_read_b128 v[54:57], %[eaddr] offset:16\n"                                               \
+        "s_waitcnt lgkmcnt(2)\n"                                                                    \
+        SGR_DEEP_TAIL(OPS, "v40", "v44", "v45", "v46", "v47")                                       \
+        "s_cbranch_execz 3f\n"                                                                      \
+        "s_add_i32 %[n], %[n], -1\n"                                                                \
+        "s_cmp_eq_u32 %[n], 0\n"                                                                    \
+        "s_cbranch_scc1 3f\n"                                                                       \
+        "ds_read_b32 v40, %[aaddr] offset:512\n"                                                    \
+        "ds_read_b128 v[44:47], %[eaddr] offset:32\n"                                               \
+        "v_add_u32 %[aaddr], 512, %[aaddr]\n"                                                       \
+        "v_add_u32 %[eaddr], 32, %[eaddr]\n"                                                        \
+        "s_waitcnt lgkmcnt(2)\n"                                                                    \
+        SGR_DEEP_TAIL(OPS, "v50", "v54", "v55", "v56", "v57")                                       \
+        "s_cbranch_execz 3f\n"                                                                      \
+        "s_add_i32 %[n], %[n], -1\n"                                                                \
+        "s_cmp_eq_u32 %[n], 0\n"                                                                    \
+        "s_cbranch_scc0 1b\n"                                                                       \
+        "3:\n"                                                                                      \
+        "s_waitcnt lgkmcnt(0)\n"                                                                    \
+        "s_mov_b64 exec, %[full]\n"
+#define SGR_DEEP_WALK_OPERANDS                                                                      \
+        : [T] "+v"(T), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [last] "+v"(last), [aaddr] "+v"(aaddr), [eaddr] "+v"(eaddr), \
+          [n] "+s"(n), [live] "+s"(live), [full] "=&s"(full)                                        \
+        :                                                                                           \
+        : "v40", "v44", "v45", "v46", "v47", "v50", "v54", "v55", "v56", "v57", "v60", "v61", "vcc", "scc", "memory"
+template <bool EXACT>
+__device__ __forceinline__ void deep_walk(uint32_t aaddr, uint32_t eaddr, int& n, unsigned long long& live, float& T, float& C0, float& C1,
+                                          float& C2, uint32_t& last)
+{
+    unsigned long long full;
+    if constexpr (EXACT) asm volatile(SGR_DEEP_WALK_ASM(SGR_DEEP_T_EXACT) SGR_DEEP_WALK_OPERANDS);
+    else asm volatile(SGR_DEEP_WALK_ASM(SGR_DEEP_T_FAST) SGR_DEEP_WALK_OPERANDS);
+}
+
 template <bool EXACT>
 __device__ __forceinline__ float deep_alpha(float x, float y, float cx, float cy, float cz, float op, float px, float py)
 {
@@ -557,7 +671,7 @@ k_blend_fwd_deep(SGR_FWD_PARAMS, const uint32_t* __restrict__ tile_need, const u
     float4* s_ent = reinterpret_cast<float4*>(s_deep + DEEP_WAVES * DEEP_ROWS * 64);      // [DEEP_WAVES][DEEP_ROWS] {r, g, b, position}
     uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_ent + DEEP_WAVES * DEEP_ROWS);        // [DEEP_WAVES] survivors of the wave's batch, [8] stop
     if (header[SGR_HDR_R] > list_cap || header[4 + SGR_B2_HDR_OVERFLOW]) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t n_deep = header[SGR_HDR_DEEP];
     for (uint32_t slot = blockIdx.x; slot < 4u * n_deep; slot += gridDim.x) {
         const int tile = (int)min(deep_list[slot >> 2], (uint32_t)(T_tiles - 1)), sub = (int)(slot & 3u);
@@ -601,35 +715,19 @@ k_blend_fwd_deep(SGR_FWD_PARAMS, const uint32_t* __restrict__ tile_need, const u
             }
             if (lane == 0) s_cnt[wave] = cnt;
             __syncthreads();
-            // ---------------- phase B: wave 0, in list order
+            // ---------------- phase B: wave 0, in list order (deep_walk)
             if (wave == 0) {
                 bool stop = false;
                 for (int w = 0; w < DEEP_WAVES && !stop; w++) {
                     if (seg + w >= n_b) break;
                     batches_seen = seg + w + 1;
-                    const int n = (int)s_cnt[w];
-                    const float* arow = s_alpha + ((size_t)w * DEEP_ROWS) * 64 + lane;
-                    for (int r = 0; r < n; r++) {
-                        const float a = arow[(size_t)r * 64];
-                        const float4 e = s_ent[w * DEEP_ROWS + r];
-                        bool fin = false;
-                        if (((live >> lane) & 1ull) && a != 0.f) {
-                            float test_T, aT;
-                            {
-#pragma clang fp contract(off)
-                                aT = a * T;
-                                test_T = EXACT ? T * (1.0f - a) : T - aT;
-                            }
-                            if (test_T < 0.0001f) fin = true;
-                            else {
-                                C0 = __builtin_fmaf(e.x, aT, C0); C1 = __builtin_fmaf(e.y, aT, C1); C2 = __builtin_fmaf(e.z, aT, C2);
-                                T = test_T;
-                                last_contributor = __float_as_uint(e.w);
-                            }
-                        }
-                        live &= ~__ballot(fin);
-                        if (live == 0ull) { walked = __float_as_uint(e.w); stop = true; break; }
-                    }
+                    int n = __builtin_amdgcn_readfirstlane((int)s_cnt[w]);
+                    if (n == 0) continue;
+                    const int n0 = n;
+                    const uint32_t a0 = (uint32_t)(uintptr_t)(s_alpha + ((size_t)w * DEEP_ROWS) * 64 + lane);
+                    const uint32_t e0 = (uint32_t)(uintptr_t)(s_ent + w * DEEP_ROWS);
+                    deep_walk<EXACT>(a0, e0, n, live, T, C0, C1, C2, last_contributor);
+                    if (live == 0ull) { walked = __float_as_uint(s_ent[w * DEEP_ROWS + (n0 - n)].w); stop = true; }
                 }
                 if (lane == 0) s_cnt[DEEP_WAVES] = stop ? 1u : 0u;
             }
@@ -1134,6 +1232,15 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
                        tile_need ? repair_flag : nullptr, repair_list, tile_need ? deep_min : 0u);
 }
 
+// the list of tiles whose hinted list is longer than deep_min (on the caller's stream, before the fork: as the first kernel of the
+// side stream it waited 80 us for a slot next to the one-wave kernel)
+void sgr_launch_deep_list(int gx, int gy, const uint32_t* tile_start, const uint32_t* tile_need, uint32_t deep_min, uint32_t* header,
+                          uint32_t list_cap, uint32_t* deep_list, hipStream_t s)
+{
+    const int T = gx * gy;
+    hipLaunchKernelGGL(k_deep_list, dim3((T + 255) / 256), dim3(256), 0, s, T, tile_start, tile_need, deep_min, header, list_cap, deep_list);
+}
+
 // the blocks of tiles whose hinted list is longer than deep_min, eight waves per block (the kernel above skips exactly those)
 void sgr_launch_blend_fwd_deep(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list, const GeomRec* rec,
                                const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc, uint32_t* tile_walked,
@@ -1149,7 +1256,6 @@ void sgr_launch_blend_fwd_deep(int W, int H, int gx, int gy, const uint32_t* til
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_blend_fwd_deep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
     }
-    hipLaunchKernelGGL(k_deep_list, dim3((T + 255) / 256), dim3(256), 0, s, T, tile_start, tile_need, deep_min, header, list_cap, deep_list);
     if (exact)
         hipLaunchKernelGGL(k_blend_fwd_deep<true>, dim3(256), dim3(64 * DEEP_WAVES), lds, s, W, H, gx, T, tile_start, point_list, rec, bg, final_T,
                            n_contrib, tile_maxc, tile_walked, out_color, blk_mask, blk_nb, header, list_cap, tile_need, deep_list, repair_flag,

@@ -132,7 +132,8 @@ int sgr_exact_alpha()
 static int g_deep_min = -1;
 uint32_t sgr_deep_min()
 {
-    if (g_deep_min < 0) { const char* e = getenv("SGR_DEEP_MIN"); g_deep_min = e ? atoi(e) : 1024; if (g_deep_min < 0) g_deep_min = 0; }
+    // (default 0 = off: as measured in round 6 the eight-wave kernel does not beat the one-wave walk yet -- profiles/r06_blend_fwd_deep_lists_ab.txt)
+    if (g_deep_min < 0) { const char* e = getenv("SGR_DEEP_MIN"); g_deep_min = e ? atoi(e) : 0; if (g_deep_min < 0) g_deep_min = 0; }
     return (uint32_t)g_deep_min;
 }
 
@@ -358,6 +359,8 @@ int64_t sgr_forward_ex(sgr_alloc_fn geom_alloc, void* geom_user, sgr_alloc_fn bi
             SideStream* dside = (deep_cfg && opts->tile_need && two_level && !debug && !(flags & SGR_FLAG_NO_DEEP)) ? side_stream() : nullptr;
             const uint32_t deep_min = dside ? deep_cfg : 0u;
             if (dside) {
+                sgr_launch_deep_list(IL.gx, IL.gy, tile_start, opts->tile_need, deep_min, header, (uint32_t)R_,
+                                     reinterpret_cast<uint32_t*>(img + IL.deep_list), s);
                 HIP_TRY(hipEventRecord(dside->fork, s));
                 HIP_TRY(hipStreamWaitEvent(dside->st, dside->fork, 0));
                 sgr_launch_blend_fwd_deep(width, height, IL.gx, IL.gy, tile_start, point_list, rec, background, final_T, n_contrib, tile_maxc,

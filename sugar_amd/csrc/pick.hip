@@ -9,9 +9,9 @@
 //   key(i)   = a bijective 32-bit hash of (pixel index ^ seed): distinct pixels have distinct keys, so "the k smallest keys among the
 //              valid pixels" is a well-defined, uniformly distributed k-subset (every pixel is equally likely to be in it; the order of
 //              the output is raster order, which no consumer of the sampler depends on)
-//   select   = two-level radix select of the k-th smallest key: a 65 536-bin histogram of the keys' upper halves, one workgroup finds
-//              the bin the k-th key falls into, a second histogram of the lower halves inside that bin, the same workgroup kernel finds
-//              the threshold key
+//   select   = three-level radix select of the k-th smallest key (11 + 11 + 10 key bits): a 2048-bin histogram per level -- level 1 over
+//              all valid pixels through workgroup-private LDS histograms, levels 2 and 3 over the few keys under the prefix found so
+//              far -- and after each one workgroup finds the bin the k-th key falls into
 //   compact  = ordered compaction of the pixels with key <= threshold (block counts, one-workgroup scan, write)
 //
 // and, behind the level-set kernel, sgr_compact_level_rows gathers every level's valid rows to the front of fixed-size outputs and
@@ -21,12 +21,12 @@
 
 namespace {
 
-#define PICK_BINS 65536
+#define PICK_BINS 2048     // bins per level of the radix select: key bits 31..21, 20..10, 9..0 (the last level uses 1024 of them)
 #define PICK_BLOCK 1024   // pixels per workgroup of the compaction passes
 
-// words of the selection state (device): 0 n_valid, 1 k_eff, 2 bin of level 1, 3 keys still needed inside that bin, 4 threshold key,
-// 5 "select nothing" flag
-struct PickState { uint32_t n_valid, k_eff, bin1, need1, thresh, none, pad0, pad1; };
+// selection state (device): n_valid; k_eff = min(k, n_valid); prefix = the key bits fixed so far (levels above the current one);
+// need = keys still to take inside the current prefix; thresh = the k-th smallest key (final); none = "select nothing"
+struct PickState { uint32_t n_valid, k_eff, prefix, need, thresh, none, pad0, pad1; };
 
 __device__ __forceinline__ uint32_t pick_key(uint32_t i, uint32_t seed)
 {
@@ -36,31 +36,40 @@ __device__ __forceinline__ uint32_t pick_key(uint32_t i, uint32_t seed)
 }
 __device__ __forceinline__ bool pick_valid(float d) { return !(d < 0.f); }   // sugar_model.py:1929: no_proj_mask = depth < 0
 
-__global__ void __launch_bounds__(256) k_pick_hist1(int n, const float* __restrict__ depth, uint32_t seed, uint32_t* __restrict__ hist,
-                                                    PickState* __restrict__ st)
+// level 1: the 11 upper key bits of every valid pixel, in a workgroup-private LDS histogram first (a 65 536-bin histogram in global
+// memory -- the first version -- was 727 000 global atomics per view, 75 us at the ~10 atomics per ns this part sustains)
+__global__ void __launch_bounds__(1024) k_pick_hist1(int n, const float* __restrict__ depth, uint32_t seed, uint32_t* __restrict__ hist,
+                                                     PickState* __restrict__ st)
 {
+    __shared__ uint32_t s_h[PICK_BINS];
+    for (int b = threadIdx.x; b < PICK_BINS; b += 1024) s_h[b] = 0u;
+    __syncthreads();
     uint32_t cnt = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        if (pick_valid(depth[i])) { atomicAdd(&hist[pick_key((uint32_t)i, seed) >> 16], 1u); cnt++; }
+    for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
+        if (pick_valid(depth[i])) { atomicAdd(&s_h[pick_key((uint32_t)i, seed) >> 21], 1u); cnt++; }
     }
     for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&st->n_valid, cnt);
+    __syncthreads();
+    for (int b = threadIdx.x; b < PICK_BINS; b += 1024) { const uint32_t c = s_h[b]; if (c) atomicAdd(&hist[b], c); }
 }
 
-__global__ void __launch_bounds__(256) k_pick_hist2(int n, const float* __restrict__ depth, uint32_t seed, uint32_t* __restrict__ hist,
-                                                    const PickState* __restrict__ st)
+// levels 2 and 3: only the keys under the prefix found so far (a few hundred, then a handful): straight to the global histogram
+__global__ void __launch_bounds__(256) k_pick_hist23(int n, const float* __restrict__ depth, uint32_t seed, uint32_t* __restrict__ hist,
+                                                     const PickState* __restrict__ st, int level)
 {
     if (st->none) return;
-    const uint32_t bin1 = st->bin1;
+    const uint32_t prefix = st->prefix;
+    const int sh_hi = level == 2 ? 21 : 10, sh_lo = level == 2 ? 10 : 0;
+    const uint32_t mask = level == 2 ? 0x7FFu : 0x3FFu;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         if (!pick_valid(depth[i])) continue;
         const uint32_t k = pick_key((uint32_t)i, seed);
-        if ((k >> 16) == bin1) atomicAdd(&hist[k & 0xFFFFu], 1u);
+        if ((k >> sh_hi) == (prefix >> sh_hi)) atomicAdd(&hist[(k >> sh_lo) & mask], 1u);
     }
 }
 
-// one workgroup: the smallest bin b with (bins 0..b summed) >= need.  level 1: need = min(k, n_valid), writes bin1 / need1 and zeroes
-// the level-2 histogram's... (the histograms are zeroed by the launcher); level 2: need = need1, writes the threshold key.
+// one workgroup: the smallest bin b with (bins 0..b summed) >= need; the prefix takes the bin's bits, need becomes the rank inside it
 __global__ void __launch_bounds__(1024) k_pick_select(const uint32_t* __restrict__ hist, PickState* __restrict__ st, int level, uint32_t k)
 {
     __shared__ uint32_t s_wave[16];
@@ -70,14 +79,13 @@ __global__ void __launch_bounds__(1024) k_pick_select(const uint32_t* __restrict
         need = min(k, st->n_valid);
         if (tid == 0) { st->k_eff = need; st->none = need == 0u ? 1u : 0u; }
     } else {
-        need = st->need1;
+        need = st->need;
         if (st->none) return;
     }
     if (need == 0u) return;
     constexpr int PER = PICK_BINS / 1024;
     uint32_t sum = 0;
     for (int j = 0; j < PER; j++) sum += hist[tid * PER + j];
-    // inclusive scan of the 1024 partial sums
     uint32_t incl = sum;
     const int lane = tid & 63, wave = tid >> 6;
     for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += y; }
@@ -92,8 +100,11 @@ __global__ void __launch_bounds__(1024) k_pick_select(const uint32_t* __restrict
         for (int j = 0; j < PER; j++) {
             const uint32_t c = hist[tid * PER + j];
             if (run + c >= need) {
-                if (level == 1) { st->bin1 = (uint32_t)(tid * PER + j); st->need1 = need - run; }
-                else st->thresh = (st->bin1 << 16) | (uint32_t)(tid * PER + j);
+                const uint32_t bin = (uint32_t)(tid * PER + j);
+                const uint32_t p = level == 1 ? (bin << 21) : (level == 2 ? (st->prefix | (bin << 10)) : (st->prefix | bin));
+                st->prefix = p;
+                st->need = need - run;
+                if (level == 3) st->thresh = p;   // keys are distinct: exactly one pixel carries it
                 break;
             }
             run += c;
@@ -249,7 +260,7 @@ extern "C" {
 size_t sgr_pick_pixels_scratch_bytes(int n_pix)
 {
     const size_t blocks = ((size_t)(n_pix > 0 ? n_pix : 1) + PICK_BLOCK - 1) / PICK_BLOCK;
-    return sgr_align(2 * (size_t)PICK_BINS * 4 + sizeof(PickState)) + sgr_align(blocks * 4);
+    return sgr_align(3 * (size_t)PICK_BINS * 4 + sizeof(PickState)) + sgr_align(blocks * 4);
 }
 
 size_t sgr_compact_level_rows_scratch_bytes(int N, int L)
@@ -264,15 +275,19 @@ int sgr_pick_pixels(int n_pix, const float* depth, int k, uint32_t seed, int64_t
     hipStream_t s = (hipStream_t)stream;
     uint32_t* hist1 = reinterpret_cast<uint32_t*>(scratch);
     uint32_t* hist2 = hist1 + PICK_BINS;
-    PickState* st = reinterpret_cast<PickState*>(hist2 + PICK_BINS);
-    uint32_t* blk = reinterpret_cast<uint32_t*>(scratch + sgr_align(2 * (size_t)PICK_BINS * 4 + sizeof(PickState)));
-    if (hipMemsetAsync(scratch, 0, 2 * (size_t)PICK_BINS * 4 + sizeof(PickState), s) != hipSuccess) return SGR_E_HIP;
+    uint32_t* hist3 = hist2 + PICK_BINS;
+    PickState* st = reinterpret_cast<PickState*>(hist3 + PICK_BINS);
+    uint32_t* blk = reinterpret_cast<uint32_t*>(scratch + sgr_align(3 * (size_t)PICK_BINS * 4 + sizeof(PickState)));
+    if (hipMemsetAsync(scratch, 0, 3 * (size_t)PICK_BINS * 4 + sizeof(PickState), s) != hipSuccess) return SGR_E_HIP;
     const int grid = (n_pix + 255) / 256 < 2048 ? (n_pix + 255) / 256 : 2048;
+    const int grid1 = (n_pix + 32767) / 32768 < 256 ? (n_pix + 32767) / 32768 : 256;   // ~32 pixels per thread: few flushes of the LDS histogram
     const int blocks = (n_pix + PICK_BLOCK - 1) / PICK_BLOCK;
-    hipLaunchKernelGGL(k_pick_hist1, dim3(grid), dim3(256), 0, s, n_pix, depth, seed, hist1, st);
+    hipLaunchKernelGGL(k_pick_hist1, dim3(grid1), dim3(1024), 0, s, n_pix, depth, seed, hist1, st);
     hipLaunchKernelGGL(k_pick_select, dim3(1), dim3(1024), 0, s, hist1, st, 1, (uint32_t)k);
-    hipLaunchKernelGGL(k_pick_hist2, dim3(grid), dim3(256), 0, s, n_pix, depth, seed, hist2, st);
+    hipLaunchKernelGGL(k_pick_hist23, dim3(grid), dim3(256), 0, s, n_pix, depth, seed, hist2, st, 2);
     hipLaunchKernelGGL(k_pick_select, dim3(1), dim3(1024), 0, s, hist2, st, 2, (uint32_t)k);
+    hipLaunchKernelGGL(k_pick_hist23, dim3(grid), dim3(256), 0, s, n_pix, depth, seed, hist3, st, 3);
+    hipLaunchKernelGGL(k_pick_select, dim3(1), dim3(1024), 0, s, hist3, st, 3, (uint32_t)k);
     hipLaunchKernelGGL(k_pick_count, dim3(blocks), dim3(PICK_BLOCK), 0, s, n_pix, depth, seed, st, blk);
     hipLaunchKernelGGL(k_pick_scan, dim3(1), dim3(1024), 0, s, blocks, blk);
     hipLaunchKernelGGL(k_pick_write, dim3(blocks), dim3(PICK_BLOCK), 0, s, n_pix, depth, seed, st, blk, k, picked, count, n_valid);

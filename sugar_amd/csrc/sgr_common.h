@@ -228,6 +228,8 @@ void sgr_launch_blend_fwd(int W, int H, int gx, int gy, const uint32_t* tile_sta
                           uint32_t* header, uint32_t list_cap, const uint32_t* tile_need, const uint32_t* launch_order, hipStream_t s,
                           uint32_t* repair_flag = nullptr, uint32_t* repair_list = nullptr, int exact = 0, uint32_t deep_min = 0u);
 // blocks of tiles whose hinted list is longer than deep_min entries: eight waves per block (blend.hip); deep_list: [T] words of scratch
+void sgr_launch_deep_list(int gx, int gy, const uint32_t* tile_start, const uint32_t* tile_need, uint32_t deep_min, uint32_t* header,
+                          uint32_t list_cap, uint32_t* deep_list, hipStream_t s);
 void sgr_launch_blend_fwd_deep(int W, int H, int gx, int gy, const uint32_t* tile_start, const uint32_t* point_list, const GeomRec* rec,
                                const float* bg, float* final_T, uint32_t* n_contrib, uint32_t* tile_maxc, uint32_t* tile_walked,
                                float* out_color, unsigned long long* blk_mask, uint32_t* blk_nb, uint32_t* header, uint32_t list_cap,
