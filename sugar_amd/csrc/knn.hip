@@ -244,11 +244,30 @@ __global__ void __launch_bounds__(256) k_grid_bbox(int M, const float* __restric
     if (threadIdx.x < 3) { s_min[threadIdx.x] = 0xFFFFFFFFu; s_max[threadIdx.x] = 0u; }
     __syncthreads();
     unsigned int mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < M; i += gridDim.x * 256)
+    // four points per thread and round, all twelve loads requested before the first is used (a plain loop waits for each), clamped
+    // indices (a repeated point does not change a minimum); one LDS atomic per wave and bound instead of one per thread: 38 -> ~10 us at 1M
+    const int stride = gridDim.x * 256;
+    for (int base = blockIdx.x * 256 + threadIdx.x; base < M; base += 4 * stride) {
+        float v[4][3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) { const unsigned int o = f2ord(pts[3 * (size_t)i + c]); mn[c] = min(mn[c], o); mx[c] = max(mx[c], o); }
+        for (int u = 0; u < 4; u++) {
+            const size_t i = (size_t)min(base + u * stride, M - 1);
 #pragma unroll
-    for (int c = 0; c < 3; c++) { atomicMin(&s_min[c], mn[c]); atomicMax(&s_max[c], mx[c]); }
+            for (int c = 0; c < 3; c++) v[u][c] = pts[3 * i + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) { const unsigned int o = f2ord(v[u][c]); mn[c] = min(mn[c], o); mx[c] = max(mx[c], o); }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = min(mn[c], (unsigned int)__shfl_xor((int)mn[c], o));
+            mx[c] = max(mx[c], (unsigned int)__shfl_xor((int)mx[c], o));
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&s_min[c], mn[c]); atomicMax(&s_max[c], mx[c]); }
+    }
     __syncthreads();
     if (threadIdx.x < 3) { atomicMin(&h->minb[threadIdx.x], s_min[threadIdx.x]); atomicMax(&h->maxb[threadIdx.x], s_max[threadIdx.x]); }
 }
