@@ -10,7 +10,7 @@ timeout 1200 python bench.py > "$OUT/bench_metric.json" 2> "$OUT/bench_metric.er
 for w in config2 config3 config5 config4 config4_opaque; do
   timeout 900 python bench.py --workload $w --steps 20 --warmup 5 --preroll 64 --drift-steps 0 --no-densify-variant --no-reference-loop > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"; echo "bench $w rc $?"
 done
-timeout 600 python bench.py --force-collectives --no-cpu-baseline --no-reference-loop --cameras 0 --drift-steps 0 --no-densify-variant > "$OUT/bench_metric_forced_collectives_in_library.json" 2> "$OUT/bench_forced.err"
+timeout 600 python bench.py --force-collectives --native-collectives --no-cpu-baseline --no-reference-loop --cameras 0 --drift-steps 0 --no-densify-variant > "$OUT/bench_metric_forced_collectives_in_library.json" 2> "$OUT/bench_forced.err"
 SGR_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 6 --warmup 2 --no-cpu-baseline > "$OUT/bench_two_rank_gloo_selflaunch.json" 2> "$OUT/bench_gloo2.err"; echo "gloo2 rc $?"
 cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/prof_kt
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python "$R/bench.py" --steps 20 --warmup 5 --preroll 24 --no-cpu-baseline --no-densify-variant --drift-steps 0 --no-reference-loop --cameras 0 > "$OUT/bench_under_rocprof.log" 2>&1
