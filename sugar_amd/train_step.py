@@ -625,6 +625,7 @@ class NativeTrainer:
         # torch.distributed path, whose ten phase calls per step the host cannot enqueue inside the 0.27 ms the GPU still has queued
         # when the forward's header arrives); `native_collectives=False` or SGR_NATIVE_COLLECTIVES=0 selects the torch.distributed
         # path (the one the two-rank gloo tests exercise; same plan, same kernels, same bits).
+        explicit = native_collectives is True   # (asked for by the caller: a failure is an error, not a fall-back)
         if native_collectives is None:
             env = _os.environ.get("SGR_NATIVE_COLLECTIVES")
             native_collectives = (env == "1") if env is not None else (self.exchange and self.world > 1 and dist.get_backend() == "nccl")
@@ -632,17 +633,34 @@ class NativeTrainer:
         if native_collectives and self.exchange:
             if dist.get_backend() != "nccl":
                 raise RuntimeError("native_collectives needs the RCCL (\"nccl\") process group backend")
+            # Every rank must end up on the SAME path: a rank that cannot bring its communicator up (RCCL not loadable, a failed
+            # init) while the others can would leave them waiting in a collective it never joins.  So the outcome is agreed on
+            # through the process group (a MIN all-reduce of "it worked here"), and if it failed anywhere every rank tears its
+            # communicator down again and takes the torch.distributed exchange (explicitly requested: an error instead).
             idbuf = C.create_string_buffer(128)
-            if dist.get_rank() == 0 and lib.sgr_rccl_unique_id(idbuf) < 0:
-                raise RuntimeError("sgr_rccl_unique_id failed: " + lib.sgr_trainer_last_error().decode(errors="replace"))
-            box = [idbuf.raw]
+            have_id = 1 if (dist.get_rank() != 0 or lib.sgr_rccl_unique_id(idbuf) >= 0) else 0
+            box = [idbuf.raw, have_id]
             dist.broadcast_object_list(box, src=0)
-            with torch.cuda.device(dev):
-                rc = lib.sgr_trainer_comm_init(self._h, box[0], self.world, dist.get_rank(), self._recv.data_ptr(), self._recv.numel() * 4)
-            if rc < 0:
-                raise RuntimeError("sgr_trainer_comm_init failed: " + lib.sgr_trainer_last_error().decode(errors="replace"))
-            self.native_collectives = True
-            lib.sgr_trainer_set_exchange_chunks(self._h, self.exchange_chunks)
+            ok, why = bool(box[1]), "sgr_rccl_unique_id failed on rank 0"
+            if ok:
+                with torch.cuda.device(dev):
+                    rc = lib.sgr_trainer_comm_init(self._h, box[0], self.world, dist.get_rank(), self._recv.data_ptr(), self._recv.numel() * 4)
+                ok = rc >= 0
+                if not ok:
+                    why = "sgr_trainer_comm_init failed: " + lib.sgr_trainer_last_error().decode(errors="replace")
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                self.native_collectives = True
+                lib.sgr_trainer_set_exchange_chunks(self._h, self.exchange_chunks)
+            else:
+                if ok:
+                    lib.sgr_trainer_comm_destroy(self._h)
+                    why = "another rank could not initialise its communicator"
+                if explicit:
+                    raise RuntimeError("native_collectives: " + why)
+                import warnings
+                warnings.warn("in-library gradient exchange unavailable (" + why + "): using torch.distributed collectives")
 
     def set_exchange_chunks(self, n: int):
         """pieces of the gradient exchange (1 .. 16); the results do not depend on it (on one or two ranks: bit for bit)"""
