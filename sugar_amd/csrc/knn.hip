@@ -320,13 +320,11 @@ __global__ void __launch_bounds__(256) k_grid_count(int M, const float* __restri
         cell_of[i] = c;
     }
     // Runs of neighbouring lanes in the same cell (points of a mesh or of a scan come in spatial order) take ONE atomic: the run's
-    // first lane adds the run's length (1M returning atomics, many on the same address within a wave, made this kernel 0.15 ms);
-    // and the occupied-cell count takes one atomic per wave instead of one per first touch of a cell.
+    // first lane adds the run's length.  The occupied-cell count is NOT kept here any more: one atomic per first touch of a cell (then
+    // per wave) on ONE address serialised the whole kernel -- 0.13 ms at 1M points; k_grid_blocksum counts the non-empty cells it
+    // reads anyway.
     unsigned int len;
-    const bool head = grid_run_head(c, live, len);
-    const bool fresh = head && atomicAdd(&cell_count[c], len) == 0u;
-    const unsigned long long fm = __ballot(fresh);
-    if (fm && (threadIdx.x & 63) == (unsigned int)__builtin_ctzll(fm)) atomicAdd(&hdr->occupied, (unsigned int)__popcll(fm));
+    if (grid_run_head(c, live, len)) atomicAdd(&cell_count[c], len);
 }
 
 // exclusive scan of the cell counts (G^3 <= 2M cells), two launches: sums of 4096-cell blocks, then every block adds up the sums
@@ -374,13 +372,26 @@ __device__ __forceinline__ unsigned int grid_block_scan(unsigned int x, unsigned
     return total;
 }
 
-__global__ void __launch_bounds__(256) k_grid_blocksum(int n, const unsigned int* __restrict__ cnt, unsigned int* __restrict__ part)
+__global__ void __launch_bounds__(256) k_grid_blocksum(int n, const unsigned int* __restrict__ cnt, unsigned int* __restrict__ part,
+                                                       GridHdr* __restrict__ hdr)
 {
     __shared__ unsigned int s_wave[4];
     unsigned int v[16], excl;
     const unsigned int sum = grid_scan_load16(n, cnt, (int)blockIdx.x * GRID_SCAN_BLOCK + (int)threadIdx.x * 16, v);
-    const unsigned int total = grid_block_scan(sum, s_wave, excl);
-    if (threadIdx.x == 0) part[blockIdx.x] = total;
+    // non-empty cells (the grid's occupancy, read by the host's asynchronous probe): one atomic per wave of this small grid
+    unsigned int occ = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) occ += v[j] != 0u ? 1u : 0u;
+    __shared__ unsigned int s_occ[4];
+    for (int o = 32; o > 0; o >>= 1) occ += (unsigned int)__shfl_xor((int)occ, o);
+    if ((threadIdx.x & 63) == 0) s_occ[threadIdx.x >> 6] = occ;
+    const unsigned int total = grid_block_scan(sum, s_wave, excl);   // (has the workgroup barriers that publish s_occ)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = total;
+        const unsigned int o4 = s_occ[0] + s_occ[1] + s_occ[2] + s_occ[3];
+        if (o4) atomicAdd(&hdr->occupied, o4);   // one atomic per workgroup: the word is one address
+    }
 }
 
 __global__ void __launch_bounds__(256) k_grid_scan(int n, const unsigned int* __restrict__ cnt, const unsigned int* __restrict__ part,
@@ -1014,6 +1025,9 @@ int build_grid(int M, const float* ref, const GridScratch& gs, hipStream_t s)
         const int rc = count_cells(M, ref, gs, G, s);
         if (rc < 0) return rc;
     }
+    const size_t cells = (size_t)G * G * G;
+    const int scan_blocks = (int)((cells + GRID_SCAN_BLOCK - 1) / GRID_SCAN_BLOCK);
+    hipLaunchKernelGGL(k_grid_blocksum, dim3(scan_blocks), dim3(256), 0, s, (int)cells, gs.cell_count, gs.scan_part, gs.hdr);
     if (probe) {
         ProbeSlot& pr = g_probe;
         const bool due = !(pr.last_M == M && pr.last_G > 0) || ++pr.reused > GRID_PROBE_REUSE;
@@ -1025,9 +1039,6 @@ int build_grid(int M, const float* ref, const GridScratch& gs, hipStream_t s)
             pr.pending = true; pr.pending_M = M; pr.pending_G = G;
         }
     }
-    const size_t cells = (size_t)G * G * G;
-    const int scan_blocks = (int)((cells + GRID_SCAN_BLOCK - 1) / GRID_SCAN_BLOCK);
-    hipLaunchKernelGGL(k_grid_blocksum, dim3(scan_blocks), dim3(256), 0, s, (int)cells, gs.cell_count, gs.scan_part);
     hipLaunchKernelGGL(k_grid_scan, dim3(scan_blocks), dim3(256), 0, s, (int)cells, gs.cell_count, gs.scan_part, gs.cell_start);
     hipLaunchKernelGGL(k_grid_scatter, dim3((M + 255) / 256), dim3(256), 0, s, M, ref, gs.cell_of, gs.cell_start, gs.cursor, gs.sorted);
     if (hipMemsetAsync(gs.coarse, 0, GRID_COARSE_WORDS * 4, s) != hipSuccess) return SGR_E_HIP;
