@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define SGR_ABI_VERSION 3 /* 2: sgr_forward_ex takes an options struct, binning mode per call, trainer API; 3: sgr_forward_info.speculation, SGR_FLAG_SPECULATIVE */
+#define SGR_ABI_VERSION 4 /* 2: sgr_forward_ex takes an options struct, binning mode per call, trainer API; 3: sgr_forward_info.speculation, SGR_FLAG_SPECULATIVE;
+                             4: sgr_train_view.flags, sgr_train_exchange ranges, exact alpha the default, sgr_compact_level_rows / sgr_pick_pixels */
 
 #define SGR_E_INVALID (-1) /* bad argument (e.g. NUM_CHANNELS != 3 path, rasterizer_impl.cu:242-245) */
 #define SGR_E_HIP (-2)     /* a HIP runtime call or kernel failed (CHECK_CUDA, auxiliary.h:166-173) */

@@ -101,7 +101,7 @@ SIGNATURES = {
     "sgr_rasterize_meshes": (_i64, [_vp, _i64, _i64, _i, _i, _f, _i, _i, _i, _i, _vp, _sz, ALLOC_FN, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
-ABI_VERSION = 3  # SGR_ABI_VERSION of include/sugar_raster.h these bindings were written for
+ABI_VERSION = 4  # SGR_ABI_VERSION of include/sugar_raster.h these bindings were written for
 
 
 # ---- structs of include/sugar_raster.h

@@ -64,7 +64,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert not missing, missing
     from sugar_amd import _lib
     assert sorted(_lib.SIGNATURES) == decl, "ctypes signature table and header disagree"
-    assert hip_lib.sgr_abi_version() == _lib.ABI_VERSION == 3
+    assert hip_lib.sgr_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_scratch_layout_queries(hip_lib):
