@@ -474,7 +474,7 @@ def main():
         achieved = alg_bytes / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else 0.0
         # counter-derived figures come from a committed reduction of separate rocprofv3 --pmc passes over THIS command
         # (scripts/pmc_on_box.sh -> profiles/pmc_blend_fwd.json); they are per workload: another --workload gets null
-        traffic, valu, pmc_src = None, None, None
+        traffic, valu, pmc_src, bwd_traffic = None, None, None, None
         pmc = os.path.join(ROOT, "profiles", f"pmc_blend_fwd_{args.workload}.json")
         if not os.path.exists(pmc):
             pmc = os.path.join(ROOT, "profiles", "pmc_blend_fwd.json")
@@ -483,6 +483,7 @@ def main():
                 pj = json.load(open(pmc))
                 if pj.get("workload_key") == args.workload and args.gaussians is None:
                     traffic = pj.get("hbm_bytes_per_launch")
+                    bwd_traffic = pj.get("blend_bwd_hbm_bytes_per_launch")
                     pmc_src = pj.get("source")
                     if pj.get("valu_wave_insts_per_launch") and blend_ms > 0:
                         n_inst, dt_ns, simds = float(pj["valu_wave_insts_per_launch"]), float(pj["simd_issue_interval_ns"]), 1024
@@ -572,7 +573,7 @@ def main():
             bb = 112.0 * R_b + 20.0 * W * H + 8.0 * T
             others = [{"kernel": "k_blend_bwd_wx" if lib.sgr_get_exact_alpha() else "k_blend_bwd_w", "bound": "hbm", "algorithmic_bytes_per_launch": bb,
                        "launch_ms": stages["blend_bwd"], "achieved": bb / (stages["blend_bwd"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": bb / (stages["blend_bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                       "frac": bb / (stages["blend_bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": bwd_traffic,
                        "what": "latency-bound: a dependent chain per (entry, block) at 5 waves per SIMD (DESIGN.md section 5)"}]
             if stages.get("sh_adam", 0) > 0:
                 M_ = int(getattr(params, "M", 16))

@@ -40,4 +40,11 @@ out = {
     "note": "launch order: tiles by depth class of the camera's previous visit (default); the first, raster-ordered visit of a camera fetches "
             "less (the min of FETCH_SIZE_KiB_min_max)",
 }
+try:   # the backward blend's traffic from the same passes (bench.py: roofline_other_kernels)
+    bf = avg(os.path.join(d, prefix + "FETCH_SIZE.txt"), "FETCH_SIZE", "k_blend_bwd_w")
+    bw = avg(os.path.join(d, prefix + "WRITE_SIZE.txt"), "WRITE_SIZE", "k_blend_bwd_w")
+    out["blend_bwd_hbm_bytes_per_launch"] = (2.0 * bf[0] + bw[0]) * 1024.0
+    out["blend_bwd_valu_wave_insts_per_launch"] = avg(os.path.join(d, prefix + "SQ_INSTS_VALU.txt"), "SQ_INSTS_VALU", "k_blend_bwd_w")[0]
+except (SystemExit, OSError):
+    pass
 print(json.dumps(out, indent=1))
