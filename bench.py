@@ -587,6 +587,9 @@ def main():
                              "norm-wise AND >= 99.9 % of its elements within 1e-4 relative (floor 1e-3 of the tensor's largest magnitude), next "
                              "to the reference's own run-to-run spread from float atomics (~2e-6)")
         out["exact_alpha"] = bool(lib.sgr_get_exact_alpha())
+        out["parity_unpinned"] = ("not on this line's path, stated for completeness: the mesh z-buffer behind pytorch3d.renderer.MeshRasterizer "
+                                  "(csrc/mesh_raster.hip, the coarse-mesh sampler's default depth path) is bit-exact against oracle/mesh_rasterizer.c, "
+                                  "which RESTATES pytorch3d 0.7.4 -- absent from the image, so nothing checks it against pytorch3d itself")
         if coarse_sdf:
             out["coarse_sdf_step"] = trainer.report(args.steps)
         if refine_cfg:
