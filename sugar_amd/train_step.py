@@ -553,6 +553,15 @@ class ViewShardedTrainer:
         return loss.detach(), pkg
 
 
+def exchange_pieces(P: int, n_small: int, pieces: int):
+    """Cut points of the gradient exchange in `pieces` pieces (csrc/train.hip: sgr_trainer_step_exchange uses the same rule):
+    Gaussian ranges [g[k], g[k+1]) on multiples of 256 for the colour all-gather / SH-Adam, float ranges [f[k], f[k+1]) on multiples
+    of 1024 for the small all-reduce / flat Adam; empty pieces are allowed (tiny models), the last piece takes the remainder."""
+    g = [0] + [(P * k // pieces) & ~255 for k in range(1, pieces)] + [P]
+    f = [0] + [(n_small * k // pieces) & ~1023 for k in range(1, pieces)] + [n_small]
+    return g, f
+
+
 class NativeTrainer:
     """ViewShardedTrainer.step with the interpreter taken out: one `sgr_trainer_step` call (include/sugar_raster.h) enqueues the
     whole step -- sync-free rasterizer forward in raw-parameter mode, fused loss and its backward, rasterizer backward into
@@ -937,8 +946,8 @@ class NativeTrainer:
         # reduction: only the first piece of each collective (and whatever the wire cannot hide) is exposed.
         C = self.exchange_chunks
         n_small = self.params.n_small
-        g_at = lambda k: P if k >= C else (0 if k <= 0 else (P * k // C) & ~255)
-        f_at = lambda k: n_small if k >= C else (0 if k <= 0 else (n_small * k // C) & ~1023)
+        g_cut, f_cut = exchange_pieces(P, n_small, C)
+        g_at, f_at = (lambda k: g_cut[k]), (lambda k: f_cut[k])
         send, recv = self._send.view(-1), self._recv.view(-1)
         w_cam = dist.all_gather_into_tensor(self._cams_all.view(-1), send[3 * P: 3 * P + 3], async_op=True)
         gathers = []

@@ -273,3 +273,15 @@ def test_the_fallback_of_fused_adam_runs_the_step_hooks_once():
         opt.step()
         assert calls == ["pre", "post"], calls
         assert float(p.detach()[0]) < 1.0
+
+
+def test_the_pieces_of_the_gradient_exchange_tile_their_ranges():
+    """sugar_amd.train_step.exchange_pieces (the rule sgr_trainer_step_exchange applies in C++): monotone cut points on the
+    alignments the kernels need (SH-Adam works on 64-Gaussian waves, flat Adam on float4s), covering [0, P) and [0, n_small)"""
+    from sugar_amd.train_step import exchange_pieces
+    for P in (1, 255, 256, 20_000, 1_000_000, 6_000_001):
+        for pieces in (1, 2, 4, 7, 16):
+            g, f = exchange_pieces(P, 11 * P, pieces)
+            assert len(g) == len(f) == pieces + 1 and g[0] == f[0] == 0 and g[-1] == P and f[-1] == 11 * P
+            assert all(a <= b for a, b in zip(g, g[1:])) and all(a <= b for a, b in zip(f, f[1:]))
+            assert all(x % 64 == 0 for x in g[:-1]) and all(x % 4 == 0 for x in f[:-1])
