@@ -1195,8 +1195,13 @@ blend_bwd_body(int W, int H, int gx, int T_tiles, const uint32_t* __restrict__ t
         const float *__restrict__ final_Ts, const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,                      \
         float *__restrict__ acc, const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ header, uint32_t list_cap
 #define SGR_BWD_ARGS W, H, gx, T_tiles, tile_start, point_list, binning, blk_nb, rec, bg, final_Ts, n_contrib, dL_dpix, acc, tile_order, header, list_cap
-__global__ void __launch_bounds__(64) k_blend_bwd_w(SGR_BWD_PARAMS) { blend_bwd_body<false>(SGR_BWD_ARGS); }
-__global__ void __launch_bounds__(64) k_blend_bwd_wx(SGR_BWD_PARAMS) { blend_bwd_body<true>(SGR_BWD_ARGS); }  // exact alpha (SGR_BWD_HEAD_X)
+#ifdef SGR_BWD_WAVES   // (A/B build option: force the waves per SIMD the register allocation aims at)
+#define SGR_BWD_OCC __attribute__((amdgpu_waves_per_eu(SGR_BWD_WAVES, SGR_BWD_WAVES)))
+#else
+#define SGR_BWD_OCC
+#endif
+__global__ void __launch_bounds__(64) SGR_BWD_OCC k_blend_bwd_w(SGR_BWD_PARAMS) { blend_bwd_body<false>(SGR_BWD_ARGS); }
+__global__ void __launch_bounds__(64) SGR_BWD_OCC k_blend_bwd_wx(SGR_BWD_PARAMS) { blend_bwd_body<true>(SGR_BWD_ARGS); }  // exact alpha (SGR_BWD_HEAD_X)
 
 // Launch order of the backward: tiles by how deep the forward walked them (tile_maxc), deepest first, so that the waves still
 // running when the grid drains are the short ones.  (Workgroups start in index order; with ~2.5 dispatch rounds of waves whose
